@@ -1,0 +1,141 @@
+/*
+ * nsc_hip.h - C ABI of libnsc_hip.so: the MI355X (gfx950) kernels behind the NSC/CMRL hot path.
+ *
+ * The reference (cocosci/NSC) has no FFI: its boundary is the Python module of free functions
+ * nn_core_operator.py (+ the loss functions of loss_terms_and_measures.py), every one of which
+ * bottoms out in a TensorFlow op.  Each entry point below replaces the TF op(s) behind one of those
+ * functions; the Python side (nsc_amd/nn_core_operator.py, nsc_amd/loss_terms_and_measures.py)
+ * keeps the reference's names/arguments and binds these symbols with ctypes.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every buffer is caller-owned DEVICE memory (fp32 unless stated);
+ *  - activations are time-contiguous  [B, C, T]  ("bct"); the reference's channels_last [B, T, C]
+ *    is converted at the op surface with nsc_transpose_last2 (for C == 1 both layouts coincide);
+ *  - conv kernels keep the TF layout  [K, Cin, Cout];
+ *  - every call takes an explicit hipStream_t (as void*), allocates nothing, never synchronises,
+ *    and is safe to capture into a hipGraph;
+ *  - return value: 0 on success, negative nsc_status on error (never throws); nsc_last_error()
+ *    returns a thread-local message for the last failure.
+ *  - "accumulate" outputs (dw, db, hist, dalpha, dbins) are atomically ADDED to; the caller zeroes
+ *    them (one memset of the flat gradient buffer per step).
+ */
+#ifndef NSC_HIP_H
+#define NSC_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum nsc_status {
+  NSC_OK = 0,
+  NSC_ERR_BAD_ARG = -1,     /* null pointer / non-positive size */
+  NSC_ERR_UNSUPPORTED = -2, /* shape outside what the kernels are built for */
+  NSC_ERR_LAUNCH = -3       /* HIP launch failure (message has hipGetErrorString) */
+};
+
+enum nsc_act { NSC_ACT_NONE = 0, NSC_ACT_TANH = 1, NSC_ACT_LRELU = 2 }; /* lrelu alpha = 0.2 */
+
+int nsc_version(void);
+const char* nsc_last_error(void);
+
+/* ---- conv1d (replaces tf.compat.v1.layers.conv1d behind nn_core_operator.py:6-14 `conv1d`,
+ *      :45-54 `change_channel`, and neural_speech_coding_module.py:152-156 `_down_sampling_mod`) ----
+ * y[b,o,t] = epilogue( sum_{k,i} xin[b,i, t*stride + k*dil - padL] * w[k,i,o] )
+ * epilogue(v): v += bias[o]; v += res (res_mode); v = act(v); v *= act'(aux) (mul_mode);
+ *              store (plain | sub-pixel-shuffled | accumulate).
+ * TF 'SAME' padding is expressed through padL (zero fill outside [0,Tin)); Tout is explicit.
+ * in_up=1 reads a virtual zero-upsampled-by-2 input (transposed conv = dgrad of a stride-2 conv).
+ */
+typedef struct nsc_conv_desc {
+  int B, Cin, Cout, Tin, Tout, K, dil, stride, padL;
+  int act;        /* nsc_act */
+  int res_mode;   /* 0 none, 1 res[B,Cout,Tout], 2 broadcast res[B,1,Tout] */
+  int mul_mode;   /* 0 none, 1 v *= lrelu'(aux), 2 v *= tanh'(aux) = 1-aux^2 ; aux[B,Cout,Tout] is an activation OUTPUT */
+  int out_mode;   /* 0 plain y[B,Cout,Tout]; 1 sub-pixel shuffle: y[B,Cout/2,2*Tout], y[b,o>>1,2t+(o&1)] (nsc_module:158-167) */
+  int in_up;      /* 0 plain; 1 virtual input u: x[u/2] if u even else 0, virtual length 2*Tin */
+  int accumulate; /* 0 y = v ; 1 y += v */
+} nsc_conv_desc;
+
+/* MFMA (v_mfma_f32_16x16x4_f32) implicit-GEMM forward; Cout >= 1 (small Cout wastes tiles: use _cout1). */
+int nsc_conv1d_fwd(const nsc_conv_desc* d, const float* x, const float* w, const float* bias,
+                   const float* res, const float* aux, float* y, void* stream);
+/* Cout == 1 special case (k55 C->1 convs, nsc_module:236,255-259): VALU dot products. Same epilogue. */
+int nsc_conv1d_cout1_fwd(const nsc_conv_desc* d, const float* x, const float* w, const float* bias,
+                         const float* res, const float* aux, float* y, void* stream);
+/* weight gradient: dw[k,i,o] += sum_{b,t} xin[b,i,t*stride+k*dil-padL] * dz[b,o,t];  db[o] += sum dz (db nullable).
+ * flip_taps=1 writes tap k to row K-1-k (used when x/dz roles are swapped for Cout==1 convs). */
+int nsc_conv1d_wgrad(const nsc_conv_desc* d, const float* x, const float* dz, float* dw, float* db,
+                     int flip_taps, void* stream);
+/* wt[K-1-k, o, i] = w[k, i, o] : weights of the data-gradient conv (dgrad == nsc_conv1d_fwd on wt). */
+int nsc_weight_flip_transpose(const float* w, float* wt, int K, int Cin, int Cout, void* stream);
+
+/* ---- separable conv pieces (replaces tf.keras.layers.SeparableConv1D behind nn_core_operator.py:17-21) ---- */
+int nsc_depthwise_fwd(const float* x, const float* wd /*[K,C]*/, float* y, int B, int C, int T, int K, void* stream);
+int nsc_depthwise_bwd(const float* x, const float* wd, const float* dy, float* dx, float* dwd /*accumulate*/,
+                      int B, int C, int T, int K, void* stream);
+
+/* ---- gate (tf.multiply(left, tanh-right), nn_core_operator.py:100) on a fused [B,2n,T] pre-activation ----
+ * fwd: a[:, n:] <- tanh(a[:, n:]) in place; g = a[:, :n] * a[:, n:].   bwd: da from dg and the saved a. */
+int nsc_gate_fwd(float* a, float* g, int B, int n, int T, void* stream);
+int nsc_gate_bwd(const float* a, const float* dg, float* da, int B, int n, int T, void* stream);
+
+/* separate-branch form used by the unfused path: g = lin * th (th = tanh branch output), and its backward
+ * dlin = dg*th, dgate_pre = dg*lin*(1-th^2). */
+int nsc_mul(const float* a, const float* b, float* out, long n, void* stream);
+int nsc_glu_bwd(const float* lin, const float* th, const float* dg, float* dlin, float* dgate, long n, void* stream);
+
+/* ---- small glue ---- */
+int nsc_gather(const float* src, const int* idx, float* dst, long n, void* stream); /* dst[e] = src[idx[e]] */
+int nsc_axpby(const float* x, const float* y, float* out, float a, float b, long n, void* stream); /* out = a*x + b*y (y nullable) */
+int nsc_channel_sum(const float* x, float* out, int B, int C, int T, int accumulate, void* stream); /* out[b,0,t] (+)= sum_c x[b,c,t] */
+int nsc_unshuffle2(const float* ys /*[B,C/2,2T]*/, float* y /*[B,C,T]*/, int B, int C, int T, void* stream);
+int nsc_transpose_last2(const float* x /*[B,R,Cc]*/, float* y /*[B,Cc,R]*/, int B, int R, int Cc, void* stream);
+int nsc_sum_all(const float* x, float* out /*accumulate [1]*/, long n, void* stream);
+
+/* ---- soft-to-hard scalar quantizer (replaces nn_core_operator.py:140-164 `scalar_softmax_quantization`,
+ *      fused with loss_terms_and_measures.py:257-259 `quan_loss` and :262-267 `entropy_coding_loss` partials) ----
+ * code[B*L]; p = softmax_k(alpha*|c-bins_k|); q = sum_k sel_k*bins_k (sel = p if soft else one_hot(argmax p,
+ * lowest index on ties)); out = (1-is_quan_on)*c + is_quan_on*q.
+ * p_out (nullable) [B*L,nb];  quan_out (nullable) [B] = mean_l sum_k sqrt(p+1e-20);
+ * hist (nullable, accumulate) [nb] += sum_{b,l} p. */
+int nsc_quantize_fwd(const float* code, const float* alpha, const float* bins, float is_quan_on, int soft,
+                     int B, int L, int nb, float* p_out, float* out, float* quan_out, float* hist, void* stream);
+/* entropy from a (possibly all-reduced) histogram: ent[0] = -sum h log2(h+1e-7), h = hist/sum(hist);
+ * ghist[k] = d ent / d hist[k]. */
+int nsc_entropy_from_hist(const float* hist, int nb, float* ent, float* ghist, void* stream);
+/* backward.  Upstream gradients: dout[B*L] (of `out`), dp (nullable, explicit dL/dp [B*L,nb]),
+ * plus the analytically fused loss terms  c_quan*quan_loss(p)[b] summed over b  and  ent_scale*entropy(p):
+ *   dL/dp += c_quan/L * 0.5/sqrt(p+1e-20) + ent_scale*ghist[k].
+ * pre_tanh=1 additionally multiplies dcode by (1-code^2) (code = tanh(z): returns dL/dz).
+ * dalpha[1], dbins[nb] are accumulated (nullable = not trainable). */
+int nsc_quantize_bwd(const float* code, const float* alpha, const float* bins, float is_quan_on, int soft,
+                     int B, int L, int nb, const float* dout, const float* dp, float c_quan,
+                     const float* ghist, float ent_scale, int pre_tanh,
+                     float* dcode, float* dalpha, float* dbins, void* stream);
+
+/* ---- reconstruction losses (replaces loss_terms_and_measures.py:77-79 `mse_loss`, :178-183 `tf_stft`,
+ *      :130-148 `mfcc_transform`, :151-175 `mfcc_loss`): one workgroup per 512-sample frame, radix-2 FFT in LDS ----
+ * time_out[b] = sqrt(mean_t (d-o)^2 + 1e-7);  freq_out[b] = mean over 4 mel banks of sqrt(mean_m (dlogmel)^2 + 1e-7).
+ * grad (nullable) [B,512] = d( sum_b gt[b]*time[b] + gf[b]*freq[b] ) / d decoded, where gt/gf are per-frame
+ * upstream weights (nullable -> the scalars ct / cf).  mel [257,184] row-major, melT [184,257]. */
+int nsc_recon_loss(const float* decoded, const float* target, int B, float ct, float cf,
+                   const float* gt, const float* gf, const float* mel, const float* melT,
+                   float* time_out, float* freq_out, float* grad, void* stream);
+/* bare rFFT-512 magnitude (tf_stft): re/im/mag [B,257] (any nullable). */
+int nsc_rfft512(const float* sig, int B, float* re, float* im, float* mag, void* stream);
+
+/* ---- optimizer (replaces tf.compat.v1.train.AdamOptimizer, nsc_module:922-925): TF1 Adam on flat buffers ----
+ * lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v EMA; p -= lr_t*m/(sqrt(v)+eps).  t is read from t_dev[0] if non-null. */
+int nsc_adam_tf1_step(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
+                      float eps, int t, const int* t_dev, void* stream);
+int nsc_increment(int* counter, void* stream);
+
+/* ---- framing (utilities.py:7-39): frames[i,:] = utt[480 i : 480 i + 512] * window; overlap-add back ---- */
+int nsc_frame_utterance(const float* utt, long n, const float* window /*nullable [512]*/, float* frames, int nframes, void* stream);
+int nsc_overlap_add(const float* frames, int nframes, const float* win3 /*[3,512]: first, middle, last Hann variants*/,
+                    float* out /*[480(n-1)+512]*/, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NSC_HIP_H */

@@ -1,0 +1,105 @@
+"""ctypes binding of libnsc_hip.so (the C ABI declared in include/nsc_hip.h).
+
+There is NO fallback: if the HIP library is missing or a call fails, this module raises.  The oracle under
+``oracle/`` is test infrastructure and is never imported from here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnsc_hip.so")
+
+ACT_NONE, ACT_TANH, ACT_LRELU = 0, 1, 2
+
+
+class ConvDesc(C.Structure):
+    """Mirror of ``nsc_conv_desc`` (include/nsc_hip.h)."""
+    _fields_ = [(n, C.c_int) for n in
+                ("B", "Cin", "Cout", "Tin", "Tout", "K", "dil", "stride", "padL", "act", "res_mode", "mul_mode",
+                 "out_mode", "in_up", "accumulate")]
+
+
+_P = C.c_void_p
+_F = C.c_float
+_I = C.c_int
+_L = C.c_long
+
+# name -> argtypes (all return int except the two noted)
+PROTOTYPES = {
+    "nsc_conv1d_fwd": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P],
+    "nsc_conv1d_cout1_fwd": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P],
+    "nsc_conv1d_wgrad": [C.POINTER(ConvDesc), _P, _P, _P, _P, _I, _P],
+    "nsc_weight_flip_transpose": [_P, _P, _I, _I, _I, _P],
+    "nsc_depthwise_fwd": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "nsc_depthwise_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "nsc_gate_fwd": [_P, _P, _I, _I, _I, _P],
+    "nsc_gate_bwd": [_P, _P, _P, _I, _I, _I, _P],
+    "nsc_mul": [_P, _P, _P, _L, _P],
+    "nsc_glu_bwd": [_P, _P, _P, _P, _P, _L, _P],
+    "nsc_gather": [_P, _P, _P, _L, _P],
+    "nsc_axpby": [_P, _P, _P, _F, _F, _L, _P],
+    "nsc_channel_sum": [_P, _P, _I, _I, _I, _I, _P],
+    "nsc_unshuffle2": [_P, _P, _I, _I, _I, _P],
+    "nsc_transpose_last2": [_P, _P, _I, _I, _I, _P],
+    "nsc_sum_all": [_P, _P, _L, _P],
+    "nsc_quantize_fwd": [_P, _P, _P, _F, _I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "nsc_entropy_from_hist": [_P, _I, _P, _P, _P],
+    "nsc_quantize_bwd": [_P, _P, _P, _F, _I, _I, _I, _I, _P, _P, _F, _P, _F, _I, _P, _P, _P, _P],
+    "nsc_recon_loss": [_P, _P, _I, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P],
+    "nsc_rfft512": [_P, _I, _P, _P, _P, _P],
+    "nsc_adam_tf1_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _P, _P],
+    "nsc_increment": [_P, _P],
+    "nsc_frame_utterance": [_P, _L, _P, _P, _I, _P],
+    "nsc_overlap_add": [_P, _I, _P, _P, _P],
+}
+EXPORTS = sorted(list(PROTOTYPES) + ["nsc_version", "nsc_last_error"])
+
+
+class NscError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; raise loudly if it is absent (no CPU fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NscError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       f"or `make -C nsc_amd/csrc`. nsc_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argt in PROTOTYPES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argt
+        fn.restype = C.c_int
+    lib.nsc_version.restype = C.c_int
+    lib.nsc_last_error.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().nsc_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = last_error()
+        if rc == -1:
+            raise ValueError(f"{what}: {msg}")
+        raise NscError(f"{what}: rc={rc}: {msg}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,527 @@
+// conv.hip - dilated/strided Conv1d (+bias +residual +activation) as implicit GEMM on the CDNA4 matrix
+// cores, exact fp32 (v_mfma_f32_16x16x4_f32: bitwise an fmaf chain), layout [B, C, T] (time contiguous).
+//
+// Replaces tf.compat.v1.layers.conv1d behind nn_core_operator.py:6-14 (reference), forward, data-gradient
+// (same kernel on flipped/transposed weights) and weight-gradient.
+//
+// MFMA mapping (guide: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], D col=l&15,row=4*(l>>4)+reg):
+//   forward : rows i = output channel, cols j = time, k = (tap, ci) ; A = weights (global/L2), B = x tile (LDS)
+//   wgrad   : rows i = (tap, ci),      cols j = output channel, k = time ; A = x tile (LDS), B = dz tile (LDS)
+// so D's lane index is always the memory-contiguous axis of the output (time for y, Cout for dW).
+#include "nsc_common.h"
+#include <cstdarg>
+#include <algorithm>
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing (shared by all translation units)
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void nsc_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* nsc_last_error(void) { return g_err; }
+extern "C" int nsc_version(void) { return 100; }
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+// Workgroup = 4 waves; each wave owns NC column tiles (16 time steps each) and all RT row tiles
+// (16 output channels each) of one frame.  x tile (with halo) is staged once in LDS; weight fragments
+// stream from global (identical for every wave and workgroup -> L1/L2 resident), prefetched one
+// k-step ahead so the MFMA chain of step s covers the latency of step s+1's loads.
+template <int RT, int NC, bool CIN1>
+__global__ __launch_bounds__(256) void conv1d_fwd_kernel(nsc_conv_desc d, const float* __restrict__ x,
+                                                         const float* __restrict__ w,
+                                                         const float* __restrict__ bias,
+                                                         const float* __restrict__ res,
+                                                         const float* __restrict__ aux, float* __restrict__ y,
+                                                         int ldx, int win) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, kq = lane >> 4;
+  const int TT = 4 * NC * 16;
+  const int b = blockIdx.y;
+  const int t0 = blockIdx.x * TT;
+  const int rt0 = blockIdx.z * RT;
+  const int Cin4 = CIN1 ? 1 : ((d.Cin + 3) & ~3);
+  const int Tin_virt = d.in_up ? 2 * d.Tin : d.Tin;
+
+  // ---- stage x tile: xs[ci][j] = xin[b, ci, t0*stride - padL + j], zero outside ----
+  {
+    const int u0 = t0 * d.stride - d.padL;
+    const float* xb = x + (long)b * d.Cin * d.Tin;
+    const int total = Cin4 * ldx;
+    for (int e = tid; e < total; e += 256) {
+      const int ci = e / ldx, j = e - ci * ldx;
+      const int u = u0 + j;
+      float v = 0.f;
+      if (ci < d.Cin && j < win && u >= 0 && u < Tin_virt) {
+        if (d.in_up) {
+          if (!(u & 1)) v = xb[(long)ci * d.Tin + (u >> 1)];
+        } else {
+          v = xb[(long)ci * d.Tin + u];
+        }
+      }
+      xs[e] = v;
+    }
+  }
+  __syncthreads();
+
+  f32x4 acc[RT][NC];
+#pragma unroll
+  for (int r = 0; r < RT; ++r)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int tcol0 = wave * NC * 16 + l15;  // this lane's first column (time offset inside the tile)
+  const int Cout = d.Cout;
+
+  if constexpr (CIN1) {
+    // K order = tap; k-step s covers taps 4s..4s+3 (lane group kq).  xs has 3*dil zero slack at the end.
+    const int nsteps = (d.K + 3) >> 2;
+    float a_cur[RT], a_nxt[RT];
+    {
+      const int tap = kq;
+#pragma unroll
+      for (int r = 0; r < RT; ++r) {
+        const int o = (rt0 + r) * 16 + l15;
+        a_cur[r] = (tap < d.K && o < Cout) ? w[(long)tap * Cout + o] : 0.f;
+      }
+    }
+    for (int s = 0; s < nsteps; ++s) {
+      const int tapn = 4 * (s + 1) + kq;
+#pragma unroll
+      for (int r = 0; r < RT; ++r) {
+        const int o = (rt0 + r) * 16 + l15;
+        a_nxt[r] = (s + 1 < nsteps && tapn < d.K && o < Cout) ? w[(long)tapn * Cout + o] : 0.f;
+      }
+      const int tap = 4 * s + kq;
+      float bf[NC];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) bf[c] = xs[(tcol0 + c * 16) * d.stride + tap * d.dil];
+#pragma unroll
+      for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+          acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[r], bf[c], acc[r][c], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < RT; ++r) a_cur[r] = a_nxt[r];
+    }
+  } else {
+    // K order = (tap, ci) with ci fastest, ci padded to a multiple of 4 (pad rows of xs are zero).
+    const int ncq = Cin4 >> 2;
+    const int nsteps = d.K * ncq;
+    float a_cur[RT], a_nxt[RT];
+    {
+      const int ci = kq;
+#pragma unroll
+      for (int r = 0; r < RT; ++r) {
+        const int o = (rt0 + r) * 16 + l15;
+        a_cur[r] = (ci < d.Cin && o < Cout) ? w[(long)ci * Cout + o] : 0.f;
+      }
+    }
+    int tap = 0, cq = 0;
+    for (int s = 0; s < nsteps; ++s) {
+      int tapn = tap, cqn = cq + 1;
+      if (cqn == ncq) { cqn = 0; tapn = tap + 1; }
+      {
+        const int ci = cqn * 4 + kq;
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+          const int o = (rt0 + r) * 16 + l15;
+          a_nxt[r] = (tapn < d.K && ci < d.Cin && o < Cout) ? w[((long)tapn * d.Cin + ci) * Cout + o] : 0.f;
+        }
+      }
+      const int ci = cq * 4 + kq;
+      const float* xrow = xs + ci * ldx + tap * d.dil;
+      float bf[NC];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) bf[c] = xrow[(tcol0 + c * 16) * d.stride];
+#pragma unroll
+      for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+          acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[r], bf[c], acc[r][c], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < RT; ++r) a_cur[r] = a_nxt[r];
+      tap = tapn;
+      cq = cqn;
+    }
+  }
+
+  // ---- epilogue: D col = l15 -> time, row = 4*kq + reg -> channel ----
+#pragma unroll
+  for (int r = 0; r < RT; ++r) {
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int ch = (rt0 + r) * 16 + kq * 4 + reg;
+      if (ch >= Cout) continue;
+      const float bv = bias ? bias[ch] : 0.f;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int t = t0 + tcol0 + c * 16;
+        if (t >= d.Tout) continue;
+        float v = acc[r][c][reg] + bv;
+        const long idx = ((long)b * Cout + ch) * d.Tout + t;
+        if (d.res_mode == 1) v += res[idx];
+        else if (d.res_mode == 2) v += res[(long)b * d.Tout + t];
+        v = nsc_apply_act(v, d.act);
+        if (d.mul_mode) v *= nsc_act_grad_from_out(aux[idx], d.mul_mode);
+        long oidx = idx;
+        if (d.out_mode == 1) oidx = ((long)b * (Cout >> 1) + (ch >> 1)) * (2L * d.Tout) + 2 * t + (ch & 1);
+        if (d.accumulate) y[oidx] += v;
+        else y[oidx] = v;
+      }
+    }
+  }
+}
+
+static int round_ldx_fwd(int win, int stride) {
+  // conflict-free ds_read_b32 of the B fragment: lanes 0-15 read one row, 16-31 the next row.
+  if (stride == 1) {
+    int l = win;
+    while ((l & 31) != 16) ++l;
+    return l;
+  }
+  return win | 1;
+}
+
+template <int RT, int NC, bool CIN1>
+static int launch_fwd(const nsc_conv_desc* d, const float* x, const float* w, const float* bias, const float* res,
+                      const float* aux, float* y, hipStream_t st) {
+  const int TT = 4 * NC * 16;
+  int win = (TT - 1) * d->stride + (d->K - 1) * d->dil + 1;
+  if (CIN1) win += 3 * d->dil;  // slack so taps K..K+2 of the last k-step read zeros
+  const int ldx = round_ldx_fwd(win, d->stride);
+  const int Cin4 = CIN1 ? 1 : ((d->Cin + 3) & ~3);
+  const size_t smem = (size_t)Cin4 * ldx * sizeof(float);
+  NSC_REQUIRE(smem <= 160 * 1024, NSC_ERR_UNSUPPORTED, "conv1d_fwd: x tile %zu B exceeds LDS", smem);
+  auto kern = conv1d_fwd_kernel<RT, NC, CIN1>;
+  if (smem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "conv1d_fwd: set smem attr: %s", hipGetErrorString(e));
+  }
+  const int nrt = nsc_cdiv(d->Cout, 16);
+  dim3 grid(nsc_cdiv(d->Tout, TT), d->B, nsc_cdiv(nrt, RT));
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, *d, x, w, bias, res, aux, y, ldx, win);
+  NSC_CHECK_LAUNCH("conv1d_fwd");
+  return NSC_OK;
+}
+
+template <int NC, bool CIN1>
+static int dispatch_rt(const nsc_conv_desc* d, const float* x, const float* w, const float* bias, const float* res,
+                       const float* aux, float* y, hipStream_t st) {
+  const int nrt = nsc_cdiv(d->Cout, 16);
+  switch (nrt) {
+    case 1: return launch_fwd<1, NC, CIN1>(d, x, w, bias, res, aux, y, st);
+    case 2: return launch_fwd<2, NC, CIN1>(d, x, w, bias, res, aux, y, st);
+    case 3: return launch_fwd<3, NC, CIN1>(d, x, w, bias, res, aux, y, st);
+    case 4: return launch_fwd<4, NC, CIN1>(d, x, w, bias, res, aux, y, st);
+    case 5: case 6: case 7: return launch_fwd<7, NC, CIN1>(d, x, w, bias, res, aux, y, st);
+    default: return launch_fwd<4, NC, CIN1>(d, x, w, bias, res, aux, y, st);  // grid.z walks groups of 4 row tiles
+  }
+}
+
+static int check_desc(const nsc_conv_desc* d, const char* who) {
+  NSC_REQUIRE(d, NSC_ERR_BAD_ARG, "%s: null desc", who);
+  NSC_REQUIRE(d->B > 0 && d->Cin > 0 && d->Cout > 0 && d->Tin > 0 && d->Tout > 0 && d->K > 0 && d->dil > 0 &&
+                  d->stride > 0 && d->padL >= 0,
+              NSC_ERR_BAD_ARG, "%s: non-positive size in desc (B=%d Cin=%d Cout=%d Tin=%d Tout=%d K=%d)", who, d->B,
+              d->Cin, d->Cout, d->Tin, d->Tout, d->K);
+  NSC_REQUIRE(d->act >= 0 && d->act <= 2 && d->res_mode >= 0 && d->res_mode <= 2 && d->mul_mode >= 0 &&
+                  d->mul_mode <= 2 && d->out_mode >= 0 && d->out_mode <= 1,
+              NSC_ERR_BAD_ARG, "%s: bad mode field", who);
+  NSC_REQUIRE(d->stride <= 2, NSC_ERR_UNSUPPORTED, "%s: stride %d > 2 unsupported", who, d->stride);
+  NSC_REQUIRE(!(d->out_mode == 1 && (d->Cout & 1)), NSC_ERR_BAD_ARG, "%s: shuffle needs even Cout", who);
+  NSC_REQUIRE(!(d->in_up && d->stride != 1), NSC_ERR_UNSUPPORTED, "%s: in_up needs stride 1", who);
+  return NSC_OK;
+}
+
+extern "C" int nsc_conv1d_fwd(const nsc_conv_desc* d, const float* x, const float* w, const float* bias,
+                              const float* res, const float* aux, float* y, void* stream) {
+  int rc = check_desc(d, "nsc_conv1d_fwd");
+  if (rc) return rc;
+  NSC_REQUIRE(x && w && y, NSC_ERR_BAD_ARG, "nsc_conv1d_fwd: null x/w/y");
+  NSC_REQUIRE(!(d->res_mode && !res), NSC_ERR_BAD_ARG, "nsc_conv1d_fwd: res_mode set but res null");
+  NSC_REQUIRE(!(d->mul_mode && !aux), NSC_ERR_BAD_ARG, "nsc_conv1d_fwd: mul_mode set but aux null");
+  hipStream_t st = (hipStream_t)stream;
+  // NC=2 (128-step time tiles) when the x tile stays small enough for >= 2 workgroups per CU.
+  const bool cin1 = d->Cin == 1;
+  const int Cin4 = cin1 ? 1 : ((d->Cin + 3) & ~3);
+  const long smem2 = (long)Cin4 * ((127L) * d->stride + (d->K - 1) * d->dil + 40) * 4;
+  const bool nc2 = smem2 <= 72 * 1024 && d->Tout >= 128;
+  if (cin1) return nc2 ? dispatch_rt<2, true>(d, x, w, bias, res, aux, y, st)
+                       : dispatch_rt<1, true>(d, x, w, bias, res, aux, y, st);
+  return nc2 ? dispatch_rt<2, false>(d, x, w, bias, res, aux, y, st)
+             : dispatch_rt<1, false>(d, x, w, bias, res, aux, y, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Cout == 1 (k55 C->1): VALU dot products; 128 outputs per workgroup, channels split over 2 thread halves
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv1d_cout1_kernel(nsc_conv_desc d, const float* __restrict__ x,
+                                                           const float* __restrict__ w,
+                                                           const float* __restrict__ bias,
+                                                           const float* __restrict__ res,
+                                                           const float* __restrict__ aux, float* __restrict__ y,
+                                                           int ldx) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* xs = sm;                       // [Cin][ldx]
+  float* ws = sm + d.Cin * ldx;         // [K*Cin]  (w[k,ci,0])
+  float* part = ws + d.K * d.Cin;       // [128]
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y, t0 = blockIdx.x * 128;
+  const int Tin_virt = d.in_up ? 2 * d.Tin : d.Tin;
+  const int u0 = t0 * d.stride - d.padL;
+  const float* xb = x + (long)b * d.Cin * d.Tin;
+  for (int e = tid; e < d.Cin * ldx; e += 256) {
+    const int ci = e / ldx, j = e - ci * ldx;
+    const int u = u0 + j;
+    float v = 0.f;
+    if (u >= 0 && u < Tin_virt) {
+      if (d.in_up) { if (!(u & 1)) v = xb[(long)ci * d.Tin + (u >> 1)]; }
+      else v = xb[(long)ci * d.Tin + u];
+    }
+    xs[e] = v;
+  }
+  for (int e = tid; e < d.K * d.Cin; e += 256) ws[e] = w[e];
+  __syncthreads();
+  const int tl = tid & 127, half = tid >> 7;
+  const int chalf = (d.Cin + 1) >> 1;
+  const int c0 = half * chalf, c1 = min(d.Cin, c0 + chalf);
+  float acc = 0.f;
+  for (int ci = c0; ci < c1; ++ci) {
+    const float* xr = xs + ci * ldx + tl * d.stride;
+    for (int k = 0; k < d.K; ++k) acc = fmaf(xr[k * d.dil], ws[k * d.Cin + ci], acc);
+  }
+  if (half == 1) part[tl] = acc;
+  __syncthreads();
+  if (half == 0) {
+    const int t = t0 + tl;
+    if (t < d.Tout) {
+      float v = acc + part[tl] + (bias ? bias[0] : 0.f);
+      const long idx = (long)b * d.Tout + t;
+      if (d.res_mode) v += res[idx];
+      v = nsc_apply_act(v, d.act);
+      if (d.mul_mode) v *= nsc_act_grad_from_out(aux[idx], d.mul_mode);
+      if (d.accumulate) y[idx] += v;
+      else y[idx] = v;
+    }
+  }
+}
+
+extern "C" int nsc_conv1d_cout1_fwd(const nsc_conv_desc* d, const float* x, const float* w, const float* bias,
+                                    const float* res, const float* aux, float* y, void* stream) {
+  int rc = check_desc(d, "nsc_conv1d_cout1_fwd");
+  if (rc) return rc;
+  NSC_REQUIRE(d->Cout == 1 && d->out_mode == 0, NSC_ERR_BAD_ARG, "nsc_conv1d_cout1_fwd: needs Cout == 1, plain store");
+  NSC_REQUIRE(x && w && y, NSC_ERR_BAD_ARG, "nsc_conv1d_cout1_fwd: null x/w/y");
+  NSC_REQUIRE(!(d->res_mode && !res) && !(d->mul_mode && !aux), NSC_ERR_BAD_ARG, "nsc_conv1d_cout1_fwd: null res/aux");
+  int ldx = 127 * d->stride + (d->K - 1) * d->dil + 1;
+  ldx |= 1;
+  const size_t smem = ((size_t)d->Cin * ldx + (size_t)d->K * d->Cin + 128) * sizeof(float);
+  NSC_REQUIRE(smem <= 160 * 1024, NSC_ERR_UNSUPPORTED, "conv1d_cout1: tile %zu B exceeds LDS", smem);
+  if (smem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv1d_cout1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)smem);
+    NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "conv1d_cout1: set smem attr: %s", hipGetErrorString(e));
+  }
+  dim3 grid(nsc_cdiv(d->Tout, 128), d->B);
+  hipLaunchKernelGGL(conv1d_cout1_kernel, grid, dim3(256), smem, (hipStream_t)stream, *d, x, w, bias, res, aux, y, ldx);
+  NSC_CHECK_LAUNCH("conv1d_cout1");
+  return NSC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient
+// ------------------------------------------------------------------------------------------------
+// rows = kk = tap*Cin + ci (+1 bias row fed by a row of ones), cols = output channel, reduction = (b, t).
+// Workgroup = 4 waves; wave wv owns row tiles [(blockIdx.y*4 + wv)*RT, +RT) x all CT column tiles.
+// blockIdx.x walks (frame, 64-step time chunk) pairs with stride gridDim.x (split-K); partial sums are
+// added to dw/db with global float atomics (64-B contiguous segments per 16 lanes).
+template <int RT, int CT>
+__global__ __launch_bounds__(256) void conv1d_wgrad_kernel(nsc_conv_desc d, const float* __restrict__ x,
+                                                           const float* __restrict__ dz, float* __restrict__ dw,
+                                                           float* __restrict__ db, int flip, int ldx, int win,
+                                                           int nchunk_t) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  constexpr int TT = 64, LDZ = 66;  // 66 % 32 == 2: conflict-free B-fragment reads
+  float* xs = sm;                          // [Cin + 2][ldx] : rows Cin = zeros, Cin+1 = ones
+  float* dzs = sm + (d.Cin + 2) * ldx;     // [CT*16][LDZ]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, kq = lane >> 4;
+  const int nrows = d.K * d.Cin + (db ? 1 : 0);
+  const int Tin_virt = d.in_up ? 2 * d.Tin : d.Tin;
+
+  // per-lane A-row offsets (row = rowtile*16 + l15)
+  int rowoff[RT];
+#pragma unroll
+  for (int r = 0; r < RT; ++r) {
+    const int kk = ((blockIdx.y * 4 + wave) * RT + r) * 16 + l15;
+    if (kk < d.K * d.Cin) {
+      const int tap = kk / d.Cin, ci = kk - tap * d.Cin;
+      rowoff[r] = ci * ldx + tap * d.dil;
+    } else if (kk < nrows) {
+      rowoff[r] = (d.Cin + 1) * ldx;  // ones row -> bias gradient
+    } else {
+      rowoff[r] = d.Cin * ldx;        // zero row
+    }
+  }
+  f32x4 acc[RT][CT];
+#pragma unroll
+  for (int r = 0; r < RT; ++r)
+#pragma unroll
+    for (int c = 0; c < CT; ++c) acc[r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // constant rows
+  for (int j = tid; j < ldx; j += 256) {
+    xs[d.Cin * ldx + j] = 0.f;
+    xs[(d.Cin + 1) * ldx + j] = 1.f;
+  }
+  const int nchunks = d.B * nchunk_t;
+  for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    const int b = chunk / nchunk_t, tc = chunk - b * nchunk_t;
+    const int t0 = tc * TT;
+    __syncthreads();  // previous chunk's reads done
+    {
+      const int u0 = t0 * d.stride - d.padL;
+      const float* xb = x + (long)b * d.Cin * d.Tin;
+      const int total = d.Cin * ldx;
+      for (int e = tid; e < total; e += 256) {
+        const int ci = e / ldx, j = e - ci * ldx;
+        const int u = u0 + j;
+        float v = 0.f;
+        if (j < win && u >= 0 && u < Tin_virt) {
+          if (d.in_up) { if (!(u & 1)) v = xb[(long)ci * d.Tin + (u >> 1)]; }
+          else v = xb[(long)ci * d.Tin + u];
+        }
+        xs[e] = v;
+      }
+      const float* dzb = dz + (long)b * d.Cout * d.Tout;
+      for (int e = tid; e < CT * 16 * TT; e += 256) {
+        const int o = e >> 6, j = e & 63;
+        const int t = t0 + j;
+        dzs[o * LDZ + j] = (o < d.Cout && t < d.Tout) ? dzb[(long)o * d.Tout + t] : 0.f;
+      }
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int tt = 0; tt < TT / 4; ++tt) {
+      const int tloc = 4 * tt + kq;
+      float af[RT], bf[CT];
+#pragma unroll
+      for (int r = 0; r < RT; ++r) af[r] = xs[rowoff[r] + tloc * d.stride];
+#pragma unroll
+      for (int c = 0; c < CT; ++c) bf[c] = dzs[(c * 16 + l15) * LDZ + tloc];
+#pragma unroll
+      for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+          acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r], bf[c], acc[r][c], 0, 0, 0);
+    }
+  }
+  // ---- flush: D col = l15 -> output channel, row = 4*kq + reg -> kk ----
+#pragma unroll
+  for (int r = 0; r < RT; ++r) {
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int kk = ((blockIdx.y * 4 + wave) * RT + r) * 16 + kq * 4 + reg;
+      if (kk >= nrows) continue;
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        const int o = c * 16 + l15;
+        if (o >= d.Cout) continue;
+        const float v = acc[r][c][reg];
+        if (kk < d.K * d.Cin) {
+          int kko = kk;
+          if (flip) {
+            const int tap = kk / d.Cin, ci = kk - tap * d.Cin;
+            kko = (d.K - 1 - tap) * d.Cin + ci;
+          }
+          atomicAdd(dw + (long)kko * d.Cout + o, v);
+        } else {
+          atomicAdd(db + o, v);
+        }
+      }
+    }
+  }
+}
+
+template <int RT, int CT>
+static int launch_wgrad(const nsc_conv_desc* d, const float* x, const float* dz, float* dw, float* db, int flip,
+                        hipStream_t st) {
+  const int TT = 64;
+  const int win = (TT - 1) * d->stride + (d->K - 1) * d->dil + 1;
+  int ldx = win;
+  while ((ldx & 31) != 2) ++ldx;  // A-fragment rows (consecutive ci) land on distinct even banks, kq on odd
+  const size_t smem = ((size_t)(d->Cin + 2) * ldx + (size_t)CT * 16 * 66) * sizeof(float);
+  NSC_REQUIRE(smem <= 160 * 1024, NSC_ERR_UNSUPPORTED, "conv1d_wgrad: tiles %zu B exceed LDS", smem);
+  auto kern = conv1d_wgrad_kernel<RT, CT>;
+  if (smem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "conv1d_wgrad: set smem attr: %s", hipGetErrorString(e));
+  }
+  const int nrows = d->K * d->Cin + (db ? 1 : 0);
+  const int nrt = nsc_cdiv(nrows, 16);
+  const int gy = nsc_cdiv(nrt, 4 * RT);
+  const int nchunk_t = nsc_cdiv(d->Tout, TT);
+  const int nchunks = d->B * nchunk_t;
+  int gx = 768 / gy;
+  if (gx < 1) gx = 1;
+  if (gx > nchunks) gx = nchunks;
+  hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(256), smem, st, *d, x, dz, dw, db, flip, ldx, win, nchunk_t);
+  NSC_CHECK_LAUNCH("conv1d_wgrad");
+  return NSC_OK;
+}
+
+template <int CT>
+static int dispatch_wgrad_rt(const nsc_conv_desc* d, const float* x, const float* dz, float* dw, float* db, int flip,
+                             hipStream_t st) {
+  const int nrt = nsc_cdiv(d->K * d->Cin + (db ? 1 : 0), 16);
+  if (nrt <= 4) return launch_wgrad<1, CT>(d, x, dz, dw, db, flip, st);
+  if (nrt <= 8) return launch_wgrad<2, CT>(d, x, dz, dw, db, flip, st);
+  return launch_wgrad<4, CT>(d, x, dz, dw, db, flip, st);
+}
+
+extern "C" int nsc_conv1d_wgrad(const nsc_conv_desc* d, const float* x, const float* dz, float* dw, float* db,
+                                int flip_taps, void* stream) {
+  int rc = check_desc(d, "nsc_conv1d_wgrad");
+  if (rc) return rc;
+  NSC_REQUIRE(x && dz && dw, NSC_ERR_BAD_ARG, "nsc_conv1d_wgrad: null x/dz/dw");
+  NSC_REQUIRE(d->Cout <= 112, NSC_ERR_UNSUPPORTED, "nsc_conv1d_wgrad: Cout %d > 112", d->Cout);
+  hipStream_t st = (hipStream_t)stream;
+  const int nct = nsc_cdiv(d->Cout, 16);
+  switch (nct) {
+    case 1: return dispatch_wgrad_rt<1>(d, x, dz, dw, db, flip_taps, st);
+    case 2: return dispatch_wgrad_rt<2>(d, x, dz, dw, db, flip_taps, st);
+    case 3: return dispatch_wgrad_rt<3>(d, x, dz, dw, db, flip_taps, st);
+    case 4: return dispatch_wgrad_rt<4>(d, x, dz, dw, db, flip_taps, st);
+    default: return dispatch_wgrad_rt<7>(d, x, dz, dw, db, flip_taps, st);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// wt[K-1-k, o, i] = w[k, i, o]
+// ------------------------------------------------------------------------------------------------
+__global__ void weight_flip_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int K, int Cin,
+                                             int Cout) {
+  const int n = K * Cin * Cout;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+    // e indexes wt [K][Cout][Cin]
+    const int i = e % Cin;
+    const int o = (e / Cin) % Cout;
+    const int kt = e / (Cin * Cout);
+    wt[e] = w[((long)(K - 1 - kt) * Cin + i) * Cout + o];
+  }
+}
+extern "C" int nsc_weight_flip_transpose(const float* w, float* wt, int K, int Cin, int Cout, void* stream) {
+  NSC_REQUIRE(w && wt && K > 0 && Cin > 0 && Cout > 0, NSC_ERR_BAD_ARG, "nsc_weight_flip_transpose: bad args");
+  const int n = K * Cin * Cout;
+  hipLaunchKernelGGL(weight_flip_transpose_kernel, dim3(std::min(1024, nsc_cdiv(n, 256))), dim3(256), 0,
+                     (hipStream_t)stream, w, wt, K, Cin, Cout);
+  NSC_CHECK_LAUNCH("weight_flip_transpose");
+  return NSC_OK;
+}

@@ -1,0 +1,362 @@
+// misc.hip - HBM-bound glue kernels of the NSC/CMRL hot path: depthwise part of SeparableConv1D, the GLU
+// gate, cascade arithmetic, layout permutations, TF1 Adam, framing / overlap-add.  All fp32, [B, C, T].
+#include "nsc_common.h"
+#include <algorithm>
+
+// ---------------- depthwise conv (Keras SeparableConv1D depthwise stage; nn_core_operator.py:17-21) ----------------
+__global__ void depthwise_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wd, float* __restrict__ y,
+                                     int C, int T, int K, long n) {
+  const int padL = (K - 1) / 2;  // SAME, stride 1: pad = K-1, padL = (K-1)//2
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    const int t = (int)(e % T);
+    const int c = (int)((e / T) % C);
+    const float* xr = x + (e - t);
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) {
+      const int u = t + k - padL;
+      if (u >= 0 && u < T) acc = fmaf(xr[u], wd[k * C + c], acc);
+    }
+    y[e] = acc;
+  }
+}
+extern "C" int nsc_depthwise_fwd(const float* x, const float* wd, float* y, int B, int C, int T, int K, void* stream) {
+  NSC_REQUIRE(x && wd && y && B > 0 && C > 0 && T > 0 && K > 0, NSC_ERR_BAD_ARG, "nsc_depthwise_fwd: bad args");
+  const long n = (long)B * C * T;
+  hipLaunchKernelGGL(depthwise_fwd_kernel, dim3(std::min<long>(4096, nsc_cdiv(n, 256))), dim3(256), 0,
+                     (hipStream_t)stream, x, wd, y, C, T, K, n);
+  NSC_CHECK_LAUNCH("depthwise_fwd");
+  return NSC_OK;
+}
+
+// dx[c,t] = sum_k dy[c, t-k+padL] wd[k,c] ; dwd[k,c] += sum_{b,t} x[c,t+k-padL] dy[c,t]
+__global__ void depthwise_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ wd,
+                                        float* __restrict__ dx, int C, int T, int K, long n) {
+  const int padL = (K - 1) / 2;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    const int t = (int)(e % T);
+    const int c = (int)((e / T) % C);
+    const float* dr = dy + (e - t);
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) {
+      const int u = t - k + padL;
+      if (u >= 0 && u < T) acc = fmaf(dr[u], wd[k * C + c], acc);
+    }
+    dx[e] = acc;
+  }
+}
+// grid (C, nsplit): block handles channel c, frames b = blockIdx.y, += gridDim.y
+__global__ __launch_bounds__(256) void depthwise_bwd_dw_kernel(const float* __restrict__ x,
+                                                               const float* __restrict__ dy, float* __restrict__ dwd,
+                                                               int B, int C, int T, int K) {
+  __shared__ float red[4][16];
+  const int c = blockIdx.x, padL = (K - 1) / 2;
+  float acc[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+  for (int b = blockIdx.y; b < B; b += gridDim.y) {
+    const float* xr = x + ((long)b * C + c) * T;
+    const float* dr = dy + ((long)b * C + c) * T;
+    for (int t = threadIdx.x; t < T; t += 256) {
+      const float g = dr[t];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        if (k < K) {
+          const int u = t + k - padL;
+          if (u >= 0 && u < T) acc[k] = fmaf(xr[u], g, acc[k]);
+        }
+      }
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const float s = wave_sum(acc[k]);
+    if (lane == 0) red[wave][k] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < K) {
+    const int k = threadIdx.x;
+    atomicAdd(dwd + k * C + c, red[0][k] + red[1][k] + red[2][k] + red[3][k]);
+  }
+}
+extern "C" int nsc_depthwise_bwd(const float* x, const float* wd, const float* dy, float* dx, float* dwd, int B, int C,
+                                 int T, int K, void* stream) {
+  NSC_REQUIRE(x && wd && dy && B > 0 && C > 0 && T > 0 && K > 0, NSC_ERR_BAD_ARG, "nsc_depthwise_bwd: bad args");
+  NSC_REQUIRE(K <= 16, NSC_ERR_UNSUPPORTED, "nsc_depthwise_bwd: K %d > 16", K);
+  const long n = (long)B * C * T;
+  if (dx) {
+    hipLaunchKernelGGL(depthwise_bwd_dx_kernel, dim3(std::min<long>(4096, nsc_cdiv(n, 256))), dim3(256), 0,
+                       (hipStream_t)stream, dy, wd, dx, C, T, K, n);
+    NSC_CHECK_LAUNCH("depthwise_bwd_dx");
+  }
+  if (dwd) {
+    hipLaunchKernelGGL(depthwise_bwd_dw_kernel, dim3(C, std::min(B, 8)), dim3(256), 0, (hipStream_t)stream, x, dy, dwd,
+                       B, C, T, K);
+    NSC_CHECK_LAUNCH("depthwise_bwd_dw");
+  }
+  return NSC_OK;
+}
+
+// ---------------- GLU gate (nn_core_operator.py:90-100) on a fused [B, 2n, T] pre-activation ----------------
+__global__ void gate_fwd_kernel(float* __restrict__ a, float* __restrict__ g, int n, int T, long total) {
+  const long nT = (long)n * T;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long b = e / nT, r = e - b * nT;
+    float* ab = a + b * 2 * nT;
+    const float th = tanhf(ab[nT + r]);
+    ab[nT + r] = th;
+    g[e] = ab[r] * th;
+  }
+}
+__global__ void gate_bwd_kernel(const float* __restrict__ a, const float* __restrict__ dg, float* __restrict__ da,
+                                int n, int T, long total) {
+  const long nT = (long)n * T;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long b = e / nT, r = e - b * nT;
+    const float* ab = a + b * 2 * nT;
+    float* db = da + b * 2 * nT;
+    const float lin = ab[r], th = ab[nT + r], gg = dg[e];
+    db[r] = gg * th;
+    db[nT + r] = gg * lin * (1.f - th * th);
+  }
+}
+extern "C" int nsc_gate_fwd(float* a, float* g, int B, int n, int T, void* stream) {
+  NSC_REQUIRE(a && g && B > 0 && n > 0 && T > 0, NSC_ERR_BAD_ARG, "nsc_gate_fwd: bad args");
+  const long total = (long)B * n * T;
+  hipLaunchKernelGGL(gate_fwd_kernel, dim3(std::min<long>(4096, nsc_cdiv(total, 256))), dim3(256), 0,
+                     (hipStream_t)stream, a, g, n, T, total);
+  NSC_CHECK_LAUNCH("gate_fwd");
+  return NSC_OK;
+}
+extern "C" int nsc_gate_bwd(const float* a, const float* dg, float* da, int B, int n, int T, void* stream) {
+  NSC_REQUIRE(a && dg && da && B > 0 && n > 0 && T > 0, NSC_ERR_BAD_ARG, "nsc_gate_bwd: bad args");
+  const long total = (long)B * n * T;
+  hipLaunchKernelGGL(gate_bwd_kernel, dim3(std::min<long>(4096, nsc_cdiv(total, 256))), dim3(256), 0,
+                     (hipStream_t)stream, a, dg, da, n, T, total);
+  NSC_CHECK_LAUNCH("gate_bwd");
+  return NSC_OK;
+}
+
+// ---------------- glue ----------------
+__global__ void axpby_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out,
+                             float a, float b, long n) {
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x)
+    out[e] = y ? fmaf(a, x[e], b * y[e]) : a * x[e];
+}
+extern "C" int nsc_axpby(const float* x, const float* y, float* out, float a, float b, long n, void* stream) {
+  NSC_REQUIRE(x && out && n > 0, NSC_ERR_BAD_ARG, "nsc_axpby: bad args");
+  hipLaunchKernelGGL(axpby_kernel, dim3(std::min<long>(4096, nsc_cdiv(n, 256))), dim3(256), 0, (hipStream_t)stream, x,
+                     y, out, a, b, n);
+  NSC_CHECK_LAUNCH("axpby");
+  return NSC_OK;
+}
+
+__global__ void channel_sum_kernel(const float* __restrict__ x, float* __restrict__ out, int C, int T, int accumulate,
+                                   long n) {
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    const long b = e / T;
+    const int t = (int)(e - b * T);
+    const float* xb = x + b * C * T + t;
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += xb[(long)c * T];
+    if (accumulate) out[e] += s;
+    else out[e] = s;
+  }
+}
+extern "C" int nsc_channel_sum(const float* x, float* out, int B, int C, int T, int accumulate, void* stream) {
+  NSC_REQUIRE(x && out && B > 0 && C > 0 && T > 0, NSC_ERR_BAD_ARG, "nsc_channel_sum: bad args");
+  const long n = (long)B * T;
+  hipLaunchKernelGGL(channel_sum_kernel, dim3(std::min<long>(4096, nsc_cdiv(n, 256))), dim3(256), 0,
+                     (hipStream_t)stream, x, out, C, T, accumulate, n);
+  NSC_CHECK_LAUNCH("channel_sum");
+  return NSC_OK;
+}
+
+// y[b,c,t] = ys[b, c>>1, 2t + (c&1)]   (inverse of the sub-pixel shuffle, nsc_module:158-167)
+__global__ void unshuffle2_kernel(const float* __restrict__ ys, float* __restrict__ y, int C, int T, long n) {
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    const int t = (int)(e % T);
+    const int c = (int)((e / T) % C);
+    const long b = e / ((long)T * C);
+    y[e] = ys[(b * (C >> 1) + (c >> 1)) * (2L * T) + 2 * t + (c & 1)];
+  }
+}
+extern "C" int nsc_unshuffle2(const float* ys, float* y, int B, int C, int T, void* stream) {
+  NSC_REQUIRE(ys && y && B > 0 && C > 0 && !(C & 1) && T > 0, NSC_ERR_BAD_ARG, "nsc_unshuffle2: bad args");
+  const long n = (long)B * C * T;
+  hipLaunchKernelGGL(unshuffle2_kernel, dim3(std::min<long>(4096, nsc_cdiv(n, 256))), dim3(256), 0,
+                     (hipStream_t)stream, ys, y, C, T, n);
+  NSC_CHECK_LAUNCH("unshuffle2");
+  return NSC_OK;
+}
+
+// y[b, c, r] = x[b, r, c] through a 32x33 LDS tile (channels_last <-> time-contiguous at the op surface)
+__global__ __launch_bounds__(256) void transpose_last2_kernel(const float* __restrict__ x, float* __restrict__ y, int R,
+                                                              int Cc) {
+  __shared__ float tile[32][33];
+  const long b = blockIdx.z;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < R && c < Cc) ? x[(b * R + r) * Cc + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + tx;
+    if (r < R && c < Cc) y[(b * Cc + c) * R + r] = tile[tx][i];
+  }
+}
+extern "C" int nsc_transpose_last2(const float* x, float* y, int B, int R, int Cc, void* stream) {
+  NSC_REQUIRE(x && y && B > 0 && R > 0 && Cc > 0, NSC_ERR_BAD_ARG, "nsc_transpose_last2: bad args");
+  hipLaunchKernelGGL(transpose_last2_kernel, dim3(nsc_cdiv(Cc, 32), nsc_cdiv(R, 32), B), dim3(256), 0,
+                     (hipStream_t)stream, x, y, R, Cc);
+  NSC_CHECK_LAUNCH("transpose_last2");
+  return NSC_OK;
+}
+
+__global__ __launch_bounds__(256) void sum_all_kernel(const float* __restrict__ x, float* __restrict__ out, long n) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) s += x[e];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+extern "C" int nsc_sum_all(const float* x, float* out, long n, void* stream) {
+  NSC_REQUIRE(x && out && n > 0, NSC_ERR_BAD_ARG, "nsc_sum_all: bad args");
+  hipLaunchKernelGGL(sum_all_kernel, dim3(std::min<long>(256, nsc_cdiv(n, 1024))), dim3(256), 0, (hipStream_t)stream,
+                     x, out, n);
+  NSC_CHECK_LAUNCH("sum_all");
+  return NSC_OK;
+}
+
+// ---------------- TF1 Adam on flat buffers (tf.compat.v1.train.AdamOptimizer; nsc_module:922-925) ----------------
+__global__ void adam_tf1_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                float* __restrict__ v, long n, float lr, float b1, float b2, float eps, int t,
+                                const int* __restrict__ t_dev) {
+  const int tt = t_dev ? t_dev[0] : t;
+  const float lr_t = lr * sqrtf(1.f - powf(b2, (float)tt)) / (1.f - powf(b1, (float)tt));
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    const float ge = g[e];
+    const float me = b1 * m[e] + (1.f - b1) * ge;
+    const float ve = b2 * v[e] + (1.f - b2) * ge * ge;
+    m[e] = me;
+    v[e] = ve;
+    p[e] -= lr_t * me / (sqrtf(ve) + eps);
+  }
+}
+extern "C" int nsc_adam_tf1_step(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
+                                 float eps, int t, const int* t_dev, void* stream) {
+  NSC_REQUIRE(p && g && m && v && n > 0, NSC_ERR_BAD_ARG, "nsc_adam_tf1_step: bad args");
+  NSC_REQUIRE(t_dev || t >= 1, NSC_ERR_BAD_ARG, "nsc_adam_tf1_step: step t must be >= 1");
+  hipLaunchKernelGGL(adam_tf1_kernel, dim3(std::min<long>(2048, nsc_cdiv(n, 256))), dim3(256), 0, (hipStream_t)stream,
+                     p, g, m, v, n, lr, b1, b2, eps, t, t_dev);
+  NSC_CHECK_LAUNCH("adam_tf1");
+  return NSC_OK;
+}
+__global__ void increment_kernel(int* c) { if (threadIdx.x == 0 && blockIdx.x == 0) c[0] += 1; }
+extern "C" int nsc_increment(int* counter, void* stream) {
+  NSC_REQUIRE(counter, NSC_ERR_BAD_ARG, "nsc_increment: null");
+  hipLaunchKernelGGL(increment_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counter);
+  NSC_CHECK_LAUNCH("increment");
+  return NSC_OK;
+}
+
+// ---------------- framing / Hann overlap-add (utilities.py:7-39; cmrl.py:595-597) ----------------
+__global__ void frame_utterance_kernel(const float* __restrict__ utt, long n, const float* __restrict__ window,
+                                       float* __restrict__ frames, int nframes) {
+  const long total = (long)nframes * 512;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long i = e >> 9;
+    const int j = (int)(e & 511);
+    const long src = i * 480 + j;
+    const float v = src < n ? utt[src] : 0.f;
+    frames[e] = window ? v * window[j] : v;
+  }
+}
+extern "C" int nsc_frame_utterance(const float* utt, long n, const float* window, float* frames, int nframes,
+                                   void* stream) {
+  NSC_REQUIRE(utt && frames && n > 0 && nframes >= 0, NSC_ERR_BAD_ARG, "nsc_frame_utterance: bad args");
+  if (nframes == 0) return NSC_OK;
+  const long total = (long)nframes * 512;
+  hipLaunchKernelGGL(frame_utterance_kernel, dim3(std::min<long>(4096, nsc_cdiv(total, 256))), dim3(256), 0,
+                     (hipStream_t)stream, utt, n, window, frames, nframes);
+  NSC_CHECK_LAUNCH("frame_utterance");
+  return NSC_OK;
+}
+
+// out[s] = sum over the (at most two) frames covering sample s of frames[i, s-480 i] * win_i[s-480 i];
+// win3 = the three Hann variants of utilities.py:10-15 (first, middle, last), built on the host in float64.
+__device__ __forceinline__ float hann_variant(const float* __restrict__ win3, int j, int i, int nframes) {
+  const int which = (i == 0) ? 0 : ((i == nframes - 1) ? 2 : 1);
+  return win3[which * 512 + j];
+}
+__global__ void overlap_add_kernel(const float* __restrict__ frames, int nframes, const float* __restrict__ win3,
+                                   float* __restrict__ out, long n) {
+  for (long s = blockIdx.x * (long)blockDim.x + threadIdx.x; s < n; s += (long)gridDim.x * blockDim.x) {
+    long i = s / 480;
+    if (i >= nframes) i = nframes - 1;
+    float acc = 0.f;
+    const long j = s - i * 480;
+    if (j < 512) acc += frames[i * 512 + j] * hann_variant(win3, (int)j, (int)i, nframes);
+    if (i > 0) {
+      const long j2 = s - (i - 1) * 480;
+      if (j2 < 512) acc += frames[(i - 1) * 512 + j2] * hann_variant(win3, (int)j2, (int)(i - 1), nframes);
+    }
+    out[s] = acc;
+  }
+}
+extern "C" int nsc_overlap_add(const float* frames, int nframes, const float* win3, float* out, void* stream) {
+  NSC_REQUIRE(frames && out && win3 && nframes > 0, NSC_ERR_BAD_ARG, "nsc_overlap_add: bad args");
+  const long n = 480L * (nframes - 1) + 512;
+  hipLaunchKernelGGL(overlap_add_kernel, dim3(std::min<long>(4096, nsc_cdiv(n, 256))), dim3(256), 0,
+                     (hipStream_t)stream, frames, nframes, win3, out, n);
+  NSC_CHECK_LAUNCH("overlap_add");
+  return NSC_OK;
+}
+
+// dst[e] = src[idx[e]]  (one launch rebuilds every flipped/transposed dgrad weight from the flat parameter buffer)
+__global__ void gather_kernel(const float* __restrict__ src, const int* __restrict__ idx, float* __restrict__ dst,
+                              long n) {
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x)
+    dst[e] = src[idx[e]];
+}
+extern "C" int nsc_gather(const float* src, const int* idx, float* dst, long n, void* stream) {
+  NSC_REQUIRE(src && idx && dst && n > 0, NSC_ERR_BAD_ARG, "nsc_gather: bad args");
+  hipLaunchKernelGGL(gather_kernel, dim3(std::min<long>(2048, nsc_cdiv(n, 256))), dim3(256), 0, (hipStream_t)stream,
+                     src, idx, dst, n);
+  NSC_CHECK_LAUNCH("gather");
+  return NSC_OK;
+}
+
+// elementwise product (tf.multiply of the two gate branches) and its backward given lin, th = tanh(gate)
+__global__ void mul_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long n) {
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x)
+    out[e] = a[e] * b[e];
+}
+extern "C" int nsc_mul(const float* a, const float* b, float* out, long n, void* stream) {
+  NSC_REQUIRE(a && b && out && n > 0, NSC_ERR_BAD_ARG, "nsc_mul: bad args");
+  hipLaunchKernelGGL(mul_kernel, dim3(std::min<long>(4096, nsc_cdiv(n, 256))), dim3(256), 0, (hipStream_t)stream, a, b,
+                     out, n);
+  NSC_CHECK_LAUNCH("mul");
+  return NSC_OK;
+}
+__global__ void glu_bwd_kernel(const float* __restrict__ lin, const float* __restrict__ th,
+                               const float* __restrict__ dg, float* __restrict__ dlin, float* __restrict__ dgate,
+                               long n) {
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    const float g = dg[e], t = th[e];
+    dlin[e] = g * t;
+    dgate[e] = g * lin[e] * (1.f - t * t);
+  }
+}
+extern "C" int nsc_glu_bwd(const float* lin, const float* th, const float* dg, float* dlin, float* dgate, long n,
+                           void* stream) {
+  NSC_REQUIRE(lin && th && dg && dlin && dgate && n > 0, NSC_ERR_BAD_ARG, "nsc_glu_bwd: bad args");
+  hipLaunchKernelGGL(glu_bwd_kernel, dim3(std::min<long>(4096, nsc_cdiv(n, 256))), dim3(256), 0, (hipStream_t)stream,
+                     lin, th, dg, dlin, dgate, n);
+  NSC_CHECK_LAUNCH("glu_bwd");
+  return NSC_OK;
+}

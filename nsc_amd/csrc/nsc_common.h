@@ -1,0 +1,51 @@
+// Shared helpers for libnsc_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include "../../include/nsc_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define NSC_LRELU_ALPHA 0.2f
+
+void nsc_set_error(const char* fmt, ...);
+
+#define NSC_REQUIRE(cond, code, ...)          \
+  do {                                        \
+    if (!(cond)) {                            \
+      nsc_set_error(__VA_ARGS__);             \
+      return (code);                          \
+    }                                         \
+  } while (0)
+
+#define NSC_CHECK_LAUNCH(name)                                                     \
+  do {                                                                             \
+    hipError_t e__ = hipGetLastError();                                            \
+    if (e__ != hipSuccess) {                                                       \
+      nsc_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));        \
+      return NSC_ERR_LAUNCH;                                                       \
+    }                                                                              \
+  } while (0)
+
+__device__ __forceinline__ float nsc_apply_act(float v, int act) {
+  if (act == NSC_ACT_TANH) return tanhf(v);
+  if (act == NSC_ACT_LRELU) return v > 0.f ? v : NSC_LRELU_ALPHA * v;
+  return v;
+}
+__device__ __forceinline__ float nsc_act_grad_from_out(float out, int mode) {
+  if (mode == 1) return out > 0.f ? 1.f : NSC_LRELU_ALPHA;  // lrelu'(z) from y = lrelu(z): sign(y) == sign(z)
+  if (mode == 2) return 1.f - out * out;                    // tanh'
+  return 1.f;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+static inline int nsc_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

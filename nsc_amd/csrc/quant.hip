@@ -1,0 +1,378 @@
+// quant.hip - soft-to-hard scalar quantizer (nn_core_operator.py:140-164 of the reference) fused with the
+// quan_loss / entropy_coding_loss partials (loss_terms_and_measures.py:257-267).  HBM-bound.
+//
+// Mapping: one workgroup per frame; LPC lanes cooperate on one code (each lane owns 4*ITER bins kept in
+// registers), so a wave handles 64/LPC codes per pass and its float4 store of p is one contiguous
+// 1-KiB segment.  max / sum / dot reductions are xor-shuffles inside the LPC-lane group; the histogram and
+// d(bins) are accumulated in registers across a frame, merged with LDS float atomics, then one global
+// atomic per bin per workgroup.
+#include "nsc_common.h"
+#include <algorithm>
+
+#define QEPS 1e-20f
+
+template <int LPC>
+__device__ __forceinline__ float grp_sum(float v) {
+#pragma unroll
+  for (int o = LPC / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <int LPC>
+__device__ __forceinline__ float grp_max(float v) {
+#pragma unroll
+  for (int o = LPC / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Computes this lane's p values for code c.  Returns d_k = |c-b_k| in dist[], p in p[].
+template <int LPC, int ITER>
+__device__ __forceinline__ void softmax_bins(float c, float alpha, const float (&bv)[ITER][4], const bool (&ok)[ITER][4],
+                                             float (&dist)[ITER][4], float (&p)[ITER][4]) {
+  float z[ITER][4];
+  float m = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < ITER; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      dist[i][j] = fabsf(c - bv[i][j]);
+      z[i][j] = ok[i][j] ? alpha * dist[i][j] : -INFINITY;
+      m = fmaxf(m, z[i][j]);
+    }
+  m = grp_max<LPC>(m);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < ITER; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      p[i][j] = ok[i][j] ? expf(z[i][j] - m) : 0.f;
+      s += p[i][j];
+    }
+  s = grp_sum<LPC>(s);
+  const float inv = 1.f / s;
+#pragma unroll
+  for (int i = 0; i < ITER; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p[i][j] *= inv;
+}
+
+// lowest-index argmax over the LPC-lane group (tf.nn.top_k tie rule)
+template <int LPC>
+__device__ __forceinline__ int grp_argmax(float best, int idx) {
+#pragma unroll
+  for (int o = LPC / 2; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(idx, o, 64);
+    if (ob > best || (ob == best && oi < idx)) { best = ob; idx = oi; }
+  }
+  return idx;
+}
+
+template <int LPC, int ITER>
+__global__ __launch_bounds__(256) void quantize_fwd_kernel(const float* __restrict__ code,
+                                                           const float* __restrict__ alpha_p,
+                                                           const float* __restrict__ bins, float on, int soft, int L,
+                                                           int nb, float* __restrict__ p_out, float* __restrict__ out,
+                                                           float* __restrict__ quan_out, float* __restrict__ hist) {
+  extern __shared__ __attribute__((aligned(16))) float sh[];  // [nbpad] histogram + [4] quan partials
+  constexpr int CPW = 64 / LPC;
+  const int nbpad = 4 * LPC * ITER;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int gl = lane % LPC, gc = lane / LPC;
+  const int b = blockIdx.x;
+  const float alpha = alpha_p[0];
+  float bv[ITER][4];
+  bool ok[ITER][4];
+#pragma unroll
+  for (int i = 0; i < ITER; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = (i * LPC + gl) * 4 + j;
+      ok[i][j] = k < nb;
+      bv[i][j] = ok[i][j] ? bins[k] : 0.f;
+    }
+  for (int k = tid; k < nbpad + 4; k += 256) sh[k] = 0.f;
+  __syncthreads();
+  float hacc[ITER][4];
+#pragma unroll
+  for (int i = 0; i < ITER; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) hacc[i][j] = 0.f;
+  float qacc = 0.f;
+  const bool vec_ok = (nb & 3) == 0;
+  for (int l0 = wave * CPW; l0 < L; l0 += 4 * CPW) {
+    const int l = l0 + gc;
+    const bool live = l < L;
+    const long ci = (long)b * L + (live ? l : 0);
+    const float c = code[ci];
+    float dist[ITER][4], p[ITER][4];
+    softmax_bins<LPC, ITER>(c, alpha, bv, ok, dist, p);
+    float q;
+    if (soft) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < ITER; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s = fmaf(p[i][j], bv[i][j], s);
+      q = grp_sum<LPC>(s);
+    } else {
+      float best = -1.f;
+      int idx = 0x7fffffff;
+#pragma unroll
+      for (int i = 0; i < ITER; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int k = (i * LPC + gl) * 4 + j;
+          if (ok[i][j] && p[i][j] > best) { best = p[i][j]; idx = k; }
+        }
+      idx = grp_argmax<LPC>(best, idx);
+      q = bins[idx];
+    }
+    if (live) {
+#pragma unroll
+      for (int i = 0; i < ITER; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          hacc[i][j] += p[i][j];
+          if (ok[i][j]) qacc += sqrtf(p[i][j] + QEPS);
+        }
+      if (p_out) {
+        float* pr = p_out + ci * nb;
+#pragma unroll
+        for (int i = 0; i < ITER; ++i) {
+          const int k0 = (i * LPC + gl) * 4;
+          if (vec_ok) {
+            if (k0 < nb) *reinterpret_cast<float4*>(pr + k0) = make_float4(p[i][0], p[i][1], p[i][2], p[i][3]);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (ok[i][j]) pr[k0 + j] = p[i][j];
+          }
+        }
+      }
+      if (gl == 0) out[ci] = (1.f - on) * c + on * q;
+    }
+  }
+  // merge
+#pragma unroll
+  for (int i = 0; i < ITER; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = (i * LPC + gl) * 4 + j;
+      if (ok[i][j]) atomicAdd(&sh[k], hacc[i][j]);
+    }
+  qacc = wave_sum(qacc);
+  if (lane == 0) sh[nbpad + wave] = qacc;
+  __syncthreads();
+  if (hist)
+    for (int k = tid; k < nb; k += 256) atomicAdd(hist + k, sh[k]);
+  if (quan_out && tid == 0)
+    quan_out[b] = (sh[nbpad] + sh[nbpad + 1] + sh[nbpad + 2] + sh[nbpad + 3]) / (float)L;
+}
+
+template <int LPC, int ITER>
+__global__ __launch_bounds__(256) void quantize_bwd_kernel(
+    const float* __restrict__ code, const float* __restrict__ alpha_p, const float* __restrict__ bins, float on,
+    int soft, int L, int nb, const float* __restrict__ dout, const float* __restrict__ dp, float cq,
+    const float* __restrict__ ghist, float ent_scale, int pre_tanh, float* __restrict__ dcode,
+    float* __restrict__ dalpha, float* __restrict__ dbins) {
+  extern __shared__ __attribute__((aligned(16))) float sh[];  // [nbpad] dbins + [4] dalpha partials
+  constexpr int CPW = 64 / LPC;
+  const int nbpad = 4 * LPC * ITER;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int gl = lane % LPC, gc = lane / LPC;
+  const int b = blockIdx.x;
+  const float alpha = alpha_p[0];
+  float bv[ITER][4], gh[ITER][4];
+  bool ok[ITER][4];
+#pragma unroll
+  for (int i = 0; i < ITER; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = (i * LPC + gl) * 4 + j;
+      ok[i][j] = k < nb;
+      bv[i][j] = ok[i][j] ? bins[k] : 0.f;
+      gh[i][j] = (ok[i][j] && ghist) ? ent_scale * ghist[k] : 0.f;
+    }
+  for (int k = tid; k < nbpad + 4; k += 256) sh[k] = 0.f;
+  __syncthreads();
+  float dbacc[ITER][4];
+#pragma unroll
+  for (int i = 0; i < ITER; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dbacc[i][j] = 0.f;
+  float daacc = 0.f;
+  for (int l0 = wave * CPW; l0 < L; l0 += 4 * CPW) {
+    const int l = l0 + gc;
+    const bool live = l < L;
+    const long ci = (long)b * L + (live ? l : 0);
+    const float c = code[ci];
+    const float go = (dout && live) ? dout[ci] : 0.f;
+    float dist[ITER][4], p[ITER][4], gp[ITER][4];
+    softmax_bins<LPC, ITER>(c, alpha, bv, ok, dist, p);
+    int hidx = -1;
+    if (!soft) {
+      float best = -1.f;
+      int idx = 0x7fffffff;
+#pragma unroll
+      for (int i = 0; i < ITER; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int k = (i * LPC + gl) * 4 + j;
+          if (ok[i][j] && p[i][j] > best) { best = p[i][j]; idx = k; }
+        }
+      hidx = grp_argmax<LPC>(best, idx);
+    }
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < ITER; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float g = 0.f;
+        if (ok[i][j] && live) {
+          g = gh[i][j] + cq * 0.5f / sqrtf(p[i][j] + QEPS);
+          if (dp) g += dp[ci * nb + (i * LPC + gl) * 4 + j];
+          if (soft) g = fmaf(on * go, bv[i][j], g);
+        }
+        gp[i][j] = g;
+        dot = fmaf(p[i][j], g, dot);
+      }
+    dot = grp_sum<LPC>(dot);
+    float dcp = 0.f;
+#pragma unroll
+    for (int i = 0; i < ITER; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float gz = p[i][j] * (gp[i][j] - dot);
+        daacc = fmaf(gz, dist[i][j], daacc);
+        const float df = c - bv[i][j];
+        const float sgn = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
+        const float gd = gz * alpha * sgn;
+        dcp += gd;
+        float dbk = -gd;
+        if (soft) dbk = fmaf(on * go, p[i][j], dbk);
+        else if ((i * LPC + gl) * 4 + j == hidx) dbk += on * go;
+        if (ok[i][j] && live) dbacc[i][j] += dbk;
+      }
+    dcp = grp_sum<LPC>(dcp);
+    if (live && gl == 0 && dcode) {
+      float dc = (1.f - on) * go + dcp;
+      if (pre_tanh) dc *= (1.f - c * c);
+      dcode[ci] = dc;
+    }
+  }
+  if (dbins) {
+#pragma unroll
+    for (int i = 0; i < ITER; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = (i * LPC + gl) * 4 + j;
+        if (ok[i][j]) atomicAdd(&sh[k], dbacc[i][j]);
+      }
+  }
+  daacc = wave_sum(daacc);
+  if (lane == 0) sh[nbpad + wave] = daacc;
+  __syncthreads();
+  if (dbins)
+    for (int k = tid; k < nb; k += 256) atomicAdd(dbins + k, sh[k]);
+  if (dalpha && tid == 0) atomicAdd(dalpha, sh[nbpad] + sh[nbpad + 1] + sh[nbpad + 2] + sh[nbpad + 3]);
+}
+
+// pick (LPC, ITER) for nb bins
+#define QDISPATCH(NB, CALL)                                    \
+  do {                                                         \
+    const int q4__ = ((NB) + 3) / 4;                           \
+    if (q4__ <= 1) { CALL(1, 1); }                             \
+    else if (q4__ <= 2) { CALL(2, 1); }                        \
+    else if (q4__ <= 4) { CALL(4, 1); }                        \
+    else if (q4__ <= 8) { CALL(8, 1); }                        \
+    else if (q4__ <= 16) { CALL(16, 1); }                      \
+    else if (q4__ <= 32) { CALL(32, 1); }                      \
+    else if (q4__ <= 64) { CALL(64, 1); }                      \
+    else if (q4__ <= 128) { CALL(64, 2); }                     \
+    else { CALL(64, 4); }                                      \
+  } while (0)
+
+extern "C" int nsc_quantize_fwd(const float* code, const float* alpha, const float* bins, float is_quan_on, int soft,
+                                int B, int L, int nb, float* p_out, float* out, float* quan_out, float* hist,
+                                void* stream) {
+  NSC_REQUIRE(code && alpha && bins && out, NSC_ERR_BAD_ARG, "nsc_quantize_fwd: null code/alpha/bins/out");
+  NSC_REQUIRE(B > 0 && L > 0 && nb > 0, NSC_ERR_BAD_ARG, "nsc_quantize_fwd: non-positive B/L/nb");
+  NSC_REQUIRE(nb <= 1024, NSC_ERR_UNSUPPORTED, "nsc_quantize_fwd: nb %d > 1024", nb);
+  hipStream_t st = (hipStream_t)stream;
+#define CALLF(LPC_, IT_)                                                                                          \
+  hipLaunchKernelGGL((quantize_fwd_kernel<LPC_, IT_>), dim3(B), dim3(256), (4 * LPC_ * IT_ + 4) * sizeof(float), st, \
+                     code, alpha, bins, is_quan_on, soft, L, nb, p_out, out, quan_out, hist)
+  QDISPATCH(nb, CALLF);
+#undef CALLF
+  NSC_CHECK_LAUNCH("quantize_fwd");
+  return NSC_OK;
+}
+
+extern "C" int nsc_quantize_bwd(const float* code, const float* alpha, const float* bins, float is_quan_on, int soft,
+                                int B, int L, int nb, const float* dout, const float* dp, float c_quan,
+                                const float* ghist, float ent_scale, int pre_tanh, float* dcode, float* dalpha,
+                                float* dbins, void* stream) {
+  NSC_REQUIRE(code && alpha && bins, NSC_ERR_BAD_ARG, "nsc_quantize_bwd: null code/alpha/bins");
+  NSC_REQUIRE(B > 0 && L > 0 && nb > 0, NSC_ERR_BAD_ARG, "nsc_quantize_bwd: non-positive B/L/nb");
+  NSC_REQUIRE(nb <= 1024, NSC_ERR_UNSUPPORTED, "nsc_quantize_bwd: nb %d > 1024", nb);
+  hipStream_t st = (hipStream_t)stream;
+  const float cq = c_quan / (float)L;
+#define CALLB(LPC_, IT_)                                                                                          \
+  hipLaunchKernelGGL((quantize_bwd_kernel<LPC_, IT_>), dim3(B), dim3(256), (4 * LPC_ * IT_ + 4) * sizeof(float), st, \
+                     code, alpha, bins, is_quan_on, soft, L, nb, dout, dp, cq, ghist, ent_scale, pre_tanh, dcode,   \
+                     dalpha, dbins)
+  QDISPATCH(nb, CALLB);
+#undef CALLB
+  NSC_CHECK_LAUNCH("quantize_bwd");
+  return NSC_OK;
+}
+
+// entropy_coding_loss from the batch histogram (loss_terms_and_measures.py:262-267) + its gradient wrt hist
+__global__ __launch_bounds__(256) void entropy_from_hist_kernel(const float* __restrict__ hist, int nb,
+                                                                float* __restrict__ ent, float* __restrict__ ghist) {
+  __shared__ float red[4];
+  __shared__ float bc[2];
+  const int tid = threadIdx.x;
+  const float kInvLn2 = 1.4426950408889634f;
+  float s = 0.f;
+  for (int k = tid; k < nb; k += 256) s += hist[k];
+  s = wave_sum(s);
+  if ((tid & 63) == 0) red[tid >> 6] = s;
+  __syncthreads();
+  if (tid == 0) bc[0] = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();
+  const float S = bc[0];
+  float e = 0.f, gh = 0.f;
+  for (int k = tid; k < nb; k += 256) {
+    const float h = hist[k] / S;
+    const float lg = logf(h + 1e-7f);
+    e -= h * lg * kInvLn2;
+    const float g = -(lg + h / (h + 1e-7f)) * kInvLn2;
+    gh += g * h;
+  }
+  e = wave_sum(e);
+  gh = wave_sum(gh);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = e;
+  __syncthreads();
+  if (tid == 0 && ent) ent[0] = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = gh;
+  __syncthreads();
+  if (tid == 0) bc[1] = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();
+  if (ghist) {
+    const float gdot = bc[1];
+    for (int k = tid; k < nb; k += 256) {
+      const float h = hist[k] / S;
+      const float g = -(logf(h + 1e-7f) + h / (h + 1e-7f)) * kInvLn2;
+      ghist[k] = (g - gdot) / S;
+    }
+  }
+}
+extern "C" int nsc_entropy_from_hist(const float* hist, int nb, float* ent, float* ghist, void* stream) {
+  NSC_REQUIRE(hist && nb > 0, NSC_ERR_BAD_ARG, "nsc_entropy_from_hist: bad args");
+  hipLaunchKernelGGL(entropy_from_hist_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, hist, nb, ent, ghist);
+  NSC_CHECK_LAUNCH("entropy_from_hist");
+  return NSC_OK;
+}

@@ -1,0 +1,583 @@
+"""Explicit forward/backward engine of the NSC/CMRL codec cascade on MI355X.
+
+Host logic only: this file sequences calls into libnsc_hip.so (C ABI, include/nsc_hip.h) on caller-owned,
+pre-allocated device buffers (time-contiguous ``[B, C, T]``).  PyTorch is used for device memory, streams and
+``torch.distributed`` - no torch arithmetic, no autograd, no CPU fallback.  Every launch is on the current
+stream and allocation-free after the first step, so a whole train step can be captured in a hipGraph.
+
+Reference structure being replaced (file:line in cocosci/NSC):
+  neural_speech_coding_module.py:152-295  encoder / decoder / codec graph builders
+  nn_core_operator.py:82-112, 140-164     gated bottleneck, soft-to-hard quantizer
+  loss_terms_and_measures.py:77-183, 257-267  losses
+  cmrl.py:22-135, 295-511                 cascade wiring, follower / finetune phases
+  neural_speech_coding_module.py:908-926  loss assembly + two TF1 Adam optimizers
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ACT_LRELU, ACT_NONE, ACT_TANH, ConvDesc, check
+from .constants import (beta_boundary, frame_length, init_alpha, lpc_coeff_lsf_bins)
+from .loss_terms_and_measures import mel_matrix_cat
+
+KIND_MUL = {"none": 0, "lrelu": 1, "tanh": 2}
+KIND_ACT = {"none": ACT_NONE, "lrelu": ACT_LRELU, "tanh": ACT_TANH}
+
+
+def same_pad(T, k, dil=1, stride=1):
+    """TF 'SAME' (SURVEY 8a a1): returns (T_out, padL)."""
+    t_out = -(-T // stride)
+    pad = max((t_out - 1) * stride + (k - 1) * dil + 1 - T, 0)
+    return t_out, pad // 2
+
+
+class ParamLayout:
+    """Flat fp32 parameter buffer layout; creation order == TF trainable_variables order inside a scope."""
+
+    def __init__(self):
+        self.entries = OrderedDict()  # name -> (offset, shape)
+        self.size = 0
+        self._counts = {}
+
+    def uniq(self, scope, base):
+        n = self._counts.get((scope, base), 0)
+        self._counts[(scope, base)] = n + 1
+        return f"{scope}/{base}" if n == 0 else f"{scope}/{base}_{n}"
+
+    def add(self, name, shape):
+        n = int(np.prod(shape)) if len(shape) else 1
+        off = self.size
+        self.entries[name] = (off, tuple(shape))
+        self.size += n
+        return off
+
+    def scope_range(self, scope):
+        offs = [(o, o + (int(np.prod(s)) if len(s) else 1)) for k, (o, s) in self.entries.items()
+                if k.startswith(scope + "/")]
+        return min(a for a, _ in offs), max(b for _, b in offs)
+
+
+class _Conv:
+    """One conv layer: offsets into the flat buffers + fwd / dgrad / wgrad launchers."""
+
+    def __init__(self, eng, scope, K, Cin, Cout, dil=1, stride=1, T_in=frame_length, pointwise_of=None):
+        self.eng, self.K, self.Cin, self.Cout, self.dil, self.stride, self.Tin = eng, K, Cin, Cout, dil, stride, T_in
+        self.Tout, self.padL = same_pad(T_in, K, dil, stride)
+        lay = eng.layout
+        if pointwise_of is None:
+            name = lay.uniq(scope, "conv1d")
+            self.w_off = lay.add(name + "/kernel", (K, Cin, Cout))
+            self.b_off = lay.add(name + "/bias", (Cout,))
+        else:  # separable conv: depthwise declared by the caller, then pointwise + bias
+            self.w_off = lay.add(pointwise_of + "/pointwise_kernel", (1, Cin, Cout))
+            self.b_off = lay.add(pointwise_of + "/bias", (Cout,))
+        self.name = name if pointwise_of is None else pointwise_of
+        eng.convs.append(self)
+
+    # ---- pointer helpers ----
+    def _p(self, base, off):
+        return base + 4 * off
+
+    def desc(self, **kw):
+        d = ConvDesc(B=self.eng.B, Cin=self.Cin, Cout=self.Cout, Tin=self.Tin, Tout=self.Tout, K=self.K, dil=self.dil,
+                     stride=self.stride, padL=self.padL, act=0, res_mode=0, mul_mode=0, out_mode=0, in_up=0,
+                     accumulate=0)
+        for k, v in kw.items():
+            setattr(d, k, v)
+        return d
+
+    def fwd(self, x, y, act="none", res=None, res_mode=0, out_mode=0):
+        e = self.eng
+        d = self.desc(act=KIND_ACT[act], res_mode=res_mode, out_mode=out_mode)
+        fn = e.lib.nsc_conv1d_cout1_fwd if self.Cout == 1 else e.lib.nsc_conv1d_fwd
+        check(fn(C.byref(d), x.data_ptr(), self._p(e.p_ptr, self.w_off), self._p(e.p_ptr, self.b_off),
+                 _lib.ptr(res), None, y.data_ptr(), e.stream()), f"conv fwd {self.name}")
+
+    def dgrad(self, dz, dx, res=None, res_mode=0, mul_kind="none", aux=None):
+        """dx = conv^T(dz) (+res) (* act'(aux)); runs the forward kernel on the flipped/transposed weights."""
+        e = self.eng
+        padl = (self.K - 1) * self.dil - self.padL
+        d = ConvDesc(B=e.B, Cin=self.Cout, Cout=self.Cin, Tin=self.Tout, Tout=self.Tin, K=self.K, dil=self.dil,
+                     stride=1, padL=padl, act=0, res_mode=res_mode, mul_mode=KIND_MUL[mul_kind], out_mode=0,
+                     in_up=1 if self.stride == 2 else 0, accumulate=0)
+        fn = e.lib.nsc_conv1d_cout1_fwd if self.Cin == 1 else e.lib.nsc_conv1d_fwd
+        check(fn(C.byref(d), dz.data_ptr(), self._p(e.wt_ptr, self.w_off), None, _lib.ptr(res),
+                 _lib.ptr(aux) if mul_kind != "none" else None, dx.data_ptr(), e.stream()), f"conv dgrad {self.name}")
+
+    def wgrad(self, x, dz):
+        e = self.eng
+        dw, db = self._p(e.g_ptr, self.w_off), self._p(e.g_ptr, self.b_off)
+        if self.Cout == 1:
+            # swap roles (SURVEY/DESIGN): "input" = dz (1 channel), "grad" = x (Cin channels); flipped taps
+            assert self.stride == 1
+            d = ConvDesc(B=e.B, Cin=1, Cout=self.Cin, Tin=self.Tout, Tout=self.Tin, K=self.K, dil=self.dil, stride=1,
+                         padL=(self.K - 1) * self.dil - self.padL, act=0, res_mode=0, mul_mode=0, out_mode=0, in_up=0,
+                         accumulate=0)
+            check(e.lib.nsc_conv1d_wgrad(C.byref(d), dz.data_ptr(), x.data_ptr(), dw, None, 1, e.stream()),
+                  f"conv wgrad(swapped) {self.name}")
+            check(e.lib.nsc_sum_all(dz.data_ptr(), db, dz.numel(), e.stream()), "bias grad")
+        else:
+            d = self.desc()
+            check(e.lib.nsc_conv1d_wgrad(C.byref(d), x.data_ptr(), dz.data_ptr(), dw, db, 0, e.stream()),
+                  f"conv wgrad {self.name}")
+
+    def wt_index(self):
+        """Index map e -> source offset so that wt[w_off + ((K-1-k)*Cout + o)*Cin + i] = p[w_off + (k*Cin+i)*Cout + o]."""
+        K, Ci, Co = self.K, self.Cin, self.Cout
+        src = np.arange(K * Ci * Co, dtype=np.int64).reshape(K, Ci, Co)
+        return (self.w_off + src[::-1].transpose(0, 2, 1).reshape(-1)).astype(np.int32)
+
+
+class _Block:
+    """gated_bottleneck (nn_core_operator.py:82-112): 1x1 -> lrelu -> {k15 dil, k15 dil + tanh} -> mul -> k9 -> +x -> lrelu."""
+
+    def __init__(self, eng, scope, uid, Cin, wide, narrow, k9, dil, flat, T):
+        self.eng, self.uid, self.Cin, self.wide, self.narrow, self.flat, self.T = eng, uid, Cin, wide, narrow, flat, T
+        self.c1 = _Conv(eng, scope, 1, Cin, narrow, 1, 1, T)
+        self.cl = _Conv(eng, scope, 15, narrow, narrow, dil, 1, T)   # kernel size 15 hard-coded (:92, :97)
+        self.cr = _Conv(eng, scope, 15, narrow, narrow, dil, 1, T)
+        self.c9 = _Conv(eng, scope, k9, narrow, wide, 1, 1, T)
+        self.out_kind = "none" if flat else "lrelu"
+
+    def fwd(self, x):
+        e, u = self.eng, self.uid
+        B, n, T = e.B, self.narrow, self.T
+        self.x = x
+        self.h = e.buf(u + ".h", (B, n, T))
+        self.lin = e.buf(u + ".lin", (B, n, T))
+        self.th = e.buf(u + ".th", (B, n, T))
+        self.g = e.buf(u + ".g", (B, n, T))
+        self.out = e.buf(u + ".out", (B, self.wide, T))
+        self.c1.fwd(x, self.h, "lrelu")
+        self.cl.fwd(self.h, self.lin, "none")
+        self.cr.fwd(self.h, self.th, "tanh")
+        check(e.lib.nsc_mul(self.lin.data_ptr(), self.th.data_ptr(), self.g.data_ptr(), self.g.numel(), e.stream()), "mul")
+        self.c9.fwd(self.g, self.out, self.out_kind, res=x, res_mode=2 if self.Cin == 1 else 1)
+        return self.out
+
+    def bwd(self, dz, in_kind, need_dx=True):
+        """dz = dL/d(pre-activation of out).  Returns dL/d(pre-activation of the producer of x)."""
+        e, u = self.eng, self.uid
+        B, n, T = e.B, self.narrow, self.T
+        dg = e.buf(u + ".dg", (B, n, T))
+        dlin = e.buf(u + ".dlin", (B, n, T))
+        dgate = e.buf(u + ".dgate", (B, n, T))
+        dh = e.buf(u + ".dh", (B, n, T))
+        self.c9.wgrad(self.g, dz)
+        self.c9.dgrad(dz, dg)
+        check(e.lib.nsc_glu_bwd(self.lin.data_ptr(), self.th.data_ptr(), dg.data_ptr(), dlin.data_ptr(),
+                                dgate.data_ptr(), dg.numel(), e.stream()), "glu_bwd")
+        self.cl.wgrad(self.h, dlin)
+        self.cr.wgrad(self.h, dgate)
+        dh0 = e.buf(u + ".dh0", (B, n, T))
+        self.cl.dgrad(dlin, dh0)
+        self.cr.dgrad(dgate, dh, res=dh0, res_mode=1, mul_kind="lrelu", aux=self.h)
+        self.c1.wgrad(self.x, dh)
+        if not need_dx:
+            return None
+        dx = e.buf(u + ".dx", (B, self.Cin, T))
+        if self.Cin == 1:
+            assert in_kind == "none"
+            self.c1.dgrad(dh, dx)
+            check(e.lib.nsc_channel_sum(dz.data_ptr(), dx.data_ptr(), B, self.wide, T, 1, e.stream()), "channel_sum")
+        else:
+            self.c1.dgrad(dh, dx, res=dz, res_mode=1, mul_kind=in_kind, aux=self.x)
+        return dx
+
+
+class _Codec:
+    """One neural codec (neural_speech_coding_module.py:262-295): encoder -> quantizer -> decoder."""
+
+    def __init__(self, eng, scope, bkd, strides, nb):
+        self.eng, self.scope, self.strides, self.nb = eng, scope, list(strides), nb
+        lay = eng.layout
+        self.alpha_off = lay.add(scope + "/alpha", ())
+        self.bins_off = lay.add(scope + "/bins", (nb,))
+        wide, narrow, k9 = bkd[2], bkd[3], bkd[1]
+        dils = bkd[4:]
+        T = frame_length
+        uid = [0]
+
+        def stack(Cin, T):
+            blocks = []
+            w = wide if Cin == 1 else Cin
+            c = Cin
+            for i, dl in enumerate(dils):
+                uid[0] += 1
+                blocks.append(_Block(eng, scope, f"{scope}.b{uid[0]}", c, w, narrow, k9, dl, i == len(dils) - 1, T))
+                c = w
+            return blocks, w
+
+        # ---- encoder (:219-237) ----
+        self.in_conv = _Conv(eng, scope, 55, 1, wide, 1, 1, T)
+        self.enc_stages = []  # (blocks, down_conv)
+        C_ = wide
+        for s in self.strides:
+            blocks, C_ = stack(C_, T)
+            down = _Conv(eng, scope, 9, C_, wide, 1, s, T)
+            T = down.Tout
+            C_ = wide
+            self.enc_stages.append((blocks, down))
+        self.enc_tail, C_ = stack(C_, T)
+        self.enc_out = _Conv(eng, scope, 55, C_, 1, 1, 1, T)
+        self.L = T
+        # ---- decoder (:239-260) ----
+        self.dec_stages = []  # (blocks, depthwise_off, pointwise conv, T_before, C)
+        C_ = 1
+        for s in self.strides:
+            assert s == 2, "sub-pixel up-sampling is implemented for stride 2"
+            blocks, C_ = stack(C_, T)
+            name = lay.uniq(scope, "separable_conv1d")
+            dw_off = lay.add(name + "/depthwise_kernel", (9, C_, 1))
+            pw = _Conv(eng, scope, 1, C_, C_, 1, 1, T, pointwise_of=name)
+            self.dec_stages.append((blocks, dw_off, pw, T, C_))
+            T, C_ = T * s, C_ // s
+        self.dec_tail, C_ = stack(C_, T)
+        self.dec_out = _Conv(eng, scope, 55, C_, 1, 1, 1, T)
+
+    # -------------------------------------------------------------------------------------------
+    def forward(self, x, is_quan_on, soft, want_p=False):
+        e, s = self.eng, self.scope
+        B = e.B
+        self.x_in = x
+        self.h0 = e.buf(s + ".h0", (B, self.in_conv.Cout, frame_length))
+        self.in_conv.fwd(x, self.h0, "lrelu")
+        h = self.h0
+        self.down_out = []
+        for i, (blocks, down) in enumerate(self.enc_stages):
+            for blk in blocks:
+                h = blk.fwd(h)
+            d = e.buf(f"{s}.down{i}", (B, down.Cout, down.Tout))
+            down.fwd(h, d, "lrelu")
+            self.down_out.append((h, d))
+            h = d
+        for blk in self.enc_tail:
+            h = blk.fwd(h)
+        self.enc_feat = h
+        self.code = e.buf(s + ".code", (B, 1, self.L))
+        self.enc_out.fwd(h, self.code, "tanh")
+        # ---- quantizer + fused quan/entropy partials ----
+        self.qcode = e.buf(s + ".qcode", (B, 1, self.L))
+        self.quan = e.buf(s + ".quan", (B,))
+        self.hist = e.buf(s + ".hist", (self.nb,))
+        self.p = e.buf(s + ".p", (B, self.L, self.nb)) if want_p else None
+        self.hist.zero_()
+        self.is_quan_on, self.soft = float(is_quan_on), int(bool(soft))
+        check(e.lib.nsc_quantize_fwd(self.code.data_ptr(), e.p_ptr + 4 * self.alpha_off, e.p_ptr + 4 * self.bins_off,
+                                     self.is_quan_on, self.soft, B, self.L, self.nb, _lib.ptr(self.p),
+                                     self.qcode.data_ptr(), self.quan.data_ptr(), self.hist.data_ptr(), e.stream()),
+              "quantize_fwd")
+        # ---- decoder ----
+        h = self.qcode
+        self.up_saved = []
+        for i, (blocks, dw_off, pw, T, C_) in enumerate(self.dec_stages):
+            for blk in blocks:
+                h = blk.fwd(h)
+            dwo = e.buf(f"{s}.dw{i}", (B, C_, T))
+            check(e.lib.nsc_depthwise_fwd(h.data_ptr(), e.p_ptr + 4 * dw_off, dwo.data_ptr(), B, C_, T, 9, e.stream()),
+                  "depthwise_fwd")
+            up = e.buf(f"{s}.up{i}", (B, C_ // 2, T * 2))
+            pw.fwd(dwo, up, "lrelu", out_mode=1)
+            self.up_saved.append((h, dwo, up))
+            h = up
+        for blk in self.dec_tail:
+            h = blk.fwd(h)
+        self.dec_feat = h
+        self.dec = e.buf(s + ".dec", (B, 1, frame_length))
+        self.dec_out.fwd(h, self.dec, "none")
+        return self.dec
+
+    def entropy(self):
+        """entropy_coding_loss from the (possibly all-reduced) histogram; also prepares d ent / d hist."""
+        e, s = self.eng, self.scope
+        self.ent = e.buf(s + ".ent", (1,))
+        self.ghist = e.buf(s + ".ghist", (self.nb,))
+        check(e.lib.nsc_entropy_from_hist(self.hist.data_ptr(), self.nb, self.ent.data_ptr(), self.ghist.data_ptr(),
+                                          e.stream()), "entropy_from_hist")
+        return self.ent
+
+    def backward(self, ddec, c_quan, ent_scale, need_dx=False):
+        """ddec [B,1,512] = dL/d dec.  c_quan: coefficient on sum_b quan_loss[b]; ent_scale: coefficient on the
+        entropy scalar (tau * global batch).  Accumulates parameter grads; returns dL/dx_in if need_dx."""
+        e, s = self.eng, self.scope
+        B = e.B
+        # decoder
+        dz = e.buf(s + ".d_decfeat", tuple(self.dec_feat.shape))
+        self.dec_out.wgrad(self.dec_feat, ddec)
+        self.dec_out.dgrad(ddec, dz)  # dec_feat comes from a flat block: no activation gradient
+        for j in range(len(self.dec_tail) - 1, -1, -1):
+            in_kind = "lrelu" if j > 0 else ("lrelu" if self.dec_stages else "none")
+            dz = self.dec_tail[j].bwd(dz, in_kind)
+        for i in range(len(self.dec_stages) - 1, -1, -1):
+            blocks, dw_off, pw, T, C_ = self.dec_stages[i]
+            xin, dwo, up = self.up_saved[i]
+            dzp = e.buf(f"{s}.dzp{i}", (B, C_, T))
+            check(e.lib.nsc_unshuffle2(dz.data_ptr(), dzp.data_ptr(), B, C_, T, e.stream()), "unshuffle2")
+            pw.wgrad(dwo, dzp)
+            ddw = e.buf(f"{s}.ddw{i}", (B, C_, T))
+            pw.dgrad(dzp, ddw)
+            dz = e.buf(f"{s}.dxup{i}", (B, C_, T))
+            check(e.lib.nsc_depthwise_bwd(xin.data_ptr(), e.p_ptr + 4 * dw_off, ddw.data_ptr(), dz.data_ptr(),
+                                          e.g_ptr + 4 * dw_off, B, C_, T, 9, e.stream()), "depthwise_bwd")
+            for j in range(len(blocks) - 1, -1, -1):
+                if j > 0:
+                    in_kind = "lrelu"
+                else:
+                    in_kind = "none" if i == 0 else "lrelu"   # stage 0 input is the quantized code
+                dz = blocks[j].bwd(dz, in_kind)
+        dq = dz  # [B,1,L]: dL/d qcode
+        # quantizer (+ fused quan / entropy loss gradients), returns dL/d(pre-tanh code)
+        dcode = e.buf(s + ".dcode", (B, 1, self.L))
+        check(e.lib.nsc_quantize_bwd(self.code.data_ptr(), e.p_ptr + 4 * self.alpha_off, e.p_ptr + 4 * self.bins_off,
+                                     self.is_quan_on, self.soft, B, self.L, self.nb, dq.data_ptr(), None,
+                                     float(c_quan), self.ghist.data_ptr() if ent_scale != 0.0 else None,
+                                     float(ent_scale), 1, dcode.data_ptr(), e.g_ptr + 4 * self.alpha_off,
+                                     e.g_ptr + 4 * self.bins_off, e.stream()), "quantize_bwd")
+        # encoder
+        self.enc_out.wgrad(self.enc_feat, dcode)
+        dz = e.buf(s + ".d_encfeat", tuple(self.enc_feat.shape))
+        self.enc_out.dgrad(dcode, dz)
+        for j in range(len(self.enc_tail) - 1, -1, -1):
+            dz = self.enc_tail[j].bwd(dz, "lrelu")   # input of block 0 is the lrelu output of the down conv / in conv
+        for i in range(len(self.enc_stages) - 1, -1, -1):
+            blocks, down = self.enc_stages[i]
+            hin, dout = self.down_out[i]
+            down.wgrad(hin, dz)
+            dzi = e.buf(f"{s}.d_down{i}", tuple(hin.shape))
+            down.dgrad(dz, dzi)                       # hin comes from a flat block
+            dz = dzi
+            for j in range(len(blocks) - 1, -1, -1):
+                dz = blocks[j].bwd(dz, "lrelu")
+        self.in_conv.wgrad(self.x_in, dz)
+        if need_dx:
+            dx = e.buf(s + ".dx_in", (B, 1, frame_length))
+            self.in_conv.dgrad(dz, dx)
+            return dx
+        return None
+
+
+class CascadeEngine:
+    """N-codec CMRL cascade + losses + TF1 Adam on flat buffers (cmrl.py:22-135, 295-511)."""
+
+    def __init__(self, batch, num_codecs=1, bkd=(9, 9, 100, 20, 1, 2), strides=None, num_bins=None, res_scalar=1.0,
+                 scale_first=False, lpc=False, device="cuda", seed=20200504, layout_only=False):
+        if not layout_only:
+            if not torch.cuda.is_available():
+                raise _lib.NscError("nsc_amd.engine needs a GPU: the HIP path has no CPU fallback")
+            self.lib = _lib.load()
+        self.B, self.N = int(batch), int(num_codecs)
+        self.device = torch.device(device)
+        self.bkd = list(bkd)
+        strides = strides or [[2]] * self.N
+        num_bins = num_bins or [32] * self.N
+        self.res_scalar, self.scale_first, self.lpc = float(res_scalar), bool(scale_first), bool(lpc)
+        self.layout = ParamLayout()
+        self.convs = []
+        self._bufs = {}
+        if self.lpc:  # 'lpc_quan' scope is created before scope_1 (nsc_module:993-996)
+            self.lpc_alpha_off = self.layout.add("lpc_quan/alpha", ())
+            self.lpc_bins_off = self.layout.add("lpc_quan/bins", (len(lpc_coeff_lsf_bins),))
+        self.codecs = [_Codec(self, f"scope_{i + 1}", self.bkd, strides[i], num_bins[i]) for i in range(self.N)]
+        n = self.layout.size
+        if layout_only:
+            return
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.params = torch.zeros(n, **f32)
+        self.grads = torch.zeros(n, **f32)
+        self.wt = torch.zeros(n, **f32)
+        self.p_ptr, self.g_ptr, self.wt_ptr = self.params.data_ptr(), self.grads.data_ptr(), self.wt.data_ptr()
+        idx = np.arange(n, dtype=np.int32)
+        for c in self.convs:
+            idx[c.w_off:c.w_off + c.K * c.Cin * c.Cout] = c.wt_index()
+        self.wt_idx = torch.from_numpy(idx).to(self.device)
+        # two Adam slot sets (no-quan op / quan op) with independent state (nsc_module:922-926)
+        self.adam = [dict(m=torch.zeros(n, **f32), v=torch.zeros(n, **f32), t=0) for _ in range(2)]
+        mel = mel_matrix_cat().astype(np.float32)
+        self.mel = torch.from_numpy(mel).to(self.device).contiguous()
+        self.melT = torch.from_numpy(np.ascontiguousarray(mel.T)).to(self.device)
+        self.init_params(seed)
+
+    # ---- plumbing ----
+    def stream(self):
+        return torch.cuda.current_stream().cuda_stream
+
+    def buf(self, name, shape):
+        t = self._bufs.get(name)
+        if t is None or tuple(t.shape) != tuple(shape):
+            t = torch.empty(shape, dtype=torch.float32, device=self.device)
+            self._bufs[name] = t
+        return t
+
+    def view(self, name, which="params"):
+        off, shape = self.layout.entries[name]
+        n = int(np.prod(shape)) if len(shape) else 1
+        base = getattr(self, which)
+        return base[off:off + n].view(shape if len(shape) else (1,))
+
+    def init_params(self, seed=20200504):
+        """Glorot-uniform kernels, zero biases, alpha=-300, bins=linspace (nsc_module:268-269; SURVEY 8c seeds)."""
+        rng = np.random.default_rng(seed)
+        host = np.zeros(self.layout.size, np.float32)
+        for name, (off, shape) in self.layout.entries.items():
+            n = int(np.prod(shape)) if len(shape) else 1
+            if name.endswith("/alpha"):
+                host[off] = init_alpha
+            elif name == "lpc_quan/bins":
+                host[off:off + n] = np.asarray(lpc_coeff_lsf_bins, np.float32)
+            elif name.endswith("/bins"):
+                host[off:off + n] = np.linspace(-beta_boundary, beta_boundary, n)
+            elif name.endswith("/bias"):
+                pass
+            else:
+                K, Ci, Co = shape
+                if name.endswith("depthwise_kernel"):
+                    fi, fo = K * Ci, K
+                elif name.endswith("pointwise_kernel"):
+                    fi, fo = Ci, Co
+                else:
+                    fi, fo = K * Ci, K * Co
+                lim = math.sqrt(6.0 / (fi + fo))
+                host[off:off + n] = rng.uniform(-lim, lim, size=n).astype(np.float32)
+        self.params.copy_(torch.from_numpy(host))
+
+    def load_named(self, named):
+        """Copy a name->array dict (oracle ParamStore layout, TF shapes) into the flat buffer."""
+        host = self.params.cpu().numpy()
+        for name, (off, shape) in self.layout.entries.items():
+            if name in named:
+                a = np.asarray(named[name], np.float32).reshape(-1)
+                host[off:off + a.size] = a
+        self.params.copy_(torch.from_numpy(host))
+
+    def named(self, which="params"):
+        host = getattr(self, which).detach().cpu().numpy()
+        out = OrderedDict()
+        for name, (off, shape) in self.layout.entries.items():
+            n = int(np.prod(shape)) if len(shape) else 1
+            out[name] = host[off:off + n].reshape(shape).copy()
+        return out
+
+    def refresh_wt(self):
+        check(self.lib.nsc_gather(self.p_ptr, self.wt_idx.data_ptr(), self.wt_ptr, self.layout.size, self.stream()),
+              "gather wt")
+
+    # ---- forward ----
+    def forward(self, x, is_quan_on=1.0, soft=True, lpc_x=None, want_p=False):
+        """x [B,1,512] (time-domain frame, or the fed LPC residual).  Returns decoded [B,1,512] (sum of codecs)."""
+        e = self
+        B, rs = self.B, self.res_scalar
+        assert tuple(x.shape) == (B, 1, frame_length) and x.dtype == torch.float32 and x.is_contiguous()
+        self.x = x
+        n = B * frame_length
+        self.decoded = self.buf("decoded", (B, 1, frame_length))
+        self.xin = []
+        for i, c in enumerate(self.codecs):
+            scaled = (i > 0) or self.scale_first
+            if i == 0:
+                if scaled and rs != 1.0:
+                    xin = self.buf("xin0", (B, 1, frame_length))
+                    check(self.lib.nsc_axpby(x.data_ptr(), None, xin.data_ptr(), rs, 0.0, n, self.stream()), "axpby")
+                else:
+                    xin = x
+            else:
+                xin = self.buf(f"xin{i}", (B, 1, frame_length))
+                check(self.lib.nsc_axpby(x.data_ptr(), self.decoded.data_ptr(), xin.data_ptr(), rs, -rs, n,
+                                         self.stream()), "axpby")
+            self.xin.append(xin)
+            dec = c.forward(xin, is_quan_on, soft, want_p)
+            sc = (1.0 / rs) if scaled else 1.0
+            if i == 0:
+                check(self.lib.nsc_axpby(dec.data_ptr(), None, self.decoded.data_ptr(), sc, 0.0, n, self.stream()), "axpby")
+            else:
+                check(self.lib.nsc_axpby(dec.data_ptr(), self.decoded.data_ptr(), self.decoded.data_ptr(), sc, 1.0, n,
+                                         self.stream()), "axpby")
+        if self.lpc and lpc_x is not None:
+            # LSF quantizer (nsc_module:993-1005): only its soft assignment enters the loss (py_func has no grad)
+            L, nb = lpc_x.shape[1], len(lpc_coeff_lsf_bins)
+            self.lpc_x = lpc_x
+            self.lpc_q = self.buf("lpc.q", (B, L, 1))
+            self.lpc_quan = self.buf("lpc.quan", (B,))
+            self.lpc_hist = self.buf("lpc.hist", (nb,))
+            self.lpc_hist.zero_()
+            check(self.lib.nsc_quantize_fwd(lpc_x.data_ptr(), self.p_ptr + 4 * self.lpc_alpha_off,
+                                            self.p_ptr + 4 * self.lpc_bins_off, float(is_quan_on), int(bool(soft)), B, L,
+                                            nb, None, self.lpc_q.data_ptr(), self.lpc_quan.data_ptr(),
+                                            self.lpc_hist.data_ptr(), self.stream()), "lpc quantize_fwd")
+        return self.decoded
+
+    # ---- losses + backward ----
+    def loss_backward(self, target, c_time, c_freq, c_quan, c_ent, trainable, c_quan_lpc=0.0, c_ent_lpc=0.0,
+                      global_batch=None, hist_allreduce=None):
+        """loss = sum_b [c_time*time + c_freq*freq + sum_i c_quan[i]*quan_i[b]] + Bglobal * sum_i c_ent[i]*ent_i
+        (vector loss => implicit sum over the batch).  trainable: list of bool per codec.
+        Returns dict of loss terms (device tensors)."""
+        B, rs = self.B, self.res_scalar
+        Bg = float(global_batch or B)
+        self.time = self.buf("loss.time", (B,))
+        self.freq = self.buf("loss.freq", (B,))
+        G = self.buf("loss.G", (B, 1, frame_length))
+        check(self.lib.nsc_recon_loss(self.decoded.data_ptr(), target.data_ptr(), B, float(c_time), float(c_freq), None,
+                                      None, self.mel.data_ptr(), self.melT.data_ptr(), self.time.data_ptr(),
+                                      self.freq.data_ptr(), G.data_ptr(), self.stream()), "recon_loss")
+        if hist_allreduce is not None:
+            hist_allreduce([c.hist for c in self.codecs] + ([self.lpc_hist] if self.lpc and hasattr(self, "lpc_hist") else []))
+        ents = [c.entropy() for c in self.codecs]
+        n = B * frame_length
+        dsum = None  # running sum over later codecs of dL/dxin_j
+        first_needed = min([i for i, t in enumerate(trainable) if t], default=self.N)
+        for i in range(self.N - 1, -1, -1):
+            c = self.codecs[i]
+            if i < first_needed:
+                break
+            scaled = (i > 0) or self.scale_first
+            sc = (1.0 / rs) if scaled else 1.0
+            ddec = self.buf(f"ddec{i}", (B, 1, frame_length))
+            # d yhat_i = G - rs * sum_{j>i} dxin_j ; d dec_i = d yhat_i * sc
+            if dsum is None:
+                check(self.lib.nsc_axpby(G.data_ptr(), None, ddec.data_ptr(), sc, 0.0, n, self.stream()), "axpby")
+            else:
+                check(self.lib.nsc_axpby(G.data_ptr(), dsum.data_ptr(), ddec.data_ptr(), sc, -rs * sc, n, self.stream()), "axpby")
+            need_dx = i > first_needed
+            if trainable[i]:
+                dx = c.backward(ddec, c_quan[i], c_ent[i] * Bg, need_dx=need_dx)
+            else:
+                raise NotImplementedError("a frozen codec between trainable ones is not a reference configuration")
+            if need_dx:
+                if dsum is None:
+                    dsum = dx
+                else:
+                    acc = self.buf("dsum", (B, 1, frame_length))
+                    check(self.lib.nsc_axpby(dx.data_ptr(), dsum.data_ptr(), acc.data_ptr(), 1.0, 1.0, n, self.stream()), "axpby")
+                    dsum = acc
+        if self.lpc and (c_quan_lpc != 0.0 or c_ent_lpc != 0.0) and hasattr(self, "lpc_x"):
+            L, nb = self.lpc_x.shape[1], len(lpc_coeff_lsf_bins)
+            ent = self.buf("lpc.ent", (1,))
+            gh = self.buf("lpc.ghist", (nb,))
+            check(self.lib.nsc_entropy_from_hist(self.lpc_hist.data_ptr(), nb, ent.data_ptr(), gh.data_ptr(), self.stream()), "lpc ent")
+            check(self.lib.nsc_quantize_bwd(self.lpc_x.data_ptr(), self.p_ptr + 4 * self.lpc_alpha_off,
+                                            self.p_ptr + 4 * self.lpc_bins_off, self.codecs[0].is_quan_on,
+                                            self.codecs[0].soft, B, L, nb, None, None, float(c_quan_lpc),
+                                            gh.data_ptr() if c_ent_lpc != 0.0 else None, float(c_ent_lpc) * Bg, 0, None,
+                                            self.g_ptr + 4 * self.lpc_alpha_off, self.g_ptr + 4 * self.lpc_bins_off,
+                                            self.stream()), "lpc quantize_bwd")
+        return dict(time=self.time, freq=self.freq, quan=[c.quan for c in self.codecs], ent=ents)
+
+    def adam_step(self, scopes, lr, slot=1, beta1=0.9, beta2=0.999, eps=1e-8):
+        """TF1 Adam on the flat ranges of the given scopes (independent state per optimizer slot)."""
+        st = self.adam[slot]
+        st["t"] += 1
+        for sc in scopes:
+            a, b = self.layout.scope_range(sc)
+            check(self.lib.nsc_adam_tf1_step(self.p_ptr + 4 * a, self.g_ptr + 4 * a, st["m"].data_ptr() + 4 * a,
+                                             st["v"].data_ptr() + 4 * a, b - a, float(lr), beta1, beta2, eps, st["t"],
+                                             None, self.stream()), "adam")
+
+    def reset_adam(self):
+        for st in self.adam:
+            st["m"].zero_(); st["v"].zero_(); st["t"] = 0

@@ -1,0 +1,56 @@
+"""Shared helpers for the parity tests (the oracle is the checker; nsc_amd is the thing checked)."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from oracle import nsc_oracle as O
+from oracle import nsc_oracle_torch as OT
+
+BKD = [9, 9, 100, 20, 1, 2]
+RTOL = 1e-4  # north_star: fp32 conv/quantizer within 1e-4 rel
+
+
+def relerr(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-30))
+
+
+def assert_close(a, b, tol=RTOL, what=""):
+    assert np.asarray(a).shape == np.asarray(b).shape, (what, np.asarray(a).shape, np.asarray(b).shape)
+    e = relerr(a, b)
+    assert np.all(np.isfinite(np.asarray(a))), f"{what}: non-finite output"
+    assert e <= tol, f"{what}: max rel err {e:.3e} > {tol:.1e}"
+
+
+def dev(a):
+    return torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device="cuda")
+
+
+def synth_frames(B, seed=1234):
+    """SURVEY 8d synthetic input: 0.03*N(0,1), clipped, training window."""
+    rng = np.random.default_rng(seed)
+    x = np.clip(0.03 * rng.standard_normal((B, 512, 1)), -1, 1) * O.training_window()[None, :, None]
+    return x.astype(np.float32).astype(np.float64)
+
+
+def make_store(num_codecs, strides, bins, seed=20200504, rand_bias=True, alpha=-20.0, lpc=False):
+    """Oracle ParamStore with float32-representable values; optional random biases / softer alpha so that
+    every gradient path is exercised (alpha=-300 saturates the softmax)."""
+    ps = O.ParamStore(np.random.default_rng(seed))
+    if lpc:
+        ps.var("lpc_quan", "alpha", O.INIT_ALPHA)
+        import json, os
+        kats = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_kats.json")))
+        ps.var("lpc_quan", "bins", np.array(kats["lsf_bins"], np.float32).astype(np.float64))
+    x0 = np.zeros((1, 512, 1))
+    for i in range(num_codecs):
+        O.codec_forward(x0, ps, f"scope_{i + 1}", BKD, strides[i], bins[i], 0.0, True)
+    rng = np.random.default_rng(seed + 1)
+    for k in ps.params:
+        if rand_bias and k.endswith("/bias"):
+            ps.params[k] = (0.05 * rng.standard_normal(ps.params[k].shape)).astype(np.float32).astype(np.float64)
+        if alpha is not None and k.endswith("/alpha"):
+            ps.params[k] = np.array(float(alpha))
+    return ps

@@ -1,0 +1,375 @@
+"""GPU parity tests of every C-ABI kernel against the CPU oracle (called through ctypes on raw device pointers)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nsc_oracle as O
+from oracle import nsc_oracle_torch as OT
+from tests._util import assert_close, dev, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from nsc_amd import _lib
+    return _lib.load()
+
+
+def _desc(**kw):
+    from nsc_amd._lib import ConvDesc
+    base = dict(B=1, Cin=1, Cout=1, Tin=1, Tout=1, K=1, dil=1, stride=1, padL=0, act=0, res_mode=0, mul_mode=0,
+                out_mode=0, in_up=0, accumulate=0)
+    base.update(kw)
+    return ConvDesc(**base)
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+ACT = {"none": 0, "tanh": 1, "lrelu": 2}
+
+CONV_CASES = [
+    # B, Cin, Cout, T, K, dil, stride, act, res_mode
+    (3, 1, 100, 512, 55, 1, 1, "lrelu", 0),
+    (2, 100, 20, 512, 1, 1, 1, "lrelu", 0),
+    (2, 20, 20, 512, 15, 2, 1, "none", 0),
+    (2, 20, 20, 256, 15, 1, 1, "tanh", 0),
+    (2, 20, 100, 512, 9, 1, 1, "lrelu", 1),
+    (2, 20, 100, 256, 9, 1, 1, "none", 2),
+    (2, 100, 100, 512, 9, 1, 2, "lrelu", 0),
+    (2, 50, 50, 512, 9, 1, 1, "none", 1),
+    (2, 1, 20, 256, 1, 1, 1, "lrelu", 0),
+    (1, 100, 1, 256, 55, 1, 1, "tanh", 0),
+    (2, 50, 1, 512, 55, 1, 1, "none", 0),
+    (2, 7, 13, 300, 5, 3, 1, "tanh", 0),      # ragged: odd channels, T not a tile multiple
+    (2, 6, 130, 77, 3, 1, 2, "none", 0),      # Cout > 112 (grid.z), odd T with stride 2
+    (1, 100, 100, 128, 1, 1, 1, "lrelu", 0),  # pointwise
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv1d_fwd(lib, case):
+    B, Cin, Cout, T, K, dil, s, act, res_mode = case
+    rng = np.random.default_rng(sum(int(v) * (i + 3) for i, v in enumerate(case) if not isinstance(v, str)))
+    x = rng.standard_normal((B, T, Cin)).astype(np.float32)
+    W = (rng.standard_normal((K, Cin, Cout)) / np.sqrt(K * Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    Tout, padL, _ = O.same_pad(T, K, dil, s)
+    ref = O.conv1d(x, W, b, dil, s, None)
+    res = None
+    if res_mode == 1:
+        res = rng.standard_normal((B, Tout, Cout)).astype(np.float32)
+        ref = ref + res
+    elif res_mode == 2:
+        res = rng.standard_normal((B, Tout, 1)).astype(np.float32)
+        ref = ref + res
+    ref = O._act(ref, act)
+    xd, wd, bd = dev(x.transpose(0, 2, 1)), dev(W), dev(b)
+    rd = dev(res.transpose(0, 2, 1)) if res is not None else None
+    y = torch.full((B, Cout, Tout), float("nan"), device="cuda")
+    d = _desc(B=B, Cin=Cin, Cout=Cout, Tin=T, Tout=Tout, K=K, dil=dil, stride=s, padL=padL, act=ACT[act], res_mode=res_mode)
+    fn = lib.nsc_conv1d_cout1_fwd if Cout == 1 else lib.nsc_conv1d_fwd
+    rc = fn(C.byref(d), xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), rd.data_ptr() if rd is not None else None, None,
+            y.data_ptr(), _st())
+    assert rc == 0, lib.nsc_last_error()
+    torch.cuda.synchronize()
+    assert_close(y.cpu().numpy().transpose(0, 2, 1), ref, what=f"conv fwd {case}")
+
+
+def test_conv1d_fwd_generic_kernel_with_cout1(lib):
+    """The MFMA kernel itself must also be right for Cout == 1 (it is the dgrad path of Cin == 1 convs)."""
+    rng = np.random.default_rng(5)
+    B, Cin, T, K = 2, 20, 256, 15
+    x = rng.standard_normal((B, T, Cin)).astype(np.float32)
+    W = rng.standard_normal((K, Cin, 1)).astype(np.float32)
+    ref = O.conv1d(x, W, None, 2, 1, None)
+    y = torch.empty((B, 1, T), device="cuda")
+    d = _desc(B=B, Cin=Cin, Cout=1, Tin=T, Tout=T, K=K, dil=2, padL=14)
+    assert lib.nsc_conv1d_fwd(C.byref(d), dev(x.transpose(0, 2, 1)).data_ptr(), dev(W).data_ptr(), None, None, None,
+                              y.data_ptr(), _st()) == 0
+    assert_close(y.cpu().numpy().transpose(0, 2, 1), ref, what="generic cout1")
+
+
+def test_conv1d_shuffle_and_mul_epilogues(lib):
+    rng = np.random.default_rng(9)
+    B, C_, T = 2, 100, 256
+    x = rng.standard_normal((B, T, C_)).astype(np.float32)
+    W = (rng.standard_normal((1, C_, C_)) / 10).astype(np.float32)
+    b = rng.standard_normal(C_).astype(np.float32)
+    ref = O.subpixel_shuffle(O.conv1d(x, W, b, 1, 1, "lrelu"), 2)          # [B, 512, 50]
+    y = torch.empty((B, C_ // 2, 2 * T), device="cuda")
+    d = _desc(B=B, Cin=C_, Cout=C_, Tin=T, Tout=T, K=1, act=2, out_mode=1)
+    xd = dev(x.transpose(0, 2, 1))
+    assert lib.nsc_conv1d_fwd(C.byref(d), xd.data_ptr(), dev(W).data_ptr(), dev(b).data_ptr(), None, None,
+                              y.data_ptr(), _st()) == 0
+    assert_close(y.cpu().numpy().transpose(0, 2, 1), ref, what="shuffle epilogue")
+    # unshuffle is the inverse permutation
+    back = torch.empty((B, C_, T), device="cuda")
+    assert lib.nsc_unshuffle2(y.data_ptr(), back.data_ptr(), B, C_, T, _st()) == 0
+    assert_close(back.cpu().numpy().transpose(0, 2, 1), O.conv1d(x, W, b, 1, 1, "lrelu"), what="unshuffle")
+    # mul_mode: v * lrelu'(aux) and v * tanh'(aux)
+    aux = rng.standard_normal((B, T, C_)).astype(np.float32)
+    for mode, g in ((1, np.where(aux > 0, 1.0, 0.2)), (2, 1 - aux.astype(np.float64) ** 2)):
+        d = _desc(B=B, Cin=C_, Cout=C_, Tin=T, Tout=T, K=1, mul_mode=mode)
+        y2 = torch.empty((B, C_, T), device="cuda")
+        assert lib.nsc_conv1d_fwd(C.byref(d), xd.data_ptr(), dev(W).data_ptr(), dev(b).data_ptr(), None,
+                                  dev(aux.transpose(0, 2, 1)).data_ptr(), y2.data_ptr(), _st()) == 0
+        assert_close(y2.cpu().numpy().transpose(0, 2, 1), O.conv1d(x, W, b, 1, 1, None) * g, what=f"mul_mode {mode}")
+
+
+GRAD_CASES = [
+    (3, 1, 100, 512, 55, 1, 1), (2, 100, 20, 512, 1, 1, 1), (2, 20, 20, 512, 15, 2, 1), (2, 20, 100, 256, 9, 1, 1),
+    (2, 100, 100, 512, 9, 1, 2), (2, 100, 1, 256, 55, 1, 1), (2, 50, 1, 512, 55, 1, 1), (2, 1, 20, 256, 1, 1, 1),
+    (2, 7, 13, 300, 5, 3, 1), (3, 50, 50, 512, 15, 1, 1), (2, 100, 100, 256, 1, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", GRAD_CASES)
+def test_conv1d_dgrad_wgrad(lib, case):
+    """dgrad = forward kernel on nsc_weight_flip_transpose'd weights; wgrad incl. bias row; vs autograd oracle."""
+    B, Cin, Cout, T, K, dil, s = case
+    rng = np.random.default_rng(sum(int(v) * (i + 3) for i, v in enumerate(case) if not isinstance(v, str)))
+    x = rng.standard_normal((B, T, Cin)).astype(np.float32)
+    W = (rng.standard_normal((K, Cin, Cout)) / np.sqrt(K * Cin)).astype(np.float32)
+    b = np.zeros(Cout, np.float32)
+    Tout, padL, _ = O.same_pad(T, K, dil, s)
+    dz = rng.standard_normal((B, Tout, Cout)).astype(np.float32)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    Wt = torch.tensor(W, dtype=torch.float64, requires_grad=True)
+    bt = torch.tensor(b, dtype=torch.float64, requires_grad=True)
+    (OT.conv1d(xt, Wt, bt, dil, s, None) * torch.tensor(dz, dtype=torch.float64)).sum().backward()
+    xd, wd, dzd = dev(x.transpose(0, 2, 1)), dev(W), dev(dz.transpose(0, 2, 1))
+    # ---- wgrad ----
+    dw = torch.zeros((K, Cin, Cout), device="cuda")
+    db = torch.zeros((Cout,), device="cuda")
+    if Cout == 1:   # role swap (see nsc_amd/engine.py _Conv.wgrad)
+        d = _desc(B=B, Cin=1, Cout=Cin, Tin=Tout, Tout=T, K=K, dil=dil, padL=(K - 1) * dil - padL)
+        assert lib.nsc_conv1d_wgrad(C.byref(d), dzd.data_ptr(), xd.data_ptr(), dw.data_ptr(), None, 1, _st()) == 0, lib.nsc_last_error()
+        assert lib.nsc_sum_all(dzd.data_ptr(), db.data_ptr(), dzd.numel(), _st()) == 0
+    else:
+        d = _desc(B=B, Cin=Cin, Cout=Cout, Tin=T, Tout=Tout, K=K, dil=dil, stride=s, padL=padL)
+        assert lib.nsc_conv1d_wgrad(C.byref(d), xd.data_ptr(), dzd.data_ptr(), dw.data_ptr(), db.data_ptr(), 0, _st()) == 0, lib.nsc_last_error()
+    assert_close(dw.cpu().numpy(), Wt.grad.numpy(), what=f"wgrad {case}")
+    assert_close(db.cpu().numpy(), bt.grad.numpy(), what=f"bias grad {case}")
+    # ---- dgrad ----
+    wt = torch.empty((K, Cout, Cin), device="cuda")
+    assert lib.nsc_weight_flip_transpose(wd.data_ptr(), wt.data_ptr(), K, Cin, Cout, _st()) == 0
+    assert np.array_equal(wt.cpu().numpy(), W[::-1].transpose(0, 2, 1))
+    dx = torch.full((B, Cin, T), float("nan"), device="cuda")
+    d = _desc(B=B, Cin=Cout, Cout=Cin, Tin=Tout, Tout=T, K=K, dil=dil, stride=1, padL=(K - 1) * dil - padL,
+              in_up=1 if s == 2 else 0)
+    fn = lib.nsc_conv1d_cout1_fwd if Cin == 1 else lib.nsc_conv1d_fwd
+    assert fn(C.byref(d), dzd.data_ptr(), wt.data_ptr(), None, None, None, dx.data_ptr(), _st()) == 0, lib.nsc_last_error()
+    assert_close(dx.cpu().numpy().transpose(0, 2, 1), xt.grad.numpy(), what=f"dgrad {case}")
+
+
+def test_depthwise_fwd_bwd(lib):
+    rng = np.random.default_rng(11)
+    B, C_, T, K = 3, 100, 256, 9
+    x = rng.standard_normal((B, T, C_)).astype(np.float32)
+    Wd = rng.standard_normal((K, C_, 1)).astype(np.float32)
+    dy = rng.standard_normal((B, T, C_)).astype(np.float32)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    wt = torch.tensor(Wd, dtype=torch.float64, requires_grad=True)
+    eye = torch.eye(C_, dtype=torch.float64).reshape(1, C_, C_)
+    yt = OT.conv1d_depth(xt, wt, eye, torch.zeros(C_, dtype=torch.float64))
+    (yt * torch.tensor(dy, dtype=torch.float64)).sum().backward()
+    xd, wdd, dyd = dev(x.transpose(0, 2, 1)), dev(Wd.reshape(K, C_)), dev(dy.transpose(0, 2, 1))
+    y = torch.empty((B, C_, T), device="cuda")
+    assert lib.nsc_depthwise_fwd(xd.data_ptr(), wdd.data_ptr(), y.data_ptr(), B, C_, T, K, _st()) == 0
+    assert_close(y.cpu().numpy().transpose(0, 2, 1), yt.detach().numpy(), what="depthwise fwd")
+    dx = torch.empty((B, C_, T), device="cuda")
+    dwd = torch.zeros((K, C_), device="cuda")
+    assert lib.nsc_depthwise_bwd(xd.data_ptr(), wdd.data_ptr(), dyd.data_ptr(), dx.data_ptr(), dwd.data_ptr(), B, C_, T, K, _st()) == 0
+    assert_close(dx.cpu().numpy().transpose(0, 2, 1), xt.grad.numpy(), what="depthwise dx")
+    assert_close(dwd.cpu().numpy(), wt.grad.numpy()[:, :, 0], what="depthwise dw")
+
+
+def test_glue_kernels(lib):
+    rng = np.random.default_rng(13)
+    a = rng.standard_normal((2, 40, 128)).astype(np.float32)
+    ad = dev(a)
+    g = torch.empty((2, 20, 128), device="cuda")
+    assert lib.nsc_gate_fwd(ad.data_ptr(), g.data_ptr(), 2, 20, 128, _st()) == 0
+    th = np.tanh(a[:, 20:].astype(np.float64))
+    assert_close(g.cpu().numpy(), a[:, :20] * th, what="gate fwd")
+    dg = rng.standard_normal((2, 20, 128)).astype(np.float32)
+    da = torch.empty((2, 40, 128), device="cuda")
+    assert lib.nsc_gate_bwd(ad.data_ptr(), dev(dg).data_ptr(), da.data_ptr(), 2, 20, 128, _st()) == 0
+    assert_close(da.cpu().numpy()[:, :20], dg * th, what="gate bwd lin")
+    assert_close(da.cpu().numpy()[:, 20:], dg * a[:, :20] * (1 - th ** 2), what="gate bwd gate")
+    lin, t2 = dev(a[:, :20]), dev(th)
+    gg = torch.empty((2, 20, 128), device="cuda")
+    assert lib.nsc_mul(lin.data_ptr(), t2.data_ptr(), gg.data_ptr(), gg.numel(), _st()) == 0
+    assert_close(gg.cpu().numpy(), a[:, :20] * th, what="mul")
+    d1, d2 = torch.empty_like(gg), torch.empty_like(gg)
+    assert lib.nsc_glu_bwd(lin.data_ptr(), t2.data_ptr(), dev(dg).data_ptr(), d1.data_ptr(), d2.data_ptr(), gg.numel(), _st()) == 0
+    assert_close(d1.cpu().numpy(), dg * th, what="glu dlin")
+    assert_close(d2.cpu().numpy(), dg * a[:, :20] * (1 - th ** 2), what="glu dgate")
+    x, y = dev(a), dev(2 * a + 1)
+    out = torch.empty_like(x)
+    assert lib.nsc_axpby(x.data_ptr(), y.data_ptr(), out.data_ptr(), 0.5, -2.0, x.numel(), _st()) == 0
+    assert_close(out.cpu().numpy(), 0.5 * a - 2.0 * (2 * a + 1), what="axpby")
+    cs = torch.ones((2, 1, 128), device="cuda")
+    assert lib.nsc_channel_sum(x.data_ptr(), cs.data_ptr(), 2, 40, 128, 1, _st()) == 0
+    assert_close(cs.cpu().numpy()[:, 0], 1 + a.astype(np.float64).sum(1), what="channel_sum")
+    tr = torch.empty((2, 128, 40), device="cuda")
+    assert lib.nsc_transpose_last2(x.data_ptr(), tr.data_ptr(), 2, 40, 128, _st()) == 0
+    assert np.array_equal(tr.cpu().numpy(), a.transpose(0, 2, 1))
+    s = torch.zeros(1, device="cuda")
+    assert lib.nsc_sum_all(x.data_ptr(), s.data_ptr(), x.numel(), _st()) == 0
+    assert abs(float(s) - a.astype(np.float64).sum()) < 1e-3 * np.abs(a).sum() ** 0.5
+    idx = torch.tensor(rng.permutation(a.size).astype(np.int32), device="cuda")
+    gt = torch.empty(a.size, device="cuda")
+    assert lib.nsc_gather(x.data_ptr(), idx.data_ptr(), gt.data_ptr(), a.size, _st()) == 0
+    assert np.array_equal(gt.cpu().numpy(), a.reshape(-1)[idx.cpu().numpy()])
+
+
+QUANT_CASES = [(4, 256, 32, -20.0, True), (4, 256, 32, -300.0, True), (3, 16, 256, -50.0, True), (2, 128, 32, -20.0, False),
+               (2, 37, 20, -10.0, True), (2, 64, 64, -30.0, True), (2, 9, 7, -5.0, True), (1, 16, 300, -40.0, True)]
+
+
+@pytest.mark.parametrize("case", QUANT_CASES)
+def test_quantizer_fwd_bwd(lib, case):
+    B, L, nb, alpha, soft = case
+    rng = np.random.default_rng(B * 1000 + L + nb)
+    code = np.tanh(rng.standard_normal((B, L, 1))).astype(np.float32)
+    bins = np.linspace(-1, 1, nb).astype(np.float32) + (0.01 * rng.standard_normal(nb)).astype(np.float32)
+    on = 1.0
+    c_quan, tau_scale = 10.0, 0.7 * B
+    ct = torch.tensor(code, dtype=torch.float64, requires_grad=True)
+    at = torch.tensor(alpha, dtype=torch.float64, requires_grad=True)
+    bt = torch.tensor(bins, dtype=torch.float64, requires_grad=True)
+    p, out = OT.scalar_softmax_quantization(ct, at, bt, on, soft)
+    dout = rng.standard_normal((B, L, 1)).astype(np.float32)
+    dp = rng.standard_normal((B, L, nb)).astype(np.float32)
+    ent = OT.entropy_coding_loss(p)
+    loss = (out * torch.tensor(dout, dtype=torch.float64)).sum() + (p * torch.tensor(dp, dtype=torch.float64)).sum() \
+        + c_quan * OT.quan_loss(p).sum() + tau_scale * ent
+    loss.backward()
+    cd, ad, bd = dev(code), dev(np.array([alpha])), dev(bins)
+    pd = torch.full((B, L, nb), float("nan"), device="cuda")
+    od = torch.empty((B, L, 1), device="cuda")
+    qd = torch.empty((B,), device="cuda")
+    hist = torch.zeros((nb,), device="cuda")
+    rc = lib.nsc_quantize_fwd(cd.data_ptr(), ad.data_ptr(), bd.data_ptr(), on, int(soft), B, L, nb, pd.data_ptr(),
+                              od.data_ptr(), qd.data_ptr(), hist.data_ptr(), _st())
+    assert rc == 0, lib.nsc_last_error()
+    assert_close(pd.cpu().numpy(), p.detach().numpy(), what="p")
+    assert_close(od.cpu().numpy(), out.detach().numpy(), what="out")
+    assert_close(qd.cpu().numpy(), OT.quan_loss(p).detach().numpy(), what="quan partial")
+    assert_close(hist.cpu().numpy(), p.detach().numpy().reshape(-1, nb).sum(0), what="hist")
+    e = torch.empty(1, device="cuda"); gh = torch.empty(nb, device="cuda")
+    assert lib.nsc_entropy_from_hist(hist.data_ptr(), nb, e.data_ptr(), gh.data_ptr(), _st()) == 0
+    assert abs(float(e) - float(ent)) < 1e-4 * max(1.0, abs(float(ent)))
+    dc = torch.full((B, L, 1), float("nan"), device="cuda")
+    da = torch.zeros(1, device="cuda"); db = torch.zeros(nb, device="cuda")
+    rc = lib.nsc_quantize_bwd(cd.data_ptr(), ad.data_ptr(), bd.data_ptr(), on, int(soft), B, L, nb, dev(dout).data_ptr(),
+                              dev(dp).data_ptr(), c_quan, gh.data_ptr(), tau_scale, 0, dc.data_ptr(), da.data_ptr(),
+                              db.data_ptr(), _st())
+    assert rc == 0, lib.nsc_last_error()
+    assert_close(dc.cpu().numpy(), ct.grad.numpy(), tol=2e-4, what="dcode")
+    assert_close(db.cpu().numpy(), bt.grad.numpy(), tol=2e-4, what="dbins")
+    assert abs(float(da) - float(at.grad)) <= 2e-4 * max(abs(float(at.grad)), 1e-3), ("dalpha", float(da), float(at.grad))
+
+
+def test_quantizer_identity_and_nearest_bin(lib):
+    rng = np.random.default_rng(2)
+    B, L, nb = 2, 256, 32
+    code = rng.uniform(-0.99, 0.99, (B, L, 1)).astype(np.float32)
+    bins = np.linspace(-1, 1, nb).astype(np.float32)
+    cd, ad, bd = dev(code), dev(np.array([-300.0])), dev(bins)
+    od = torch.empty((B, L, 1), device="cuda")
+    assert lib.nsc_quantize_fwd(cd.data_ptr(), ad.data_ptr(), bd.data_ptr(), 0.0, 1, B, L, nb, None, od.data_ptr(), None, None, _st()) == 0
+    assert np.array_equal(od.cpu().numpy(), code)                       # is_quan_on = 0 -> identity, bit exact
+    assert lib.nsc_quantize_fwd(cd.data_ptr(), ad.data_ptr(), bd.data_ptr(), 1.0, 0, B, L, nb, None, od.data_ptr(), None, None, _st()) == 0
+    idx = np.argmin(np.abs(code.astype(np.float64) - bins.astype(np.float64)), axis=-1)
+    assert np.array_equal(od.cpu().numpy()[..., 0], bins[idx])          # hard: exact bin values, exact indices
+    # tie -> lowest index
+    assert lib.nsc_quantize_fwd(dev(np.array([[[0.5]]])).data_ptr(), ad.data_ptr(), dev(np.array([0.0, 1.0, 2.0, 3.0])).data_ptr(),
+                                1.0, 0, 1, 1, 4, None, od.data_ptr(), None, None, _st()) == 0
+    assert float(od.reshape(-1)[0]) == 0.0
+
+
+def test_recon_loss_and_rfft(lib):
+    from nsc_amd.loss_terms_and_measures import mel_matrix_cat
+    rng = np.random.default_rng(17)
+    B = 5
+    tgt = (0.03 * rng.standard_normal((B, 512))).astype(np.float32)
+    dec = (tgt + 0.01 * rng.standard_normal((B, 512))).astype(np.float32)
+    dec[0] = tgt[0]                                                      # zero-error frame: eps paths
+    dt = torch.tensor(dec, dtype=torch.float64, requires_grad=True)
+    tt = torch.tensor(tgt, dtype=torch.float64)
+    tl, fl = OT.mse_loss(dt, tt), OT.mfcc_loss(dt, tt)
+    (60.0 * tl + 10.0 * fl).sum().backward()
+    mel = mel_matrix_cat()
+    md, mtd = dev(mel), dev(np.ascontiguousarray(mel.T))
+    to, fo = torch.empty(B, device="cuda"), torch.empty(B, device="cuda")
+    g = torch.empty((B, 512), device="cuda")
+    rc = lib.nsc_recon_loss(dev(dec).data_ptr(), dev(tgt).data_ptr(), B, 60.0, 10.0, None, None, md.data_ptr(),
+                            mtd.data_ptr(), to.data_ptr(), fo.data_ptr(), g.data_ptr(), _st())
+    assert rc == 0, lib.nsc_last_error()
+    assert_close(to.cpu().numpy(), tl.detach().numpy(), what="time loss")
+    assert_close(fo.cpu().numpy(), fl.detach().numpy(), tol=3e-4, what="freq loss")
+    assert_close(g.cpu().numpy()[1:], dt.grad.numpy()[1:], tol=5e-4, what="recon grad")
+    # bare rFFT + cosine KAT
+    sig = np.stack([np.cos(2 * np.pi * 5 * np.arange(512) / 512), rng.standard_normal(512)]).astype(np.float32)
+    re, im, mag = (torch.empty((2, 257), device="cuda") for _ in range(3))
+    assert lib.nsc_rfft512(dev(sig).data_ptr(), 2, re.data_ptr(), im.data_ptr(), mag.data_ptr(), _st()) == 0
+    st, m = O.tf_stft(sig)
+    assert abs(float(mag[0, 5]) - 256.0) < 1e-3
+    assert_close(re.cpu().numpy(), st.real, what="rfft re")
+    assert_close(im.cpu().numpy(), st.imag, what="rfft im")
+    assert_close(mag.cpu().numpy(), m, what="rfft mag")
+
+
+def test_adam_tf1(lib):
+    rng = np.random.default_rng(19)
+    n = 10007
+    p = rng.standard_normal(n).astype(np.float32)
+    pd = dev(p); m = torch.zeros(n, device="cuda"); v = torch.zeros(n, device="cuda")
+    pr, mr, vr = p.astype(np.float64), np.zeros(n), np.zeros(n)
+    for t in range(1, 4):
+        g = rng.standard_normal(n).astype(np.float32)
+        g[::7] = 0.0
+        assert lib.nsc_adam_tf1_step(pd.data_ptr(), dev(g).data_ptr(), m.data_ptr(), v.data_ptr(), n, 2e-4, 0.9, 0.999, 1e-8, t, None, _st()) == 0
+        pr, mr, vr = O.adam_tf1_step(pr, g.astype(np.float64), mr, vr, t, 2e-4)
+    assert np.max(np.abs(pd.cpu().numpy() - pr)) < 2e-7
+    z = dev(np.ones(4)); mz = torch.zeros(4, device="cuda"); vz = torch.zeros(4, device="cuda")
+    assert lib.nsc_adam_tf1_step(z.data_ptr(), torch.zeros(4, device="cuda").data_ptr(), mz.data_ptr(), vz.data_ptr(), 4, 1e-3, 0.9, 0.999, 1e-8, 1, None, _st()) == 0
+    assert np.array_equal(z.cpu().numpy(), np.ones(4, np.float32))      # zero gradient must not move a variable
+
+
+def test_framing_and_overlap_add(lib):
+    rng = np.random.default_rng(23)
+    for n in (513, 993, 2000, 16000):
+        utt = rng.standard_normal(n).astype(np.float32)
+        ref = O.utterance_to_segment(utt.astype(np.float64), True)
+        nf = ref.shape[0]
+        fr = torch.empty((nf, 512), device="cuda")
+        assert lib.nsc_frame_utterance(dev(utt).data_ptr(), n, None, fr.data_ptr(), nf, _st()) == 0
+        assert np.array_equal(fr.cpu().numpy(), ref.astype(np.float32))   # bit-exact frame indexing
+        win = O.training_window().astype(np.float32)
+        assert lib.nsc_frame_utterance(dev(utt).data_ptr(), n, dev(win).data_ptr(), fr.data_ptr(), nf, _st()) == 0
+        assert np.array_equal(fr.cpu().numpy(), utt_frames_win(utt, win, nf))
+        win3 = np.stack([O.hann_process(np.ones(512), 0, 3), O.hann_process(np.ones(512), 1, 3), O.hann_process(np.ones(512), 2, 3)]).astype(np.float32)
+        out = torch.empty(480 * (nf - 1) + 512, device="cuda")
+        frames = rng.standard_normal((nf, 512)).astype(np.float32)
+        assert lib.nsc_overlap_add(dev(frames).data_ptr(), nf, dev(win3).data_ptr(), out.data_ptr(), _st()) == 0
+        assert_close(out.cpu().numpy(), O.overlap_add(frames.astype(np.float64)), tol=1e-6, what=f"overlap_add n={n}")
+
+
+def utt_frames_win(utt, win, nf):
+    return np.stack([utt[480 * i:480 * i + 512] * win for i in range(nf)]).astype(np.float32)
+
+
+def test_bad_arguments_return_status(lib):
+    d = _desc(B=0)
+    assert lib.nsc_conv1d_fwd(C.byref(d), None, None, None, None, None, None, None) == -1
+    assert b"desc" in lib.nsc_last_error() or b"size" in lib.nsc_last_error()
+    assert lib.nsc_quantize_fwd(None, None, None, 1.0, 1, 1, 1, 1, None, None, None, None, None) == -1
+    assert lib.nsc_adam_tf1_step(None, None, None, None, 0, 0.0, 0.9, 0.999, 1e-8, 1, None, None) == -1
