@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py - headline benchmark of the NSC/CMRL hot path on MI355X.
+
+Metric (BASELINE.json): 512-sample frames/s of one full train step (forward + losses + backward + TF1 Adam
+[+ gradient all-reduce]) of the 2-codec CMRL cascade.  Workload = BASELINE config 3 (the north-star step):
+2 codecs, strides [2] each (256 codes/frame, 32 bins), LPC-residual input fed as a tensor, 16x256-bin LSF
+quantizer, joint "finetune_lpc" step (all scopes trainable, cmrl.py:392-511), batch 128 frames per GPU,
+synthetic 16 kHz frames.  A "step" = one optimizer step over one batch resident in HBM.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (the MFMA implicit-GEMM conv), timed
+live with HIP events on the launch stream over extra instrumented steps of the same workload; `cpu_baseline`
+times the float32 PyTorch-CPU oracle (a port of the reference TF graph - TF itself is not installable) on a
+bounded sample on rank 0 at N=1.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+BKD = [9, 9, 100, 20, 1, 2]
+COEFF = [60.0, 10.0, 10.0, 0.0]          # --coeff_term '60 10 10 0' (README of the reference)
+LR = 2e-4
+RES_SCALAR = 1.0
+MFLOP_PER_FRAME_JOINT = 1428.2           # 2 codecs x 3 x 238.04 MFLOP
+PEAK_F32_MFMA_TFLOPS = 157.3             # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 (exact fp32)
+
+
+def synth_batch(B, rank, device):
+    """frames 0.03*N(0,1) clipped to [-1,1] times the training window; LSF inputs sorted U(0.03,3.1)."""
+    rng = np.random.default_rng(1234 + rank)
+    o = 32
+    win = np.concatenate([np.hanning(2 * o - 1)[:o], np.ones(512 - 2 * o), np.hanning(2 * o - 1)[o - 1:]])
+    x = (np.clip(0.03 * rng.standard_normal((B, 1, 512)), -1, 1) * win[None, None, :]).astype(np.float32)
+    lpc = np.sort(rng.uniform(0.03, 3.1, (B, 16, 1)), axis=1).astype(np.float32)
+    return torch.from_numpy(x).to(device), torch.from_numpy(lpc).to(device), x, lpc
+
+
+def step_cfg():
+    return dict(is_quan_on=1.0, c_time=COEFF[0], c_freq=COEFF[1], c_quan=[COEFF[2], COEFF[2]], c_ent=[0.0, 0.0],
+                trainable=[True, True], lr=LR, slot=1, c_quan_lpc=COEFF[2], c_ent_lpc=0.0)
+
+
+def cpu_baseline(B, x_np, lpc_np, steps=2):
+    """float32 PyTorch-CPU port of the same joint step (oracle/nsc_oracle_torch.py), all host cores."""
+    from oracle import nsc_oracle_torch as OT
+    from tests._util import make_store
+    ps = make_store(2, [[2], [2]], [32, 32], rand_bias=False, alpha=None, lpc=True)
+    tp = OT.TorchParams(ps, dtype=torch.float32)
+    plist = [tp.t[k] for k in tp.names]
+    ms = [torch.zeros_like(p) for p in plist]
+    vs = [torch.zeros_like(p) for p in plist]
+    x = torch.tensor(np.ascontiguousarray(x_np.transpose(0, 2, 1)))
+    lpc = torch.tensor(lpc_np)
+
+    def one(t):
+        for p in plist:
+            p.grad = None
+        outs, dec = OT.cascade_forward(x, tp, BKD, [[2], [2]], 1.0, True, RES_SCALAR, True)
+        pl, _ = OT.scalar_softmax_quantization(lpc, tp.t["lpc_quan/alpha"], tp.t["lpc_quan/bins"], 1.0, True)
+        OT.total_loss_sum(dec, x[:, :, 0], [o["p"] for o in outs], COEFF, 0.0, "finetune_lpc", (pl,)).backward()
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in plist]
+        OT.adam_tf1_step_(plist, grads, ms, vs, t, LR)
+
+    one(1)
+    t0 = time.perf_counter()
+    for t in range(steps):
+        one(t + 2)
+    dt = time.perf_counter() - t0
+    return dict(value=B * steps / dt, unit="frames/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{steps} joint train steps of the same 2-codec CMRL config, batch {B}, float32 PyTorch-CPU "
+                       f"restatement of the reference TF graph ({dt:.1f} s)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=128, help="frames per GPU (BASELINE: 128)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--prof-steps", type=int, default=3)
+    args = ap.parse_args()
+
+    from nsc_amd.dist import Comm
+    from nsc_amd.engine import CascadeEngine
+    comm = Comm()
+    assert comm.world == args.gpus or comm.world == 1, f"WORLD_SIZE {comm.world} != --gpus {args.gpus}"
+    if args.gpus > 1 and comm.world == 1:
+        raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    torch.cuda.set_device(comm.local_rank)
+    dev = torch.device("cuda", comm.local_rank)
+    B = args.batch
+    eng = CascadeEngine(B, 2, BKD, [[2], [2]], [32, 32], res_scalar=RES_SCALAR, scale_first=True, lpc=True, device=dev)
+    xd, lpcd, x_np, lpc_np = synth_batch(B, comm.rank, dev)
+    cfg = step_cfg()
+    dcomm = comm if comm.world > 1 else None
+
+    def step():
+        eng.train_step(xd, xd, cfg, lpc_x=lpcd, comm=dcomm)
+
+    use_graph = (not args.no_graph) and comm.world == 1
+    graph = None
+    n_warm_eager = max(1, min(args.warmup, 2)) if use_graph else args.warmup
+    for _ in range(n_warm_eager):
+        step()
+    torch.cuda.synchronize()
+    if use_graph:
+        try:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                step()
+            torch.cuda.current_stream().wait_stream(s)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=s):
+                step()
+        except Exception as ex:  # fall back to eager launches, say so in the JSON
+            print(f"[bench] hipGraph capture failed ({type(ex).__name__}: {ex}); running eagerly", file=sys.stderr)
+            graph = None
+        for _ in range(max(0, args.warmup - n_warm_eager)):
+            graph.replay() if graph is not None else step()
+    run = (graph.replay if graph is not None else step)
+
+    comm.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    torch.cuda.synchronize()
+    comm.barrier()
+    dt = comm.max_float(time.perf_counter() - t0, dev)
+    fps = comm.world * B * args.steps / dt
+
+    # ---- roofline of the dominant kernel: per-launch HIP events on extra (eager) steps of the same workload ----
+    eng.prof = []
+    for _ in range(args.prof_steps):
+        step()
+    torch.cuda.synchronize()
+    summ = eng.prof_summary()
+    eng.prof = None
+    roof = None
+    if "conv_mfma" in summ:
+        n, ms, fl = summ["conv_mfma"]
+        ach = fl / (ms * 1e-3) / 1e12
+        roof = dict(bound="mfma", kernel="conv1d_fwd_kernel (fwd + dgrad launches)", achieved=round(ach, 3),
+                    peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
+                    launches_per_step=n // args.prof_steps, avg_launch_us=round(1e3 * ms / n, 2),
+                    flop_per_launch_avg=fl / n)
+    kern_ms = {k: round(v[1] / args.prof_steps, 3) for k, v in summ.items()}
+
+    cpu = None
+    if comm.rank == 0 and comm.world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(B, x_np, lpc_np)
+
+    if comm.rank == 0:
+        out = {
+            "metric": "512-sample frames/s train step (2-codec CMRL)", "value": round(fps, 1), "unit": "frames/s",
+            "n_gpus": comm.world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE config 3: 2-codec CMRL (strides [2], 32 bins) on fed LPC residual + 16x256 "
+                                   "LSF quantizer, joint finetune step, fwd+loss+bwd+TF1-Adam" +
+                                   ("+RCCL grad all-reduce(sum)" if comm.world > 1 else ""),
+                       "batch_per_gpu": B, "global_batch": B * comm.world, "frame": 512,
+                       "parallelism": f"dp{comm.world}", "launch": "hipGraph" if graph is not None else "eager"},
+            "model_tflops": round(fps * MFLOP_PER_FRAME_JOINT * 1e6 / 1e12, 2),
+            "roofline": roof, "cpu_baseline": cpu, "conv_ms_per_step_by_kernel": kern_ms,
+        }
+        print(json.dumps(out))
+    comm.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -92,12 +92,18 @@ class _Conv:
             setattr(d, k, v)
         return d
 
+    def flops(self):
+        """Algorithmic FLOPs of one pass over this layer (2*MAC), identical for fwd, dgrad and wgrad."""
+        return 2.0 * self.eng.B * self.Tout * self.Cout * self.K * self.Cin
+
     def fwd(self, x, y, act="none", res=None, res_mode=0, out_mode=0):
         e = self.eng
         d = self.desc(act=KIND_ACT[act], res_mode=res_mode, out_mode=out_mode)
         fn = e.lib.nsc_conv1d_cout1_fwd if self.Cout == 1 else e.lib.nsc_conv1d_fwd
+        tok = e.prof_begin("conv_cout1" if self.Cout == 1 else "conv_mfma", self.flops())
         check(fn(C.byref(d), x.data_ptr(), self._p(e.p_ptr, self.w_off), self._p(e.p_ptr, self.b_off),
                  _lib.ptr(res), None, y.data_ptr(), e.stream()), f"conv fwd {self.name}")
+        e.prof_end(tok)
 
     def dgrad(self, dz, dx, res=None, res_mode=0, mul_kind="none", aux=None):
         """dx = conv^T(dz) (+res) (* act'(aux)); runs the forward kernel on the flipped/transposed weights."""
@@ -107,12 +113,20 @@ class _Conv:
                      stride=1, padL=padl, act=0, res_mode=res_mode, mul_mode=KIND_MUL[mul_kind], out_mode=0,
                      in_up=1 if self.stride == 2 else 0, accumulate=0)
         fn = e.lib.nsc_conv1d_cout1_fwd if self.Cin == 1 else e.lib.nsc_conv1d_fwd
+        tok = e.prof_begin("conv_cout1" if self.Cin == 1 else "conv_mfma", self.flops())
         check(fn(C.byref(d), dz.data_ptr(), self._p(e.wt_ptr, self.w_off), None, _lib.ptr(res),
                  _lib.ptr(aux) if mul_kind != "none" else None, dx.data_ptr(), e.stream()), f"conv dgrad {self.name}")
+        e.prof_end(tok)
 
     def wgrad(self, x, dz):
         e = self.eng
         dw, db = self._p(e.g_ptr, self.w_off), self._p(e.g_ptr, self.b_off)
+        tok = e.prof_begin("wgrad_mfma", self.flops())
+        self._wgrad(x, dz, dw, db)
+        e.prof_end(tok)
+
+    def _wgrad(self, x, dz, dw, db):
+        e = self.eng
         if self.Cout == 1:
             # swap roles (SURVEY/DESIGN): "input" = dz (1 channel), "grad" = x (Cin channels); flipped taps
             assert self.stride == 1
@@ -397,7 +411,8 @@ class CascadeEngine:
             idx[c.w_off:c.w_off + c.K * c.Cin * c.Cout] = c.wt_index()
         self.wt_idx = torch.from_numpy(idx).to(self.device)
         # two Adam slot sets (no-quan op / quan op) with independent state (nsc_module:922-926)
-        self.adam = [dict(m=torch.zeros(n, **f32), v=torch.zeros(n, **f32), t=0) for _ in range(2)]
+        self.adam = [dict(m=torch.zeros(n, **f32), v=torch.zeros(n, **f32), t=0,
+                          t_dev=torch.zeros(1, dtype=torch.int32, device=self.device)) for _ in range(2)]
         mel = mel_matrix_cat().astype(np.float32)
         self.mel = torch.from_numpy(mel).to(self.device).contiguous()
         self.melT = torch.from_numpy(np.ascontiguousarray(mel.T)).to(self.device)
@@ -406,6 +421,29 @@ class CascadeEngine:
     # ---- plumbing ----
     def stream(self):
         return torch.cuda.current_stream().cuda_stream
+
+    # per-launch HIP-event timing of the conv kernels (bench.py roofline); events sit on the launch stream
+    prof = None
+
+    def prof_begin(self, tag, flops):
+        if self.prof is None:
+            return None
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        return (tag, flops, a, b)
+
+    def prof_end(self, tok):
+        if tok is not None:
+            tok[3].record()
+            self.prof.append(tok)
+
+    def prof_summary(self):
+        """tag -> (launches, total ms, total algorithmic FLOPs); call after torch.cuda.synchronize()."""
+        out = {}
+        for tag, fl, a, b in self.prof or []:
+            n, ms, f = out.get(tag, (0, 0.0, 0.0))
+            out[tag] = (n + 1, ms + a.elapsed_time(b), f + fl)
+        return out
 
     def buf(self, name, shape):
         t = self._bufs.get(name)
@@ -571,13 +609,35 @@ class CascadeEngine:
     def adam_step(self, scopes, lr, slot=1, beta1=0.9, beta2=0.999, eps=1e-8):
         """TF1 Adam on the flat ranges of the given scopes (independent state per optimizer slot)."""
         st = self.adam[slot]
-        st["t"] += 1
+        st["t"] += 1   # host mirror; the kernel reads the device counter so a captured graph stays valid
+        check(self.lib.nsc_increment(st["t_dev"].data_ptr(), self.stream()), "increment")
         for sc in scopes:
             a, b = self.layout.scope_range(sc)
             check(self.lib.nsc_adam_tf1_step(self.p_ptr + 4 * a, self.g_ptr + 4 * a, st["m"].data_ptr() + 4 * a,
                                              st["v"].data_ptr() + 4 * a, b - a, float(lr), beta1, beta2, eps, st["t"],
-                                             None, self.stream()), "adam")
+                                             st["t_dev"].data_ptr(), self.stream()), "adam")
 
     def reset_adam(self):
         for st in self.adam:
-            st["m"].zero_(); st["v"].zero_(); st["t"] = 0
+            st["m"].zero_(); st["v"].zero_(); st["t_dev"].zero_(); st["t"] = 0
+
+    def train_step(self, x, target, cfg, lpc_x=None, comm=None):
+        """One optimizer step (nsc_module:455-458 sess.run(trainop)): zero grads, refresh dgrad weights, forward,
+        losses, backward, [gradient all-reduce], TF1 Adam.  cfg: dict(is_quan_on, c_time, c_freq, c_quan, c_ent,
+        trainable, lr, slot, c_quan_lpc, c_ent_lpc).  comm: nsc_amd.dist.Comm or None."""
+        self.grads.zero_()
+        self.refresh_wt()
+        self.forward(x, cfg["is_quan_on"], True, lpc_x=lpc_x)
+        gb = self.B * (comm.world if comm else 1)
+        terms = self.loss_backward(target, cfg["c_time"], cfg["c_freq"], cfg["c_quan"], cfg["c_ent"], cfg["trainable"],
+                                   c_quan_lpc=cfg.get("c_quan_lpc", 0.0), c_ent_lpc=cfg.get("c_ent_lpc", 0.0),
+                                   global_batch=gb,
+                                   hist_allreduce=(comm.allreduce_list if comm and cfg.get("global_entropy", True) and
+                                                   any(c != 0.0 for c in cfg["c_ent"]) else None))
+        if comm:
+            comm.allreduce(self.grads)   # SUM, not mean: the reference's vector loss sums over the batch (a18)
+        scopes = [f"scope_{i + 1}" for i, t in enumerate(cfg["trainable"]) if t]
+        if self.lpc and (cfg.get("c_quan_lpc", 0.0) != 0.0 or cfg.get("c_ent_lpc", 0.0) != 0.0):
+            scopes = ["lpc_quan"] + scopes
+        self.adam_step(scopes, cfg["lr"], cfg.get("slot", 1))
+        return terms

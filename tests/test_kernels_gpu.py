@@ -30,6 +30,20 @@ def _st():
     return torch.cuda.current_stream().cuda_stream
 
 
+_KEEP = []
+
+
+def P(a):
+    """Upload a host array and return its device pointer; the tensor is kept alive until the test module ends
+    (a temporary's memory could be recycled by the caching allocator before the asynchronous kernel runs)."""
+    t = a if isinstance(a, torch.Tensor) else dev(a)
+    _KEEP.append(t)
+    if len(_KEEP) > 256:
+        torch.cuda.synchronize()
+        del _KEEP[:128]
+    return t.data_ptr()
+
+
 ACT = {"none": 0, "tanh": 1, "lrelu": 2}
 
 CONV_CASES = [
@@ -89,7 +103,7 @@ def test_conv1d_fwd_generic_kernel_with_cout1(lib):
     ref = O.conv1d(x, W, None, 2, 1, None)
     y = torch.empty((B, 1, T), device="cuda")
     d = _desc(B=B, Cin=Cin, Cout=1, Tin=T, Tout=T, K=K, dil=2, padL=14)
-    assert lib.nsc_conv1d_fwd(C.byref(d), dev(x.transpose(0, 2, 1)).data_ptr(), dev(W).data_ptr(), None, None, None,
+    assert lib.nsc_conv1d_fwd(C.byref(d), P(x.transpose(0, 2, 1)), P(W), None, None, None,
                               y.data_ptr(), _st()) == 0
     assert_close(y.cpu().numpy().transpose(0, 2, 1), ref, what="generic cout1")
 
@@ -104,7 +118,7 @@ def test_conv1d_shuffle_and_mul_epilogues(lib):
     y = torch.empty((B, C_ // 2, 2 * T), device="cuda")
     d = _desc(B=B, Cin=C_, Cout=C_, Tin=T, Tout=T, K=1, act=2, out_mode=1)
     xd = dev(x.transpose(0, 2, 1))
-    assert lib.nsc_conv1d_fwd(C.byref(d), xd.data_ptr(), dev(W).data_ptr(), dev(b).data_ptr(), None, None,
+    assert lib.nsc_conv1d_fwd(C.byref(d), xd.data_ptr(), P(W), P(b), None, None,
                               y.data_ptr(), _st()) == 0
     assert_close(y.cpu().numpy().transpose(0, 2, 1), ref, what="shuffle epilogue")
     # unshuffle is the inverse permutation
@@ -116,8 +130,8 @@ def test_conv1d_shuffle_and_mul_epilogues(lib):
     for mode, g in ((1, np.where(aux > 0, 1.0, 0.2)), (2, 1 - aux.astype(np.float64) ** 2)):
         d = _desc(B=B, Cin=C_, Cout=C_, Tin=T, Tout=T, K=1, mul_mode=mode)
         y2 = torch.empty((B, C_, T), device="cuda")
-        assert lib.nsc_conv1d_fwd(C.byref(d), xd.data_ptr(), dev(W).data_ptr(), dev(b).data_ptr(), None,
-                                  dev(aux.transpose(0, 2, 1)).data_ptr(), y2.data_ptr(), _st()) == 0
+        assert lib.nsc_conv1d_fwd(C.byref(d), xd.data_ptr(), P(W), P(b), None,
+                                  P(aux.transpose(0, 2, 1)), y2.data_ptr(), _st()) == 0
         assert_close(y2.cpu().numpy().transpose(0, 2, 1), O.conv1d(x, W, b, 1, 1, None) * g, what=f"mul_mode {mode}")
 
 
@@ -199,7 +213,7 @@ def test_glue_kernels(lib):
     assert_close(g.cpu().numpy(), a[:, :20] * th, what="gate fwd")
     dg = rng.standard_normal((2, 20, 128)).astype(np.float32)
     da = torch.empty((2, 40, 128), device="cuda")
-    assert lib.nsc_gate_bwd(ad.data_ptr(), dev(dg).data_ptr(), da.data_ptr(), 2, 20, 128, _st()) == 0
+    assert lib.nsc_gate_bwd(ad.data_ptr(), P(dg), da.data_ptr(), 2, 20, 128, _st()) == 0
     assert_close(da.cpu().numpy()[:, :20], dg * th, what="gate bwd lin")
     assert_close(da.cpu().numpy()[:, 20:], dg * a[:, :20] * (1 - th ** 2), what="gate bwd gate")
     lin, t2 = dev(a[:, :20]), dev(th)
@@ -207,7 +221,7 @@ def test_glue_kernels(lib):
     assert lib.nsc_mul(lin.data_ptr(), t2.data_ptr(), gg.data_ptr(), gg.numel(), _st()) == 0
     assert_close(gg.cpu().numpy(), a[:, :20] * th, what="mul")
     d1, d2 = torch.empty_like(gg), torch.empty_like(gg)
-    assert lib.nsc_glu_bwd(lin.data_ptr(), t2.data_ptr(), dev(dg).data_ptr(), d1.data_ptr(), d2.data_ptr(), gg.numel(), _st()) == 0
+    assert lib.nsc_glu_bwd(lin.data_ptr(), t2.data_ptr(), P(dg), d1.data_ptr(), d2.data_ptr(), gg.numel(), _st()) == 0
     assert_close(d1.cpu().numpy(), dg * th, what="glu dlin")
     assert_close(d2.cpu().numpy(), dg * a[:, :20] * (1 - th ** 2), what="glu dgate")
     x, y = dev(a), dev(2 * a + 1)
@@ -268,8 +282,8 @@ def test_quantizer_fwd_bwd(lib, case):
     assert abs(float(e) - float(ent)) < 1e-4 * max(1.0, abs(float(ent)))
     dc = torch.full((B, L, 1), float("nan"), device="cuda")
     da = torch.zeros(1, device="cuda"); db = torch.zeros(nb, device="cuda")
-    rc = lib.nsc_quantize_bwd(cd.data_ptr(), ad.data_ptr(), bd.data_ptr(), on, int(soft), B, L, nb, dev(dout).data_ptr(),
-                              dev(dp).data_ptr(), c_quan, gh.data_ptr(), tau_scale, 0, dc.data_ptr(), da.data_ptr(),
+    rc = lib.nsc_quantize_bwd(cd.data_ptr(), ad.data_ptr(), bd.data_ptr(), on, int(soft), B, L, nb, P(dout),
+                              P(dp), c_quan, gh.data_ptr(), tau_scale, 0, dc.data_ptr(), da.data_ptr(),
                               db.data_ptr(), _st())
     assert rc == 0, lib.nsc_last_error()
     assert_close(dc.cpu().numpy(), ct.grad.numpy(), tol=2e-4, what="dcode")
@@ -290,7 +304,7 @@ def test_quantizer_identity_and_nearest_bin(lib):
     idx = np.argmin(np.abs(code.astype(np.float64) - bins.astype(np.float64)), axis=-1)
     assert np.array_equal(od.cpu().numpy()[..., 0], bins[idx])          # hard: exact bin values, exact indices
     # tie -> lowest index
-    assert lib.nsc_quantize_fwd(dev(np.array([[[0.5]]])).data_ptr(), ad.data_ptr(), dev(np.array([0.0, 1.0, 2.0, 3.0])).data_ptr(),
+    assert lib.nsc_quantize_fwd(P(np.array([[[0.5]]])), ad.data_ptr(), P(np.array([0.0, 1.0, 2.0, 3.0])),
                                 1.0, 0, 1, 1, 4, None, od.data_ptr(), None, None, _st()) == 0
     assert float(od.reshape(-1)[0]) == 0.0
 
@@ -310,7 +324,7 @@ def test_recon_loss_and_rfft(lib):
     md, mtd = dev(mel), dev(np.ascontiguousarray(mel.T))
     to, fo = torch.empty(B, device="cuda"), torch.empty(B, device="cuda")
     g = torch.empty((B, 512), device="cuda")
-    rc = lib.nsc_recon_loss(dev(dec).data_ptr(), dev(tgt).data_ptr(), B, 60.0, 10.0, None, None, md.data_ptr(),
+    rc = lib.nsc_recon_loss(P(dec), P(tgt), B, 60.0, 10.0, None, None, md.data_ptr(),
                             mtd.data_ptr(), to.data_ptr(), fo.data_ptr(), g.data_ptr(), _st())
     assert rc == 0, lib.nsc_last_error()
     assert_close(to.cpu().numpy(), tl.detach().numpy(), what="time loss")
@@ -319,7 +333,7 @@ def test_recon_loss_and_rfft(lib):
     # bare rFFT + cosine KAT
     sig = np.stack([np.cos(2 * np.pi * 5 * np.arange(512) / 512), rng.standard_normal(512)]).astype(np.float32)
     re, im, mag = (torch.empty((2, 257), device="cuda") for _ in range(3))
-    assert lib.nsc_rfft512(dev(sig).data_ptr(), 2, re.data_ptr(), im.data_ptr(), mag.data_ptr(), _st()) == 0
+    assert lib.nsc_rfft512(P(sig), 2, re.data_ptr(), im.data_ptr(), mag.data_ptr(), _st()) == 0
     st, m = O.tf_stft(sig)
     assert abs(float(mag[0, 5]) - 256.0) < 1e-3
     assert_close(re.cpu().numpy(), st.real, what="rfft re")
@@ -336,7 +350,7 @@ def test_adam_tf1(lib):
     for t in range(1, 4):
         g = rng.standard_normal(n).astype(np.float32)
         g[::7] = 0.0
-        assert lib.nsc_adam_tf1_step(pd.data_ptr(), dev(g).data_ptr(), m.data_ptr(), v.data_ptr(), n, 2e-4, 0.9, 0.999, 1e-8, t, None, _st()) == 0
+        assert lib.nsc_adam_tf1_step(pd.data_ptr(), P(g), m.data_ptr(), v.data_ptr(), n, 2e-4, 0.9, 0.999, 1e-8, t, None, _st()) == 0
         pr, mr, vr = O.adam_tf1_step(pr, g.astype(np.float64), mr, vr, t, 2e-4)
     assert np.max(np.abs(pd.cpu().numpy() - pr)) < 2e-7
     z = dev(np.ones(4)); mz = torch.zeros(4, device="cuda"); vz = torch.zeros(4, device="cuda")
@@ -351,15 +365,15 @@ def test_framing_and_overlap_add(lib):
         ref = O.utterance_to_segment(utt.astype(np.float64), True)
         nf = ref.shape[0]
         fr = torch.empty((nf, 512), device="cuda")
-        assert lib.nsc_frame_utterance(dev(utt).data_ptr(), n, None, fr.data_ptr(), nf, _st()) == 0
+        assert lib.nsc_frame_utterance(P(utt), n, None, fr.data_ptr(), nf, _st()) == 0
         assert np.array_equal(fr.cpu().numpy(), ref.astype(np.float32))   # bit-exact frame indexing
         win = O.training_window().astype(np.float32)
-        assert lib.nsc_frame_utterance(dev(utt).data_ptr(), n, dev(win).data_ptr(), fr.data_ptr(), nf, _st()) == 0
+        assert lib.nsc_frame_utterance(P(utt), n, P(win), fr.data_ptr(), nf, _st()) == 0
         assert np.array_equal(fr.cpu().numpy(), utt_frames_win(utt, win, nf))
         win3 = np.stack([O.hann_process(np.ones(512), 0, 3), O.hann_process(np.ones(512), 1, 3), O.hann_process(np.ones(512), 2, 3)]).astype(np.float32)
         out = torch.empty(480 * (nf - 1) + 512, device="cuda")
         frames = rng.standard_normal((nf, 512)).astype(np.float32)
-        assert lib.nsc_overlap_add(dev(frames).data_ptr(), nf, dev(win3).data_ptr(), out.data_ptr(), _st()) == 0
+        assert lib.nsc_overlap_add(P(frames), nf, P(win3), out.data_ptr(), _st()) == 0
         assert_close(out.cpu().numpy(), O.overlap_add(frames.astype(np.float64)), tol=1e-6, what=f"overlap_add n={n}")
 
 
