@@ -56,19 +56,18 @@ FP32_ERR = {}
 def _check_grads(eng, grads, scopes, tol=5e-4):
     """Per tensor: max |hip - f64| / max |f64| <= max(5e-4, 4 x the error of the float32 CPU oracle)."""
     mine = eng.named("grads")
-    worst = ("", 0.0)
+    fails = []
     for name, g in grads.items():
         if not any(name.startswith(s + "/") for s in scopes):
             continue
         a, b = mine[name].reshape(-1), np.asarray(g).reshape(-1)
         scale = max(np.max(np.abs(b)), 1e-6)
         err = np.max(np.abs(a - b)) / scale
-        if err > worst[1]:
-            worst = (name, err)
         assert np.all(np.isfinite(a)), name
         lim = max(tol, 4.0 * FP32_ERR.get(name, 0.0))
-        assert err <= lim, f"grad {name}: rel err {err:.3e} > {lim:.3e} (scale {scale:.3e}, cpu-fp32 err {FP32_ERR.get(name, 0):.3e})"
-    return worst
+        if err > lim:
+            fails.append(f"{name}: rel err {err:.3e} > {lim:.3e} (scale {scale:.3e}, cpu-fp32 err {FP32_ERR.get(name, 0):.3e})")
+    assert not fails, "gradient mismatches:\n" + "\n".join(fails)
 
 
 def test_single_codec_forward_matches_golden_and_oracle():
@@ -161,7 +160,10 @@ def test_two_codec_lpc_finetune():
     quan_loss, every codec scaled by res_scalar, no entropy term (cmrl.py:392-511)."""
     B = 2
     ps = make_store(2, [[2], [2]], [32, 32], lpc=True)
-    x = synth_frames(B)
+    # seed 1234 puts one pre-activation of codec 2's up-sampler at |z| ~ 1e-8, i.e. ON the leaky-relu kink: the
+    # float64 oracle and any float32 run may then legitimately pick different slopes for that element (measured:
+    # tests/debug_lpc.py).  Use a seed without such an element; kink handling itself is unit-tested per kernel.
+    x = synth_frames(B, seed=4321)
     rng = np.random.default_rng(3)
     lpc_x = np.sort(rng.uniform(0.03, 3.1, (B, 16, 1)), axis=1).astype(np.float32).astype(np.float64)
     coeff = [60.0, 10.0, 10.0, 0.0]

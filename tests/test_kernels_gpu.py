@@ -352,7 +352,7 @@ def test_adam_tf1(lib):
         g[::7] = 0.0
         assert lib.nsc_adam_tf1_step(pd.data_ptr(), P(g), m.data_ptr(), v.data_ptr(), n, 2e-4, 0.9, 0.999, 1e-8, t, None, _st()) == 0
         pr, mr, vr = O.adam_tf1_step(pr, g.astype(np.float64), mr, vr, t, 2e-4)
-    assert np.max(np.abs(pd.cpu().numpy() - pr)) < 2e-7
+    assert np.max(np.abs(pd.cpu().numpy() - pr)) < 1e-6   # p ~ N(0,1): a few fp32 ulps after 3 steps
     z = dev(np.ones(4)); mz = torch.zeros(4, device="cuda"); vz = torch.zeros(4, device="cuda")
     assert lib.nsc_adam_tf1_step(z.data_ptr(), torch.zeros(4, device="cuda").data_ptr(), mz.data_ptr(), vz.data_ptr(), 4, 1e-3, 0.9, 0.999, 1e-8, 1, None, _st()) == 0
     assert np.array_equal(z.cpu().numpy(), np.ones(4, np.float32))      # zero gradient must not move a variable
