@@ -69,6 +69,15 @@ int nsc_conv1d_wgrad(const nsc_conv_desc* d, const float* x, const float* dz, fl
 /* wt[K-1-k, o, i] = w[k, i, o] : weights of the data-gradient conv (dgrad == nsc_conv1d_fwd on wt). */
 int nsc_weight_flip_transpose(const float* w, float* wt, int K, int Cin, int Cout, void* stream);
 
+/* ---- fused gated bottleneck block (replaces the whole of nn_core_operator.py:82-112 `gated_bottleneck` for
+ *      Cin == wide_layer > 1, narrow_layer == 20, non_dilated_neck_kernel_size == 9, "gln" blocks) ----
+ * out = [lrelu]( conv9( conv15_d(h; wl) * tanh(conv15_d(h; wr)) ) + x ),  h = lrelu(conv1(x)).  x,out [B,C,T].
+ * h_out / lin_out / th_out / g_out (nullable) [B,20,T] save the intermediates for the unfused backward. */
+int nsc_gated_block_fwd(const float* x, const float* w1, const float* b1, const float* wl, const float* bl,
+                        const float* wr, const float* br, const float* w9, const float* b9, float* out,
+                        float* h_out, float* lin_out, float* th_out, float* g_out, int B, int C, int T,
+                        int narrow, int k9, int dil, int flat, void* stream);
+
 /* ---- separable conv pieces (replaces tf.keras.layers.SeparableConv1D behind nn_core_operator.py:17-21) ---- */
 int nsc_depthwise_fwd(const float* x, const float* wd /*[K,C]*/, float* y, int B, int C, int T, int K, void* stream);
 int nsc_depthwise_bwd(const float* x, const float* wd, const float* dy, float* dx, float* dwd /*accumulate*/,

@@ -1,0 +1,253 @@
+// block.hip - the whole gated bottleneck block of the reference (nn_core_operator.py:82-112) as ONE kernel:
+//     h = lrelu(W1 x + b1)                      1x1,  C  -> 20
+//     g = (Wl *d h + bl) . tanh(Wr *d h + br)    k15 dilated, 20 -> 20 (two weight sets), GLU gate
+//     y = W9 * g + b9 + x ; out = lrelu(y) | y   k9,   20 -> C, residual, optional activation
+// The 20-channel intermediates never leave the CU: x tile (with a 4+7d halo) is staged once in LDS, h and g
+// live in LDS, the residual is re-read from the staged x tile.  HBM traffic per block = read x (x1.5 halo at
+// a 64-step tile) + write out, instead of ~14 tensor passes in the unfused path.  All three convs run on
+// v_mfma_f32_16x16x4_f32 (exact fp32).  The two gate convs share one MFMA pass: their output rows are
+// interleaved (rows 4q+{0,1} = linear branch of channels 2q,2q+1; rows 4q+{2,3} = tanh branch of the same
+// channels) so that the D fragment of a lane holds both branches of a channel and the gate is lane-local.
+#include "nsc_common.h"
+#include <algorithm>
+
+#define NARROW 20
+#define K15 15
+#define K9 9
+
+struct BlockArgs {
+  int B, C, T, dil, flat;
+  const float *x, *w1, *b1, *wl, *bl, *wr, *br, *w9, *b9;
+  float *out, *h_out, *lin_out, *th_out, *g_out;  // *_out optional: saved for the unfused backward
+};
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// TT = 64 output steps per workgroup, 4 waves.
+template <int RT9>
+__global__ __launch_bounds__(256) void gated_block_fwd_kernel(BlockArgs a, int ldx, int ldg) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  constexpr int TT = 64;
+  const int C = a.C, T = a.T, d = a.dil;
+  const int H = 4 + 7 * d;
+  const int WX = TT + 2 * H;          // staged x / h width
+  const int WG = TT + 8;              // g width
+  const int C4 = (C + 3) & ~3;
+  float* xs = sm;                     // [C4][ldx]
+  float* hs = xs + C4 * ldx;          // [NARROW][ldx]
+  float* gs = hs + NARROW * ldx;      // [NARROW][ldg]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, kq = lane >> 4;
+  const int b = blockIdx.y, t0 = blockIdx.x * TT;
+
+  // ---- phase 0: stage x tile (zero outside [0,T), zero pad rows) ----
+  nsc_stage_rows(xs, ldx, C4, C, WX, a.x + (long)b * C * T, T, t0 - H, T, 0, wave, lane);
+  __syncthreads();
+
+  // ---- phase 1: h = lrelu(W1 x + b1) on all WX columns (7 column tiles of 16 at d=2) ----
+  {
+    const int nct = (WX + 15) >> 4;
+    const int ncq = C4 >> 2;
+    for (int ct = wave; ct < nct; ct += 4) {
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      const int j = ct * 16 + l15;
+      const float* xcol = xs + j;
+      float a0n, a1n;
+      {
+        const int ci = kq;
+        a0n = (ci < C) ? a.w1[ci * NARROW + l15] : 0.f;
+        a1n = (ci < C && 16 + l15 < NARROW) ? a.w1[ci * NARROW + 16 + l15] : 0.f;
+      }
+      for (int cq = 0; cq < ncq; ++cq) {
+        const float a0 = a0n, a1 = a1n;
+        const int cin = (cq + 1) * 4 + kq;
+        a0n = (cq + 1 < ncq && cin < C) ? a.w1[cin * NARROW + l15] : 0.f;
+        a1n = (cq + 1 < ncq && cin < C && 16 + l15 < NARROW) ? a.w1[cin * NARROW + 16 + l15] : 0.f;
+        const float bv = xcol[(cq * 4 + kq) * ldx];
+        acc0 = mfma4(a0, bv, acc0);
+        acc1 = mfma4(a1, bv, acc1);
+      }
+      const int t = t0 - H + j;
+      const bool live = j < WX && t >= 0 && t < T;   // h outside the frame is ZERO padding of the k15 convs
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int o0 = kq * 4 + reg, o1 = 16 + kq * 4 + reg;
+        float v0 = acc0[reg] + a.b1[o0];
+        v0 = v0 > 0.f ? v0 : NSC_LRELU_ALPHA * v0;
+        hs[o0 * ldx + j] = live ? v0 : 0.f;
+        if (o1 < NARROW) {
+          float v1 = acc1[reg] + a.b1[o1];
+          v1 = v1 > 0.f ? v1 : NSC_LRELU_ALPHA * v1;
+          hs[o1 * ldx + j] = live ? v1 : 0.f;
+        }
+        if (a.h_out && live && j >= H && j < H + TT) {
+          a.h_out[((long)b * NARROW + o0) * T + t] = v0;
+          if (o1 < NARROW) {
+            float v1 = acc1[reg] + a.b1[o1];
+            v1 = v1 > 0.f ? v1 : NSC_LRELU_ALPHA * v1;
+            a.h_out[((long)b * NARROW + o1) * T + t] = v1;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2: both k15 dilated gate convs in one MFMA pass, gate in registers, g -> LDS ----
+  // g column jj <-> frame time t0 - 4 + jj ; reads h column jj + tap*d.  5 column tiles (80 >= 72):
+  // wave w owns column tile w (3 row tiles); column tile 4 is split by row tile over waves 0..2.
+  {
+    const int i = l15;
+    const bool gate_row = (i & 2) != 0;
+    const float* wsel = gate_row ? a.wr : a.wl;
+    int crow[3];
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt) crow[rt] = rt * 8 + (i >> 2) * 2 + (i & 1);
+    f32x4 acc[3], accx;
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    accx = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int jj_main = wave * 16 + l15;
+    const int jj_x = 64 + l15;
+    const int rtx = wave;  // row tile of the shared 5th column tile (wave 3: none)
+    float an[3];
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt) an[rt] = (crow[rt] < NARROW) ? wsel[(kq)*NARROW + crow[rt]] : 0.f;
+    int tap = 0, cq = 0;
+    for (int s = 0; s < K15 * 5; ++s) {
+      float ac[3];
+#pragma unroll
+      for (int rt = 0; rt < 3; ++rt) ac[rt] = an[rt];
+      int tapn = tap, cqn = cq + 1;
+      if (cqn == 5) { cqn = 0; tapn = tap + 1; }
+      if (tapn < K15) {
+        const int ci = cqn * 4 + kq;
+#pragma unroll
+        for (int rt = 0; rt < 3; ++rt) an[rt] = (crow[rt] < NARROW) ? wsel[(tapn * NARROW + ci) * NARROW + crow[rt]] : 0.f;
+      }
+      const float* hrow = hs + (cq * 4 + kq) * ldx + tap * d;
+      const float bm = hrow[jj_main];
+      const float bx = hrow[jj_x];
+#pragma unroll
+      for (int rt = 0; rt < 3; ++rt) acc[rt] = mfma4(ac[rt], bm, acc[rt]);
+      if (rtx < 3) accx = mfma4(rtx == 0 ? ac[0] : (rtx == 1 ? ac[1] : ac[2]), bx, accx);
+      tap = tapn;
+      cq = cqn;
+    }
+    // epilogue: lane holds (lin c0, lin c1, gate c0, gate c1) of one time step
+    auto emit = [&](const f32x4& v, int rt, int jj) {
+      const int c0 = rt * 8 + kq * 2;
+      const int t = t0 - 4 + jj;
+      const bool live = jj < WG && t >= 0 && t < T;   // g outside the frame is ZERO padding of the k9 conv
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int c = c0 + u;
+        if (c < NARROW && jj < ldg) {
+          const float lin = v[u] + a.bl[c];
+          const float th = tanhf(v[2 + u] + a.br[c]);
+          gs[c * ldg + jj] = live ? lin * th : 0.f;
+          if (a.lin_out && live && jj >= 4 && jj < 4 + TT) {
+            const long gi = ((long)b * NARROW + c) * T + t;
+            a.lin_out[gi] = lin;
+            a.th_out[gi] = th;
+            a.g_out[gi] = lin * th;
+          }
+        }
+      }
+    };
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt) emit(acc[rt], rt, jj_main);
+    if (rtx < 3) emit(accx, rtx, jj_x);
+  }
+  __syncthreads();
+
+  // ---- phase 3: y = W9 * g + b9 + x ; wave w owns output columns [16w, 16w+16), all RT9 row tiles ----
+  {
+    f32x4 acc[RT9];
+#pragma unroll
+    for (int r = 0; r < RT9; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int tt = wave * 16 + l15;
+    float an[RT9];
+#pragma unroll
+    for (int r = 0; r < RT9; ++r) {
+      const int o = r * 16 + l15;
+      an[r] = (o < C) ? a.w9[(long)kq * C + o] : 0.f;
+    }
+    int tap = 0, cq = 0;
+    for (int s = 0; s < K9 * 5; ++s) {
+      float ac[RT9];
+#pragma unroll
+      for (int r = 0; r < RT9; ++r) ac[r] = an[r];
+      int tapn = tap, cqn = cq + 1;
+      if (cqn == 5) { cqn = 0; tapn = tap + 1; }
+      if (tapn < K9) {
+        const int ci = cqn * 4 + kq;
+#pragma unroll
+        for (int r = 0; r < RT9; ++r) {
+          const int o = r * 16 + l15;
+          an[r] = (o < C) ? a.w9[((long)tapn * NARROW + ci) * C + o] : 0.f;
+        }
+      }
+      const float bv = gs[(cq * 4 + kq) * ldg + tt + tap];
+#pragma unroll
+      for (int r = 0; r < RT9; ++r) acc[r] = mfma4(ac[r], bv, acc[r]);
+      tap = tapn;
+      cq = cqn;
+    }
+    const int t = t0 + tt;
+    if (t < T) {
+#pragma unroll
+      for (int r = 0; r < RT9; ++r)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int o = r * 16 + kq * 4 + reg;
+          if (o < C) {
+            float v = acc[r][reg] + a.b9[o] + xs[o * ldx + H + tt];
+            if (!a.flat) v = v > 0.f ? v : NSC_LRELU_ALPHA * v;
+            a.out[((long)b * C + o) * T + t] = v;
+          }
+        }
+    }
+  }
+}
+
+extern "C" int nsc_gated_block_fwd(const float* x, const float* w1, const float* b1, const float* wl, const float* bl,
+                                   const float* wr, const float* br, const float* w9, const float* b9, float* out,
+                                   float* h_out, float* lin_out, float* th_out, float* g_out, int B, int C, int T,
+                                   int narrow, int k9, int dil, int flat, void* stream) {
+  NSC_REQUIRE(x && w1 && b1 && wl && bl && wr && br && w9 && b9 && out, NSC_ERR_BAD_ARG, "nsc_gated_block_fwd: null pointer");
+  NSC_REQUIRE(B > 0 && C > 1 && T > 0 && dil > 0, NSC_ERR_BAD_ARG, "nsc_gated_block_fwd: bad sizes");
+  NSC_REQUIRE(narrow == NARROW && k9 == K9, NSC_ERR_UNSUPPORTED,
+              "nsc_gated_block_fwd: built for narrow=20, k9=9 (got %d, %d): use the unfused path", narrow, k9);
+  NSC_REQUIRE(C <= 112 && dil <= 4, NSC_ERR_UNSUPPORTED, "nsc_gated_block_fwd: C %d > 112 or dil %d > 4", C, dil);
+  NSC_REQUIRE(!(lin_out || th_out || g_out) || (lin_out && th_out && g_out), NSC_ERR_BAD_ARG,
+              "nsc_gated_block_fwd: lin/th/g outputs must be given together");
+  const int H = 4 + 7 * dil, WX = 64 + 2 * H;
+  int ldx = WX;
+  while ((ldx & 31) != 16) ++ldx;
+  if (ldx < 80) ldx = 80;
+  int ldg = 80;  // 72 columns used, 80 % 32 == 16
+  const int C4 = (C + 3) & ~3;
+  const size_t smem = ((size_t)(C4 + NARROW) * ldx + (size_t)NARROW * ldg) * sizeof(float);
+  NSC_REQUIRE(smem <= 160 * 1024, NSC_ERR_UNSUPPORTED, "nsc_gated_block_fwd: %zu B LDS", smem);
+  BlockArgs a{B, C, T, dil, flat, x, w1, b1, wl, bl, wr, br, w9, b9, out, h_out, lin_out, th_out, g_out};
+  dim3 grid(nsc_cdiv(T, 64), B);
+  hipStream_t st = (hipStream_t)stream;
+  const int nrt = nsc_cdiv(C, 16);
+#define LAUNCH_BLK(RT)                                                                                              \
+  do {                                                                                                              \
+    auto kern = gated_block_fwd_kernel<RT>;                                                                         \
+    if (smem > 64 * 1024) {                                                                                         \
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+      NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "gated_block_fwd: smem attr: %s", hipGetErrorString(e));         \
+    }                                                                                                               \
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, a, ldx, ldg);                                               \
+  } while (0)
+  if (nrt <= 4) LAUNCH_BLK(4);
+  else LAUNCH_BLK(7);
+#undef LAUNCH_BLK
+  NSC_CHECK_LAUNCH("gated_block_fwd");
+  return NSC_OK;
+}

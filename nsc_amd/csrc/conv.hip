@@ -49,25 +49,9 @@ __global__ __launch_bounds__(256) void conv1d_fwd_kernel(nsc_conv_desc d, const 
   const int Cin4 = CIN1 ? 1 : ((d.Cin + 3) & ~3);
   const int Tin_virt = d.in_up ? 2 * d.Tin : d.Tin;
 
-  // ---- stage x tile: xs[ci][j] = xin[b, ci, t0*stride - padL + j], zero outside ----
-  {
-    const int u0 = t0 * d.stride - d.padL;
-    const float* xb = x + (long)b * d.Cin * d.Tin;
-    const int total = Cin4 * ldx;
-    for (int e = tid; e < total; e += 256) {
-      const int ci = e / ldx, j = e - ci * ldx;
-      const int u = u0 + j;
-      float v = 0.f;
-      if (ci < d.Cin && j < win && u >= 0 && u < Tin_virt) {
-        if (d.in_up) {
-          if (!(u & 1)) v = xb[(long)ci * d.Tin + (u >> 1)];
-        } else {
-          v = xb[(long)ci * d.Tin + u];
-        }
-      }
-      xs[e] = v;
-    }
-  }
+  // ---- stage x tile: xs[ci][j] = xin[b, ci, t0*stride - padL + j], zero outside (wave per row, lanes along time) ----
+  nsc_stage_rows(xs, ldx, Cin4, d.Cin, win, x + (long)b * d.Cin * d.Tin, d.Tin, t0 * d.stride - d.padL, Tin_virt,
+                 d.in_up, wave, lane);
   __syncthreads();
 
   f32x4 acc[RT][NC];
@@ -277,16 +261,7 @@ __global__ __launch_bounds__(256) void conv1d_cout1_kernel(nsc_conv_desc d, cons
   const int Tin_virt = d.in_up ? 2 * d.Tin : d.Tin;
   const int u0 = t0 * d.stride - d.padL;
   const float* xb = x + (long)b * d.Cin * d.Tin;
-  for (int e = tid; e < d.Cin * ldx; e += 256) {
-    const int ci = e / ldx, j = e - ci * ldx;
-    const int u = u0 + j;
-    float v = 0.f;
-    if (u >= 0 && u < Tin_virt) {
-      if (d.in_up) { if (!(u & 1)) v = xb[(long)ci * d.Tin + (u >> 1)]; }
-      else v = xb[(long)ci * d.Tin + u];
-    }
-    xs[e] = v;
-  }
+  nsc_stage_rows(xs, ldx, d.Cin, d.Cin, ldx, xb, d.Tin, u0, Tin_virt, d.in_up, tid >> 6, tid & 63);
   for (int e = tid; e < d.K * d.Cin; e += 256) ws[e] = w[e];
   __syncthreads();
   const int tl = tid & 127, half = tid >> 7;
@@ -387,24 +362,12 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(nsc_conv_desc d, cons
     const int t0 = tc * TT;
     __syncthreads();  // previous chunk's reads done
     {
-      const int u0 = t0 * d.stride - d.padL;
-      const float* xb = x + (long)b * d.Cin * d.Tin;
-      const int total = d.Cin * ldx;
-      for (int e = tid; e < total; e += 256) {
-        const int ci = e / ldx, j = e - ci * ldx;
-        const int u = u0 + j;
-        float v = 0.f;
-        if (j < win && u >= 0 && u < Tin_virt) {
-          if (d.in_up) { if (!(u & 1)) v = xb[(long)ci * d.Tin + (u >> 1)]; }
-          else v = xb[(long)ci * d.Tin + u];
-        }
-        xs[e] = v;
-      }
+      nsc_stage_rows(xs, ldx, d.Cin, d.Cin, win, x + (long)b * d.Cin * d.Tin, d.Tin, t0 * d.stride - d.padL, Tin_virt,
+                     d.in_up, wave, lane);
       const float* dzb = dz + (long)b * d.Cout * d.Tout;
-      for (int e = tid; e < CT * 16 * TT; e += 256) {
-        const int o = e >> 6, j = e & 63;
-        const int t = t0 + j;
-        dzs[o * LDZ + j] = (o < d.Cout && t < d.Tout) ? dzb[(long)o * d.Tout + t] : 0.f;
+      for (int o = wave; o < CT * 16; o += 4) {
+        const int t = t0 + lane;
+        dzs[o * LDZ + lane] = (o < d.Cout && t < d.Tout) ? dzb[(long)o * d.Tout + t] : 0.f;
       }
     }
     __syncthreads();

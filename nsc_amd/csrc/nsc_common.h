@@ -48,4 +48,25 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+// Stage rows of a [rows, Tin] tensor into LDS: xs[r*ldx + j] = src[r*Tin + u0 + j] for j < width, zero outside the
+// tensor / for pad rows (r >= rows_valid) / for j >= width.  One wave per row, lanes along time (coalesced 256-B reads).
+// in_up: virtual zero-upsampled-by-2 source (u even -> src[u/2], odd -> 0), virtual length Tvirt = 2*Tin.
+__device__ __forceinline__ void nsc_stage_rows(float* __restrict__ xs, int ldx, int rows_total, int rows_valid, int width,
+                                               const float* __restrict__ src, int Tin, int u0, int Tvirt, int in_up,
+                                               int wave, int lane) {
+  for (int r = wave; r < rows_total; r += 4) {
+    const float* row = src + (long)r * Tin;
+    float* dst = xs + r * ldx;
+    const bool rv = r < rows_valid;
+    for (int j = lane; j < ldx; j += 64) {
+      const int u = u0 + j;
+      float v = 0.f;
+      if (rv && j < width && u >= 0 && u < Tvirt) {
+        if (in_up) { if (!(u & 1)) v = row[u >> 1]; }
+        else v = row[u];
+      }
+      dst[j] = v;
+    }
+  }
+}
 static inline int nsc_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

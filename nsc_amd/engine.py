@@ -168,6 +168,16 @@ class _Block:
         self.th = e.buf(u + ".th", (B, n, T))
         self.g = e.buf(u + ".g", (B, n, T))
         self.out = e.buf(u + ".out", (B, self.wide, T))
+        if e.fused_fwd and self.Cin > 1 and n == 20 and self.c9.K == 9:
+            P = lambda c, base=e.p_ptr: (base + 4 * c.w_off, base + 4 * c.b_off)
+            (w1, b1), (wl, bl), (wr, br), (w9, b9) = P(self.c1), P(self.cl), P(self.cr), P(self.c9)
+            tok = e.prof_begin("block_fwd", self.c1.flops() + self.cl.flops() + self.cr.flops() + self.c9.flops())
+            check(e.lib.nsc_gated_block_fwd(x.data_ptr(), w1, b1, wl, bl, wr, br, w9, b9, self.out.data_ptr(),
+                                            self.h.data_ptr(), self.lin.data_ptr(), self.th.data_ptr(),
+                                            self.g.data_ptr(), B, self.Cin, T, n, 9, self.cl.dil, int(self.flat),
+                                            e.stream()), "gated_block_fwd")
+            e.prof_end(tok)
+            return self.out
         self.c1.fwd(x, self.h, "lrelu")
         self.cl.fwd(self.h, self.lin, "none")
         self.cr.fwd(self.h, self.th, "tanh")
@@ -422,6 +432,7 @@ class CascadeEngine:
     def stream(self):
         return torch.cuda.current_stream().cuda_stream
 
+    fused_fwd = True   # gated blocks run as one kernel (csrc/block.hip); False = one launch per conv
     # per-launch HIP-event timing of the conv kernels (bench.py roofline); events sit on the launch stream
     prof = None
 

@@ -387,3 +387,41 @@ def test_bad_arguments_return_status(lib):
     assert b"desc" in lib.nsc_last_error() or b"size" in lib.nsc_last_error()
     assert lib.nsc_quantize_fwd(None, None, None, 1.0, 1, 1, 1, 1, None, None, None, None, None) == -1
     assert lib.nsc_adam_tf1_step(None, None, None, None, 0, 0.0, 0.9, 0.999, 1e-8, 1, None, None) == -1
+
+
+@pytest.mark.parametrize("case", [(2, 100, 512, 2, 0), (2, 100, 256, 1, 1), (3, 50, 512, 2, 0), (2, 50, 512, 1, 1),
+                                  (1, 100, 200, 2, 0), (2, 36, 70, 1, 0)])
+def test_fused_gated_block_fwd(lib, case):
+    """csrc/block.hip vs the oracle's gated_bottleneck (nn_core_operator.py:82-112), incl. saved intermediates."""
+    B, C_, T, dil, flat = case
+    rng = np.random.default_rng(100 + C_ + T + dil)
+    ps = O.ParamStore(rng)
+    x = rng.standard_normal((B, T, C_)).astype(np.float32)
+    tape = []
+    ref = O.gated_bottleneck(x, ps, "s", C_, 20, 9, dil, bool(flat), tape)
+    names = ["s/conv1d", "s/conv1d_1", "s/conv1d_2", "s/conv1d_3"]
+    for n in names:
+        ps.params[n + "/bias"] = (0.1 * rng.standard_normal(ps.params[n + "/bias"].shape)).astype(np.float32).astype(np.float64)
+    ps.begin_replay()
+    tape = []
+    ref = O.gated_bottleneck(x, ps, "s", C_, 20, 9, dil, bool(flat), tape)
+    t = tape[0][1]
+    W = [P(ps.params[n + "/kernel"]) for n in names]
+    Bv = [P(ps.params[n + "/bias"]) for n in names]
+    out = torch.full((B, C_, T), float("nan"), device="cuda")
+    h, lin, th, g = (torch.full((B, 20, T), float("nan"), device="cuda") for _ in range(4))
+    rc = lib.nsc_gated_block_fwd(P(x.transpose(0, 2, 1)), W[0], Bv[0], W[1], Bv[1], W[2], Bv[2], W[3], Bv[3],
+                                 out.data_ptr(), h.data_ptr(), lin.data_ptr(), th.data_ptr(), g.data_ptr(), B, C_, T,
+                                 20, 9, dil, flat, _st())
+    assert rc == 0, lib.nsc_last_error()
+    tr = lambda v: v.cpu().numpy().transpose(0, 2, 1)
+    assert_close(tr(h), t["h"], what="fused h")
+    assert_close(tr(lin), t["left"], what="fused lin")
+    assert_close(tr(th), t["right"], what="fused tanh branch")
+    assert_close(tr(g), t["g"], what="fused g")
+    assert_close(tr(out), ref, what=f"fused block out {case}")
+    # without the optional outputs
+    out2 = torch.full((B, C_, T), float("nan"), device="cuda")
+    assert lib.nsc_gated_block_fwd(P(x.transpose(0, 2, 1)), W[0], Bv[0], W[1], Bv[1], W[2], Bv[2], W[3], Bv[3],
+                                   out2.data_ptr(), None, None, None, None, B, C_, T, 20, 9, dil, flat, _st()) == 0
+    assert torch.equal(out, out2)
