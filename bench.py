@@ -144,6 +144,8 @@ def main():
     fps = comm.world * B * args.steps / dt
 
     # ---- roofline of the dominant kernel: per-launch HIP events on extra (eager) steps of the same workload ----
+    for _ in range(3):      # keep the stream busy so the instrumented launches below are queued behind real work:
+        step()              # their events then time the GPU, not the host's launch latency
     eng.prof = []
     for _ in range(args.prof_steps):
         step()

@@ -54,20 +54,31 @@ __global__ __launch_bounds__(256) void gated_block_fwd_kernel(BlockArgs a, int l
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
       const int j = ct * 16 + l15;
       const float* xcol = xs + j;
-      float a0n, a1n;
-      {
-        const int ci = kq;
-        a0n = (ci < C) ? a.w1[ci * NARROW + l15] : 0.f;
-        a1n = (ci < C && 16 + l15 < NARROW) ? a.w1[ci * NARROW + 16 + l15] : 0.f;
-      }
-      for (int cq = 0; cq < ncq; ++cq) {
-        const float a0 = a0n, a1 = a1n;
-        const int cin = (cq + 1) * 4 + kq;
-        a0n = (cq + 1 < ncq && cin < C) ? a.w1[cin * NARROW + l15] : 0.f;
-        a1n = (cq + 1 < ncq && cin < C && 16 + l15 < NARROW) ? a.w1[cin * NARROW + 16 + l15] : 0.f;
-        const float bv = xcol[(cq * 4 + kq) * ldx];
-        acc0 = mfma4(a0, bv, acc0);
-        acc1 = mfma4(a1, bv, acc1);
+      constexpr int G1 = 8;
+      float an0[G1], an1[G1];
+      auto fetch1 = [&](int cq0) {
+#pragma unroll
+        for (int u = 0; u < G1; ++u) {
+          const int ci = (cq0 + u) * 4 + kq;
+          const bool ok = (cq0 + u) < ncq && ci < C;
+          an0[u] = ok ? a.w1[ci * NARROW + l15] : 0.f;
+          an1[u] = (ok && 16 + l15 < NARROW) ? a.w1[ci * NARROW + 16 + l15] : 0.f;
+        }
+      };
+      fetch1(0);
+      for (int cq0 = 0; cq0 < ncq; cq0 += G1) {
+        float c0[G1], c1[G1];
+#pragma unroll
+        for (int u = 0; u < G1; ++u) { c0[u] = an0[u]; c1[u] = an1[u]; }
+        if (cq0 + G1 < ncq) fetch1(cq0 + G1);
+#pragma unroll
+        for (int u = 0; u < G1; ++u) {
+          if (cq0 + u < ncq) {
+            const float bv = xcol[((cq0 + u) * 4 + kq) * ldx];
+            acc0 = mfma4(c0[u], bv, acc0);
+            acc1 = mfma4(c1[u], bv, acc1);
+          }
+        }
       }
       const int t = t0 - H + j;
       const bool live = j < WX && t >= 0 && t < T;   // h outside the frame is ZERO padding of the k15 convs
@@ -112,29 +123,34 @@ __global__ __launch_bounds__(256) void gated_block_fwd_kernel(BlockArgs a, int l
     const int jj_main = wave * 16 + l15;
     const int jj_x = 64 + l15;
     const int rtx = wave;  // row tile of the shared 5th column tile (wave 3: none)
-    float an[3];
+    constexpr int G2 = 5;                       // one tap (5 k-steps of 4 channels) per group
+    float an[G2][3];
+    auto fetch2 = [&](int tapf) {
 #pragma unroll
-    for (int rt = 0; rt < 3; ++rt) an[rt] = (crow[rt] < NARROW) ? wsel[(kq)*NARROW + crow[rt]] : 0.f;
-    int tap = 0, cq = 0;
-    for (int s = 0; s < K15 * 5; ++s) {
-      float ac[3];
+      for (int u = 0; u < G2; ++u) {
+        const int ci = u * 4 + kq;
 #pragma unroll
-      for (int rt = 0; rt < 3; ++rt) ac[rt] = an[rt];
-      int tapn = tap, cqn = cq + 1;
-      if (cqn == 5) { cqn = 0; tapn = tap + 1; }
-      if (tapn < K15) {
-        const int ci = cqn * 4 + kq;
-#pragma unroll
-        for (int rt = 0; rt < 3; ++rt) an[rt] = (crow[rt] < NARROW) ? wsel[(tapn * NARROW + ci) * NARROW + crow[rt]] : 0.f;
+        for (int rt = 0; rt < 3; ++rt)
+          an[u][rt] = (tapf < K15 && crow[rt] < NARROW) ? wsel[(tapf * NARROW + ci) * NARROW + crow[rt]] : 0.f;
       }
-      const float* hrow = hs + (cq * 4 + kq) * ldx + tap * d;
-      const float bm = hrow[jj_main];
-      const float bx = hrow[jj_x];
+    };
+    fetch2(0);
+    for (int tap = 0; tap < K15; ++tap) {
+      float ac[G2][3];
 #pragma unroll
-      for (int rt = 0; rt < 3; ++rt) acc[rt] = mfma4(ac[rt], bm, acc[rt]);
-      if (rtx < 3) accx = mfma4(rtx == 0 ? ac[0] : (rtx == 1 ? ac[1] : ac[2]), bx, accx);
-      tap = tapn;
-      cq = cqn;
+      for (int u = 0; u < G2; ++u)
+#pragma unroll
+        for (int rt = 0; rt < 3; ++rt) ac[u][rt] = an[u][rt];
+      if (tap + 1 < K15) fetch2(tap + 1);
+#pragma unroll
+      for (int u = 0; u < G2; ++u) {
+        const float* hrow = hs + (u * 4 + kq) * ldx + tap * d;
+        const float bm = hrow[jj_main];
+        const float bx = hrow[jj_x];
+#pragma unroll
+        for (int rt = 0; rt < 3; ++rt) acc[rt] = mfma4(ac[u][rt], bm, acc[rt]);
+        if (rtx < 3) accx = mfma4(rtx == 0 ? ac[u][0] : (rtx == 1 ? ac[u][1] : ac[u][2]), bx, accx);
+      }
     }
     // epilogue: lane holds (lin c0, lin c1, gate c0, gate c1) of one time step
     auto emit = [&](const f32x4& v, int rt, int jj) {
@@ -169,32 +185,33 @@ __global__ __launch_bounds__(256) void gated_block_fwd_kernel(BlockArgs a, int l
 #pragma unroll
     for (int r = 0; r < RT9; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int tt = wave * 16 + l15;
-    float an[RT9];
+    constexpr int G3 = 5;                       // one tap per group
+    float an[G3][RT9];
+    auto fetch3 = [&](int tapf) {
 #pragma unroll
-    for (int r = 0; r < RT9; ++r) {
-      const int o = r * 16 + l15;
-      an[r] = (o < C) ? a.w9[(long)kq * C + o] : 0.f;
-    }
-    int tap = 0, cq = 0;
-    for (int s = 0; s < K9 * 5; ++s) {
-      float ac[RT9];
-#pragma unroll
-      for (int r = 0; r < RT9; ++r) ac[r] = an[r];
-      int tapn = tap, cqn = cq + 1;
-      if (cqn == 5) { cqn = 0; tapn = tap + 1; }
-      if (tapn < K9) {
-        const int ci = cqn * 4 + kq;
+      for (int u = 0; u < G3; ++u) {
+        const int ci = u * 4 + kq;
 #pragma unroll
         for (int r = 0; r < RT9; ++r) {
           const int o = r * 16 + l15;
-          an[r] = (o < C) ? a.w9[((long)tapn * NARROW + ci) * C + o] : 0.f;
+          an[u][r] = (tapf < K9 && o < C) ? a.w9[((long)tapf * NARROW + ci) * C + o] : 0.f;
         }
       }
-      const float bv = gs[(cq * 4 + kq) * ldg + tt + tap];
+    };
+    fetch3(0);
+    for (int tap = 0; tap < K9; ++tap) {
+      float ac[G3][RT9];
 #pragma unroll
-      for (int r = 0; r < RT9; ++r) acc[r] = mfma4(ac[r], bv, acc[r]);
-      tap = tapn;
-      cq = cqn;
+      for (int u = 0; u < G3; ++u)
+#pragma unroll
+        for (int r = 0; r < RT9; ++r) ac[u][r] = an[u][r];
+      if (tap + 1 < K9) fetch3(tap + 1);
+#pragma unroll
+      for (int u = 0; u < G3; ++u) {
+        const float bv = gs[(u * 4 + kq) * ldg + tt + tap];
+#pragma unroll
+        for (int r = 0; r < RT9; ++r) acc[r] = mfma4(ac[u][r], bv, acc[r]);
+      }
     }
     const int t = t0 + tt;
     if (t < T) {

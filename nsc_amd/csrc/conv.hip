@@ -96,43 +96,52 @@ __global__ __launch_bounds__(256) void conv1d_fwd_kernel(nsc_conv_desc d, const 
     }
   } else {
     // K order = (tap, ci) with ci fastest, ci padded to a multiple of 4 (pad rows of xs are zero).
+    // Weight fragments come from global/L2; they are fetched G k-steps ahead as a group so that one L2 round trip
+    // is amortised over >= 32 MFMAs (a 1-step-ahead prefetch left every k-step waiting ~200 ns on its own load).
+    constexpr int G = (RT * NC >= 14) ? 2 : ((RT * NC >= 7) ? 4 : ((RT * NC >= 4) ? 8 : 16));
     const int ncq = Cin4 >> 2;
     const int nsteps = d.K * ncq;
-    float a_cur[RT], a_nxt[RT];
-    {
-      const int ci = kq;
+    float an[G][RT];
+    // prefetch cursor (tapp, cqp) walks G steps ahead of the compute cursor (tap, cq)
+    int tapp = 0, cqp = 0;
+    auto fetch_group = [&](float (&dst)[G][RT]) {
 #pragma unroll
-      for (int r = 0; r < RT; ++r) {
-        const int o = (rt0 + r) * 16 + l15;
-        a_cur[r] = (ci < d.Cin && o < Cout) ? w[(long)ci * Cout + o] : 0.f;
-      }
-    }
-    int tap = 0, cq = 0;
-    for (int s = 0; s < nsteps; ++s) {
-      int tapn = tap, cqn = cq + 1;
-      if (cqn == ncq) { cqn = 0; tapn = tap + 1; }
-      {
-        const int ci = cqn * 4 + kq;
+      for (int u = 0; u < G; ++u) {
+        const int ci = cqp * 4 + kq;
+        const bool okk = tapp < d.K && ci < d.Cin;
+        const float* wrow = w + ((long)tapp * d.Cin + ci) * Cout;
 #pragma unroll
         for (int r = 0; r < RT; ++r) {
           const int o = (rt0 + r) * 16 + l15;
-          a_nxt[r] = (tapn < d.K && ci < d.Cin && o < Cout) ? w[((long)tapn * d.Cin + ci) * Cout + o] : 0.f;
+          dst[u][r] = (okk && o < Cout) ? wrow[o] : 0.f;
+        }
+        if (++cqp == ncq) { cqp = 0; ++tapp; }
+      }
+    };
+    fetch_group(an);
+    int tap = 0, cq = 0;
+    for (int s0 = 0; s0 < nsteps; s0 += G) {
+      float ac[G][RT];
+#pragma unroll
+      for (int u = 0; u < G; ++u)
+#pragma unroll
+        for (int r = 0; r < RT; ++r) ac[u][r] = an[u][r];
+      if (s0 + G < nsteps) fetch_group(an);
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        if (s0 + u < nsteps) {
+          const float* xrow = xs + (cq * 4 + kq) * ldx + tap * d.dil;
+          float bf[NC];
+#pragma unroll
+          for (int c = 0; c < NC; ++c) bf[c] = xrow[(tcol0 + c * 16) * d.stride];
+#pragma unroll
+          for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+              acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[u][r], bf[c], acc[r][c], 0, 0, 0);
+          if (++cq == ncq) { cq = 0; ++tap; }
         }
       }
-      const int ci = cq * 4 + kq;
-      const float* xrow = xs + ci * ldx + tap * d.dil;
-      float bf[NC];
-#pragma unroll
-      for (int c = 0; c < NC; ++c) bf[c] = xrow[(tcol0 + c * 16) * d.stride];
-#pragma unroll
-      for (int r = 0; r < RT; ++r)
-#pragma unroll
-        for (int c = 0; c < NC; ++c)
-          acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[r], bf[c], acc[r][c], 0, 0, 0);
-#pragma unroll
-      for (int r = 0; r < RT; ++r) a_cur[r] = a_nxt[r];
-      tap = tapn;
-      cq = cqn;
     }
   }
 
@@ -432,8 +441,13 @@ static int launch_wgrad(const nsc_conv_desc* d, const float* x, const float* dz,
   const int gy = nsc_cdiv(nrt, 4 * RT);
   const int nchunk_t = nsc_cdiv(d->Tout, TT);
   const int nchunks = d->B * nchunk_t;
-  int gx = 768 / gy;
-  if (gx < 1) gx = 1;
+  // Parallelism comes from splitting the (tap,ci) ROWS over workgroups first (gy) and the (b,t) reduction second (gx):
+  // every K-split adds the whole dW tile with float atomics to the SAME addresses, which is what bounded the first
+  // version (768 splits).  Aim for ~2.5 workgroups per CU, at least 8 and at most 160 K-splits.
+  int gx = 640 / gy;
+  if (gx < 8) gx = 8;
+  if (gx > 160) gx = 160;
+  if (RT == 4) gx = 768 / gy;   // very tall dW (stride-2 k9 100->100): measured faster with more K-splits (1 WG/CU by LDS)
   if (gx > nchunks) gx = nchunks;
   hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(256), smem, st, *d, x, dz, dw, db, flip, ldx, win, nchunk_t);
   NSC_CHECK_LAUNCH("conv1d_wgrad");
@@ -444,8 +458,7 @@ template <int CT>
 static int dispatch_wgrad_rt(const nsc_conv_desc* d, const float* x, const float* dz, float* dw, float* db, int flip,
                              hipStream_t st) {
   const int nrt = nsc_cdiv(d->K * d->Cin + (db ? 1 : 0), 16);
-  if (nrt <= 4) return launch_wgrad<1, CT>(d, x, dz, dw, db, flip, st);
-  if (nrt <= 8) return launch_wgrad<2, CT>(d, x, dz, dw, db, flip, st);
+  if (nrt <= 24) return launch_wgrad<1, CT>(d, x, dz, dw, db, flip, st);   // one row tile per wave: split rows over WGs
   return launch_wgrad<4, CT>(d, x, dz, dw, db, flip, st);
 }
 
