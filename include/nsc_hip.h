@@ -93,6 +93,14 @@ int nsc_gate_bwd(const float* a, const float* dg, float* da, int B, int n, int T
 int nsc_mul(const float* a, const float* b, float* out, long n, void* stream);
 int nsc_glu_bwd(const float* lin, const float* th, const float* dg, float* dlin, float* dgate, long n, void* stream);
 
+/* stand-alone activation (nn_core_operator.py:24-31 `activation_func` = leaky_relu 0.2; tanh for conv epilogues) */
+int nsc_act_fwd(const float* x, float* y, long n, int act, void* stream);
+int nsc_act_bwd(const float* dy, const float* y, float* dx, long n, int act, void* stream); /* dx = dy * act'(.) from the OUTPUT y */
+/* quan_loss / entropy histogram of a materialised soft assignment p[B,L,nb] (op-surface form of
+ * loss_terms_and_measures.py:257-267) and the matching elementwise backward dp = gq[b]/L*0.5/sqrt(p+1e-20) + gh[k]. */
+int nsc_p_stats(const float* p, int B, int L, int nb, float* quan /*[B] nullable*/, float* hist /*[nb] accumulate, nullable*/, void* stream);
+int nsc_p_stats_bwd(const float* p, const float* gq, const float* gh, float* dp, int B, int L, int nb, void* stream);
+
 /* ---- small glue ---- */
 int nsc_gather(const float* src, const int* idx, float* dst, long n, void* stream); /* dst[e] = src[idx[e]] */
 int nsc_axpby(const float* x, const float* y, float* out, float a, float b, long n, void* stream); /* out = a*x + b*y (y nullable) */

@@ -40,6 +40,10 @@ PROTOTYPES = {
     "nsc_mul": [_P, _P, _P, _L, _P],
     "nsc_glu_bwd": [_P, _P, _P, _P, _P, _L, _P],
     "nsc_gather": [_P, _P, _P, _L, _P],
+    "nsc_act_fwd": [_P, _P, _L, _I, _P],
+    "nsc_act_bwd": [_P, _P, _P, _L, _I, _P],
+    "nsc_p_stats": [_P, _I, _I, _I, _P, _P, _P],
+    "nsc_p_stats_bwd": [_P, _P, _P, _P, _I, _I, _I, _P],
     "nsc_axpby": [_P, _P, _P, _F, _F, _L, _P],
     "nsc_channel_sum": [_P, _P, _I, _I, _I, _I, _P],
     "nsc_unshuffle2": [_P, _P, _I, _I, _I, _P],

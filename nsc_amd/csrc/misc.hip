@@ -360,3 +360,78 @@ extern "C" int nsc_glu_bwd(const float* lin, const float* th, const float* dg, f
   NSC_CHECK_LAUNCH("glu_bwd");
   return NSC_OK;
 }
+
+// activation forward / backward as stand-alone ops (op surface: nn_core_operator.activation_func)
+__global__ void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n, int act) {
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x)
+    y[e] = nsc_apply_act(x[e], act);
+}
+__global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx, long n,
+                               int act) {
+  const int mode = act == NSC_ACT_LRELU ? 1 : (act == NSC_ACT_TANH ? 2 : 0);
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x)
+    dx[e] = dy[e] * nsc_act_grad_from_out(y[e], mode);
+}
+extern "C" int nsc_act_fwd(const float* x, float* y, long n, int act, void* stream) {
+  NSC_REQUIRE(x && y && n > 0 && act >= 0 && act <= 2, NSC_ERR_BAD_ARG, "nsc_act_fwd: bad args");
+  hipLaunchKernelGGL(act_fwd_kernel, dim3(std::min<long>(4096, nsc_cdiv(n, 256))), dim3(256), 0, (hipStream_t)stream, x,
+                     y, n, act);
+  NSC_CHECK_LAUNCH("act_fwd");
+  return NSC_OK;
+}
+extern "C" int nsc_act_bwd(const float* dy, const float* y, float* dx, long n, int act, void* stream) {
+  NSC_REQUIRE(dy && y && dx && n > 0 && act >= 0 && act <= 2, NSC_ERR_BAD_ARG, "nsc_act_bwd: bad args");
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(std::min<long>(4096, nsc_cdiv(n, 256))), dim3(256), 0, (hipStream_t)stream,
+                     dy, y, dx, n, act);
+  NSC_CHECK_LAUNCH("act_bwd");
+  return NSC_OK;
+}
+
+// quan_loss (loss_terms_and_measures.py:257-259) on a materialised p: out[b] = mean_l sum_k sqrt(p + 1e-20);
+// hist[k] += sum_{b,l} p (nullable).  One workgroup per frame.  Backward of both is elementwise (see ops.py).
+__global__ __launch_bounds__(256) void p_stats_kernel(const float* __restrict__ p, int L, int nb, float* __restrict__ quan,
+                                                      float* __restrict__ hist) {
+  __shared__ float red[4];
+  const long b = blockIdx.x;
+  const float* pb = p + b * (long)L * nb;
+  float s = 0.f;
+  for (int e = threadIdx.x; e < L * nb; e += 256) s += sqrtf(pb[e] + 1e-20f);
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0 && quan) quan[b] = (red[0] + red[1] + red[2] + red[3]) / (float)L;
+  if (hist) {
+    for (int k = threadIdx.x; k < nb; k += 256) {
+      float h = 0.f;
+      for (int l = 0; l < L; ++l) h += pb[(long)l * nb + k];
+      atomicAdd(hist + k, h);
+    }
+  }
+}
+extern "C" int nsc_p_stats(const float* p, int B, int L, int nb, float* quan, float* hist, void* stream) {
+  NSC_REQUIRE(p && B > 0 && L > 0 && nb > 0, NSC_ERR_BAD_ARG, "nsc_p_stats: bad args");
+  hipLaunchKernelGGL(p_stats_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, p, L, nb, quan, hist);
+  NSC_CHECK_LAUNCH("p_stats");
+  return NSC_OK;
+}
+// dp[b,l,k] = gq[b]/L * 0.5/sqrt(p+1e-20) + gh[k]   (gq, gh nullable)
+__global__ void p_stats_bwd_kernel(const float* __restrict__ p, const float* __restrict__ gq,
+                                   const float* __restrict__ gh, float* __restrict__ dp, int L, int nb, long n) {
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    const long b = e / ((long)L * nb);
+    const int k = (int)(e % nb);
+    float g = 0.f;
+    if (gq) g += gq[b] / (float)L * 0.5f / sqrtf(p[e] + 1e-20f);
+    if (gh) g += gh[k];
+    dp[e] = g;
+  }
+}
+extern "C" int nsc_p_stats_bwd(const float* p, const float* gq, const float* gh, float* dp, int B, int L, int nb,
+                               void* stream) {
+  NSC_REQUIRE(p && dp && B > 0 && L > 0 && nb > 0, NSC_ERR_BAD_ARG, "nsc_p_stats_bwd: bad args");
+  const long n = (long)B * L * nb;
+  hipLaunchKernelGGL(p_stats_bwd_kernel, dim3(std::min<long>(4096, nsc_cdiv(n, 256))), dim3(256), 0, (hipStream_t)stream,
+                     p, gq, gh, dp, L, nb, n);
+  NSC_CHECK_LAUNCH("p_stats_bwd");
+  return NSC_OK;
+}

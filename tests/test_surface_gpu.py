@@ -1,0 +1,150 @@
+"""GPU tests of the drop-in surface: the reference-named ops (autograd over the C ABI), the reference-named builder
+methods, the CLI phases, and the framing helpers."""
+import argparse
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nsc_oracle as O
+from oracle import nsc_oracle_torch as OT
+from tests._util import BKD, assert_close, dev, make_store, relerr, synth_frames
+
+pytestmark = pytest.mark.gpu
+
+
+def _module():
+    from nsc_amd.neural_speech_coding_module import neuralSpeechCodingModule
+    m = neuralSpeechCodingModule.__new__(neuralSpeechCodingModule)
+    m._bottleneck_kernel_and_dilation = list(BKD)
+    return m
+
+
+def test_op_surface_codec_matches_oracle_forward_and_gradients():
+    """computational_graph_end2end_quan_on built from nn_core_operator ops == oracle codec (values + grads)."""
+    from nsc_amd import loss_terms_and_measures as L
+    from nsc_amd.scope import VariableStore, set_store
+    B = 2
+    ps = make_store(1, [[2]], [32])
+    x = synth_frames(B)
+    st = VariableStore(device="cuda")
+    set_store(st)
+    try:
+        m = _module()
+        xd = dev(x)
+        # first pass creates the variables; then overwrite them with the oracle's values and re-trace
+        m.computational_graph_end2end_quan_on(xd, True, 1.0, 32, "scope_1", [2])
+        assert list(st.vars.keys()) == list(ps.params.keys())          # same names, same creation order as TF
+        with torch.no_grad():
+            for k, v in st.vars.items():
+                v.copy_(torch.tensor(np.asarray(ps.params[k], np.float32).reshape(tuple(v.shape)), device="cuda"))
+        st.begin_pass()
+        p, _, _, code0, decoded, alpha, bins, _ = m.computational_graph_end2end_quan_on(xd, True, 1.0, 32, "scope_1", [2])
+        tgt = xd[:, :, 0].contiguous()
+        time_loss, freq_loss = L.mse_loss(decoded, tgt), L.mfcc_loss(decoded, tgt)
+        loss = (60.0 * time_loss + 10.0 * freq_loss + 10.0 * L.quan_loss(p)).sum() + B * 0.4 * L.entropy_coding_loss(p)
+        loss.backward()
+        tp = OT.TorchParams(ps)
+        outs, dec = OT.cascade_forward(torch.tensor(x), tp, BKD, [[2]], 1.0, True)
+        ref = OT.total_loss_sum(dec, torch.tensor(x)[:, :, 0], [outs[0]["p"]], [60.0, 10.0, 10.0, 0.0], 0.4, "quan_last")
+        ref.backward()
+        assert_close(decoded.detach().cpu().numpy(), dec.detach().numpy(), what="surface decoded")
+        assert_close(p.detach().cpu().numpy(), outs[0]["p"].detach().numpy(), what="surface p")
+        assert abs(float(loss) - float(ref)) < 1e-4 * abs(float(ref))
+        for k, v in st.vars.items():
+            g = tp.t[k].grad.numpy()
+            assert relerr(v.grad.cpu().numpy().reshape(g.shape), g) < 5e-4, k
+        # hard codes (the_share False) through the same surface
+        st.begin_pass()
+        _, _, _, _, dec_h, _, _, _ = m.computational_graph_end2end_quan_on(xd, False, 1.0, 32, "scope_1", [2])
+        tp.reset()
+        oh = OT.codec_forward(torch.tensor(x), tp, "scope_1", BKD, [2], 1.0, False)
+        assert_close(dec_h.detach().cpu().numpy(), oh["decoded"].detach().numpy(), what="surface hard decoded")
+    finally:
+        set_store(None)
+
+
+def test_surface_rejects_cpu_tensors_and_bad_shapes():
+    from nsc_amd import _lib, nn_core_operator as nn
+    from nsc_amd.scope import VariableStore, set_store
+    set_store(VariableStore(device="cuda"))
+    try:
+        with pytest.raises(_lib.NscError):
+            nn.conv1d(torch.zeros(1, 8, 2), 4, 3)
+        with pytest.raises(ValueError):
+            nn.scalar_softmax_quantization(torch.zeros(1, 8, 1, device="cuda"), -1.0, torch.zeros(4, device="cuda"), 1.0, True, 8, 5)
+        with pytest.raises(ValueError):
+            nn.conv1d(torch.zeros(1, 8, 2, device="cuda"), 4, 3, padding='VALID')
+    finally:
+        set_store(None)
+
+
+def _args(tmp, **kw):
+    base = dict(learning_rate_tanh=2e-4, learning_rate_greedy_followers="2e-5 2e-6", epoch_tanh=2,
+                epoch_greedy_followers="1 1", from_where_step=2, batch_size=8, num_resnets=2, training_mode="4",
+                base_model_id="", suffix="end2endcascade", window_size=512, bottleneck_kernel_and_dilation="9 9 100 20 1 2",
+                is_cq=0, the_strides="2 2", save_unique_mark="", coeff_term="60 10 10 0", res_scalar=1.0, pretrain_step=1,
+                target_entropy=2.2, num_bins_for_follower="32 32", lpc_domain=False, data_root=None,
+                max_batches_per_epoch=2, out_root=str(tmp), model_id="1234567", seed=1)
+    base.update(kw)
+    return argparse.Namespace(**base)
+
+
+def test_cli_phases_cascaded_then_finetune_then_feedforward(tmp_path):
+    """README flow of the reference: mode 4 (codec 1 pretrain+quan, follower), mode 5 (joint finetune), mode 0."""
+    from nsc_amd.cmrl import CMRL
+    a = _args(tmp_path, the_strides="2")
+    m = CMRL(a)
+    m.model("cascaded", a)
+    ck = sorted(os.path.basename(p) for p in glob.glob(str(tmp_path / "check" / "*.npz")))
+    assert ck == ["model_bnn_ac_1234567_.ckpt.npz", "model_bnn_ac_1234567_follower_1end2endcascade.ckpt.npz"]
+    z1 = np.load(tmp_path / "check" / ck[0])
+    z2 = np.load(tmp_path / "check" / ck[1])
+    k = "scope_1|conv1d_3|kernel"
+    assert np.array_equal(z1[k], z2[k])                       # codec 1 is frozen during the follower phase
+    assert "scope_2|conv1d|kernel" in z2.files and "scope_2|conv1d|kernel" not in z1.files
+    journal = open(glob.glob(str(tmp_path / "doc" / "*_journal.txt"))[0]).read()
+    assert journal.count("Epoch") == 3                        # 2 epochs of codec 1 + 1 follower epoch
+    a5 = _args(tmp_path, the_strides="2", training_mode="5", base_model_id="1234567")
+    m5 = CMRL(a5)
+    m5.model("finetune", a5)
+    z3 = np.load(tmp_path / "check" / "model_bnn_ac_1234567_finetune_2end2endcascade.ckpt.npz")
+    assert not np.array_equal(z3[k], z2[k])                   # joint phase trains codec 1 again
+    assert np.all(np.isfinite(z3[k]))
+    a0 = _args(tmp_path, the_strides="2", training_mode="0", base_model_id="1234567")
+    dec = CMRL(a0)._feedforward(2)
+    assert tuple(dec.shape) == (8, 1, 512) and bool(torch.isfinite(dec).all())
+
+
+def test_cli_lpc_collaborative_quantisation_phase(tmp_path):
+    """is_cq=1, LPC-residual domain (constants.is_pure_time_domain=False in the reference): one_ae_lpc + finetune_lpc."""
+    from nsc_amd.cmrl import CMRL
+    a = _args(tmp_path, the_strides="2 2", is_cq=1, lpc_domain=True, num_resnets=2, epoch_tanh=2)
+    m = CMRL(a)
+    m.model("cascaded", a)
+    z = np.load(tmp_path / "check" / "model_bnn_ac_1234567_follower_1end2endcascade.ckpt.npz")
+    assert "lpc_quan|bins" in z.files and z["lpc_quan|bins"].shape == (256,)
+    a5 = _args(tmp_path, the_strides="2 2", is_cq=1, lpc_domain=True, training_mode="5", base_model_id="1234567")
+    m5 = CMRL(a5)
+    eng = m5._finetuning(2)
+    assert eng.lpc and eng.scale_first and bool(torch.isfinite(eng.params).all())
+    # the LSF quantizer is trainable under is_cq (its bins moved)
+    z2 = np.load(tmp_path / "check" / "model_bnn_ac_1234567_finetune_2end2endcascade.ckpt.npz")
+    assert not np.array_equal(z2["lpc_quan|bins"], z["lpc_quan|bins"])
+
+
+def test_framing_on_gpu_roundtrip():
+    from nsc_amd import utilities as U
+    rng = np.random.default_rng(5)
+    utt = rng.standard_normal(16000).astype(np.float32)
+    fr = U.frames_on_gpu(torch.tensor(utt, device="cuda"), post_window=True)
+    assert np.array_equal(fr.cpu().numpy(), O.utterance_to_segment(utt.astype(np.float64), True).astype(np.float32))
+    ola = U.overlap_add_on_gpu(fr)
+    ref = O.overlap_add(fr.cpu().numpy().astype(np.float64))
+    assert_close(ola.cpu().numpy(), ref, tol=1e-6, what="overlap-add")
+    # interior samples are reconstructed exactly where the Hann halves sum to one (mid windows)
+    n = ola.numel()
+    inner = slice(600, n - 600)
+    assert np.max(np.abs(ola.cpu().numpy()[inner] - utt[:n][inner])) < 1e-5
