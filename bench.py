@@ -91,6 +91,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--prof-steps", type=int, default=3)
+    ap.add_argument("--fused-bwd", action="store_true", help="debug: whole-block persistent backward kernel")
+    ap.add_argument("--unfused-wgrad", action="store_true", help="debug: per-conv weight gradients")
+    ap.add_argument("--unfused-fwd", action="store_true", help="debug: per-conv forward/backward (no block fusion)")
     args = ap.parse_args()
 
     from nsc_amd.dist import Comm
@@ -103,6 +106,9 @@ def main():
     dev = torch.device("cuda", comm.local_rank)
     B = args.batch
     eng = CascadeEngine(B, 2, BKD, [[2], [2]], [32, 32], res_scalar=RES_SCALAR, scale_first=True, lpc=True, device=dev)
+    eng.fused_bwd = args.fused_bwd
+    eng.fused_wgrad = not args.unfused_wgrad
+    eng.fused_fwd = not args.unfused_fwd
     xd, lpcd, x_np, lpc_np = synth_batch(B, comm.rank, dev)
     cfg = step_cfg()
     dcomm = comm if comm.world > 1 else None

@@ -78,6 +78,26 @@ int nsc_gated_block_fwd(const float* x, const float* w1, const float* b1, const 
                         float* h_out, float* lin_out, float* th_out, float* g_out, int B, int C, int T,
                         int narrow, int k9, int dil, int flat, void* stream);
 
+/* Fused backward of the same block (persistent, recompute-in-LDS): given x and dy = dL/d(pre-activation of out),
+ * writes dx = (conv1^T(dz1) + dy) * act'(x) (in_act = activation that produced x: NSC_ACT_NONE | NSC_ACT_LRELU) and
+ * ACCUMULATES all eight parameter gradients.  wt1/wtl/wtr/wt9 are the nsc_weight_flip_transpose'd kernels.
+ * Supported: narrow 20, k9 9, dil in {1,2}, C <= 112 (else NSC_ERR_UNSUPPORTED: use the per-conv entry points). */
+int nsc_gated_block_bwd(const float* x, const float* dy, const float* w1, const float* b1, const float* wl,
+                        const float* bl, const float* wr, const float* br, const float* wt1, const float* wtl,
+                        const float* wtr, const float* wt9, float* dx, float* dw1, float* db1, float* dwl, float* dbl,
+                        float* dwr, float* dbr, float* dw9, float* db9, int B, int C, int T, int narrow, int k9,
+                        int dil, int in_act, void* stream);
+
+/* Persistent weight-gradient kernel of one gated block: all eight parameter gradients (accumulated) from the saved
+ * activations x [B,C,T], h, g [B,20,T] and the data-path gradients dy [B,C,T], dlin, dgate, dz1 [B,20,T] that the
+ * per-conv backward produces (dlin/dgate = nsc_glu_bwd outputs, dz1 = dL/d(pre-activation of h)). */
+int nsc_gated_block_wgrad(const float* x, const float* h, const float* g, const float* dy, const float* dlin,
+                          const float* dgate, const float* dz1, float* dw1, float* db1, float* dwl, float* dbl,
+                          float* dwr, float* dbr, float* dw9, float* db9, int B, int C, int T, int narrow, int k9,
+                          int dil, float* workspace /*nullable: nsc_gated_block_wgrad_workspace(C) floats; enables the
+                          store+reduce flush when the eight gradients are one contiguous range*/, void* stream);
+long nsc_gated_block_wgrad_workspace(int C);
+
 /* ---- separable conv pieces (replaces tf.keras.layers.SeparableConv1D behind nn_core_operator.py:17-21) ---- */
 int nsc_depthwise_fwd(const float* x, const float* wd /*[K,C]*/, float* y, int B, int C, int T, int K, void* stream);
 int nsc_depthwise_bwd(const float* x, const float* wd, const float* dy, float* dx, float* dwd /*accumulate*/,

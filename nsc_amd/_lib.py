@@ -33,6 +33,8 @@ PROTOTYPES = {
     "nsc_conv1d_wgrad": [C.POINTER(ConvDesc), _P, _P, _P, _P, _I, _P],
     "nsc_weight_flip_transpose": [_P, _P, _I, _I, _I, _P],
     "nsc_gated_block_fwd": [_P] * 14 + [_I] * 7 + [_P],
+    "nsc_gated_block_bwd": [_P] * 21 + [_I] * 7 + [_P],
+    "nsc_gated_block_wgrad": [_P] * 15 + [_I] * 6 + [_P, _P],
     "nsc_depthwise_fwd": [_P, _P, _P, _I, _I, _I, _I, _P],
     "nsc_depthwise_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "nsc_gate_fwd": [_P, _P, _I, _I, _I, _P],
@@ -59,7 +61,7 @@ PROTOTYPES = {
     "nsc_frame_utterance": [_P, _L, _P, _P, _I, _P],
     "nsc_overlap_add": [_P, _I, _P, _P, _P],
 }
-EXPORTS = sorted(list(PROTOTYPES) + ["nsc_version", "nsc_last_error"])
+EXPORTS = sorted(list(PROTOTYPES) + ["nsc_version", "nsc_last_error", "nsc_gated_block_wgrad_workspace"])
 
 
 class NscError(RuntimeError):
@@ -82,6 +84,8 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = argt
         fn.restype = C.c_int
+    lib.nsc_gated_block_wgrad_workspace.argtypes = [C.c_int]
+    lib.nsc_gated_block_wgrad_workspace.restype = C.c_long
     lib.nsc_version.restype = C.c_int
     lib.nsc_last_error.restype = C.c_char_p
     _lib = lib

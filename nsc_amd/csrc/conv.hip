@@ -40,7 +40,8 @@ __global__ __launch_bounds__(256) void conv1d_fwd_kernel(nsc_conv_desc d, const 
                                                          const float* __restrict__ aux, float* __restrict__ y,
                                                          int ldx, int win) {
   extern __shared__ __attribute__((aligned(16))) float xs[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform (SGPR): selects, not branches
   const int l15 = lane & 15, kq = lane >> 4;
   const int TT = 4 * NC * 16;
   const int b = blockIdx.y;
@@ -65,22 +66,20 @@ __global__ __launch_bounds__(256) void conv1d_fwd_kernel(nsc_conv_desc d, const 
 
   if constexpr (CIN1) {
     // K order = tap; k-step s covers taps 4s..4s+3 (lane group kq).  xs has 3*dil zero slack at the end.
+    // No control flow inside the MFMA loop (it would make hipcc shuttle the accumulators VGPR<->AGPR every step).
     const int nsteps = (d.K + 3) >> 2;
     float a_cur[RT], a_nxt[RT];
-    {
-      const int tap = kq;
 #pragma unroll
-      for (int r = 0; r < RT; ++r) {
-        const int o = (rt0 + r) * 16 + l15;
-        a_cur[r] = (tap < d.K && o < Cout) ? w[(long)tap * Cout + o] : 0.f;
-      }
+    for (int r = 0; r < RT; ++r) {
+      const int o = (rt0 + r) * 16 + l15;
+      a_cur[r] = nsc_ldm(w, kq * Cout + o, kq < d.K && o < Cout);
     }
     for (int s = 0; s < nsteps; ++s) {
       const int tapn = 4 * (s + 1) + kq;
 #pragma unroll
       for (int r = 0; r < RT; ++r) {
         const int o = (rt0 + r) * 16 + l15;
-        a_nxt[r] = (s + 1 < nsteps && tapn < d.K && o < Cout) ? w[(long)tapn * Cout + o] : 0.f;
+        a_nxt[r] = nsc_ldm(w, tapn * Cout + o, tapn < d.K && o < Cout);
       }
       const int tap = 4 * s + kq;
       float bf[NC];
@@ -109,38 +108,45 @@ __global__ __launch_bounds__(256) void conv1d_fwd_kernel(nsc_conv_desc d, const 
       for (int u = 0; u < G; ++u) {
         const int ci = cqp * 4 + kq;
         const bool okk = tapp < d.K && ci < d.Cin;
-        const float* wrow = w + ((long)tapp * d.Cin + ci) * Cout;
+        const int wrow = (tapp * d.Cin + ci) * Cout;
 #pragma unroll
         for (int r = 0; r < RT; ++r) {
           const int o = (rt0 + r) * 16 + l15;
-          dst[u][r] = (okk && o < Cout) ? wrow[o] : 0.f;
+          dst[u][r] = nsc_ldm(w, wrow + o, okk && o < Cout);
         }
-        if (++cqp == ncq) { cqp = 0; ++tapp; }
+        const bool wrapp = (cqp + 1 == ncq);
+        cqp = wrapp ? 0 : cqp + 1;
+        tapp += wrapp ? 1 : 0;
       }
     };
     fetch_group(an);
+    // The k-loop is padded to a multiple of G: padded steps carry zero weights (masked in fetch_group) and re-read a
+    // valid x position (cursor clamped), so the MFMA loop has NO control flow - guards inside it made hipcc move every
+    // accumulator VGPR<->AGPR around each MFMA.
+    const int ngroups = (nsteps + G - 1) / G;
     int tap = 0, cq = 0;
-    for (int s0 = 0; s0 < nsteps; s0 += G) {
+    for (int g = 0; g < ngroups; ++g) {
       float ac[G][RT];
 #pragma unroll
       for (int u = 0; u < G; ++u)
 #pragma unroll
         for (int r = 0; r < RT; ++r) ac[u][r] = an[u][r];
-      if (s0 + G < nsteps) fetch_group(an);
+      fetch_group(an);   // past the end: all-masked (tapp >= K), loads hit index 0
 #pragma unroll
       for (int u = 0; u < G; ++u) {
-        if (s0 + u < nsteps) {
-          const float* xrow = xs + (cq * 4 + kq) * ldx + tap * d.dil;
-          float bf[NC];
+        const int tapc = tap < d.K ? tap : d.K - 1;
+        const float* xrow = xs + (cq * 4 + kq) * ldx + tapc * d.dil;
+        float bf[NC];
 #pragma unroll
-          for (int c = 0; c < NC; ++c) bf[c] = xrow[(tcol0 + c * 16) * d.stride];
+        for (int c = 0; c < NC; ++c) bf[c] = xrow[(tcol0 + c * 16) * d.stride];
 #pragma unroll
-          for (int r = 0; r < RT; ++r)
+        for (int r = 0; r < RT; ++r)
 #pragma unroll
-            for (int c = 0; c < NC; ++c)
-              acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[u][r], bf[c], acc[r][c], 0, 0, 0);
-          if (++cq == ncq) { cq = 0; ++tap; }
-        }
+          for (int c = 0; c < NC; ++c)
+            acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[u][r], bf[c], acc[r][c], 0, 0, 0);
+        const bool wrap = (cq + 1 == ncq);
+        cq = wrap ? 0 : cq + 1;
+        tap += wrap ? 1 : 0;
       }
     }
   }
@@ -335,7 +341,8 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(nsc_conv_desc d, cons
   constexpr int TT = 64, LDZ = 66;  // 66 % 32 == 2: conflict-free B-fragment reads
   float* xs = sm;                          // [Cin + 2][ldx] : rows Cin = zeros, Cin+1 = ones
   float* dzs = sm + (d.Cin + 2) * ldx;     // [CT*16][LDZ]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform (SGPR): selects, not branches
   const int l15 = lane & 15, kq = lane >> 4;
   const int nrows = d.K * d.Cin + (db ? 1 : 0);
   const int Tin_virt = d.in_up ? 2 * d.Tin : d.Tin;

@@ -48,24 +48,42 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+// Masked load WITHOUT a branch: hipcc turns `ok ? p[i] : 0.f` into a branch around the load plus a vmcnt(0) wait per
+// element, which serialises every weight fetch (guide: "register or load select" trap).  Load unconditionally from a
+// clamped (always valid) index and select on the VALUE instead.
+__device__ __forceinline__ float nsc_ldm(const float* __restrict__ p, int idx, bool ok) {
+  const float v = p[ok ? idx : 0];
+  return ok ? v : 0.f;
+}
 // Stage rows of a [rows, Tin] tensor into LDS: xs[r*ldx + j] = src[r*Tin + u0 + j] for j < width, zero outside the
 // tensor / for pad rows (r >= rows_valid) / for j >= width.  One wave per row, lanes along time (coalesced 256-B reads).
 // in_up: virtual zero-upsampled-by-2 source (u even -> src[u/2], odd -> 0), virtual length Tvirt = 2*Tin.
 __device__ __forceinline__ void nsc_stage_rows(float* __restrict__ xs, int ldx, int rows_total, int rows_valid, int width,
                                                const float* __restrict__ src, int Tin, int u0, int Tvirt, int in_up,
                                                int wave, int lane) {
-  for (int r = wave; r < rows_total; r += 4) {
-    const float* row = src + (long)r * Tin;
-    float* dst = xs + r * ldx;
-    const bool rv = r < rows_valid;
-    for (int j = lane; j < ldx; j += 64) {
-      const int u = u0 + j;
-      float v = 0.f;
-      if (rv && j < width && u >= 0 && u < Tvirt) {
-        if (in_up) { if (!(u & 1)) v = row[u >> 1]; }
-        else v = row[u];
+  // U rows per batch: all U loads are issued before the first LDS store, so one memory round trip covers U rows
+  // (a load->store pair per loop iteration left every row waiting on its own latency).  Loads are branch-free:
+  // clamped address + select on the value.
+  constexpr int U = 8;
+  for (int jb = 0; jb < ldx; jb += 64) {
+    const int j = jb + lane;
+    const int u = u0 + j;
+    const bool cok = j < width && u >= 0 && u < Tvirt && (!in_up || !(u & 1));
+    const int uoff = cok ? (in_up ? (u >> 1) : u) : 0;
+    for (int r0 = wave * U; r0 < rows_total; r0 += 4 * U) {
+      float v[U];
+#pragma unroll
+      for (int q = 0; q < U; ++q) {
+        const int r = r0 + q;
+        const bool ok = cok && r < rows_valid;
+        const float ld = src[(long)(ok ? r : 0) * Tin + uoff];
+        v[q] = ok ? ld : 0.f;
       }
-      dst[j] = v;
+      if (j < ldx) {
+#pragma unroll
+        for (int q = 0; q < U; ++q)
+          if (r0 + q < rows_total) xs[(r0 + q) * ldx + j] = v[q];
+      }
     }
   }
 }

@@ -172,9 +172,11 @@ class _Block:
             P = lambda c, base=e.p_ptr: (base + 4 * c.w_off, base + 4 * c.b_off)
             (w1, b1), (wl, bl), (wr, br), (w9, b9) = P(self.c1), P(self.cl), P(self.cr), P(self.c9)
             tok = e.prof_begin("block_fwd", self.c1.flops() + self.cl.flops() + self.cr.flops() + self.c9.flops())
+            save = not self.fused_bwd_ok()   # the fused backward recomputes the intermediates from x
             check(e.lib.nsc_gated_block_fwd(x.data_ptr(), w1, b1, wl, bl, wr, br, w9, b9, self.out.data_ptr(),
-                                            self.h.data_ptr(), self.lin.data_ptr(), self.th.data_ptr(),
-                                            self.g.data_ptr(), B, self.Cin, T, n, 9, self.cl.dil, int(self.flat),
+                                            self.h.data_ptr() if save else None, self.lin.data_ptr() if save else None,
+                                            self.th.data_ptr() if save else None, self.g.data_ptr() if save else None,
+                                            B, self.Cin, T, n, 9, self.cl.dil, int(self.flat),
                                             e.stream()), "gated_block_fwd")
             e.prof_end(tok)
             return self.out
@@ -185,24 +187,60 @@ class _Block:
         self.c9.fwd(self.g, self.out, self.out_kind, res=x, res_mode=2 if self.Cin == 1 else 1)
         return self.out
 
+    def fused_bwd_ok(self):
+        e = self.eng
+        return (e.fused_fwd and e.fused_bwd and self.Cin > 1 and self.narrow == 20 and self.c9.K == 9
+                and self.cl.dil in (1, 2) and self.wide <= 112)
+
     def bwd(self, dz, in_kind, need_dx=True):
         """dz = dL/d(pre-activation of out).  Returns dL/d(pre-activation of the producer of x)."""
         e, u = self.eng, self.uid
         B, n, T = e.B, self.narrow, self.T
+        if self.fused_bwd_ok():
+            dx = e.buf(u + ".dx", (B, self.Cin, T))
+            P = lambda c: (e.p_ptr + 4 * c.w_off, e.p_ptr + 4 * c.b_off)
+            G = lambda c: (e.g_ptr + 4 * c.w_off, e.g_ptr + 4 * c.b_off)
+            WT = lambda c: e.wt_ptr + 4 * c.w_off
+            (w1, b1), (wl, bl), (wr, br) = P(self.c1), P(self.cl), P(self.cr)
+            (dw1, db1), (dwl, dbl), (dwr, dbr), (dw9, db9) = G(self.c1), G(self.cl), G(self.cr), G(self.c9)
+            fl = 2.0 * (self.c1.flops() + self.cl.flops() + self.cr.flops() + self.c9.flops())
+            tok = e.prof_begin("block_bwd", fl)
+            check(e.lib.nsc_gated_block_bwd(self.x.data_ptr(), dz.data_ptr(), w1, b1, wl, bl, wr, br, WT(self.c1),
+                                            WT(self.cl), WT(self.cr), WT(self.c9), dx.data_ptr(), dw1, db1, dwl, dbl,
+                                            dwr, dbr, dw9, db9, B, self.Cin, T, n, 9, self.cl.dil,
+                                            KIND_ACT[in_kind], e.stream()), "gated_block_bwd")
+            e.prof_end(tok)
+            return dx
         dg = e.buf(u + ".dg", (B, n, T))
         dlin = e.buf(u + ".dlin", (B, n, T))
         dgate = e.buf(u + ".dgate", (B, n, T))
         dh = e.buf(u + ".dh", (B, n, T))
-        self.c9.wgrad(self.g, dz)
+        block_wgrad = (e.fused_wgrad and self.Cin > 1 and n == 20 and self.c9.K == 9 and self.cl.dil <= 4
+                       and self.wide <= 112)
+        if not block_wgrad:
+            self.c9.wgrad(self.g, dz)
         self.c9.dgrad(dz, dg)
         check(e.lib.nsc_glu_bwd(self.lin.data_ptr(), self.th.data_ptr(), dg.data_ptr(), dlin.data_ptr(),
                                 dgate.data_ptr(), dg.numel(), e.stream()), "glu_bwd")
-        self.cl.wgrad(self.h, dlin)
-        self.cr.wgrad(self.h, dgate)
+        if not block_wgrad:
+            self.cl.wgrad(self.h, dlin)
+            self.cr.wgrad(self.h, dgate)
         dh0 = e.buf(u + ".dh0", (B, n, T))
         self.cl.dgrad(dlin, dh0)
         self.cr.dgrad(dgate, dh, res=dh0, res_mode=1, mul_kind="lrelu", aux=self.h)
-        self.c1.wgrad(self.x, dh)
+        if block_wgrad:
+            # one persistent kernel for the eight parameter gradients of the block (register-resident accumulators)
+            G = lambda c: (e.g_ptr + 4 * c.w_off, e.g_ptr + 4 * c.b_off)
+            (dw1, db1), (dwl, dbl), (dwr, dbr), (dw9, db9) = G(self.c1), G(self.cl), G(self.cr), G(self.c9)
+            tok = e.prof_begin("block_wgrad", self.c1.flops() + self.cl.flops() + self.cr.flops() + self.c9.flops())
+            check(e.lib.nsc_gated_block_wgrad(self.x.data_ptr(), self.h.data_ptr(), self.g.data_ptr(), dz.data_ptr(),
+                                              dlin.data_ptr(), dgate.data_ptr(), dh.data_ptr(), dw1, db1, dwl, dbl, dwr,
+                                              dbr, dw9, db9, B, self.Cin, T, n, 9, self.cl.dil,
+                                              e.wgrad_workspace(self.Cin), e.stream()),
+                  "gated_block_wgrad")
+            e.prof_end(tok)
+        else:
+            self.c1.wgrad(self.x, dh)
         if not need_dx:
             return None
         dx = e.buf(u + ".dx", (B, self.Cin, T))
@@ -433,8 +471,20 @@ class CascadeEngine:
         return torch.cuda.current_stream().cuda_stream
 
     fused_fwd = True   # gated blocks run as one kernel (csrc/block.hip); False = one launch per conv
+    fused_bwd = False  # whole-block backward in one persistent kernel (correct, but its conv phases run at one wave
+                       # per SIMD and lose to the per-conv kernels: measured 9.0 vs 6.7 ms/step) - kept, off by default
+    fused_wgrad = True # all eight parameter gradients of a block in one persistent kernel (csrc/block.hip)
     # per-launch HIP-event timing of the conv kernels (bench.py roofline); events sit on the launch stream
     prof = None
+
+    def wgrad_workspace(self, C):
+        """Scratch for the store+reduce flush of nsc_gated_block_wgrad (shared by all blocks: launches are stream-ordered)."""
+        n = int(self.lib.nsc_gated_block_wgrad_workspace(int(C)))
+        ws = self._bufs.get("wgrad.ws")
+        if ws is None or ws.numel() < n:
+            ws = torch.empty(n, dtype=torch.float32, device=self.device)
+            self._bufs["wgrad.ws"] = ws
+        return ws.data_ptr()
 
     def prof_begin(self, tag, flops):
         if self.prof is None:
