@@ -95,35 +95,41 @@ __global__ __launch_bounds__(256) void conv1d_fwd_kernel(nsc_conv_desc d, const 
     }
   } else {
     // K order = (tap, ci) with ci fastest, ci padded to a multiple of 4 (pad rows of xs are zero).
-    // Weight fragments come from global/L2; they are fetched G k-steps ahead as a group so that one L2 round trip
-    // is amortised over >= 32 MFMAs (a 1-step-ahead prefetch left every k-step waiting ~200 ns on its own load).
+    // Weight fragments: raw buffer loads (SRD built from wave-uniform values): per-lane byte offset is loop-invariant,
+    // the k-step advances a SCALAR offset, and anything past the end of the weight array (padded k-steps) reads 0 from
+    // the hardware bounds check - so the loop carries no masks, no selects and no per-load address arithmetic.
+    // Fetched G k-steps ahead as a group so one L2 round trip is amortised over >= 32 MFMAs.  Rows o >= Cout (clamped)
+    // and channels ci >= Cin (B rows are zero) need no masking: they only feed outputs that are never stored / add 0.
     constexpr int G = (RT * NC >= 14) ? 2 : ((RT * NC >= 7) ? 4 : ((RT * NC >= 4) ? 8 : 16));
     const int ncq = Cin4 >> 2;
     const int nsteps = d.K * ncq;
+    const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(w), 0, d.K * d.Cin * Cout * 4, 0x00020000);
+    int voff[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+      const int o = (rt0 + r) * 16 + l15;
+      voff[r] = (kq * Cout + (o < Cout ? o : Cout - 1)) * 4;
+    }
+    const int step_bytes = 4 * Cout * 4;          // one k-step = 4 input channels
+    const int tap_bytes = d.Cin * Cout * 4;
     float an[G][RT];
-    // prefetch cursor (tapp, cqp) walks G steps ahead of the compute cursor (tap, cq)
-    int tapp = 0, cqp = 0;
-    auto fetch_group = [&](float (&dst)[G][RT]) {
+    int tapp = 0, cqp = 0;                         // prefetch cursor
+    auto fetch = [&](float (&dst)[G][RT]) {
 #pragma unroll
       for (int u = 0; u < G; ++u) {
-        const int ci = cqp * 4 + kq;
-        const bool okk = tapp < d.K && ci < d.Cin;
-        const int wrow = (tapp * d.Cin + ci) * Cout;
+        const int soff = __builtin_amdgcn_readfirstlane(tapp * tap_bytes + cqp * step_bytes);   // provably uniform: no waterfall
 #pragma unroll
-        for (int r = 0; r < RT; ++r) {
-          const int o = (rt0 + r) * 16 + l15;
-          dst[u][r] = nsc_ldm(w, wrow + o, okk && o < Cout);
-        }
+        for (int r = 0; r < RT; ++r)
+          dst[u][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wsrd, voff[r], soff, 0));
         const bool wrapp = (cqp + 1 == ncq);
         cqp = wrapp ? 0 : cqp + 1;
         tapp += wrapp ? 1 : 0;
       }
     };
-    fetch_group(an);
-    // The k-loop is padded to a multiple of G: padded steps carry zero weights (masked in fetch_group) and re-read a
-    // valid x position (cursor clamped), so the MFMA loop has NO control flow - guards inside it made hipcc move every
-    // accumulator VGPR<->AGPR around each MFMA.
-    const int ngroups = (nsteps + G - 1) / G;
+    fetch(an);
+    const int ngroups = (nsteps + G - 1) / G;      // padded steps multiply zero weights (out-of-range buffer reads)
+    const int bbase = kq * ldx + tcol0 * d.stride; // per-lane part of the B (x tile) address
     int tap = 0, cq = 0;
     for (int g = 0; g < ngroups; ++g) {
       float ac[G][RT];
@@ -131,14 +137,14 @@ __global__ __launch_bounds__(256) void conv1d_fwd_kernel(nsc_conv_desc d, const 
       for (int u = 0; u < G; ++u)
 #pragma unroll
         for (int r = 0; r < RT; ++r) ac[u][r] = an[u][r];
-      fetch_group(an);   // past the end: all-masked (tapp >= K), loads hit index 0
+      fetch(an);
 #pragma unroll
       for (int u = 0; u < G; ++u) {
         const int tapc = tap < d.K ? tap : d.K - 1;
-        const float* xrow = xs + (cq * 4 + kq) * ldx + tapc * d.dil;
+        const float* xrow = xs + bbase + __builtin_amdgcn_readfirstlane(cq * 4 * ldx + tapc * d.dil);
         float bf[NC];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) bf[c] = xrow[(tcol0 + c * 16) * d.stride];
+        for (int c = 0; c < NC; ++c) bf[c] = xrow[c * 16 * d.stride];
 #pragma unroll
         for (int r = 0; r < RT; ++r)
 #pragma unroll
