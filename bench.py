@@ -158,15 +158,59 @@ def main():
     torch.cuda.synchronize()
     summ = eng.prof_summary()
     eng.prof = None
-    roof = None
-    if "conv_mfma" in summ:
-        n, ms, fl = summ["conv_mfma"]
+    # dominant kernel = the instrumented kernel class with the largest share of the step
+    KERNELS = {"conv_mfma": "conv1d_fwd_kernel (per-conv forward + data-gradient launches)",
+               "block_fwd": "gated_block_fwd_kernel (fused gated block forward)",
+               "block_wgrad": "gated_block_wgrad_kernel (persistent block weight gradients)",
+               "block_bwd": "gated_block_bwd_kernel (fused gated block backward)",
+               "wgrad_mfma": "conv1d_wgrad_kernel (per-conv weight gradients)"}
+    roof, by_kernel = None, {}
+    traffic = {}
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # bytes per launch from rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE
+    if os.path.exists(tpath):
+        traffic = json.load(open(tpath))
+    for tag, (n, ms, fl) in summ.items():
+        ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        by_kernel[tag] = dict(ms_per_step=round(ms / args.prof_steps, 3), launches_per_step=n // args.prof_steps,
+                              achieved_tflops=round(ach, 2))
+    mf = {k: v for k, v in summ.items() if k in KERNELS}
+    if mf:
+        tag = max(mf, key=lambda k: mf[k][1])
+        n, ms, fl = mf[tag]
         ach = fl / (ms * 1e-3) / 1e12
-        roof = dict(bound="mfma", kernel="conv1d_fwd_kernel (fwd + dgrad launches)", achieved=round(ach, 3),
-                    peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
+        roof = dict(bound="mfma", kernel=KERNELS[tag], achieved=round(ach, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                    frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic.get(tag),
                     launches_per_step=n // args.prof_steps, avg_launch_us=round(1e3 * ms / n, 2),
-                    flop_per_launch_avg=fl / n)
-    kern_ms = {k: round(v[1] / args.prof_steps, 3) for k, v in summ.items()}
+                    flop_per_launch_avg=fl / n, peak_measured_on_box=127.4)
+    kern_ms = by_kernel
+
+    # HBM-bound quantizer at the op-surface form (p materialised, 34 816 B/frame fwd): measured at the config-5 batch
+    qroof = None
+    if comm.rank == 0:
+        import ctypes as C
+        from nsc_amd import _lib
+        lib = _lib.load()
+        Bq, L, nb = 4096, 256, 32
+        code = torch.tanh(torch.randn(Bq, L, 1, device=dev))
+        p = torch.empty(Bq, L, nb, device=dev); outq = torch.empty_like(code)
+        qv = torch.empty(Bq, device=dev); hist = torch.zeros(nb, device=dev)
+        c0 = eng.codecs[0]
+        st = torch.cuda.current_stream().cuda_stream
+        def qf():
+            _lib.check(lib.nsc_quantize_fwd(code.data_ptr(), eng.p_ptr + 4 * c0.alpha_off, eng.p_ptr + 4 * c0.bins_off, 1.0, 1,
+                                            Bq, L, nb, p.data_ptr(), outq.data_ptr(), qv.data_ptr(), hist.data_ptr(), st), "q")
+        for _ in range(3):
+            qf()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            qf()
+        e1.record(); torch.cuda.synchronize()
+        us = 1e3 * e0.elapsed_time(e1) / 20
+        byts = Bq * L * (4 + 4 * nb + 4)
+        qroof = dict(bound="hbm", kernel="quantize_fwd_kernel (p materialised, B=4096 frames)", achieved=round(byts / us / 1e3, 1),
+                     peak=8000.0, unit="GB/s", frac=round(byts / us / 1e3 / 8000.0, 4), traffic=traffic.get("quantize_fwd"),
+                     bytes_per_launch=byts, avg_launch_us=round(us, 2), peak_measured_on_box=4600.0)
 
     cpu = None
     if comm.rank == 0 and comm.world == 1 and not args.no_cpu_baseline:
@@ -184,7 +228,7 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * comm.world, "frame": 512,
                        "parallelism": f"dp{comm.world}", "launch": "hipGraph" if graph is not None else "eager"},
             "model_tflops": round(fps * MFLOP_PER_FRAME_JOINT * 1e6 / 1e12, 2),
-            "roofline": roof, "cpu_baseline": cpu, "conv_ms_per_step_by_kernel": kern_ms,
+            "roofline": roof, "roofline_quantizer": qroof, "cpu_baseline": cpu, "kernels": kern_ms,
         }
         print(json.dumps(out))
     comm.close()

@@ -1017,19 +1017,21 @@ __global__ __launch_bounds__(256, 1) void gated_block_wgrad_kernel(BlockWgradArg
     }
 }
 
-// grads[i] += sum_w slab[w * stride + i]
+// grads[i] += sum_w slab[w * stride + i]; blockIdx.y splits the slabs (8 groups) so enough loads are in flight
 __global__ void slab_reduce_kernel(const float* __restrict__ slab, long stride, int nslabs, float* __restrict__ grads, int n) {
+  const int per = (nslabs + gridDim.y - 1) / gridDim.y;
+  const int w0 = blockIdx.y * per, w1 = min(nslabs, w0 + per);
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int w = 0;
-    for (; w + 3 < nslabs; w += 4) {
+    int w = w0;
+    for (; w + 3 < w1; w += 4) {
       s0 += slab[(long)w * stride + i];
       s1 += slab[(long)(w + 1) * stride + i];
       s2 += slab[(long)(w + 2) * stride + i];
       s3 += slab[(long)(w + 3) * stride + i];
     }
-    for (; w < nslabs; ++w) s0 += slab[(long)w * stride + i];
-    grads[i] += (s0 + s1) + (s2 + s3);
+    for (; w < w1; ++w) s0 += slab[(long)w * stride + i];
+    atomicAdd(grads + i, (s0 + s1) + (s2 + s3));
   }
 }
 
@@ -1083,7 +1085,7 @@ extern "C" int nsc_gated_block_wgrad(const float* x, const float* h, const float
 #undef LAUNCH_WG
   NSC_CHECK_LAUNCH("gated_block_wgrad");
   if (use_slab) {
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(nsc_cdiv(range, 256)), dim3(256), 0, st, workspace, a.slab_stride, grid,
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(nsc_cdiv(range, 256), 8), dim3(256), 0, st, workspace, a.slab_stride, grid,
                        gbase, (int)range);
     NSC_CHECK_LAUNCH("slab_reduce");
   }
