@@ -89,13 +89,15 @@ int nsc_gated_block_bwd(const float* x, const float* dy, const float* w1, const 
                         int dil, int in_act, void* stream);
 
 /* Persistent weight-gradient kernel of one gated block: all eight parameter gradients (accumulated) from the saved
- * activations x [B,C,T], h, g [B,20,T] and the data-path gradients dy [B,C,T], dlin, dgate, dz1 [B,20,T] that the
- * per-conv backward produces (dlin/dgate = nsc_glu_bwd outputs, dz1 = dL/d(pre-activation of h)). */
-int nsc_gated_block_wgrad(const float* x, const float* h, const float* g, const float* dy, const float* dlin,
-                          const float* dgate, const float* dz1, float* dw1, float* db1, float* dwl, float* dbl,
-                          float* dwr, float* dbr, float* dw9, float* db9, int B, int C, int T, int narrow, int k9,
-                          int dil, float* workspace /*nullable: nsc_gated_block_wgrad_workspace(C) floats; enables the
-                          store+reduce flush when the eight gradients are one contiguous range*/, void* stream);
+ * activations x [B,C,T], h, g [B,20,T] and the data-path gradients dy [B,C,T], da [B,40,T] (= dlin | dgate, the
+ * nsc_glu_bwd_cat output), dz1 [B,20,T] (= dL/d(pre-activation of h)).  Optionally (dx != NULL) it also produces the
+ * block's 1x1 data gradient dx = (conv1^T(dz1) + dy) * act'(x) from the tiles it has staged anyway (wt1 = the
+ * flipped/transposed 1x1 kernel [20][C]).  workspace (nullable): nsc_gated_block_wgrad_workspace(C) floats; enables the
+ * store+reduce flush when the eight gradients are one contiguous range in creation order. */
+int nsc_gated_block_wgrad(const float* x, const float* h, const float* g, const float* dy, const float* da,
+                          const float* dz1, float* dw1, float* db1, float* dwl, float* dbl, float* dwr, float* dbr,
+                          float* dw9, float* db9, const float* wt1, float* dx, int in_act, int B, int C, int T,
+                          int narrow, int k9, int dil, float* workspace, void* stream);
 long nsc_gated_block_wgrad_workspace(int C);
 
 /* ---- separable conv pieces (replaces tf.keras.layers.SeparableConv1D behind nn_core_operator.py:17-21) ---- */
@@ -112,6 +114,7 @@ int nsc_gate_bwd(const float* a, const float* dg, float* da, int B, int n, int T
  * dlin = dg*th, dgate_pre = dg*lin*(1-th^2). */
 int nsc_mul(const float* a, const float* b, float* out, long n, void* stream);
 int nsc_glu_bwd(const float* lin, const float* th, const float* dg, float* dlin, float* dgate, long n, void* stream);
+int nsc_glu_bwd_cat(const float* lin, const float* th, const float* dg, float* da /*[B,2n,T] = dlin | dgate*/, int B, int n, int T, void* stream);
 
 /* stand-alone activation (nn_core_operator.py:24-31 `activation_func` = leaky_relu 0.2; tanh for conv epilogues) */
 int nsc_act_fwd(const float* x, float* y, long n, int act, void* stream);

@@ -835,7 +835,10 @@ extern "C" int nsc_gated_block_bwd(const float* x, const float* dy, const float*
 // =====================================================================================================
 struct BlockWgradArgs {
   int B, C, T, dil;
-  const float *x, *h, *g, *dy, *dlin, *dgate, *dz1;
+  const float *x, *h, *g, *dy, *da, *dz1;   // da [B,40,T] = dlin | dgate
+  const float* wt1;                          // nullable: flipped/transposed 1x1 kernel [20][C]; with dx enables the fused
+  float* dx;                                 //   data gradient dx = (W1^T dz1 + dy) * act'(x)
+  int in_act;
   float *dw1, *db1, *dwl, *dbl, *dwr, *dbr, *dw9, *db9;   // atomics into the gradients, or (slab != 0) plain stores into
   int ntiles, tiles_per_frame;                             // this workgroup's private partial slab (same relative layout)
   long slab_stride;                                        // floats between consecutive workgroups' slabs (0 = atomics)
@@ -923,10 +926,44 @@ __global__ __launch_bounds__(256, 1) void gated_block_wgrad_kernel(BlockWgradArg
     nsc_stage_rows(dys, ldn, C, C, TT, a.dy + (long)b * C * T, T, t0, T, 0, wave, lane);
     nsc_stage_rows(gs, ldg, NARROW, NARROW, TT + 8, a.g + (long)b * NARROW * T, T, t0 - 4, T, 0, wave, lane);
     nsc_stage_rows(hs, ldh, NARROW, NARROW, TT + 2 * Hh, a.h + (long)b * NARROW * T, T, t0 - Hh, T, 0, wave, lane);
-    nsc_stage_rows(dl, ldn, NARROW, NARROW, TT, a.dlin + (long)b * NARROW * T, T, t0, T, 0, wave, lane);
-    nsc_stage_rows(dg_, ldn, NARROW, NARROW, TT, a.dgate + (long)b * NARROW * T, T, t0, T, 0, wave, lane);
+    nsc_stage_rows(dl, ldn, 2 * NARROW, 2 * NARROW, TT, a.da + (long)b * 2 * NARROW * T, T, t0, T, 0, wave, lane);  // dlin rows 0-19, dgate 20-39
     nsc_stage_rows(dhs, ldn, NARROW, NARROW, TT, a.dz1 + (long)b * NARROW * T, T, t0, T, 0, wave, lane);
     __syncthreads();
+    if (a.dx) {
+      // fused 1x1 data gradient: dx = (W1^T dz1 + dy) * act'(x); wave owns column tile `wave`, all RT9 row tiles, K = 20
+      f32x4 acc[RT9];
+#pragma unroll
+      for (int r = 0; r < RT9; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const int tt = wave * 16 + l15;
+      float av[5][RT9];
+#pragma unroll
+      for (int s = 0; s < 5; ++s)
+#pragma unroll
+        for (int r = 0; r < RT9; ++r) {
+          const int c = r * 16 + l15;
+          av[s][r] = a.wt1[(s * 4 + kq) * C + (c < C ? c : C - 1)];
+        }
+#pragma unroll
+      for (int s = 0; s < 5; ++s) {
+        const float bv = dhs[(s * 4 + kq) * ldn + tt];
+#pragma unroll
+        for (int r = 0; r < RT9; ++r) acc[r] = mfma4(av[s][r], bv, acc[r]);
+      }
+      const int t = t0 + tt;
+      if (t < T) {
+#pragma unroll
+        for (int r = 0; r < RT9; ++r)
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) {
+            const int c = r * 16 + kq * 4 + reg;
+            if (c < C) {
+              float v = acc[r][reg] + dys[c * ldn + tt];
+              if (a.in_act == NSC_ACT_LRELU) v *= (xn[c * ldn + tt] > 0.f ? 1.f : NSC_LRELU_ALPHA);
+              a.dx[((long)b * C + c) * T + t] = v;
+            }
+          }
+      }
+    }
 #pragma unroll 2
     for (int s = 0; s < TT / 4; ++s) {
       const int tl = 4 * s + kq;
@@ -1043,12 +1080,14 @@ extern "C" long nsc_gated_block_wgrad_workspace(int C) {
   return 256L * ((range + 63) & ~63L);
 }
 
-extern "C" int nsc_gated_block_wgrad(const float* x, const float* h, const float* g, const float* dy, const float* dlin,
-                                     const float* dgate, const float* dz1, float* dw1, float* db1, float* dwl,
-                                     float* dbl, float* dwr, float* dbr, float* dw9, float* db9, int B, int C, int T,
-                                     int narrow, int k9, int dil, float* workspace, void* stream) {
-  NSC_REQUIRE(x && h && g && dy && dlin && dgate && dz1 && dw1 && db1 && dwl && dbl && dwr && dbr && dw9 && db9,
+extern "C" int nsc_gated_block_wgrad(const float* x, const float* h, const float* g, const float* dy, const float* da,
+                                     const float* dz1, float* dw1, float* db1, float* dwl, float* dbl, float* dwr,
+                                     float* dbr, float* dw9, float* db9, const float* wt1, float* dx, int in_act, int B,
+                                     int C, int T, int narrow, int k9, int dil, float* workspace, void* stream) {
+  NSC_REQUIRE(x && h && g && dy && da && dz1 && dw1 && db1 && dwl && dbl && dwr && dbr && dw9 && db9,
               NSC_ERR_BAD_ARG, "nsc_gated_block_wgrad: null pointer");
+  NSC_REQUIRE(!dx || wt1, NSC_ERR_BAD_ARG, "nsc_gated_block_wgrad: dx needs wt1");
+  NSC_REQUIRE(in_act == NSC_ACT_NONE || in_act == NSC_ACT_LRELU, NSC_ERR_BAD_ARG, "nsc_gated_block_wgrad: in_act must be none|lrelu");
   NSC_REQUIRE(B > 0 && C > 1 && T > 0 && dil > 0, NSC_ERR_BAD_ARG, "nsc_gated_block_wgrad: bad sizes");
   NSC_REQUIRE(narrow == NARROW && k9 == K9 && dil <= 4 && C <= 112, NSC_ERR_UNSUPPORTED,
               "nsc_gated_block_wgrad: built for narrow=20, k9=9, dil<=4, C<=112 (got %d, %d, %d, %d)", narrow, k9, dil, C);
@@ -1056,7 +1095,7 @@ extern "C" int nsc_gated_block_wgrad(const float* x, const float* h, const float
   const size_t fl = (size_t)(2 * C + 2) * ldn + (size_t)(NARROW + 2) * (ldg + ldh) + (size_t)3 * NARROW * ldn;
   const size_t smem = fl * sizeof(float);
   NSC_REQUIRE(smem <= 160 * 1024, NSC_ERR_UNSUPPORTED, "nsc_gated_block_wgrad: %zu B LDS", smem);
-  BlockWgradArgs a{B, C, T, dil, x, h, g, dy, dlin, dgate, dz1, dw1, db1, dwl, dbl, dwr, dbr, dw9, db9, 0, 0, 0};
+  BlockWgradArgs a{B, C, T, dil, x, h, g, dy, da, dz1, wt1, dx, in_act, dw1, db1, dwl, dbl, dwr, dbr, dw9, db9, 0, 0, 0};
   a.tiles_per_frame = nsc_cdiv(T, 64);
   a.ntiles = B * a.tiles_per_frame;
   const int grid = std::min(a.ntiles, 256);

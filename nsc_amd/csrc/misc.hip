@@ -435,3 +435,23 @@ extern "C" int nsc_p_stats_bwd(const float* p, const float* gq, const float* gh,
   NSC_CHECK_LAUNCH("p_stats_bwd");
   return NSC_OK;
 }
+
+// GLU backward writing both branch gradients into ONE [B, 2n, T] tensor (dlin | dgate) so that the two k15 data
+// gradients run as a single conv with 2n input channels.
+__global__ void glu_bwd_cat_kernel(const float* __restrict__ lin, const float* __restrict__ th, const float* __restrict__ dg,
+                                   float* __restrict__ da, long nT, long total) {
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long b = e / nT, r = e - b * nT;
+    const float g = dg[e], t = th[e];
+    da[b * 2 * nT + r] = g * t;
+    da[b * 2 * nT + nT + r] = g * lin[e] * (1.f - t * t);
+  }
+}
+extern "C" int nsc_glu_bwd_cat(const float* lin, const float* th, const float* dg, float* da, int B, int n, int T, void* stream) {
+  NSC_REQUIRE(lin && th && dg && da && B > 0 && n > 0 && T > 0, NSC_ERR_BAD_ARG, "nsc_glu_bwd_cat: bad args");
+  const long total = (long)B * n * T;
+  hipLaunchKernelGGL(glu_bwd_cat_kernel, dim3(std::min<long>(4096, nsc_cdiv(total, 256))), dim3(256), 0, (hipStream_t)stream,
+                     lin, th, dg, da, (long)n * T, total);
+  NSC_CHECK_LAUNCH("glu_bwd_cat");
+  return NSC_OK;
+}

@@ -217,30 +217,44 @@ class _Block:
         dh = e.buf(u + ".dh", (B, n, T))
         block_wgrad = (e.fused_wgrad and self.Cin > 1 and n == 20 and self.c9.K == 9 and self.cl.dil <= 4
                        and self.wide <= 112)
-        if not block_wgrad:
-            self.c9.wgrad(self.g, dz)
+        if block_wgrad:
+            # data path: k9 dgrad -> GLU backward (dlin | dgate in one tensor) -> ONE k15 dgrad over 40 input channels;
+            # then a persistent kernel does all eight parameter gradients AND the 1x1 data gradient (it has x, dy, dz1
+            # staged anyway).
+            self.c9.dgrad(dz, dg)
+            da = e.buf(u + ".da", (B, 2 * n, T))
+            check(e.lib.nsc_glu_bwd_cat(self.lin.data_ptr(), self.th.data_ptr(), dg.data_ptr(), da.data_ptr(), B, n, T,
+                                        e.stream()), "glu_bwd_cat")
+            cl = self.cl
+            d = ConvDesc(B=B, Cin=2 * n, Cout=n, Tin=T, Tout=T, K=cl.K, dil=cl.dil, stride=1,
+                         padL=(cl.K - 1) * cl.dil - cl.padL, act=0, res_mode=0, mul_mode=KIND_MUL["lrelu"], out_mode=0,
+                         in_up=0, accumulate=0)
+            tok = e.prof_begin("conv_mfma", self.cl.flops() + self.cr.flops())
+            check(e.lib.nsc_conv1d_fwd(C.byref(d), da.data_ptr(), e.wt_ptr + 4 * self.wtlr_off, None, None,
+                                       self.h.data_ptr(), dh.data_ptr(), e.stream()), "gate dgrad (fused lin|gate)")
+            e.prof_end(tok)
+            dx = e.buf(u + ".dx", (B, self.Cin, T)) if need_dx else None
+            G = lambda c: (e.g_ptr + 4 * c.w_off, e.g_ptr + 4 * c.b_off)
+            (dw1, db1), (dwl, dbl), (dwr, dbr), (dw9, db9) = G(self.c1), G(self.cl), G(self.cr), G(self.c9)
+            fl = self.c1.flops() * (2 if need_dx else 1) + self.cl.flops() + self.cr.flops() + self.c9.flops()
+            tok = e.prof_begin("block_wgrad", fl)
+            check(e.lib.nsc_gated_block_wgrad(self.x.data_ptr(), self.h.data_ptr(), self.g.data_ptr(), dz.data_ptr(),
+                                              da.data_ptr(), dh.data_ptr(), dw1, db1, dwl, dbl, dwr, dbr, dw9, db9,
+                                              e.wt_ptr + 4 * self.c1.w_off, _lib.ptr(dx), KIND_ACT[in_kind], B,
+                                              self.Cin, T, n, 9, self.cl.dil, e.wgrad_workspace(self.Cin), e.stream()),
+                  "gated_block_wgrad")
+            e.prof_end(tok)
+            return dx
+        self.c9.wgrad(self.g, dz)
         self.c9.dgrad(dz, dg)
         check(e.lib.nsc_glu_bwd(self.lin.data_ptr(), self.th.data_ptr(), dg.data_ptr(), dlin.data_ptr(),
                                 dgate.data_ptr(), dg.numel(), e.stream()), "glu_bwd")
-        if not block_wgrad:
-            self.cl.wgrad(self.h, dlin)
-            self.cr.wgrad(self.h, dgate)
+        self.cl.wgrad(self.h, dlin)
+        self.cr.wgrad(self.h, dgate)
         dh0 = e.buf(u + ".dh0", (B, n, T))
         self.cl.dgrad(dlin, dh0)
         self.cr.dgrad(dgate, dh, res=dh0, res_mode=1, mul_kind="lrelu", aux=self.h)
-        if block_wgrad:
-            # one persistent kernel for the eight parameter gradients of the block (register-resident accumulators)
-            G = lambda c: (e.g_ptr + 4 * c.w_off, e.g_ptr + 4 * c.b_off)
-            (dw1, db1), (dwl, dbl), (dwr, dbr), (dw9, db9) = G(self.c1), G(self.cl), G(self.cr), G(self.c9)
-            tok = e.prof_begin("block_wgrad", self.c1.flops() + self.cl.flops() + self.cr.flops() + self.c9.flops())
-            check(e.lib.nsc_gated_block_wgrad(self.x.data_ptr(), self.h.data_ptr(), self.g.data_ptr(), dz.data_ptr(),
-                                              dlin.data_ptr(), dgate.data_ptr(), dh.data_ptr(), dw1, db1, dwl, dbl, dwr,
-                                              dbr, dw9, db9, B, self.Cin, T, n, 9, self.cl.dil,
-                                              e.wgrad_workspace(self.Cin), e.stream()),
-                  "gated_block_wgrad")
-            e.prof_end(tok)
-        else:
-            self.c1.wgrad(self.x, dh)
+        self.c1.wgrad(self.x, dh)
         if not need_dx:
             return None
         dx = e.buf(u + ".dx", (B, self.Cin, T))
@@ -302,6 +316,15 @@ class _Codec:
             T, C_ = T * s, C_ // s
         self.dec_tail, C_ = stack(C_, T)
         self.dec_out = _Conv(eng, scope, 55, C_, 1, 1, 1, T)
+
+    def all_blocks(self):
+        out = []
+        for blocks, _ in self.enc_stages:
+            out += blocks
+        out += self.enc_tail
+        for st in self.dec_stages:
+            out += st[0]
+        return out + self.dec_tail
 
     # -------------------------------------------------------------------------------------------
     def forward(self, x, is_quan_on, soft, want_p=False):
@@ -452,11 +475,24 @@ class CascadeEngine:
         f32 = dict(dtype=torch.float32, device=self.device)
         self.params = torch.zeros(n, **f32)
         self.grads = torch.zeros(n, **f32)
-        self.wt = torch.zeros(n, **f32)
+        # wt = flipped/transposed kernels of every conv at the same offsets as the parameters, followed by one extra
+        # region per gated block holding the two k15 gate kernels concatenated along their OUTPUT channels
+        # (wt_lr[tap', c' in 0..39, ci]) so that both gate data-gradients run as a single 40-channel conv.
+        blocks = [b for c in self.codecs for b in c.all_blocks()]
+        extra = 0
+        for b in blocks:
+            b.wtlr_off = n + extra
+            extra += b.cl.K * 2 * b.narrow * b.narrow
+        self.wt = torch.zeros(n + extra, **f32)
         self.p_ptr, self.g_ptr, self.wt_ptr = self.params.data_ptr(), self.grads.data_ptr(), self.wt.data_ptr()
-        idx = np.arange(n, dtype=np.int32)
+        idx = np.arange(n + extra, dtype=np.int32)
         for c in self.convs:
             idx[c.w_off:c.w_off + c.K * c.Cin * c.Cout] = c.wt_index()
+        for b in blocks:
+            K, nn = b.cl.K, b.narrow
+            il = b.cl.wt_index().reshape(K, nn, nn)      # [tap', c, ci] source offsets
+            ir = b.cr.wt_index().reshape(K, nn, nn)
+            idx[b.wtlr_off:b.wtlr_off + K * 2 * nn * nn] = np.concatenate([il, ir], axis=1).reshape(-1)
         self.wt_idx = torch.from_numpy(idx).to(self.device)
         # two Adam slot sets (no-quan op / quan op) with independent state (nsc_module:922-926)
         self.adam = [dict(m=torch.zeros(n, **f32), v=torch.zeros(n, **f32), t=0,
@@ -563,7 +599,7 @@ class CascadeEngine:
         return out
 
     def refresh_wt(self):
-        check(self.lib.nsc_gather(self.p_ptr, self.wt_idx.data_ptr(), self.wt_ptr, self.layout.size, self.stream()),
+        check(self.lib.nsc_gather(self.p_ptr, self.wt_idx.data_ptr(), self.wt_ptr, self.wt.numel(), self.stream()),
               "gather wt")
 
     # ---- forward ----

@@ -220,6 +220,10 @@ def test_glue_kernels(lib):
     gg = torch.empty((2, 20, 128), device="cuda")
     assert lib.nsc_mul(lin.data_ptr(), t2.data_ptr(), gg.data_ptr(), gg.numel(), _st()) == 0
     assert_close(gg.cpu().numpy(), a[:, :20] * th, what="mul")
+    dcat = torch.empty((2, 40, 128), device="cuda")
+    assert lib.nsc_glu_bwd_cat(lin.data_ptr(), t2.data_ptr(), P(dg), dcat.data_ptr(), 2, 20, 128, _st()) == 0
+    assert_close(dcat.cpu().numpy()[:, :20], dg * th, what="glu_cat dlin")
+    assert_close(dcat.cpu().numpy()[:, 20:], dg * a[:, :20] * (1 - th ** 2), what="glu_cat dgate")
     d1, d2 = torch.empty_like(gg), torch.empty_like(gg)
     assert lib.nsc_glu_bwd(lin.data_ptr(), t2.data_ptr(), P(dg), d1.data_ptr(), d2.data_ptr(), gg.numel(), _st()) == 0
     assert_close(d1.cpu().numpy(), dg * th, what="glu dlin")
@@ -487,14 +491,16 @@ def test_block_wgrad_kernel(lib, case):
     dws = [torch.zeros(s, device="cuda") for s in shapes]
     dbs = [torch.zeros(s[2], device="cuda") for s in shapes]
     tr = lambda v: P(v.transpose(0, 2, 1))
-    rc = lib.nsc_gated_block_wgrad(tr(x), tr(h), tr(g), tr(dy), tr(dlin), tr(dgate), tr(dz1), dws[0].data_ptr(),
-                                   dbs[0].data_ptr(), dws[1].data_ptr(), dbs[1].data_ptr(), dws[2].data_ptr(),
-                                   dbs[2].data_ptr(), dws[3].data_ptr(), dbs[3].data_ptr(), B, C_, T, 20, 9, dil, None, _st())
+    da = np.concatenate([dlin, dgate], axis=2)                              # [B,T,40] -> dlin | dgate
+    rc = lib.nsc_gated_block_wgrad(tr(x), tr(h), tr(g), tr(dy), tr(da), tr(dz1), dws[0].data_ptr(), dbs[0].data_ptr(),
+                                   dws[1].data_ptr(), dbs[1].data_ptr(), dws[2].data_ptr(), dbs[2].data_ptr(),
+                                   dws[3].data_ptr(), dbs[3].data_ptr(), None, None, 0, B, C_, T, 20, 9, dil, None, _st())
     assert rc == 0, lib.nsc_last_error()
     for i in range(4):
         assert_close(dws[i].cpu().numpy(), ref[i][0], tol=2e-4, what=f"block wgrad dW[{i}] {case}")
         assert_close(dbs[i].cpu().numpy(), ref[i][1], tol=2e-4, what=f"block wgrad db[{i}] {case}")
-    # store + reduce flush: gradients contiguous in one flat buffer (creation order), pre-filled to check accumulation
+    # store + reduce flush (gradients contiguous in one flat buffer, pre-filled to check accumulation) together with
+    # the fused 1x1 data gradient dx = (W1^T dz1 + dy) * lrelu'(x)
     sizes = [int(np.prod(s)) for s in shapes]
     flat = torch.full((sum(sizes) + sum(s[2] for s in shapes),), 0.5, device="cuda")
     ptrs, off = [], 0
@@ -502,11 +508,16 @@ def test_block_wgrad_kernel(lib, case):
         ptrs += [flat.data_ptr() + 4 * off, flat.data_ptr() + 4 * (off + n_)]
         off += n_ + s_[2]
     ws = torch.empty(int(lib.nsc_gated_block_wgrad_workspace(C_)), device="cuda")
-    rc = lib.nsc_gated_block_wgrad(tr(x), tr(h), tr(g), tr(dy), tr(dlin), tr(dgate), tr(dz1), *ptrs, B, C_, T, 20, 9, dil,
-                                   ws.data_ptr(), _st())
+    W1 = (rng.standard_normal((1, C_, 20)) / 5).astype(np.float32)
+    wt1 = np.ascontiguousarray(W1[::-1].transpose(0, 2, 1))                  # [1,20,C]
+    dx = torch.full((B, C_, T), float("nan"), device="cuda")
+    rc = lib.nsc_gated_block_wgrad(tr(x), tr(h), tr(g), tr(dy), tr(da), tr(dz1), *ptrs, P(wt1), dx.data_ptr(), 2, B, C_, T,
+                                   20, 9, dil, ws.data_ptr(), _st())
     assert rc == 0, lib.nsc_last_error()
     got, off = flat.cpu().numpy() - 0.5, 0
     for i, (s_, n_) in enumerate(zip(shapes, sizes)):
         assert_close(got[off:off + n_].reshape(s_), ref[i][0], tol=2e-4, what=f"slab flush dW[{i}] {case}")
         assert_close(got[off + n_:off + n_ + s_[2]], ref[i][1], tol=2e-4, what=f"slab flush db[{i}] {case}")
         off += n_ + s_[2]
+    dx_ref = (dz1.astype(np.float64) @ W1[0].astype(np.float64).T + dy) * np.where(x > 0, 1.0, 0.2)
+    assert_close(dx.cpu().numpy().transpose(0, 2, 1), dx_ref, tol=2e-4, what=f"fused 1x1 dgrad {case}")
