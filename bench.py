@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--prof-steps", type=int, default=3)
+    ap.add_argument("--no-infer", action="store_true", help="skip the codec-forward us/frame measurement")
     ap.add_argument("--fused-bwd", action="store_true", help="debug: whole-block persistent backward kernel")
     ap.add_argument("--unfused-wgrad", action="store_true", help="debug: per-conv weight gradients")
     ap.add_argument("--unfused-fwd", action="store_true", help="debug: per-conv forward/backward (no block fusion)")
@@ -212,6 +213,43 @@ def main():
                      peak=8000.0, unit="GB/s", frac=round(byts / us / 1e3 / 8000.0, 4), traffic=traffic.get("quantize_fwd"),
                      bytes_per_launch=byts, avg_launch_us=round(us, 2), peak_measured_on_box=4600.0)
 
+    # ---- second half of the metric: codec forward us/frame (BASELINE config 5: 2-codec encode+quantise+decode,
+    # batch 4096 frames, hipGraph-captured forward), plus the batch-1 latency the reference's eval loop actually pays
+    infer = None
+    if comm.rank == 0 and not args.no_infer:
+        def fwd_time(Bi, reps):
+            engi = CascadeEngine(Bi, 2, BKD, [[2], [2]], [32, 32], res_scalar=RES_SCALAR, scale_first=True, lpc=True, device=dev)
+            engi.params.copy_(eng.params)
+            xi = torch.from_numpy(np.tile(x_np, (max(1, Bi // B + 1), 1, 1))[:Bi].copy()).to(dev)
+            for _ in range(2):
+                engi.forward(xi, 1.0, False)
+            torch.cuda.synchronize()
+            gi = None
+            try:
+                si = torch.cuda.Stream()
+                si.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(si):
+                    engi.forward(xi, 1.0, False)
+                torch.cuda.current_stream().wait_stream(si)
+                gi = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gi, stream=si):
+                    engi.forward(xi, 1.0, False)
+            except Exception:
+                gi = None
+            runi = gi.replay if gi is not None else (lambda: engi.forward(xi, 1.0, False))
+            runi(); torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                runi()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t1) / reps, gi is not None
+        tb, g1 = fwd_time(4096, 5)
+        t1f, g2 = fwd_time(1, 50)
+        infer = dict(batch=4096, us_per_frame=round(1e6 * tb / 4096, 3), ms_per_batch=round(1e3 * tb, 3),
+                     frames_per_s=round(4096 / tb, 1), launch="hipGraph" if g1 else "eager",
+                     batch1_latency_us=round(1e6 * t1f, 1), hard_codes=True,
+                     tflops=round(4096 / tb * 476.1e6 / 1e12, 2))
+
     cpu = None
     if comm.rank == 0 and comm.world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(B, x_np, lpc_np)
@@ -228,7 +266,7 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * comm.world, "frame": 512,
                        "parallelism": f"dp{comm.world}", "launch": "hipGraph" if graph is not None else "eager"},
             "model_tflops": round(fps * MFLOP_PER_FRAME_JOINT * 1e6 / 1e12, 2),
-            "roofline": roof, "roofline_quantizer": qroof, "cpu_baseline": cpu, "kernels": kern_ms,
+            "roofline": roof, "roofline_quantizer": qroof, "cpu_baseline": cpu, "codec_forward": infer, "kernels": kern_ms,
         }
         print(json.dumps(out))
     comm.close()

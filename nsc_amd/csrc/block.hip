@@ -842,6 +842,7 @@ struct BlockWgradArgs {
   float *dw1, *db1, *dwl, *dbl, *dwr, *dbr, *dw9, *db9;   // atomics into the gradients, or (slab != 0) plain stores into
   int ntiles, tiles_per_frame;                             // this workgroup's private partial slab (same relative layout)
   long slab_stride;                                        // floats between consecutive workgroups' slabs (0 = atomics)
+  int skip;   // timing-only probe (NSC_WG_SKIP): 1 D1, 2 wgrad MFMA loop, 4 flush, 8 staging loads, 16 staging stores
 };
 
 __device__ __forceinline__ void wg_flush(float* p, float v, bool plain) {
@@ -918,24 +919,83 @@ __global__ __launch_bounds__(256, 1) void gated_block_wgrad_kernel(BlockWgradArg
   mb1 = (16 + l15 < NARROW) ? 1.f : 0.f;
   const int offb1 = (16 + l15 < NARROW ? 16 + l15 : 0) * ldn;
 
+  // ---- software-pipelined staging: the NEXT tile's global loads are issued into registers before the MFMA loop of the
+  // current tile and written to LDS after it (one wave per SIMD cannot hide load latency any other way).  Row r of a
+  // region is owned by wave r%4; lanes walk time.  All loads are unconditional (clamped) + value select.
+  constexpr int QX = RT9 * 4;                       // rows per wave for the C-channel tensors (x, dy)
+  float rx[QX], ry[QX], ra[10], rz[5], rg[5][2], rh[5][2];
+  auto load_tile = [&](int tile) {
+    const int b = tile / a.tiles_per_frame;
+    const int t0 = (tile - b * a.tiles_per_frame) * TT;
+    const int t = t0 + lane;
+    const bool tok = t < T;
+    const int tc = tok ? t : 0;
+    const float* xb = a.x + (long)b * C * T;
+    const float* yb = a.dy + (long)b * C * T;
+#pragma unroll
+    for (int q = 0; q < QX; ++q) {
+      const int r = wave + 4 * q;
+      const bool ok = tok && r < C;
+      const long off = (long)(r < C ? r : 0) * T + tc;
+      const float vx = xb[off], vy = yb[off];
+      rx[q] = ok ? vx : 0.f;
+      ry[q] = ok ? vy : 0.f;
+    }
+    const float* ab = a.da + (long)b * 2 * NARROW * T;
+#pragma unroll
+    for (int q = 0; q < 10; ++q) { const float v = ab[(long)(wave + 4 * q) * T + tc]; ra[q] = tok ? v : 0.f; }
+    const float* zb = a.dz1 + (long)b * NARROW * T;
+    const float* gb = a.g + (long)b * NARROW * T;
+    const float* hb = a.h + (long)b * NARROW * T;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      const int r = wave + 4 * q;
+      { const float v = zb[(long)r * T + tc]; rz[q] = tok ? v : 0.f; }
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int j = lane + 64 * jj;
+        const int tg = t0 - 4 + j, thh = t0 - Hh + j;
+        const bool okg = j < TT + 8 && tg >= 0 && tg < T;
+        const bool okh = j < TT + 2 * Hh && thh >= 0 && thh < T;
+        const float vg = gb[(long)r * T + (okg ? tg : 0)];
+        const float vh = hb[(long)r * T + (okh ? thh : 0)];
+        rg[q][jj] = okg ? vg : 0.f;
+        rh[q][jj] = okh ? vh : 0.f;
+      }
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int q = 0; q < QX; ++q) {
+      const int r = wave + 4 * q;
+      if (r < C) { xn[r * ldn + lane] = rx[q]; dys[r * ldn + lane] = ry[q]; }
+    }
+#pragma unroll
+    for (int q = 0; q < 10; ++q) dl[(wave + 4 * q) * ldn + lane] = ra[q];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      const int r = wave + 4 * q;
+      dhs[r * ldn + lane] = rz[q];
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int j = lane + 64 * jj;
+        if (j < ldg) gs[r * ldg + j] = rg[q][jj];
+        if (j < ldh) hs[r * ldh + j] = rh[q][jj];
+      }
+    }
+  };
+
+  if ((int)blockIdx.x < a.ntiles) load_tile(blockIdx.x);
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const int b = tile / a.tiles_per_frame;
     const int t0 = (tile - b * a.tiles_per_frame) * TT;
+    __syncthreads();                       // everyone is done reading the previous tile
+    if (!(a.skip & 16)) store_tile();
     __syncthreads();
-    nsc_stage_rows(xn, ldn, C, C, TT, a.x + (long)b * C * T, T, t0, T, 0, wave, lane);
-    nsc_stage_rows(dys, ldn, C, C, TT, a.dy + (long)b * C * T, T, t0, T, 0, wave, lane);
-    nsc_stage_rows(gs, ldg, NARROW, NARROW, TT + 8, a.g + (long)b * NARROW * T, T, t0 - 4, T, 0, wave, lane);
-    nsc_stage_rows(hs, ldh, NARROW, NARROW, TT + 2 * Hh, a.h + (long)b * NARROW * T, T, t0 - Hh, T, 0, wave, lane);
-    nsc_stage_rows(dl, ldn, 2 * NARROW, 2 * NARROW, TT, a.da + (long)b * 2 * NARROW * T, T, t0, T, 0, wave, lane);  // dlin rows 0-19, dgate 20-39
-    nsc_stage_rows(dhs, ldn, NARROW, NARROW, TT, a.dz1 + (long)b * NARROW * T, T, t0, T, 0, wave, lane);
-    __syncthreads();
+    // weight fragments of the fused 1x1 data gradient are fetched BEFORE the next tile's prefetch: vmcnt retires in
+    // order, so anything issued after the ~90 prefetch loads would wait for all of them.
+    float av[5][RT9];
     if (a.dx) {
-      // fused 1x1 data gradient: dx = (W1^T dz1 + dy) * act'(x); wave owns column tile `wave`, all RT9 row tiles, K = 20
-      f32x4 acc[RT9];
-#pragma unroll
-      for (int r = 0; r < RT9; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      const int tt = wave * 16 + l15;
-      float av[5][RT9];
 #pragma unroll
       for (int s = 0; s < 5; ++s)
 #pragma unroll
@@ -943,6 +1003,14 @@ __global__ __launch_bounds__(256, 1) void gated_block_wgrad_kernel(BlockWgradArg
           const int c = r * 16 + l15;
           av[s][r] = a.wt1[(s * 4 + kq) * C + (c < C ? c : C - 1)];
         }
+    }
+    if (tile + (int)gridDim.x < a.ntiles && !(a.skip & 8)) load_tile(tile + gridDim.x);   // in flight during the MFMA loop below
+    if (a.dx && !(a.skip & 1)) {
+      // fused 1x1 data gradient: dx = (W1^T dz1 + dy) * act'(x); wave owns column tile `wave`, all RT9 row tiles, K = 20
+      f32x4 acc[RT9];
+#pragma unroll
+      for (int r = 0; r < RT9; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const int tt = wave * 16 + l15;
 #pragma unroll
       for (int s = 0; s < 5; ++s) {
         const float bv = dhs[(s * 4 + kq) * ldn + tt];
@@ -964,6 +1032,7 @@ __global__ __launch_bounds__(256, 1) void gated_block_wgrad_kernel(BlockWgradArg
           }
       }
     }
+    if (!(a.skip & 2))
 #pragma unroll 2
     for (int s = 0; s < TT / 4; ++s) {
       const int tl = 4 * s + kq;
@@ -1009,6 +1078,7 @@ __global__ __launch_bounds__(256, 1) void gated_block_wgrad_kernel(BlockWgradArg
   // ~100 us per block, the store + reduce path ~15 us.
   const bool plain = a.slab_stride != 0;
   const long so = (long)blockIdx.x * a.slab_stride;
+  if (a.skip & 4) return;
 #pragma unroll
   for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -1095,7 +1165,8 @@ extern "C" int nsc_gated_block_wgrad(const float* x, const float* h, const float
   const size_t fl = (size_t)(2 * C + 2) * ldn + (size_t)(NARROW + 2) * (ldg + ldh) + (size_t)3 * NARROW * ldn;
   const size_t smem = fl * sizeof(float);
   NSC_REQUIRE(smem <= 160 * 1024, NSC_ERR_UNSUPPORTED, "nsc_gated_block_wgrad: %zu B LDS", smem);
-  BlockWgradArgs a{B, C, T, dil, x, h, g, dy, da, dz1, wt1, dx, in_act, dw1, db1, dwl, dbl, dwr, dbr, dw9, db9, 0, 0, 0};
+  BlockWgradArgs a{B, C, T, dil, x, h, g, dy, da, dz1, wt1, dx, in_act, dw1, db1, dwl, dbl, dwr, dbr, dw9, db9, 0, 0, 0, 0};
+  { static int skip_env = -1; if (skip_env < 0) { const char* e = getenv("NSC_WG_SKIP"); skip_env = e ? atoi(e) : 0; } a.skip = skip_env; }
   a.tiles_per_frame = nsc_cdiv(T, 64);
   a.ntiles = B * a.tiles_per_frame;
   const int grid = std::min(a.ntiles, 256);
