@@ -851,7 +851,7 @@ __device__ __forceinline__ void wg_flush(float* p, float v, bool plain) {
 }
 
 template <int RT9>
-__global__ __launch_bounds__(256, 1) void gated_block_wgrad_kernel(BlockWgradArgs a, int ldn, int ldg, int ldh) {
+__global__ __launch_bounds__(512, 2) void gated_block_wgrad_kernel(BlockWgradArgs a, int ldn, int ldg, int ldh) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int TT = 64;
   const int C = a.C, T = a.T, d = a.dil;
@@ -867,39 +867,41 @@ __global__ __launch_bounds__(256, 1) void gated_block_wgrad_kernel(BlockWgradArg
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, kq = lane >> 4;
 
-  for (int j = tid; j < ldn; j += 256) { xn[C * ldn + j] = 0.f; xn[(C + 1) * ldn + j] = 1.f; }
-  for (int j = tid; j < ldh; j += 256) { hs[NARROW * ldh + j] = 0.f; hs[(NARROW + 1) * ldh + j] = 1.f; }
-  for (int j = tid; j < ldg; j += 256) { gs[NARROW * ldg + j] = 0.f; gs[(NARROW + 1) * ldg + j] = 1.f; }
+  // 8 waves (two per SIMD): each owns fewer accumulator tiles (100 registers) and the partner wave hides LDS /
+  // global latency that a single wave per SIMD exposed.
+  for (int j = tid; j < ldn; j += 512) { xn[C * ldn + j] = 0.f; xn[(C + 1) * ldn + j] = 1.f; }
+  for (int j = tid; j < ldh; j += 512) { hs[NARROW * ldh + j] = 0.f; hs[(NARROW + 1) * ldh + j] = 1.f; }
+  for (int j = tid; j < ldg; j += 512) { gs[NARROW * ldg + j] = 0.f; gs[(NARROW + 1) * ldg + j] = 1.f; }
 
-  f32x4 g9[3][RT9], glr[5][3], g1[2][2];
-#pragma unroll
-  for (int r = 0; r < 3; ++r)
-#pragma unroll
-    for (int c = 0; c < RT9; ++c) g9[r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int r = 0; r < 5; ++r)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) glr[r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 g9[2][RT9], glr[3][3], g1[1][2];   // row tiles {w, w+8}, {w, w+8, w+16}, {w}
 #pragma unroll
   for (int r = 0; r < 2; ++r)
 #pragma unroll
-    for (int c = 0; c < 2; ++c) g1[r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  int off9[3], offlr[5], off1[2];
+    for (int c = 0; c < RT9; ++c) g9[r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    const int kk = (wave + 4 * r) * 16 + l15;
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) glr[r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int r = 0; r < 1; ++r)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) g1[r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int off9[2], offlr[3], off1[1];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int kk = (wave + 8 * r) * 16 + l15;
     if (kk < K9 * NARROW) { const int tap = kk / NARROW, ci = kk - tap * NARROW; off9[r] = ci * ldg + tap; }
     else off9[r] = (kk == K9 * NARROW ? (NARROW + 1) : NARROW) * ldg;
   }
 #pragma unroll
-  for (int r = 0; r < 5; ++r) {
-    const int kk = (wave + 4 * r) * 16 + l15;
+  for (int r = 0; r < 3; ++r) {
+    const int kk = (wave + 8 * r) * 16 + l15;
     if (kk < K15 * NARROW) { const int tap = kk / NARROW, ci = kk - tap * NARROW; offlr[r] = ci * ldh + tap * d; }
     else offlr[r] = (kk == K15 * NARROW ? (NARROW + 1) : NARROW) * ldh;
   }
 #pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const int ci = (wave + 4 * r) * 16 + l15;
+  for (int r = 0; r < 1; ++r) {
+    const int ci = (wave + 8 * r) * 16 + l15;
     off1[r] = (ci < C ? ci : (ci == C ? C + 1 : C)) * ldn;
   }
   int offb_lr[3], offb9[RT9];
@@ -922,8 +924,8 @@ __global__ __launch_bounds__(256, 1) void gated_block_wgrad_kernel(BlockWgradArg
   // ---- software-pipelined staging: the NEXT tile's global loads are issued into registers before the MFMA loop of the
   // current tile and written to LDS after it (one wave per SIMD cannot hide load latency any other way).  Row r of a
   // region is owned by wave r%4; lanes walk time.  All loads are unconditional (clamped) + value select.
-  constexpr int QX = RT9 * 4;                       // rows per wave for the C-channel tensors (x, dy)
-  float rx[QX], ry[QX], ra[10], rz[5], rg[5][2], rh[5][2];
+  constexpr int QX = RT9 * 2;                       // rows per wave (8 waves) for the C-channel tensors (x, dy)
+  float rx[QX], ry[QX], ra[5], rz[3], rg[3][2], rh[3][2];
   auto load_tile = [&](int tile) {
     const int b = tile / a.tiles_per_frame;
     const int t0 = (tile - b * a.tiles_per_frame) * TT;
@@ -934,7 +936,7 @@ __global__ __launch_bounds__(256, 1) void gated_block_wgrad_kernel(BlockWgradArg
     const float* yb = a.dy + (long)b * C * T;
 #pragma unroll
     for (int q = 0; q < QX; ++q) {
-      const int r = wave + 4 * q;
+      const int r = wave + 8 * q;
       const bool ok = tok && r < C;
       const long off = (long)(r < C ? r : 0) * T + tc;
       const float vx = xb[off], vy = yb[off];
@@ -943,13 +945,14 @@ __global__ __launch_bounds__(256, 1) void gated_block_wgrad_kernel(BlockWgradArg
     }
     const float* ab = a.da + (long)b * 2 * NARROW * T;
 #pragma unroll
-    for (int q = 0; q < 10; ++q) { const float v = ab[(long)(wave + 4 * q) * T + tc]; ra[q] = tok ? v : 0.f; }
+    for (int q = 0; q < 5; ++q) { const float v = ab[(long)(wave + 8 * q) * T + tc]; ra[q] = tok ? v : 0.f; }
     const float* zb = a.dz1 + (long)b * NARROW * T;
     const float* gb = a.g + (long)b * NARROW * T;
     const float* hb = a.h + (long)b * NARROW * T;
 #pragma unroll
-    for (int q = 0; q < 5; ++q) {
-      const int r = wave + 4 * q;
+    for (int q = 0; q < 3; ++q) {
+      const int r0_ = wave + 8 * q;
+      const int r = r0_ < NARROW ? r0_ : 0;            // rows 20..23 of the last pass: clamped loads, never stored
       { const float v = zb[(long)r * T + tc]; rz[q] = tok ? v : 0.f; }
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
@@ -967,20 +970,22 @@ __global__ __launch_bounds__(256, 1) void gated_block_wgrad_kernel(BlockWgradArg
   auto store_tile = [&]() {
 #pragma unroll
     for (int q = 0; q < QX; ++q) {
-      const int r = wave + 4 * q;
+      const int r = wave + 8 * q;
       if (r < C) { xn[r * ldn + lane] = rx[q]; dys[r * ldn + lane] = ry[q]; }
     }
 #pragma unroll
-    for (int q = 0; q < 10; ++q) dl[(wave + 4 * q) * ldn + lane] = ra[q];
+    for (int q = 0; q < 5; ++q) dl[(wave + 8 * q) * ldn + lane] = ra[q];
 #pragma unroll
-    for (int q = 0; q < 5; ++q) {
-      const int r = wave + 4 * q;
-      dhs[r * ldn + lane] = rz[q];
+    for (int q = 0; q < 3; ++q) {
+      const int r = wave + 8 * q;
+      if (r < NARROW) {
+        dhs[r * ldn + lane] = rz[q];
 #pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        const int j = lane + 64 * jj;
-        if (j < ldg) gs[r * ldg + j] = rg[q][jj];
-        if (j < ldh) hs[r * ldh + j] = rh[q][jj];
+        for (int jj = 0; jj < 2; ++jj) {
+          const int j = lane + 64 * jj;
+          if (j < ldg) gs[r * ldg + j] = rg[q][jj];
+          if (j < ldh) hs[r * ldh + j] = rh[q][jj];
+        }
       }
     }
   };
@@ -994,36 +999,38 @@ __global__ __launch_bounds__(256, 1) void gated_block_wgrad_kernel(BlockWgradArg
     __syncthreads();
     // weight fragments of the fused 1x1 data gradient are fetched BEFORE the next tile's prefetch: vmcnt retires in
     // order, so anything issued after the ~90 prefetch loads would wait for all of them.
-    float av[5][RT9];
+    constexpr int RH = (RT9 + 1) / 2;               // row tiles per wave in D1: waves 0-3 take [0,RH), waves 4-7 [RH, 2RH)
+    const int rbase = (wave >> 2) * RH;
+    float av[5][RH];
     if (a.dx) {
 #pragma unroll
       for (int s = 0; s < 5; ++s)
 #pragma unroll
-        for (int r = 0; r < RT9; ++r) {
-          const int c = r * 16 + l15;
+        for (int r = 0; r < RH; ++r) {
+          const int c = (rbase + r) * 16 + l15;
           av[s][r] = a.wt1[(s * 4 + kq) * C + (c < C ? c : C - 1)];
         }
     }
     if (tile + (int)gridDim.x < a.ntiles && !(a.skip & 8)) load_tile(tile + gridDim.x);   // in flight during the MFMA loop below
     if (a.dx && !(a.skip & 1)) {
       // fused 1x1 data gradient: dx = (W1^T dz1 + dy) * act'(x); wave owns column tile `wave`, all RT9 row tiles, K = 20
-      f32x4 acc[RT9];
+      f32x4 acc[RH];
 #pragma unroll
-      for (int r = 0; r < RT9; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      const int tt = wave * 16 + l15;
+      for (int r = 0; r < RH; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const int tt = (wave & 3) * 16 + l15;
 #pragma unroll
       for (int s = 0; s < 5; ++s) {
         const float bv = dhs[(s * 4 + kq) * ldn + tt];
 #pragma unroll
-        for (int r = 0; r < RT9; ++r) acc[r] = mfma4(av[s][r], bv, acc[r]);
+        for (int r = 0; r < RH; ++r) acc[r] = mfma4(av[s][r], bv, acc[r]);
       }
       const int t = t0 + tt;
       if (t < T) {
 #pragma unroll
-        for (int r = 0; r < RT9; ++r)
+        for (int r = 0; r < RH; ++r)
 #pragma unroll
           for (int reg = 0; reg < 4; ++reg) {
-            const int c = r * 16 + kq * 4 + reg;
+            const int c = (rbase + r) * 16 + kq * 4 + reg;
             if (c < C) {
               float v = acc[r][reg] + dys[c * ldn + tt];
               if (a.in_act == NSC_ACT_LRELU) v *= (xn[c * ldn + tt] > 0.f ? 1.f : NSC_LRELU_ALPHA);
@@ -1037,38 +1044,33 @@ __global__ __launch_bounds__(256, 1) void gated_block_wgrad_kernel(BlockWgradArg
     for (int s = 0; s < TT / 4; ++s) {
       const int tl = 4 * s + kq;
       {
-        float af[3], bf[RT9];
+        float af[2], bf[RT9];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) af[r] = gs[off9[r] + tl];
+        for (int r = 0; r < 2; ++r) af[r] = gs[off9[r] + tl];
 #pragma unroll
         for (int c = 0; c < RT9; ++c) bf[c] = dys[offb9[c] + tl] * mb9[c];
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
+        for (int r = 0; r < 2; ++r)
 #pragma unroll
           for (int c = 0; c < RT9; ++c) g9[r][c] = mfma4(af[r], bf[c], g9[r][c]);
       }
       {
-        float af[5], bf[3];
+        float af[3], bf[3];
 #pragma unroll
-        for (int r = 0; r < 5; ++r) af[r] = hs[offlr[r] + tl];
+        for (int r = 0; r < 3; ++r) af[r] = hs[offlr[r] + tl];
 #pragma unroll
         for (int c = 0; c < 3; ++c) bf[c] = dl[offb_lr[c] + tl] * mb_lr[c];
 #pragma unroll
-        for (int r = 0; r < 5; ++r)
+        for (int r = 0; r < 3; ++r)
 #pragma unroll
           for (int c = 0; c < 3; ++c) glr[r][c] = mfma4(af[r], bf[c], glr[r][c]);
       }
       {
-        float af[2], bf[2];
-#pragma unroll
-        for (int r = 0; r < 2; ++r) af[r] = xn[off1[r] + tl];
-        bf[0] = dhs[l15 * ldn + tl];
-        bf[1] = dhs[offb1 + tl] * mb1;
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-          g1[r][0] = mfma4(af[r], bf[0], g1[r][0]);
-          g1[r][1] = mfma4(af[r], bf[1], g1[r][1]);
-        }
+        const float af1 = xn[off1[0] + tl];
+        const float b0 = dhs[l15 * ldn + tl];
+        const float b1 = dhs[offb1 + tl] * mb1;
+        g1[0][0] = mfma4(af1, b0, g1[0][0]);
+        g1[0][1] = mfma4(af1, b1, g1[0][1]);
       }
     }
   }
@@ -1080,10 +1082,10 @@ __global__ __launch_bounds__(256, 1) void gated_block_wgrad_kernel(BlockWgradArg
   const long so = (long)blockIdx.x * a.slab_stride;
   if (a.skip & 4) return;
 #pragma unroll
-  for (int r = 0; r < 3; ++r)
+  for (int r = 0; r < 2; ++r)
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
-      const int kk = (wave + 4 * r) * 16 + kq * 4 + reg;
+      const int kk = (wave + 8 * r) * 16 + kq * 4 + reg;
       if (kk > K9 * NARROW) continue;
 #pragma unroll
       for (int cc = 0; cc < RT9; ++cc) {
@@ -1094,10 +1096,10 @@ __global__ __launch_bounds__(256, 1) void gated_block_wgrad_kernel(BlockWgradArg
       }
     }
 #pragma unroll
-  for (int r = 0; r < 5; ++r)
+  for (int r = 0; r < 3; ++r)
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
-      const int kk = (wave + 4 * r) * 16 + kq * 4 + reg;
+      const int kk = (wave + 8 * r) * 16 + kq * 4 + reg;
       if (kk > K15 * NARROW) continue;
 #pragma unroll
       for (int ct = 0; ct < 3; ++ct) {
@@ -1109,10 +1111,10 @@ __global__ __launch_bounds__(256, 1) void gated_block_wgrad_kernel(BlockWgradArg
       }
     }
 #pragma unroll
-  for (int r = 0; r < 2; ++r)
+  for (int r = 0; r < 1; ++r)
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
-      const int ci = (wave + 4 * r) * 16 + kq * 4 + reg;
+      const int ci = (wave + 8 * r) * 16 + kq * 4 + reg;
       if (ci > C) continue;
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
@@ -1188,7 +1190,7 @@ extern "C" int nsc_gated_block_wgrad(const float* x, const float* h, const float
     auto kern = gated_block_wgrad_kernel<RT>;                                                                       \
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);   \
     NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "gated_block_wgrad: smem attr: %s", hipGetErrorString(e));         \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, a, ldn, ldg, ldh);                                    \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, a, ldn, ldg, ldh);                                    \
   } while (0)
   if (nsc_cdiv(C, 16) <= 4) LAUNCH_WG(4);
   else LAUNCH_WG(7);
