@@ -904,22 +904,20 @@ __global__ __launch_bounds__(512, 2) void gated_block_wgrad_kernel(BlockWgradArg
     const int ci = (wave + 8 * r) * 16 + l15;
     off1[r] = (ci < C ? ci : (ci == C ? C + 1 : C)) * ldn;
   }
+  // B-operand offsets are relative to `sm`; columns that do not exist point at the zero row of xn (no masks needed)
+  const int zrow = (int)(xn - sm) + C * ldn;
   int offb_lr[3], offb9[RT9];
-  float mb_lr[3], mb9[RT9], mb1;
 #pragma unroll
   for (int ct = 0; ct < 3; ++ct) {
     const int c = ct * 8 + (l15 >> 2) * 2 + (l15 & 1);
-    mb_lr[ct] = c < NARROW ? 1.f : 0.f;
-    offb_lr[ct] = ((l15 & 2) ? NARROW * ldn : 0) + (c < NARROW ? c : 0) * ldn;
+    offb_lr[ct] = c < NARROW ? (int)(dl - sm) + ((l15 & 2) ? NARROW * ldn : 0) + c * ldn : zrow;
   }
 #pragma unroll
   for (int c = 0; c < RT9; ++c) {
     const int o = c * 16 + l15;
-    mb9[c] = o < C ? 1.f : 0.f;
-    offb9[c] = (o < C ? o : 0) * ldn;
+    offb9[c] = o < C ? (int)(dys - sm) + o * ldn : zrow;
   }
-  mb1 = (16 + l15 < NARROW) ? 1.f : 0.f;
-  const int offb1 = (16 + l15 < NARROW ? 16 + l15 : 0) * ldn;
+  const int offb1 = (16 + l15 < NARROW) ? (int)(dhs - sm) + (16 + l15) * ldn : zrow;
 
   // ---- software-pipelined staging: the NEXT tile's global loads are issued into registers before the MFMA loop of the
   // current tile and written to LDS after it (one wave per SIMD cannot hide load latency any other way).  Row r of a
@@ -997,8 +995,43 @@ __global__ __launch_bounds__(512, 2) void gated_block_wgrad_kernel(BlockWgradArg
     __syncthreads();                       // everyone is done reading the previous tile
     if (!(a.skip & 16)) store_tile();
     __syncthreads();
-    // weight fragments of the fused 1x1 data gradient are fetched BEFORE the next tile's prefetch: vmcnt retires in
-    // order, so anything issued after the ~90 prefetch loads would wait for all of them.
+    if (tile + (int)gridDim.x < a.ntiles && !(a.skip & 8)) load_tile(tile + gridDim.x);   // in flight during the MFMA loop below
+    if (!(a.skip & 2))
+#pragma unroll 2
+    for (int s = 0; s < TT / 4; ++s) {
+      const int tl = 4 * s + kq;
+      {
+        float af[2], bf[RT9];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) af[r] = gs[off9[r] + tl];
+#pragma unroll
+        for (int c = 0; c < RT9; ++c) bf[c] = sm[offb9[c] + tl];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+          for (int c = 0; c < RT9; ++c) g9[r][c] = mfma4(af[r], bf[c], g9[r][c]);
+      }
+      {
+        float af[3], bf[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) af[r] = hs[offlr[r] + tl];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) bf[c] = sm[offb_lr[c] + tl];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) glr[r][c] = mfma4(af[r], bf[c], glr[r][c]);
+      }
+      {
+        const float af1 = xn[off1[0] + tl];
+        const float b0 = dhs[l15 * ldn + tl];
+        const float b1 = sm[offb1 + tl];
+        g1[0][0] = mfma4(af1, b0, g1[0][0]);
+        g1[0][1] = mfma4(af1, b1, g1[0][1]);
+      }
+    }
+    // fused 1x1 data gradient AFTER the MFMA loop: by now the next tile's prefetch has landed, so these weight loads do
+    // not queue behind it (vmcnt retires in order), and their registers are not live during the loop above.
     constexpr int RH = (RT9 + 1) / 2;               // row tiles per wave in D1: waves 0-3 take [0,RH), waves 4-7 [RH, 2RH)
     const int rbase = (wave >> 2) * RH;
     float av[5][RH];
@@ -1011,7 +1044,6 @@ __global__ __launch_bounds__(512, 2) void gated_block_wgrad_kernel(BlockWgradArg
           av[s][r] = a.wt1[(s * 4 + kq) * C + (c < C ? c : C - 1)];
         }
     }
-    if (tile + (int)gridDim.x < a.ntiles && !(a.skip & 8)) load_tile(tile + gridDim.x);   // in flight during the MFMA loop below
     if (a.dx && !(a.skip & 1)) {
       // fused 1x1 data gradient: dx = (W1^T dz1 + dy) * act'(x); wave owns column tile `wave`, all RT9 row tiles, K = 20
       f32x4 acc[RH];
@@ -1037,40 +1069,6 @@ __global__ __launch_bounds__(512, 2) void gated_block_wgrad_kernel(BlockWgradArg
               a.dx[((long)b * C + c) * T + t] = v;
             }
           }
-      }
-    }
-    if (!(a.skip & 2))
-#pragma unroll 2
-    for (int s = 0; s < TT / 4; ++s) {
-      const int tl = 4 * s + kq;
-      {
-        float af[2], bf[RT9];
-#pragma unroll
-        for (int r = 0; r < 2; ++r) af[r] = gs[off9[r] + tl];
-#pragma unroll
-        for (int c = 0; c < RT9; ++c) bf[c] = dys[offb9[c] + tl] * mb9[c];
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-          for (int c = 0; c < RT9; ++c) g9[r][c] = mfma4(af[r], bf[c], g9[r][c]);
-      }
-      {
-        float af[3], bf[3];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) af[r] = hs[offlr[r] + tl];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) bf[c] = dl[offb_lr[c] + tl] * mb_lr[c];
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) glr[r][c] = mfma4(af[r], bf[c], glr[r][c]);
-      }
-      {
-        const float af1 = xn[off1[0] + tl];
-        const float b0 = dhs[l15 * ldn + tl];
-        const float b1 = dhs[offb1 + tl] * mb1;
-        g1[0][0] = mfma4(af1, b0, g1[0][0]);
-        g1[0][1] = mfma4(af1, b1, g1[0][1]);
       }
     }
   }
