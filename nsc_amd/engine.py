@@ -127,18 +127,19 @@ class _Conv:
 
     def _wgrad(self, x, dz, dw, db):
         e = self.eng
+        st = e.side_fork()
         if self.Cout == 1:
             # swap roles (SURVEY/DESIGN): "input" = dz (1 channel), "grad" = x (Cin channels); flipped taps
             assert self.stride == 1
             d = ConvDesc(B=e.B, Cin=1, Cout=self.Cin, Tin=self.Tout, Tout=self.Tin, K=self.K, dil=self.dil, stride=1,
                          padL=(self.K - 1) * self.dil - self.padL, act=0, res_mode=0, mul_mode=0, out_mode=0, in_up=0,
                          accumulate=0)
-            check(e.lib.nsc_conv1d_wgrad(C.byref(d), dz.data_ptr(), x.data_ptr(), dw, None, 1, e.stream()),
+            check(e.lib.nsc_conv1d_wgrad(C.byref(d), dz.data_ptr(), x.data_ptr(), dw, None, 1, st),
                   f"conv wgrad(swapped) {self.name}")
-            check(e.lib.nsc_sum_all(dz.data_ptr(), db, dz.numel(), e.stream()), "bias grad")
+            check(e.lib.nsc_sum_all(dz.data_ptr(), db, dz.numel(), st), "bias grad")
         else:
             d = self.desc()
-            check(e.lib.nsc_conv1d_wgrad(C.byref(d), x.data_ptr(), dz.data_ptr(), dw, db, 0, e.stream()),
+            check(e.lib.nsc_conv1d_wgrad(C.byref(d), x.data_ptr(), dz.data_ptr(), dw, db, 0, st),
                   f"conv wgrad {self.name}")
 
     def wt_index(self):
@@ -236,14 +237,18 @@ class _Block:
             dx = e.buf(u + ".dx", (B, self.Cin, T)) if need_dx else None
             G = lambda c: (e.g_ptr + 4 * c.w_off, e.g_ptr + 4 * c.b_off)
             (dw1, db1), (dwl, dbl), (dwr, dbr), (dw9, db9) = G(self.c1), G(self.cl), G(self.cr), G(self.c9)
-            fl = self.c1.flops() * (2 if need_dx else 1) + self.cl.flops() + self.cr.flops() + self.c9.flops()
+            fuse_d1 = need_dx and not e.overlap_wgrad    # with overlap the 1x1 data gradient stays on the critical stream
+            fl = self.c1.flops() * (2 if fuse_d1 else 1) + self.cl.flops() + self.cr.flops() + self.c9.flops()
             tok = e.prof_begin("block_wgrad", fl)
+            st = e.side_fork()
             check(e.lib.nsc_gated_block_wgrad(self.x.data_ptr(), self.h.data_ptr(), self.g.data_ptr(), dz.data_ptr(),
                                               da.data_ptr(), dh.data_ptr(), dw1, db1, dwl, dbl, dwr, dbr, dw9, db9,
-                                              e.wt_ptr + 4 * self.c1.w_off, _lib.ptr(dx), KIND_ACT[in_kind], B,
-                                              self.Cin, T, n, 9, self.cl.dil, e.wgrad_workspace(self.Cin), e.stream()),
-                  "gated_block_wgrad")
+                                              e.wt_ptr + 4 * self.c1.w_off, _lib.ptr(dx) if fuse_d1 else None,
+                                              KIND_ACT[in_kind], B, self.Cin, T, n, 9, self.cl.dil,
+                                              e.wgrad_workspace(self.Cin), st), "gated_block_wgrad")
             e.prof_end(tok)
+            if need_dx and not fuse_d1:
+                self.c1.dgrad(dh, dx, res=dz, res_mode=1, mul_kind=in_kind, aux=self.x)
             return dx
         self.c9.wgrad(self.g, dz)
         self.c9.dgrad(dz, dg)
@@ -513,6 +518,32 @@ class CascadeEngine:
     # per-launch HIP-event timing of the conv kernels (bench.py roofline); events sit on the launch stream
     prof = None
 
+    # ---- weight gradients on a side stream: they are off the critical path (nothing downstream reads them before the
+    # optimizer), and both they and the data-gradient chain are latency- rather than throughput-bound, so running them
+    # concurrently on the same CUs is nearly additive.  fork = event on the main stream, join before Adam / all-reduce.
+    overlap_wgrad = True
+
+    def side_fork(self):
+        """Returns the stream handle weight-gradient kernels should be launched on (side stream ordered after everything
+        enqueued so far on the current stream), or the current stream when overlap is off."""
+        if not self.overlap_wgrad:
+            return self.stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self._side.wait_event(ev)
+        self._side_used = True
+        return self._side.cuda_stream
+
+    def side_join(self):
+        if self._side is not None and self._side_used:
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._side_used = False
+
+    _side = None
+    _side_used = False
+
     def wgrad_workspace(self, C):
         """Scratch for the store+reduce flush of nsc_gated_block_wgrad (shared by all blocks: launches are stream-ordered)."""
         n = int(self.lib.nsc_gated_block_wgrad_workspace(int(C)))
@@ -701,6 +732,7 @@ class CascadeEngine:
                                             gh.data_ptr() if c_ent_lpc != 0.0 else None, float(c_ent_lpc) * Bg, 0, None,
                                             self.g_ptr + 4 * self.lpc_alpha_off, self.g_ptr + 4 * self.lpc_bins_off,
                                             self.stream()), "lpc quantize_bwd")
+        self.side_join()
         return dict(time=self.time, freq=self.freq, quan=[c.quan for c in self.codecs], ent=ents)
 
     def adam_step(self, scopes, lr, slot=1, beta1=0.9, beta2=0.999, eps=1e-8):
