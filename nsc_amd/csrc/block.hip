@@ -26,9 +26,11 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// TT = 64 output steps per workgroup, 4 waves.
+// TT = 64 output steps per workgroup, 8 waves (two per SIMD at one workgroup, four at the usual two workgroups per CU):
+// every phase is split into (row tile, column tile) jobs dealt over the 8 waves, so each wave's MFMA chain is short
+// and its partner waves hide the LDS / weight-fetch latency.
 template <int RT9>
-__global__ __launch_bounds__(256) void gated_block_fwd_kernel(BlockArgs a, int ldx, int ldg) {
+__global__ __launch_bounds__(512) void gated_block_fwd_kernel(BlockArgs a, int ldx, int ldg) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int TT = 64;
   const int C = a.C, T = a.T, d = a.dil;
@@ -40,31 +42,32 @@ __global__ __launch_bounds__(256) void gated_block_fwd_kernel(BlockArgs a, int l
   float* hs = xs + C4 * ldx;          // [NARROW][ldx]
   float* gs = hs + NARROW * ldx;      // [NARROW][ldg]
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform (SGPR): selects, not branches
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7, provably wave-uniform
   const int l15 = lane & 15, kq = lane >> 4;
   const int b = blockIdx.y, t0 = blockIdx.x * TT;
 
   // ---- phase 0: stage x tile (zero outside [0,T), zero pad rows) ----
-  nsc_stage_rows(xs, ldx, C4, C, WX, a.x + (long)b * C * T, T, t0 - H, T, 0, wave, lane);
+  nsc_stage_rows<8>(xs, ldx, C4, C, WX, a.x + (long)b * C * T, T, t0 - H, T, 0, wave, lane);
   __syncthreads();
 
-  // ---- phase 1: h = lrelu(W1 x + b1) on all WX columns (7 column tiles of 16 at d=2) ----
+  // ---- phase 1: h = lrelu(W1 x + b1) on all WX columns; column tile ct -> wave ct (7 tiles at d=2) ----
   {
     const int nct = (WX + 15) >> 4;
     const int ncq = C4 >> 2;
-    for (int ct = wave; ct < nct; ct += 4) {
+    for (int ct = wave; ct < nct; ct += 8) {
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
       const int j = ct * 16 + l15;
       const float* xcol = xs + j;
       constexpr int G1 = 8;
       float an0[G1], an1[G1];
+      const int o1c = 16 + l15 < NARROW ? 16 + l15 : NARROW - 1;   // rows >= 20 of the second tile: clamped, never stored
       auto fetch1 = [&](int cq0) {
 #pragma unroll
         for (int u = 0; u < G1; ++u) {
           const int ci = (cq0 + u) * 4 + kq;
           const bool ok = (cq0 + u) < ncq && ci < C;
           an0[u] = nsc_ldm(a.w1, ci * NARROW + l15, ok);
-          an1[u] = nsc_ldm(a.w1, ci * NARROW + 16 + l15, ok && 16 + l15 < NARROW);
+          an1[u] = nsc_ldm(a.w1, ci * NARROW + o1c, ok);
         }
       };
       fetch1(0);
@@ -89,18 +92,15 @@ __global__ __launch_bounds__(256) void gated_block_fwd_kernel(BlockArgs a, int l
         float v0 = acc0[reg] + a.b1[o0];
         v0 = v0 > 0.f ? v0 : NSC_LRELU_ALPHA * v0;
         hs[o0 * ldx + j] = live ? v0 : 0.f;
+        float v1 = 0.f;
         if (o1 < NARROW) {
-          float v1 = acc1[reg] + a.b1[o1];
+          v1 = acc1[reg] + a.b1[o1];
           v1 = v1 > 0.f ? v1 : NSC_LRELU_ALPHA * v1;
           hs[o1 * ldx + j] = live ? v1 : 0.f;
         }
         if (a.h_out && live && j >= H && j < H + TT) {
           a.h_out[((long)b * NARROW + o0) * T + t] = v0;
-          if (o1 < NARROW) {
-            float v1 = acc1[reg] + a.b1[o1];
-            v1 = v1 > 0.f ? v1 : NSC_LRELU_ALPHA * v1;
-            a.h_out[((long)b * NARROW + o1) * T + t] = v1;
-          }
+          if (o1 < NARROW) a.h_out[((long)b * NARROW + o1) * T + t] = v1;
         }
       }
     }
@@ -108,62 +108,63 @@ __global__ __launch_bounds__(256) void gated_block_fwd_kernel(BlockArgs a, int l
   __syncthreads();
 
   // ---- phase 2: both k15 dilated gate convs in one MFMA pass, gate in registers, g -> LDS ----
-  // g column jj <-> frame time t0 - 4 + jj ; reads h column jj + tap*d.  5 column tiles (80 >= 72):
-  // wave w owns column tile w (3 row tiles); column tile 4 is split by row tile over waves 0..2.
+  // g column jj <-> frame time t0 - 4 + jj ; reads h column jj + tap*d.  15 jobs = 3 row tiles x 5 column tiles (80 >= 72);
+  // job q -> (row tile q % 3, column tile q / 3); wave w runs jobs w and w + 8 (wave 7's second job is a discarded duplicate).
   {
     const int i = l15;
-    const bool gate_row = (i & 2) != 0;
-    const float* wsel = gate_row ? a.wr : a.wl;
-    int crow[3];
+    const float* wsel = (i & 2) ? a.wr : a.wl;
+    int jrt[2], jcol[2], crow[2];
+    bool jlive[2];
 #pragma unroll
-    for (int rt = 0; rt < 3; ++rt) crow[rt] = rt * 8 + (i >> 2) * 2 + (i & 1);
-    f32x4 acc[3], accx;
-#pragma unroll
-    for (int rt = 0; rt < 3; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    accx = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int jj_main = wave * 16 + l15;
-    const int jj_x = 64 + l15;
-    const int rtx = wave;  // row tile of the shared 5th column tile (wave 3: none)
-    constexpr int G2 = 5;                       // one tap (5 k-steps of 4 channels) per group
-    float an[G2][3];
+    for (int e = 0; e < 2; ++e) {
+      const int q = wave + 8 * e;
+      jlive[e] = q < 15;
+      const int qq = jlive[e] ? q : wave;
+      jrt[e] = qq % 3;
+      jcol[e] = (qq / 3) * 16 + l15;
+      const int c = jrt[e] * 8 + (i >> 2) * 2 + (i & 1);
+      crow[e] = c < NARROW ? c : NARROW - 1;          // channels 20..23: clamped, never stored
+    }
+    f32x4 acc[2];
+    acc[0] = acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    constexpr int G2 = 5;                               // one tap (5 k-steps of 4 channels) per group
+    float an[G2][2];
     auto fetch2 = [&](int tapf) {
+      const int tf = tapf < K15 ? tapf : K15 - 1;       // past the end: re-fetch the last tap (unused)
 #pragma unroll
       for (int u = 0; u < G2; ++u) {
-        const int ci = u * 4 + kq;
-#pragma unroll
-        for (int rt = 0; rt < 3; ++rt)
-          an[u][rt] = nsc_ldm(wsel, (tapf * NARROW + ci) * NARROW + crow[rt], tapf < K15 && crow[rt] < NARROW);
+        const int rowb = (tf * NARROW + u * 4 + kq) * NARROW;
+        an[u][0] = wsel[rowb + crow[0]];
+        an[u][1] = wsel[rowb + crow[1]];
       }
     };
     fetch2(0);
     for (int tap = 0; tap < K15; ++tap) {
-      float ac[G2][3];
+      float ac[G2][2];
 #pragma unroll
-      for (int u = 0; u < G2; ++u)
-#pragma unroll
-        for (int rt = 0; rt < 3; ++rt) ac[u][rt] = an[u][rt];
+      for (int u = 0; u < G2; ++u) { ac[u][0] = an[u][0]; ac[u][1] = an[u][1]; }
       fetch2(tap + 1);
 #pragma unroll
       for (int u = 0; u < G2; ++u) {
         const float* hrow = hs + (u * 4 + kq) * ldx + tap * d;
-        const float bm = hrow[jj_main];
-        const float bx = hrow[jj_x];
-#pragma unroll
-        for (int rt = 0; rt < 3; ++rt) acc[rt] = mfma4(ac[u][rt], bm, acc[rt]);
-        accx = mfma4(rtx == 0 ? ac[u][0] : (rtx == 1 ? ac[u][1] : ac[u][2]), bx, accx);   // wave 3: discarded duplicate
+        acc[0] = mfma4(ac[u][0], hrow[jcol[0]], acc[0]);
+        acc[1] = mfma4(ac[u][1], hrow[jcol[1]], acc[1]);
       }
     }
     // epilogue: lane holds (lin c0, lin c1, gate c0, gate c1) of one time step
-    auto emit = [&](const f32x4& v, int rt, int jj) {
-      const int c0 = rt * 8 + kq * 2;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      if (!jlive[e]) continue;
+      const int jj = jcol[e];
+      const int c0 = jrt[e] * 8 + kq * 2;
       const int t = t0 - 4 + jj;
       const bool live = jj < WG && t >= 0 && t < T;   // g outside the frame is ZERO padding of the k9 conv
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int c = c0 + u;
         if (c < NARROW && jj < ldg) {
-          const float lin = v[u] + a.bl[c];
-          const float th = tanhf(v[2 + u] + a.br[c]);
+          const float lin = acc[e][u] + a.bl[c];
+          const float th = tanhf(acc[e][2 + u] + a.br[c]);
           gs[c * ldg + jj] = live ? lin * th : 0.f;
           if (a.lin_out && live && jj >= 4 && jj < 4 + TT) {
             const long gi = ((long)b * NARROW + c) * T + t;
@@ -173,54 +174,54 @@ __global__ __launch_bounds__(256) void gated_block_fwd_kernel(BlockArgs a, int l
           }
         }
       }
-    };
-#pragma unroll
-    for (int rt = 0; rt < 3; ++rt) emit(acc[rt], rt, jj_main);
-    if (rtx < 3) emit(accx, rtx, jj_x);
+    }
   }
   __syncthreads();
 
-  // ---- phase 3: y = W9 * g + b9 + x ; wave w owns output columns [16w, 16w+16), all RT9 row tiles ----
+  // ---- phase 3: y = W9 * g + b9 + x ; wave w owns output columns [16 (w&3), +16) and row tiles [(w>>2) RH, +RH) ----
   {
-    f32x4 acc[RT9];
+    constexpr int RH = (RT9 + 1) / 2;
+    const int rbase = (wave >> 2) * RH;
+    f32x4 acc[RH];
 #pragma unroll
-    for (int r = 0; r < RT9; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int tt = wave * 16 + l15;
+    for (int r = 0; r < RH; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int tt = (wave & 3) * 16 + l15;
+    int ocl[RH];
+#pragma unroll
+    for (int r = 0; r < RH; ++r) { const int o = (rbase + r) * 16 + l15; ocl[r] = o < C ? o : C - 1; }
     constexpr int G3 = 5;                       // one tap per group
-    float an[G3][RT9];
+    float an[G3][RH];
     auto fetch3 = [&](int tapf) {
+      const int tf = tapf < K9 ? tapf : K9 - 1;
 #pragma unroll
       for (int u = 0; u < G3; ++u) {
-        const int ci = u * 4 + kq;
+        const int rowb = (tf * NARROW + u * 4 + kq) * C;
 #pragma unroll
-        for (int r = 0; r < RT9; ++r) {
-          const int o = r * 16 + l15;
-          an[u][r] = nsc_ldm(a.w9, (tapf * NARROW + ci) * C + o, tapf < K9 && o < C);
-        }
+        for (int r = 0; r < RH; ++r) an[u][r] = a.w9[rowb + ocl[r]];
       }
     };
     fetch3(0);
     for (int tap = 0; tap < K9; ++tap) {
-      float ac[G3][RT9];
+      float ac[G3][RH];
 #pragma unroll
       for (int u = 0; u < G3; ++u)
 #pragma unroll
-        for (int r = 0; r < RT9; ++r) ac[u][r] = an[u][r];
+        for (int r = 0; r < RH; ++r) ac[u][r] = an[u][r];
       fetch3(tap + 1);
 #pragma unroll
       for (int u = 0; u < G3; ++u) {
         const float bv = gs[(u * 4 + kq) * ldg + tt + tap];
 #pragma unroll
-        for (int r = 0; r < RT9; ++r) acc[r] = mfma4(ac[u][r], bv, acc[r]);
+        for (int r = 0; r < RH; ++r) acc[r] = mfma4(ac[u][r], bv, acc[r]);
       }
     }
     const int t = t0 + tt;
     if (t < T) {
 #pragma unroll
-      for (int r = 0; r < RT9; ++r)
+      for (int r = 0; r < RH; ++r)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-          const int o = r * 16 + kq * 4 + reg;
+          const int o = (rbase + r) * 16 + kq * 4 + reg;
           if (o < C) {
             float v = acc[r][reg] + a.b9[o] + xs[o * ldx + H + tt];
             if (!a.flat) v = v > 0.f ? v : NSC_LRELU_ALPHA * v;
@@ -261,7 +262,7 @@ extern "C" int nsc_gated_block_fwd(const float* x, const float* w1, const float*
       hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
       NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "gated_block_fwd: smem attr: %s", hipGetErrorString(e));         \
     }                                                                                                               \
-    hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, a, ldx, ldg);                                               \
+    hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, a, ldx, ldg);                                               \
   } while (0)
   if (nrt <= 4) LAUNCH_BLK(4);
   else LAUNCH_BLK(7);

@@ -58,6 +58,7 @@ __device__ __forceinline__ float nsc_ldm(const float* __restrict__ p, int idx, b
 // Stage rows of a [rows, Tin] tensor into LDS: xs[r*ldx + j] = src[r*Tin + u0 + j] for j < width, zero outside the
 // tensor / for pad rows (r >= rows_valid) / for j >= width.  One wave per row, lanes along time (coalesced 256-B reads).
 // in_up: virtual zero-upsampled-by-2 source (u even -> src[u/2], odd -> 0), virtual length Tvirt = 2*Tin.
+template <int NW = 4>   // waves in the workgroup
 __device__ __forceinline__ void nsc_stage_rows(float* __restrict__ xs, int ldx, int rows_total, int rows_valid, int width,
                                                const float* __restrict__ src, int Tin, int u0, int Tvirt, int in_up,
                                                int wave, int lane) {
@@ -70,7 +71,7 @@ __device__ __forceinline__ void nsc_stage_rows(float* __restrict__ xs, int ldx, 
     const int u = u0 + j;
     const bool cok = j < width && u >= 0 && u < Tvirt && (!in_up || !(u & 1));
     const int uoff = cok ? (in_up ? (u >> 1) : u) : 0;
-    for (int r0 = wave * U; r0 < rows_total; r0 += 4 * U) {
+    for (int r0 = wave * U; r0 < rows_total; r0 += NW * U) {
       float v[U];
 #pragma unroll
       for (int q = 0; q < U; ++q) {
