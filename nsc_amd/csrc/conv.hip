@@ -32,8 +32,10 @@ extern "C" int nsc_version(void) { return 100; }
 // (16 output channels each) of one frame.  x tile (with halo) is staged once in LDS; weight fragments
 // stream from global (identical for every wave and workgroup -> L1/L2 resident), prefetched one
 // k-step ahead so the MFMA chain of step s covers the latency of step s+1's loads.
-template <int RT, int NC, bool CIN1>
-__global__ __launch_bounds__(256) void conv1d_fwd_kernel(nsc_conv_desc d, const float* __restrict__ x,
+// KS = 2: eight waves; waves 4-7 own the same output tiles as waves 0-3 but the ODD taps of the k-loop (intra-workgroup
+// split-K): twice the waves in flight per tile and half the dependent MFMA chain per wave; partial sums meet in LDS.
+template <int RT, int NC, bool CIN1, int KS>
+__global__ __launch_bounds__(256 * KS) void conv1d_fwd_kernel(nsc_conv_desc d, const float* __restrict__ x,
                                                          const float* __restrict__ w,
                                                          const float* __restrict__ bias,
                                                          const float* __restrict__ res,
@@ -41,7 +43,8 @@ __global__ __launch_bounds__(256) void conv1d_fwd_kernel(nsc_conv_desc d, const 
                                                          int ldx, int win) {
   extern __shared__ __attribute__((aligned(16))) float xs[];
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform (SGPR): selects, not branches
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform (SGPR): selects, not branches
+  const int wave = wave8 & 3, khalf = wave8 >> 2;
   const int l15 = lane & 15, kq = lane >> 4;
   const int TT = 4 * NC * 16;
   const int b = blockIdx.y;
@@ -51,8 +54,8 @@ __global__ __launch_bounds__(256) void conv1d_fwd_kernel(nsc_conv_desc d, const 
   const int Tin_virt = d.in_up ? 2 * d.Tin : d.Tin;
 
   // ---- stage x tile: xs[ci][j] = xin[b, ci, t0*stride - padL + j], zero outside (wave per row, lanes along time) ----
-  nsc_stage_rows(xs, ldx, Cin4, d.Cin, win, x + (long)b * d.Cin * d.Tin, d.Tin, t0 * d.stride - d.padL, Tin_virt,
-                 d.in_up, wave, lane);
+  nsc_stage_rows<4 * KS>(xs, ldx, Cin4, d.Cin, win, x + (long)b * d.Cin * d.Tin, d.Tin, t0 * d.stride - d.padL, Tin_virt,
+                         d.in_up, wave8, lane);
   __syncthreads();
 
   f32x4 acc[RT][NC];
@@ -102,7 +105,8 @@ __global__ __launch_bounds__(256) void conv1d_fwd_kernel(nsc_conv_desc d, const 
     // and channels ci >= Cin (B rows are zero) need no masking: they only feed outputs that are never stored / add 0.
     constexpr int G = (RT * NC >= 14) ? 2 : ((RT * NC >= 7) ? 4 : ((RT * NC >= 4) ? 8 : 16));
     const int ncq = Cin4 >> 2;
-    const int nsteps = d.K * ncq;
+    const int ntaps = (d.K - khalf + KS - 1) / KS;     // taps khalf, khalf + KS, ...
+    const int nsteps = ntaps * ncq;
     const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(w), 0, d.K * d.Cin * Cout * 4, 0x00020000);
     int voff[RT];
@@ -114,7 +118,7 @@ __global__ __launch_bounds__(256) void conv1d_fwd_kernel(nsc_conv_desc d, const 
     const int step_bytes = 4 * Cout * 4;          // one k-step = 4 input channels
     const int tap_bytes = d.Cin * Cout * 4;
     float an[G][RT];
-    int tapp = 0, cqp = 0;                         // prefetch cursor
+    int tapp = khalf, cqp = 0;                     // prefetch cursor
     auto fetch = [&](float (&dst)[G][RT]) {
 #pragma unroll
       for (int u = 0; u < G; ++u) {
@@ -124,13 +128,13 @@ __global__ __launch_bounds__(256) void conv1d_fwd_kernel(nsc_conv_desc d, const 
           dst[u][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wsrd, voff[r], soff, 0));
         const bool wrapp = (cqp + 1 == ncq);
         cqp = wrapp ? 0 : cqp + 1;
-        tapp += wrapp ? 1 : 0;
+        tapp += wrapp ? KS : 0;
       }
     };
     fetch(an);
     const int ngroups = (nsteps + G - 1) / G;      // padded steps multiply zero weights (out-of-range buffer reads)
     const int bbase = kq * ldx + tcol0 * d.stride; // per-lane part of the B (x tile) address
-    int tap = 0, cq = 0;
+    int tap = khalf, cq = 0;
     for (int g = 0; g < ngroups; ++g) {
       float ac[G][RT];
 #pragma unroll
@@ -152,9 +156,31 @@ __global__ __launch_bounds__(256) void conv1d_fwd_kernel(nsc_conv_desc d, const 
             acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[u][r], bf[c], acc[r][c], 0, 0, 0);
         const bool wrap = (cq + 1 == ncq);
         cq = wrap ? 0 : cq + 1;
-        tap += wrap ? 1 : 0;
+        tap += wrap ? KS : 0;
       }
     }
+  }
+
+  if constexpr (KS == 2) {
+    // partial sums of the odd-tap waves -> LDS (the x tile is dead by now) -> even-tap waves
+    __syncthreads();
+    float* red = xs + wave * (RT * NC * 256);
+    if (khalf == 1) {
+#pragma unroll
+      for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) red[((r * NC + c) * 4 + reg) * 64 + lane] = acc[r][c][reg];
+    }
+    __syncthreads();
+    if (khalf == 1) return;
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) acc[r][c][reg] += red[((r * NC + c) * 4 + reg) * 64 + lane];
   }
 
   // ---- epilogue: D col = l15 -> time, row = 4*kq + reg -> channel ----
@@ -194,26 +220,36 @@ static int round_ldx_fwd(int win, int stride) {
   return win | 1;
 }
 
-template <int RT, int NC, bool CIN1>
-static int launch_fwd(const nsc_conv_desc* d, const float* x, const float* w, const float* bias, const float* res,
-                      const float* aux, float* y, hipStream_t st) {
+template <int RT, int NC, bool CIN1, int KS>
+static int launch_fwd_ks(const nsc_conv_desc* d, const float* x, const float* w, const float* bias, const float* res,
+                         const float* aux, float* y, hipStream_t st) {
   const int TT = 4 * NC * 16;
   int win = (TT - 1) * d->stride + (d->K - 1) * d->dil + 1;
   if (CIN1) win += 3 * d->dil;  // slack so taps K..K+2 of the last k-step read zeros
   const int ldx = round_ldx_fwd(win, d->stride);
   const int Cin4 = CIN1 ? 1 : ((d->Cin + 3) & ~3);
-  const size_t smem = (size_t)Cin4 * ldx * sizeof(float);
+  size_t smem = (size_t)Cin4 * ldx * sizeof(float);
+  if (KS == 2) smem = std::max(smem, (size_t)4 * RT * NC * 256 * sizeof(float));
   NSC_REQUIRE(smem <= 160 * 1024, NSC_ERR_UNSUPPORTED, "conv1d_fwd: x tile %zu B exceeds LDS", smem);
-  auto kern = conv1d_fwd_kernel<RT, NC, CIN1>;
+  auto kern = conv1d_fwd_kernel<RT, NC, CIN1, KS>;
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "conv1d_fwd: set smem attr: %s", hipGetErrorString(e));
   }
   const int nrt = nsc_cdiv(d->Cout, 16);
   dim3 grid(nsc_cdiv(d->Tout, TT), d->B, nsc_cdiv(nrt, RT));
-  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, *d, x, w, bias, res, aux, y, ldx, win);
+  hipLaunchKernelGGL(kern, grid, dim3(256 * KS), smem, st, *d, x, w, bias, res, aux, y, ldx, win);
   NSC_CHECK_LAUNCH("conv1d_fwd");
   return NSC_OK;
+}
+
+template <int RT, int NC, bool CIN1>
+static int launch_fwd(const nsc_conv_desc* d, const float* x, const float* w, const float* bias, const float* res,
+                      const float* aux, float* y, hipStream_t st) {
+  if constexpr (!CIN1) {
+    if (d->K >= 2) return launch_fwd_ks<RT, NC, CIN1, 2>(d, x, w, bias, res, aux, y, st);
+  }
+  return launch_fwd_ks<RT, NC, CIN1, 1>(d, x, w, bias, res, aux, y, st);
 }
 
 template <int NC, bool CIN1>
