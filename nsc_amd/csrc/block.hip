@@ -851,8 +851,11 @@ __device__ __forceinline__ void wg_flush(float* p, float v, bool plain) {
   else atomicAdd(p, v);
 }
 
-template <int RT9>
-__global__ __launch_bounds__(512, 2) void gated_block_wgrad_kernel(BlockWgradArgs a, int ldn, int ldg, int ldh) {
+// NW = waves per workgroup.  8: two waves per SIMD (fastest alone, but it fills the register file so nothing can share
+// the CU).  4: one wave per SIMD with <= 256 registers, leaving half of the registers and 76 KB of LDS per CU to the
+// data-gradient kernels that run concurrently on the main stream.
+template <int RT9, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void gated_block_wgrad_kernel(BlockWgradArgs a, int ldn, int ldg, int ldh) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int TT = 64;
   const int C = a.C, T = a.T, d = a.dil;
@@ -870,39 +873,40 @@ __global__ __launch_bounds__(512, 2) void gated_block_wgrad_kernel(BlockWgradArg
 
   // 8 waves (two per SIMD): each owns fewer accumulator tiles (100 registers) and the partner wave hides LDS /
   // global latency that a single wave per SIMD exposed.
-  for (int j = tid; j < ldn; j += 512) { xn[C * ldn + j] = 0.f; xn[(C + 1) * ldn + j] = 1.f; }
-  for (int j = tid; j < ldh; j += 512) { hs[NARROW * ldh + j] = 0.f; hs[(NARROW + 1) * ldh + j] = 1.f; }
-  for (int j = tid; j < ldg; j += 512) { gs[NARROW * ldg + j] = 0.f; gs[(NARROW + 1) * ldg + j] = 1.f; }
+  for (int j = tid; j < ldn; j += 64 * NW) { xn[C * ldn + j] = 0.f; xn[(C + 1) * ldn + j] = 1.f; }
+  for (int j = tid; j < ldh; j += 64 * NW) { hs[NARROW * ldh + j] = 0.f; hs[(NARROW + 1) * ldh + j] = 1.f; }
+  for (int j = tid; j < ldg; j += 64 * NW) { gs[NARROW * ldg + j] = 0.f; gs[(NARROW + 1) * ldg + j] = 1.f; }
 
-  f32x4 g9[2][RT9], glr[3][3], g1[1][2];   // row tiles {w, w+8}, {w, w+8, w+16}, {w}
+  constexpr int R9 = (12 + NW - 1) / NW, RLR = (19 + NW - 1) / NW, R1 = (RT9 + NW - 1) / NW;   // row tiles per wave
+  f32x4 g9[R9][RT9], glr[RLR][3], g1[R1][2];   // row tiles {w, w+NW, ...}
 #pragma unroll
-  for (int r = 0; r < 2; ++r)
+  for (int r = 0; r < R9; ++r)
 #pragma unroll
     for (int c = 0; c < RT9; ++c) g9[r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int r = 0; r < 3; ++r)
+  for (int r = 0; r < RLR; ++r)
 #pragma unroll
     for (int c = 0; c < 3; ++c) glr[r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int r = 0; r < 1; ++r)
+  for (int r = 0; r < R1; ++r)
 #pragma unroll
     for (int c = 0; c < 2; ++c) g1[r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  int off9[2], offlr[3], off1[1];
+  int off9[R9], offlr[RLR], off1[R1];
 #pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const int kk = (wave + 8 * r) * 16 + l15;
+  for (int r = 0; r < R9; ++r) {
+    const int kk = (wave + NW * r) * 16 + l15;
     if (kk < K9 * NARROW) { const int tap = kk / NARROW, ci = kk - tap * NARROW; off9[r] = ci * ldg + tap; }
     else off9[r] = (kk == K9 * NARROW ? (NARROW + 1) : NARROW) * ldg;
   }
 #pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    const int kk = (wave + 8 * r) * 16 + l15;
+  for (int r = 0; r < RLR; ++r) {
+    const int kk = (wave + NW * r) * 16 + l15;
     if (kk < K15 * NARROW) { const int tap = kk / NARROW, ci = kk - tap * NARROW; offlr[r] = ci * ldh + tap * d; }
     else offlr[r] = (kk == K15 * NARROW ? (NARROW + 1) : NARROW) * ldh;
   }
 #pragma unroll
-  for (int r = 0; r < 1; ++r) {
-    const int ci = (wave + 8 * r) * 16 + l15;
+  for (int r = 0; r < R1; ++r) {
+    const int ci = (wave + NW * r) * 16 + l15;
     off1[r] = (ci < C ? ci : (ci == C ? C + 1 : C)) * ldn;
   }
   // B-operand offsets are relative to `sm`; columns that do not exist point at the zero row of xn (no masks needed)
@@ -923,8 +927,9 @@ __global__ __launch_bounds__(512, 2) void gated_block_wgrad_kernel(BlockWgradArg
   // ---- software-pipelined staging: the NEXT tile's global loads are issued into registers before the MFMA loop of the
   // current tile and written to LDS after it (one wave per SIMD cannot hide load latency any other way).  Row r of a
   // region is owned by wave r%4; lanes walk time.  All loads are unconditional (clamped) + value select.
-  constexpr int QX = RT9 * 2;                       // rows per wave (8 waves) for the C-channel tensors (x, dy)
-  float rx[QX], ry[QX], ra[5], rz[3], rg[3][2], rh[3][2];
+  constexpr int QX = RT9 * 16 / NW;                 // rows per wave for the C-channel tensors (x, dy)
+  constexpr int QA = 40 / NW, QN = (NARROW + NW - 1) / NW;
+  float rx[QX], ry[QX], ra[QA], rz[QN], rg[QN][2], rh[QN][2];
   auto load_tile = [&](int tile) {
     const int b = tile / a.tiles_per_frame;
     const int t0 = (tile - b * a.tiles_per_frame) * TT;
@@ -935,7 +940,7 @@ __global__ __launch_bounds__(512, 2) void gated_block_wgrad_kernel(BlockWgradArg
     const float* yb = a.dy + (long)b * C * T;
 #pragma unroll
     for (int q = 0; q < QX; ++q) {
-      const int r = wave + 8 * q;
+      const int r = wave + NW * q;
       const bool ok = tok && r < C;
       const long off = (long)(r < C ? r : 0) * T + tc;
       const float vx = xb[off], vy = yb[off];
@@ -944,13 +949,13 @@ __global__ __launch_bounds__(512, 2) void gated_block_wgrad_kernel(BlockWgradArg
     }
     const float* ab = a.da + (long)b * 2 * NARROW * T;
 #pragma unroll
-    for (int q = 0; q < 5; ++q) { const float v = ab[(long)(wave + 8 * q) * T + tc]; ra[q] = tok ? v : 0.f; }
+    for (int q = 0; q < QA; ++q) { const float v = ab[(long)(wave + NW * q) * T + tc]; ra[q] = tok ? v : 0.f; }
     const float* zb = a.dz1 + (long)b * NARROW * T;
     const float* gb = a.g + (long)b * NARROW * T;
     const float* hb = a.h + (long)b * NARROW * T;
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      const int r0_ = wave + 8 * q;
+    for (int q = 0; q < QN; ++q) {
+      const int r0_ = wave + NW * q;
       const int r = r0_ < NARROW ? r0_ : 0;            // rows 20..23 of the last pass: clamped loads, never stored
       { const float v = zb[(long)r * T + tc]; rz[q] = tok ? v : 0.f; }
 #pragma unroll
@@ -969,14 +974,14 @@ __global__ __launch_bounds__(512, 2) void gated_block_wgrad_kernel(BlockWgradArg
   auto store_tile = [&]() {
 #pragma unroll
     for (int q = 0; q < QX; ++q) {
-      const int r = wave + 8 * q;
+      const int r = wave + NW * q;
       if (r < C) { xn[r * ldn + lane] = rx[q]; dys[r * ldn + lane] = ry[q]; }
     }
 #pragma unroll
-    for (int q = 0; q < 5; ++q) dl[(wave + 8 * q) * ldn + lane] = ra[q];
+    for (int q = 0; q < QA; ++q) dl[(wave + NW * q) * ldn + lane] = ra[q];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      const int r = wave + 8 * q;
+    for (int q = 0; q < QN; ++q) {
+      const int r = wave + NW * q;
       if (r < NARROW) {
         dhs[r * ldn + lane] = rz[q];
 #pragma unroll
@@ -1002,38 +1007,41 @@ __global__ __launch_bounds__(512, 2) void gated_block_wgrad_kernel(BlockWgradArg
     for (int s = 0; s < TT / 4; ++s) {
       const int tl = 4 * s + kq;
       {
-        float af[2], bf[RT9];
+        float af[R9], bf[RT9];
 #pragma unroll
-        for (int r = 0; r < 2; ++r) af[r] = gs[off9[r] + tl];
+        for (int r = 0; r < R9; ++r) af[r] = gs[off9[r] + tl];
 #pragma unroll
         for (int c = 0; c < RT9; ++c) bf[c] = sm[offb9[c] + tl];
 #pragma unroll
-        for (int r = 0; r < 2; ++r)
+        for (int r = 0; r < R9; ++r)
 #pragma unroll
           for (int c = 0; c < RT9; ++c) g9[r][c] = mfma4(af[r], bf[c], g9[r][c]);
       }
       {
-        float af[3], bf[3];
+        float af[RLR], bf[3];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) af[r] = hs[offlr[r] + tl];
+        for (int r = 0; r < RLR; ++r) af[r] = hs[offlr[r] + tl];
 #pragma unroll
         for (int c = 0; c < 3; ++c) bf[c] = sm[offb_lr[c] + tl];
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
+        for (int r = 0; r < RLR; ++r)
 #pragma unroll
           for (int c = 0; c < 3; ++c) glr[r][c] = mfma4(af[r], bf[c], glr[r][c]);
       }
       {
-        const float af1 = xn[off1[0] + tl];
         const float b0 = dhs[l15 * ldn + tl];
         const float b1 = sm[offb1 + tl];
-        g1[0][0] = mfma4(af1, b0, g1[0][0]);
-        g1[0][1] = mfma4(af1, b1, g1[0][1]);
+#pragma unroll
+        for (int r = 0; r < R1; ++r) {
+          const float af1 = xn[off1[r] + tl];
+          g1[r][0] = mfma4(af1, b0, g1[r][0]);
+          g1[r][1] = mfma4(af1, b1, g1[r][1]);
+        }
       }
     }
     // fused 1x1 data gradient AFTER the MFMA loop: by now the next tile's prefetch has landed, so these weight loads do
     // not queue behind it (vmcnt retires in order), and their registers are not live during the loop above.
-    constexpr int RH = (RT9 + 1) / 2;               // row tiles per wave in D1: waves 0-3 take [0,RH), waves 4-7 [RH, 2RH)
+    constexpr int RH = NW == 8 ? (RT9 + 1) / 2 : RT9;  // row tiles per wave in D1 (8 waves: halves [0,RH) and [RH,2RH))
     const int rbase = (wave >> 2) * RH;
     float av[5][RH];
     if (a.dx) {
@@ -1081,10 +1089,10 @@ __global__ __launch_bounds__(512, 2) void gated_block_wgrad_kernel(BlockWgradArg
   const long so = (long)blockIdx.x * a.slab_stride;
   if (a.skip & 4) return;
 #pragma unroll
-  for (int r = 0; r < 2; ++r)
+  for (int r = 0; r < R9; ++r)
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
-      const int kk = (wave + 8 * r) * 16 + kq * 4 + reg;
+      const int kk = (wave + NW * r) * 16 + kq * 4 + reg;
       if (kk > K9 * NARROW) continue;
 #pragma unroll
       for (int cc = 0; cc < RT9; ++cc) {
@@ -1095,10 +1103,10 @@ __global__ __launch_bounds__(512, 2) void gated_block_wgrad_kernel(BlockWgradArg
       }
     }
 #pragma unroll
-  for (int r = 0; r < 3; ++r)
+  for (int r = 0; r < RLR; ++r)
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
-      const int kk = (wave + 8 * r) * 16 + kq * 4 + reg;
+      const int kk = (wave + NW * r) * 16 + kq * 4 + reg;
       if (kk > K15 * NARROW) continue;
 #pragma unroll
       for (int ct = 0; ct < 3; ++ct) {
@@ -1110,10 +1118,10 @@ __global__ __launch_bounds__(512, 2) void gated_block_wgrad_kernel(BlockWgradArg
       }
     }
 #pragma unroll
-  for (int r = 0; r < 1; ++r)
+  for (int r = 0; r < R1; ++r)
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
-      const int ci = (wave + 8 * r) * 16 + kq * 4 + reg;
+      const int ci = (wave + NW * r) * 16 + kq * 4 + reg;
       if (ci > C) continue;
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
@@ -1154,7 +1162,7 @@ extern "C" long nsc_gated_block_wgrad_workspace(int C) {
 extern "C" int nsc_gated_block_wgrad(const float* x, const float* h, const float* g, const float* dy, const float* da,
                                      const float* dz1, float* dw1, float* db1, float* dwl, float* dbl, float* dwr,
                                      float* dbr, float* dw9, float* db9, const float* wt1, float* dx, int in_act, int B,
-                                     int C, int T, int narrow, int k9, int dil, float* workspace, void* stream) {
+                                     int C, int T, int narrow, int k9, int dil, int waves, float* workspace, void* stream) {
   NSC_REQUIRE(x && h && g && dy && da && dz1 && dw1 && db1 && dwl && dbl && dwr && dbr && dw9 && db9,
               NSC_ERR_BAD_ARG, "nsc_gated_block_wgrad: null pointer");
   NSC_REQUIRE(!dx || wt1, NSC_ERR_BAD_ARG, "nsc_gated_block_wgrad: dx needs wt1");
@@ -1184,15 +1192,16 @@ extern "C" int nsc_gated_block_wgrad(const float* x, const float* h, const float
     a.dw1 += off; a.db1 += off; a.dwl += off; a.dbl += off; a.dwr += off; a.dbr += off; a.dw9 += off; a.db9 += off;
   }
   hipStream_t st = (hipStream_t)stream;
-#define LAUNCH_WG(RT)                                                                                               \
+#define LAUNCH_WG(RT, NW_)                                                                                          \
   do {                                                                                                              \
-    auto kern = gated_block_wgrad_kernel<RT>;                                                                       \
+    auto kern = gated_block_wgrad_kernel<RT, NW_>;                                                                  \
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);   \
     NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "gated_block_wgrad: smem attr: %s", hipGetErrorString(e));         \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, a, ldn, ldg, ldh);                                    \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW_), smem, st, a, ldn, ldg, ldh);                               \
   } while (0)
-  if (nsc_cdiv(C, 16) <= 4) LAUNCH_WG(4);
-  else LAUNCH_WG(7);
+  NSC_REQUIRE(waves == 4 || waves == 8, NSC_ERR_BAD_ARG, "nsc_gated_block_wgrad: waves must be 4 or 8");
+  if (nsc_cdiv(C, 16) <= 4) { if (waves == 8) LAUNCH_WG(4, 8); else LAUNCH_WG(4, 4); }
+  else { if (waves == 8) LAUNCH_WG(7, 8); else LAUNCH_WG(7, 4); }
 #undef LAUNCH_WG
   NSC_CHECK_LAUNCH("gated_block_wgrad");
   if (use_slab) {

@@ -494,7 +494,7 @@ def test_block_wgrad_kernel(lib, case):
     da = np.concatenate([dlin, dgate], axis=2)                              # [B,T,40] -> dlin | dgate
     rc = lib.nsc_gated_block_wgrad(tr(x), tr(h), tr(g), tr(dy), tr(da), tr(dz1), dws[0].data_ptr(), dbs[0].data_ptr(),
                                    dws[1].data_ptr(), dbs[1].data_ptr(), dws[2].data_ptr(), dbs[2].data_ptr(),
-                                   dws[3].data_ptr(), dbs[3].data_ptr(), None, None, 0, B, C_, T, 20, 9, dil, None, _st())
+                                   dws[3].data_ptr(), dbs[3].data_ptr(), None, None, 0, B, C_, T, 20, 9, dil, 4, None, _st())
     assert rc == 0, lib.nsc_last_error()
     for i in range(4):
         assert_close(dws[i].cpu().numpy(), ref[i][0], tol=2e-4, what=f"block wgrad dW[{i}] {case}")
@@ -512,7 +512,7 @@ def test_block_wgrad_kernel(lib, case):
     wt1 = np.ascontiguousarray(W1[::-1].transpose(0, 2, 1))                  # [1,20,C]
     dx = torch.full((B, C_, T), float("nan"), device="cuda")
     rc = lib.nsc_gated_block_wgrad(tr(x), tr(h), tr(g), tr(dy), tr(da), tr(dz1), *ptrs, P(wt1), dx.data_ptr(), 2, B, C_, T,
-                                   20, 9, dil, ws.data_ptr(), _st())
+                                   20, 9, dil, 8, ws.data_ptr(), _st())
     assert rc == 0, lib.nsc_last_error()
     got, off = flat.cpu().numpy() - 0.5, 0
     for i, (s_, n_) in enumerate(zip(shapes, sizes)):
