@@ -930,44 +930,51 @@ __global__ __launch_bounds__(64 * NW, 2) void gated_block_wgrad_kernel(BlockWgra
   constexpr int QX = RT9 * 16 / NW;                 // rows per wave for the C-channel tensors (x, dy)
   constexpr int QA = 40 / NW, QN = (NARROW + NW - 1) / NW;
   float rx[QX], ry[QX], ra[QA], rz[QN], rg[QN][2], rh[QN][2];
+  // Raw buffer loads: the descriptors are wave-uniform, the row offset is a SCALAR (soffset) and the per-lane offset is
+  // just the time index, so the ~50 prefetch loads need no per-load address registers; out-of-frame time indices are
+  // sent out of the descriptor's range and come back as 0 from the hardware bounds check (no value selects either).
+  const unsigned nbC = (unsigned)((long)a.B * C * T * 4), nbN = (unsigned)((long)a.B * NARROW * T * 4);
+  const __amdgpu_buffer_rsrc_t sx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, nbC, 0x00020000);
+  const __amdgpu_buffer_rsrc_t sy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, nbC, 0x00020000);
+  const __amdgpu_buffer_rsrc_t sa = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.da), 0, 2 * nbN, 0x00020000);
+  const __amdgpu_buffer_rsrc_t sz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dz1), 0, nbN, 0x00020000);
+  const __amdgpu_buffer_rsrc_t sg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.g), 0, nbN, 0x00020000);
+  const __amdgpu_buffer_rsrc_t sh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.h), 0, nbN, 0x00020000);
+  auto bl = [](const __amdgpu_buffer_rsrc_t& r, int voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+  };
   auto load_tile = [&](int tile) {
-    const int b = tile / a.tiles_per_frame;
-    const int t0 = (tile - b * a.tiles_per_frame) * TT;
+    const int b = __builtin_amdgcn_readfirstlane(tile / a.tiles_per_frame);
+    const int t0 = __builtin_amdgcn_readfirstlane((tile - b * a.tiles_per_frame) * TT);
+    const int OOB = 0x7ffffff0;                       // byte offset past every descriptor -> load returns 0
     const int t = t0 + lane;
-    const bool tok = t < T;
-    const int tc = tok ? t : 0;
-    const float* xb = a.x + (long)b * C * T;
-    const float* yb = a.dy + (long)b * C * T;
+    const int vt = t < T ? t * 4 : OOB;
+    int vg[2], vh[2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int j = lane + 64 * jj;
+      const int tg = t0 - 4 + j, thh = t0 - Hh + j;
+      vg[jj] = (j < TT + 8 && tg >= 0 && tg < T) ? tg * 4 : OOB;
+      vh[jj] = (j < TT + 2 * Hh && thh >= 0 && thh < T) ? thh * 4 : OOB;
+    }
+    const int sbC = b * C * T * 4, sbN = b * NARROW * T * 4;
 #pragma unroll
     for (int q = 0; q < QX; ++q) {
-      const int r = wave + NW * q;
-      const bool ok = tok && r < C;
-      const long off = (long)(r < C ? r : 0) * T + tc;
-      const float vx = xb[off], vy = yb[off];
-      rx[q] = ok ? vx : 0.f;
-      ry[q] = ok ? vy : 0.f;
+      const int r = wave + NW * q;                    // rows >= C read the next frame's data: never stored
+      const int so = sbC + r * T * 4;
+      rx[q] = bl(sx, vt, so);
+      ry[q] = bl(sy, vt, so);
     }
-    const float* ab = a.da + (long)b * 2 * NARROW * T;
 #pragma unroll
-    for (int q = 0; q < QA; ++q) { const float v = ab[(long)(wave + NW * q) * T + tc]; ra[q] = tok ? v : 0.f; }
-    const float* zb = a.dz1 + (long)b * NARROW * T;
-    const float* gb = a.g + (long)b * NARROW * T;
-    const float* hb = a.h + (long)b * NARROW * T;
+    for (int q = 0; q < QA; ++q) ra[q] = bl(sa, vt, 2 * sbN + (wave + NW * q) * T * 4);
 #pragma unroll
     for (int q = 0; q < QN; ++q) {
-      const int r0_ = wave + NW * q;
-      const int r = r0_ < NARROW ? r0_ : 0;            // rows 20..23 of the last pass: clamped loads, never stored
-      { const float v = zb[(long)r * T + tc]; rz[q] = tok ? v : 0.f; }
+      const int so = sbN + (wave + NW * q) * T * 4;   // rows >= 20: never stored
+      rz[q] = bl(sz, vt, so);
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
-        const int j = lane + 64 * jj;
-        const int tg = t0 - 4 + j, thh = t0 - Hh + j;
-        const bool okg = j < TT + 8 && tg >= 0 && tg < T;
-        const bool okh = j < TT + 2 * Hh && thh >= 0 && thh < T;
-        const float vg = gb[(long)r * T + (okg ? tg : 0)];
-        const float vh = hb[(long)r * T + (okh ? thh : 0)];
-        rg[q][jj] = okg ? vg : 0.f;
-        rh[q][jj] = okh ? vh : 0.f;
+        rg[q][jj] = bl(sg, vg[jj], so);
+        rh[q][jj] = bl(sh, vh[jj], so);
       }
     }
   };
@@ -1003,7 +1010,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gated_block_wgrad_kernel(BlockWgra
     __syncthreads();
     if (tile + (int)gridDim.x < a.ntiles && !(a.skip & 8)) load_tile(tile + gridDim.x);   // in flight during the MFMA loop below
     if (!(a.skip & 2))
-#pragma unroll 2
+#pragma unroll 1
     for (int s = 0; s < TT / 4; ++s) {
       const int tl = 4 * s + kq;
       {
