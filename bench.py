@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="weight-gradient kernels on the main stream (profiling)")
     ap.add_argument("--fused-bwd", action="store_true", help="debug: whole-block persistent backward kernel")
     ap.add_argument("--unfused-wgrad", action="store_true", help="debug: per-conv weight gradients")
+    ap.add_argument("--fused-dgrad", action="store_true", help="debug: one fused data-path backward kernel per gated block")
     ap.add_argument("--unfused-fwd", action="store_true", help="debug: per-conv forward/backward (no block fusion)")
     args = ap.parse_args()
 
@@ -111,6 +112,7 @@ def main():
     eng.overlap_wgrad = not args.no_overlap
     eng.fused_bwd = args.fused_bwd
     eng.fused_wgrad = not args.unfused_wgrad
+    eng.fused_dgrad = args.fused_dgrad
     eng.fused_fwd = not args.unfused_fwd
     xd, lpcd, x_np, lpc_np = synth_batch(B, comm.rank, dev)
     cfg = step_cfg()
@@ -184,6 +186,7 @@ def main():
                "block_fwd": "gated_block_fwd_kernel (fused gated block forward)",
                "block_wgrad": "gated_block_wgrad_kernel (persistent block weight gradients)",
                "block_bwd": "gated_block_bwd_kernel (fused gated block backward)",
+               "block_dgrad": "gated_block_dgrad_kernel (fused gated block data-path backward)",
                "wgrad_mfma": "conv1d_wgrad_kernel (per-conv weight gradients)"}
     roof, by_kernel = None, {}
     traffic = {}

@@ -88,6 +88,13 @@ int nsc_gated_block_bwd(const float* x, const float* dy, const float* w1, const 
                         float* dwr, float* dbr, float* dw9, float* db9, int B, int C, int T, int narrow, int k9,
                         int dil, int in_act, void* stream);
 
+/* Fused DATA-PATH backward of the same block (8 waves, two workgroups per CU): from the saved h, lin, th (tanh branch)
+ * [B,20,T], x and dy [B,C,T] it writes dx = (conv1^T(dz1) + dy) * act'(x), da [B,40,T] (= dlin | dgate) and
+ * dz1 [B,20,T] - exactly the inputs of nsc_gated_block_wgrad.  dil in {1,2}, narrow 20, k9 9, C <= 112. */
+int nsc_gated_block_dgrad(const float* x, const float* h, const float* lin, const float* th, const float* dy,
+                          const float* wt1, const float* wtl, const float* wtr, const float* wt9, float* dx, float* da,
+                          float* dz1, int B, int C, int T, int narrow, int k9, int dil, int in_act, void* stream);
+
 /* Persistent weight-gradient kernel of one gated block: all eight parameter gradients (accumulated) from the saved
  * activations x [B,C,T], h, g [B,20,T] and the data-path gradients dy [B,C,T], da [B,40,T] (= dlin | dgate, the
  * nsc_glu_bwd_cat output), dz1 [B,20,T] (= dL/d(pre-activation of h)).  Optionally (dx != NULL) it also produces the

@@ -1218,3 +1218,262 @@ extern "C" int nsc_gated_block_wgrad(const float* x, const float* h, const float
   }
   return NSC_OK;
 }
+
+// =====================================================================================================
+// Fused DATA-PATH backward of the gated block (8 waves, ~78 KB LDS -> two workgroups per CU):
+//   dg    = W9^T * dy                         (k9 data gradient; split over taps of both parities -> 24 half-jobs)
+//   dlin  = dg.th ; dgate = dg.lin.(1-th^2)   (GLU backward, in LDS)                       -> da [B,40,T]
+//   dz1   = (Wl^T dlin + Wr^T dgate).lrelu'(h)(both k15 data gradients in one pass)        -> dz1 [B,20,T]
+//   dx    = (W1^T dz1 + dy).act'(x)           (1x1 data gradient + residual)               -> dx [B,C,T]
+// Inputs are the activations the forward saved (h, lin, th) and dy; the three outputs are exactly what the
+// persistent weight-gradient kernel consumes.  Replaces four launches per block on the critical stream.
+// Columns: dys j <-> t0-Hh-4+j ; lin/th/dg j <-> t0-Hh+j ; dhs j <-> t0+j   (Hh = 7*dil).
+// =====================================================================================================
+struct BlockDgradArgs {
+  int B, C, T, dil, in_act;
+  const float *x, *h, *lin, *th, *dy;
+  const float *wt1, *wtl, *wtr, *wt9;
+  float *dx, *da, *dz1;
+};
+
+template <int RT9>
+__global__ __launch_bounds__(512) void gated_block_dgrad_kernel(BlockDgradArgs a, int ldy, int lda, int ldn) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  constexpr int TT = 64;
+  const int C = a.C, T = a.T, d = a.dil;
+  const int Hh = 7 * d;
+  const int W_a = TT + 2 * Hh, W_dy = W_a + 8;
+  const int C4 = (C + 3) & ~3;
+  const int nct_a = (W_a + 15) >> 4;                 // 6 (d=2) / 5 (d=1)
+  float* dys = sm;                                   // [C4][ldy]   (pad rows zero)
+  float* lin = dys + C4 * ldy;                       // [NARROW][lda]  -> dlin
+  float* th = lin + NARROW * lda;                    // [NARROW][lda]  -> dgate
+  float* dg = th + NARROW * lda;                     // [NARROW][lda]
+  float* dhs = dg + NARROW * lda;                    // [NARROW][ldn]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, kq = lane >> 4;
+  const int b = blockIdx.y, t0 = blockIdx.x * TT;
+
+  // ---- stage dy (with halo), lin, th; zero dg ----
+  nsc_stage_rows<8>(dys, ldy, C4, C, W_dy, a.dy + (long)b * C * T, T, t0 - Hh - 4, T, 0, wave, lane);
+  nsc_stage_rows<8>(lin, lda, NARROW, NARROW, W_a, a.lin + (long)b * NARROW * T, T, t0 - Hh, T, 0, wave, lane);
+  nsc_stage_rows<8>(th, lda, NARROW, NARROW, W_a, a.th + (long)b * NARROW * T, T, t0 - Hh, T, 0, wave, lane);
+  for (int e = tid; e < NARROW * lda; e += 512) dg[e] = 0.f;
+  __syncthreads();
+
+  // ---- D9: dg[ci][ja] = sum_{tap', o} wt9[tap'][o][ci] * dy[o][ja + tap'] ----
+  // job = (row tile rt, column tile ct), split in two halves over the parity of tap' -> half-job hj = 2*job + parity.
+  // wave w runs half-jobs 3w .. 3w+2 (2*nct_a*2 = 24 at d=2; at d=1 the last waves run discarded duplicates).
+  {
+    const int nhj = 2 * nct_a * 2;
+    int rt[3], par[3], jcol[3];
+    bool real[3];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      int hj = 3 * wave + e;
+      real[e] = hj < nhj;
+      hj = real[e] ? hj : 0;
+      par[e] = hj & 1;
+      const int job = hj >> 1;
+      rt[e] = job & 1;
+      jcol[e] = (job >> 1) * 16 + l15;
+    }
+    const __amdgpu_buffer_rsrc_t wsrd =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wt9), 0, K9 * C * NARROW * 4, 0x00020000);
+    int voff[3];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      const int ci = rt[e] * 16 + l15;
+      voff[e] = (kq * NARROW + (ci < NARROW ? ci : NARROW - 1)) * 4;   // rows >= 20: clamped, never stored
+    }
+    const int ncq = C4 >> 2;
+    const int tap_bytes = C * NARROW * 4, step_bytes = 4 * NARROW * 4;
+    f32x4 acc[3];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) acc[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    constexpr int G9 = 5;
+    float an[G9][3];
+    int ip = 0, cp = 0;                               // prefetch cursor: tap slot i (tap' = parity + 2 i), channel group
+    auto fetch9 = [&]() {
+#pragma unroll
+      for (int u = 0; u < G9; ++u) {
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+          // tap' >= 9 (fifth slot of the odd parity, or past the end) lands outside the descriptor -> 0
+          const int soff = __builtin_amdgcn_readfirstlane((par[e] + 2 * ip) * tap_bytes + cp * step_bytes);
+          an[u][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wsrd, voff[e], soff, 0));
+        }
+        const bool wr = (cp + 1 == ncq);
+        cp = wr ? 0 : cp + 1;
+        ip += wr ? 1 : 0;
+      }
+    };
+    fetch9();
+    const int nsteps = 5 * ncq;                        // 5 tap slots (even parity: taps 0,2,4,6,8; odd: 1,3,5,7,(9 -> zero))
+    const int ngroups = (nsteps + G9 - 1) / G9;
+    int it = 0, cq = 0;
+    for (int g = 0; g < ngroups; ++g) {
+      float ac[G9][3];
+#pragma unroll
+      for (int u = 0; u < G9; ++u)
+#pragma unroll
+        for (int e = 0; e < 3; ++e) ac[u][e] = an[u][e];
+      fetch9();
+#pragma unroll
+      for (int u = 0; u < G9; ++u) {
+        const int itc = it < 5 ? it : 4;
+        const float* yrow = dys + (cq * 4 + kq) * ldy + 2 * itc;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+          const int tp = par[e] + ((par[e] && itc == 4) ? -1 : 0);   // keep the (zero-weight) tap 9 read inside the tile
+          acc[e] = mfma4(ac[u][e], yrow[tp + jcol[e]], acc[e]);
+        }
+        const bool wr = (cq + 1 == ncq);
+        cq = wr ? 0 : cq + 1;
+        it += wr ? 1 : 0;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      if (!real[e]) continue;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int ci = rt[e] * 16 + kq * 4 + reg;
+        if (ci < NARROW && jcol[e] < lda) atomicAdd(&dg[ci * lda + jcol[e]], acc[e][reg]);
+      }
+    }
+  }
+  __syncthreads();
+  // ---- GLU backward in place (lin/th are zero outside the frame, so dlin/dgate are too); da -> global ----
+  for (int e = tid; e < NARROW * lda; e += 512) {
+    const float l = lin[e], tg = th[e], gg = dg[e];
+    const float dl_ = gg * tg, dgt = gg * l * (1.f - tg * tg);
+    lin[e] = dl_;
+    th[e] = dgt;
+    const int c = e / lda, ja = e - c * lda;
+    const int t = t0 - Hh + ja;
+    if (ja >= Hh && ja < Hh + TT && t < T) {
+      a.da[((long)b * 2 * NARROW + c) * T + t] = dl_;
+      a.da[((long)b * 2 * NARROW + NARROW + c) * T + t] = dgt;
+    }
+  }
+  __syncthreads();
+
+  // ---- D15: dz1[ci][tt] = (sum_{tap',br,c} wt{l,r}[tap'][c][ci] d{lin,gate}[c][tt + tap' d]) * lrelu'(h); one job per wave ----
+  {
+    const int rt = wave & 1, ct = wave >> 1;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int tt = ct * 16 + l15;
+    const int ci = rt * 16 + l15;
+    const int cic = ci < NARROW ? ci : NARROW - 1;
+    constexpr int G15 = 10;                             // one tap = 2 branches x 5 k-steps
+    float an[G15];
+    auto fetch15 = [&](int tapf) {
+      const int tf = tapf < K15 ? tapf : K15 - 1;
+#pragma unroll
+      for (int u = 0; u < G15; ++u) {
+        const float* wsrc = (u < 5) ? a.wtl : a.wtr;
+        an[u] = wsrc[(tf * NARROW + (u % 5) * 4 + kq) * NARROW + cic];
+      }
+    };
+    fetch15(0);
+    for (int tap = 0; tap < K15; ++tap) {
+      float ac[G15];
+#pragma unroll
+      for (int u = 0; u < G15; ++u) ac[u] = an[u];
+      fetch15(tap + 1);
+#pragma unroll
+      for (int u = 0; u < G15; ++u) {
+        const float* src = (u < 5) ? lin : th;
+        acc = mfma4(ac[u], src[((u % 5) * 4 + kq) * lda + tt + tap * d], acc);
+      }
+    }
+    const int t = t0 + tt;
+    const bool live = t < T;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int c = rt * 16 + kq * 4 + reg;
+      if (c < NARROW) {
+        const float hv = live ? a.h[((long)b * NARROW + c) * T + t] : 0.f;
+        const float v = live ? acc[reg] * (hv > 0.f ? 1.f : NSC_LRELU_ALPHA) : 0.f;
+        dhs[c * ldn + tt] = v;
+        if (live) a.dz1[((long)b * NARROW + c) * T + t] = v;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- D1: dx = (W1^T dz1 + dy) * act'(x); wave -> column tile (w & 3), row-tile half (w >> 2) ----
+  {
+    constexpr int RH = (RT9 + 1) / 2;
+    const int rbase = (wave >> 2) * RH;
+    const int tt = (wave & 3) * 16 + l15;
+    f32x4 acc[RH];
+    float av[5][RH];
+#pragma unroll
+    for (int s = 0; s < 5; ++s)
+#pragma unroll
+      for (int r = 0; r < RH; ++r) {
+        const int c = (rbase + r) * 16 + l15;
+        av[s][r] = a.wt1[(s * 4 + kq) * C + (c < C ? c : C - 1)];
+      }
+#pragma unroll
+    for (int r = 0; r < RH; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+      const float bv = dhs[(s * 4 + kq) * ldn + tt];
+#pragma unroll
+      for (int r = 0; r < RH; ++r) acc[r] = mfma4(av[s][r], bv, acc[r]);
+    }
+    const int t = t0 + tt;
+    if (t < T) {
+#pragma unroll
+      for (int r = 0; r < RH; ++r)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int c = (rbase + r) * 16 + kq * 4 + reg;
+          if (c < C) {
+            float v = acc[r][reg] + dys[c * ldy + tt + Hh + 4];
+            const long gi = ((long)b * C + c) * T + t;
+            if (a.in_act == NSC_ACT_LRELU) v *= (a.x[gi] > 0.f ? 1.f : NSC_LRELU_ALPHA);
+            a.dx[gi] = v;
+          }
+        }
+    }
+  }
+}
+
+extern "C" int nsc_gated_block_dgrad(const float* x, const float* h, const float* lin, const float* th, const float* dy,
+                                     const float* wt1, const float* wtl, const float* wtr, const float* wt9, float* dx,
+                                     float* da, float* dz1, int B, int C, int T, int narrow, int k9, int dil, int in_act,
+                                     void* stream) {
+  NSC_REQUIRE(x && h && lin && th && dy && wt1 && wtl && wtr && wt9 && dx && da && dz1, NSC_ERR_BAD_ARG,
+              "nsc_gated_block_dgrad: null pointer");
+  NSC_REQUIRE(B > 0 && C > 1 && T > 0, NSC_ERR_BAD_ARG, "nsc_gated_block_dgrad: bad sizes");
+  NSC_REQUIRE(narrow == NARROW && k9 == K9 && (dil == 1 || dil == 2) && C <= 112, NSC_ERR_UNSUPPORTED,
+              "nsc_gated_block_dgrad: built for narrow=20, k9=9, dil in {1,2}, C<=112 (got %d, %d, %d, %d)", narrow, k9, dil, C);
+  NSC_REQUIRE(in_act == NSC_ACT_NONE || in_act == NSC_ACT_LRELU, NSC_ERR_BAD_ARG, "nsc_gated_block_dgrad: in_act must be none|lrelu");
+  const int Hh = 7 * dil, W_a = 64 + 2 * Hh;
+  const int nct_a = (W_a + 15) / 16;
+  auto ld16 = [](int w) { int l = w; while ((l & 31) != 16) ++l; return l; };
+  const int ldy = ld16(nct_a * 16 + 8), lda = ld16(nct_a * 16), ldn = ld16(64);
+  const int C4 = (C + 3) & ~3;
+  const size_t smem = ((size_t)C4 * ldy + (size_t)3 * NARROW * lda + (size_t)NARROW * ldn) * sizeof(float);
+  NSC_REQUIRE(smem <= 160 * 1024, NSC_ERR_UNSUPPORTED, "nsc_gated_block_dgrad: %zu B LDS", smem);
+  BlockDgradArgs a{B, C, T, dil, in_act, x, h, lin, th, dy, wt1, wtl, wtr, wt9, dx, da, dz1};
+  dim3 grid(nsc_cdiv(T, 64), B);
+  hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_DG(RT)                                                                                               \
+  do {                                                                                                              \
+    auto kern = gated_block_dgrad_kernel<RT>;                                                                       \
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);   \
+    NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "gated_block_dgrad: smem attr: %s", hipGetErrorString(e));         \
+    hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, a, ldy, lda, ldn);                                          \
+  } while (0)
+  if (nsc_cdiv(C, 16) <= 4) LAUNCH_DG(4);
+  else LAUNCH_DG(7);
+#undef LAUNCH_DG
+  NSC_CHECK_LAUNCH("gated_block_dgrad");
+  return NSC_OK;
+}

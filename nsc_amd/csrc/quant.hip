@@ -44,11 +44,12 @@ __device__ __forceinline__ void softmax_bins(float c, float alpha, const float (
   for (int i = 0; i < ITER; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      p[i][j] = ok[i][j] ? expf(z[i][j] - m) : 0.f;
+      // v_exp_f32 path: exp(x) = 2^(x log2 e); |x| <= ~20 wherever p matters, so the product's rounding costs < 2e-6 rel.
+      p[i][j] = ok[i][j] ? __expf(z[i][j] - m) : 0.f;
       s += p[i][j];
     }
   s = grp_sum<LPC>(s);
-  const float inv = 1.f / s;
+  const float inv = __frcp_rn(s);
 #pragma unroll
   for (int i = 0; i < ITER; ++i)
 #pragma unroll
@@ -72,13 +73,14 @@ __global__ __launch_bounds__(256) void quantize_fwd_kernel(const float* __restri
                                                            const float* __restrict__ alpha_p,
                                                            const float* __restrict__ bins, float on, int soft, int L,
                                                            int nb, float* __restrict__ p_out, float* __restrict__ out,
-                                                           float* __restrict__ quan_out, float* __restrict__ hist) {
+                                                           float* __restrict__ quan_out, float* __restrict__ hist,
+                                                           int nbatch) {
   extern __shared__ __attribute__((aligned(16))) float sh[];  // [nbpad] histogram + [4] quan partials
   constexpr int CPW = 64 / LPC;
   const int nbpad = 4 * LPC * ITER;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int gl = lane % LPC, gc = lane / LPC;
-  const int b = blockIdx.x;
+  const int B = (int)nbatch;
   const float alpha = alpha_p[0];
   float bv[ITER][4];
   bool ok[ITER][4];
@@ -97,8 +99,12 @@ __global__ __launch_bounds__(256) void quantize_fwd_kernel(const float* __restri
   for (int i = 0; i < ITER; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) hacc[i][j] = 0.f;
-  float qacc = 0.f;
   const bool vec_ok = (nb & 3) == 0;
+  // A workgroup walks frames b, b + gridDim.x, ... : the histogram is accumulated across ALL its frames before the
+  // flush - one atomic per bin per workgroup with <= 1024 workgroups, instead of one per bin per FRAME (4096
+  // serialised atomics on each of the 32 addresses bounded the first version at large batch).
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+  float qacc = 0.f;
   for (int l0 = wave * CPW; l0 < L; l0 += 4 * CPW) {
     const int l = l0 + gc;
     const bool live = l < L;
@@ -133,7 +139,7 @@ __global__ __launch_bounds__(256) void quantize_fwd_kernel(const float* __restri
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           hacc[i][j] += p[i][j];
-          if (ok[i][j]) qacc += sqrtf(p[i][j] + QEPS);
+          if (ok[i][j]) qacc += __fsqrt_rn(p[i][j] + QEPS);
         }
       if (p_out) {
         float* pr = p_out + ci * nb;
@@ -152,7 +158,15 @@ __global__ __launch_bounds__(256) void quantize_fwd_kernel(const float* __restri
       if (gl == 0) out[ci] = (1.f - on) * c + on * q;
     }
   }
-  // merge
+  // per-frame quan_loss partial
+  qacc = wave_sum(qacc);
+  if (lane == 0) sh[nbpad + wave] = qacc;
+  __syncthreads();
+  if (quan_out && tid == 0)
+    quan_out[b] = (sh[nbpad] + sh[nbpad + 1] + sh[nbpad + 2] + sh[nbpad + 3]) / (float)L;
+  __syncthreads();
+  }  // frames
+  // merge the histogram of all frames of this workgroup
 #pragma unroll
   for (int i = 0; i < ITER; ++i)
 #pragma unroll
@@ -160,13 +174,9 @@ __global__ __launch_bounds__(256) void quantize_fwd_kernel(const float* __restri
       const int k = (i * LPC + gl) * 4 + j;
       if (ok[i][j]) atomicAdd(&sh[k], hacc[i][j]);
     }
-  qacc = wave_sum(qacc);
-  if (lane == 0) sh[nbpad + wave] = qacc;
   __syncthreads();
   if (hist)
     for (int k = tid; k < nb; k += 256) atomicAdd(hist + k, sh[k]);
-  if (quan_out && tid == 0)
-    quan_out[b] = (sh[nbpad] + sh[nbpad + 1] + sh[nbpad + 2] + sh[nbpad + 3]) / (float)L;
 }
 
 template <int LPC, int ITER>
@@ -300,8 +310,9 @@ extern "C" int nsc_quantize_fwd(const float* code, const float* alpha, const flo
   NSC_REQUIRE(nb <= 1024, NSC_ERR_UNSUPPORTED, "nsc_quantize_fwd: nb %d > 1024", nb);
   hipStream_t st = (hipStream_t)stream;
 #define CALLF(LPC_, IT_)                                                                                          \
-  hipLaunchKernelGGL((quantize_fwd_kernel<LPC_, IT_>), dim3(B), dim3(256), (4 * LPC_ * IT_ + 4) * sizeof(float), st, \
-                     code, alpha, bins, is_quan_on, soft, L, nb, p_out, out, quan_out, hist)
+  hipLaunchKernelGGL((quantize_fwd_kernel<LPC_, IT_>), dim3(std::min(B, 1024)), dim3(256),                        \
+                     (4 * LPC_ * IT_ + 4) * sizeof(float), st, code, alpha, bins, is_quan_on, soft, L, nb, p_out, out,  \
+                     quan_out, hist, B)
   QDISPATCH(nb, CALLF);
 #undef CALLF
   NSC_CHECK_LAUNCH("quantize_fwd");

@@ -222,22 +222,34 @@ class _Block:
             # data path: k9 dgrad -> GLU backward (dlin | dgate in one tensor) -> ONE k15 dgrad over 40 input channels;
             # then a persistent kernel does all eight parameter gradients AND the 1x1 data gradient (it has x, dy, dz1
             # staged anyway).
-            self.c9.dgrad(dz, dg)
             da = e.buf(u + ".da", (B, 2 * n, T))
-            check(e.lib.nsc_glu_bwd_cat(self.lin.data_ptr(), self.th.data_ptr(), dg.data_ptr(), da.data_ptr(), B, n, T,
-                                        e.stream()), "glu_bwd_cat")
-            cl = self.cl
-            d = ConvDesc(B=B, Cin=2 * n, Cout=n, Tin=T, Tout=T, K=cl.K, dil=cl.dil, stride=1,
-                         padL=(cl.K - 1) * cl.dil - cl.padL, act=0, res_mode=0, mul_mode=KIND_MUL["lrelu"], out_mode=0,
-                         in_up=0, accumulate=0)
-            tok = e.prof_begin("conv_mfma", self.cl.flops() + self.cr.flops())
-            check(e.lib.nsc_conv1d_fwd(C.byref(d), da.data_ptr(), e.wt_ptr + 4 * self.wtlr_off, None, None,
-                                       self.h.data_ptr(), dh.data_ptr(), e.stream()), "gate dgrad (fused lin|gate)")
-            e.prof_end(tok)
+            fused_dgrad = e.fused_dgrad and self.cl.dil in (1, 2)
+            if fused_dgrad:
+                # one 8-wave kernel for the whole data path of the block: dx, da (dlin | dgate) and dz1
+                dxf = e.buf(u + ".dx", (B, self.Cin, T))
+                WT = lambda c: e.wt_ptr + 4 * c.w_off
+                tok = e.prof_begin("block_dgrad", self.c1.flops() + self.cl.flops() + self.cr.flops() + self.c9.flops())
+                check(e.lib.nsc_gated_block_dgrad(self.x.data_ptr(), self.h.data_ptr(), self.lin.data_ptr(),
+                                                  self.th.data_ptr(), dz.data_ptr(), WT(self.c1), WT(self.cl), WT(self.cr),
+                                                  WT(self.c9), dxf.data_ptr(), da.data_ptr(), dh.data_ptr(), B, self.Cin, T,
+                                                  n, 9, self.cl.dil, KIND_ACT[in_kind], e.stream()), "gated_block_dgrad")
+                e.prof_end(tok)
+            else:
+                self.c9.dgrad(dz, dg)
+                check(e.lib.nsc_glu_bwd_cat(self.lin.data_ptr(), self.th.data_ptr(), dg.data_ptr(), da.data_ptr(), B, n, T,
+                                            e.stream()), "glu_bwd_cat")
+                cl = self.cl
+                d = ConvDesc(B=B, Cin=2 * n, Cout=n, Tin=T, Tout=T, K=cl.K, dil=cl.dil, stride=1,
+                             padL=(cl.K - 1) * cl.dil - cl.padL, act=0, res_mode=0, mul_mode=KIND_MUL["lrelu"], out_mode=0,
+                             in_up=0, accumulate=0)
+                tok = e.prof_begin("conv_mfma", self.cl.flops() + self.cr.flops())
+                check(e.lib.nsc_conv1d_fwd(C.byref(d), da.data_ptr(), e.wt_ptr + 4 * self.wtlr_off, None, None,
+                                           self.h.data_ptr(), dh.data_ptr(), e.stream()), "gate dgrad (fused lin|gate)")
+                e.prof_end(tok)
             dx = e.buf(u + ".dx", (B, self.Cin, T)) if need_dx else None
             G = lambda c: (e.g_ptr + 4 * c.w_off, e.g_ptr + 4 * c.b_off)
             (dw1, db1), (dwl, dbl), (dwr, dbr), (dw9, db9) = G(self.c1), G(self.cl), G(self.cr), G(self.c9)
-            fuse_d1 = need_dx and not e.overlap_wgrad    # with overlap the 1x1 data gradient stays on the critical stream
+            fuse_d1 = need_dx and not e.overlap_wgrad and not fused_dgrad   # with overlap the 1x1 dgrad stays on the critical stream
             fl = self.c1.flops() * (2 if fuse_d1 else 1) + self.cl.flops() + self.cr.flops() + self.c9.flops()
             tok = e.prof_begin("block_wgrad", fl)
             st = e.side_fork()
@@ -248,6 +260,8 @@ class _Block:
                                               8, e.wgrad_workspace(self.Cin), st),   # 4 waves measured slower even when overlapped
                   "gated_block_wgrad")
             e.prof_end(tok)
+            if fused_dgrad:
+                return dxf if need_dx else None
             if need_dx and not fuse_d1:
                 self.c1.dgrad(dh, dx, res=dz, res_mode=1, mul_kind=in_kind, aux=self.x)
             return dx
@@ -526,6 +540,8 @@ class CascadeEngine:
     fused_bwd = False  # whole-block backward in one persistent kernel (correct, but its conv phases run at one wave
                        # per SIMD and lose to the per-conv kernels: measured 9.0 vs 6.7 ms/step) - kept, off by default
     fused_wgrad = True # all eight parameter gradients of a block in one persistent kernel (csrc/block.hip)
+    fused_dgrad = False  # whole data path of a block (k9 -> GLU -> k15 -> 1x1 data gradients) in one 8-wave kernel:
+                         # correct, but measured slower than the three multi-wave per-conv launches (1.9 vs 1.2 ms/step)
     # per-launch HIP-event timing of the conv kernels (bench.py roofline); events sit on the launch stream
     prof = None
 

@@ -521,3 +521,46 @@ def test_block_wgrad_kernel(lib, case):
         off += n_ + s_[2]
     dx_ref = (dz1.astype(np.float64) @ W1[0].astype(np.float64).T + dy) * np.where(x > 0, 1.0, 0.2)
     assert_close(dx.cpu().numpy().transpose(0, 2, 1), dx_ref, tol=2e-4, what=f"fused 1x1 dgrad {case}")
+
+
+@pytest.mark.parametrize("case", [(2, 100, 512, 2, 2), (2, 100, 256, 1, 0), (3, 50, 512, 2, 2), (2, 50, 512, 1, 2),
+                                  (1, 100, 200, 2, 0), (5, 36, 70, 1, 2)])
+def test_fused_gated_block_dgrad(lib, case):
+    """8-wave data-path backward (dx, dlin|dgate, dz1) vs autograd of the oracle block with its saved intermediates."""
+    B, C_, T, dil, in_act = case
+    rng = np.random.default_rng(700 + C_ + T + dil)
+    names = ["s/conv1d", "s/conv1d_1", "s/conv1d_2", "s/conv1d_3"]
+    ps = O.ParamStore(rng)
+    x = rng.standard_normal((B, T, C_)).astype(np.float32)
+    O.gated_bottleneck(x, ps, "s", C_, 20, 9, dil, True)
+    for n in names:
+        ps.params[n + "/bias"] = (0.1 * rng.standard_normal(ps.params[n + "/bias"].shape)).astype(np.float32).astype(np.float64)
+    dy = rng.standard_normal((B, T, C_)).astype(np.float32)
+    tp = OT.TorchParams(ps)
+    zt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    xin = torch.nn.functional.leaky_relu(zt, 0.2) if in_act == 2 else zt
+    # forward with retained intermediates (same graph as OT.gated_bottleneck)
+    W1, b1 = tp.conv("s"); Wl, bl = tp.conv("s"); Wr, br = tp.conv("s"); W9, b9 = tp.conv("s")
+    hpre = OT.conv1d(xin, W1, b1, activation=None); hpre.retain_grad()
+    h = OT.act(hpre, "lrelu")
+    left = OT.conv1d(h, Wl, bl, dilation_rate=dil, activation=None); left.retain_grad()
+    rpre = OT.conv1d(h, Wr, br, dilation_rate=dil, activation=None); rpre.retain_grad()
+    right = torch.tanh(rpre)
+    y = OT.conv1d(left * right, W9, b9, activation=None) + xin
+    (y * torch.tensor(dy, dtype=torch.float64)).sum().backward()
+    xin_np = xin.detach().numpy().astype(np.float32)
+    wt = {n: np.ascontiguousarray(ps.params[n + "/kernel"].astype(np.float32)[::-1].transpose(0, 2, 1)) for n in names}
+    tr = lambda v: P(np.ascontiguousarray(np.asarray(v, np.float32).transpose(0, 2, 1)))
+    dx = torch.full((B, C_, T), float("nan"), device="cuda")
+    da = torch.full((B, 40, T), float("nan"), device="cuda")
+    dz1 = torch.full((B, 20, T), float("nan"), device="cuda")
+    rc = lib.nsc_gated_block_dgrad(tr(xin_np), tr(h.detach().numpy()), tr(left.detach().numpy()), tr(right.detach().numpy()),
+                                   tr(dy), P(wt[names[0]]), P(wt[names[1]]), P(wt[names[2]]), P(wt[names[3]]), dx.data_ptr(),
+                                   da.data_ptr(), dz1.data_ptr(), B, C_, T, 20, 9, dil, in_act, _st())
+    assert rc == 0, lib.nsc_last_error()
+    torch.cuda.synchronize()
+    g = lambda v: v.cpu().numpy().transpose(0, 2, 1)
+    assert_close(g(da)[:, :, :20], left.grad.numpy(), tol=2e-4, what=f"dlin {case}")
+    assert_close(g(da)[:, :, 20:], rpre.grad.numpy(), tol=2e-4, what=f"dgate {case}")
+    assert_close(g(dz1), hpre.grad.numpy(), tol=2e-4, what=f"dz1 {case}")
+    assert_close(g(dx), zt.grad.numpy(), tol=2e-4, what=f"dx {case}")
