@@ -11,16 +11,32 @@
 
 #define QEPS 1e-20f
 
+// Cross-lane exchange inside a row of 16 lanes with DPP (VALU data path, no LDS crossbar like ds_bpermute):
+// xor 1 / xor 2 = quad permutes, "xor 4" = row_half_mirror (lane i <-> 7-i inside each 8 lanes), "xor 8" = row_mirror
+// (i <-> 15-i).  After the quad steps every lane of a quad holds the quad total, so the mirrors are valid partners for
+// the symmetric reductions (sum, max) used here.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
 template <int LPC>
 __device__ __forceinline__ float grp_sum(float v) {
-#pragma unroll
-  for (int o = LPC / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  if constexpr (LPC >= 2) v += dpp_f<0xB1>(v);    // quad_perm [1,0,3,2]
+  if constexpr (LPC >= 4) v += dpp_f<0x4E>(v);    // quad_perm [2,3,0,1]
+  if constexpr (LPC >= 8) v += dpp_f<0x141>(v);   // row_half_mirror
+  if constexpr (LPC >= 16) v += dpp_f<0x140>(v);  // row_mirror
+  if constexpr (LPC >= 32) v += __shfl_xor(v, 16, 64);
+  if constexpr (LPC >= 64) v += __shfl_xor(v, 32, 64);
   return v;
 }
 template <int LPC>
 __device__ __forceinline__ float grp_max(float v) {
-#pragma unroll
-  for (int o = LPC / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  if constexpr (LPC >= 2) v = fmaxf(v, dpp_f<0xB1>(v));
+  if constexpr (LPC >= 4) v = fmaxf(v, dpp_f<0x4E>(v));
+  if constexpr (LPC >= 8) v = fmaxf(v, dpp_f<0x141>(v));
+  if constexpr (LPC >= 16) v = fmaxf(v, dpp_f<0x140>(v));
+  if constexpr (LPC >= 32) v = fmaxf(v, __shfl_xor(v, 16, 64));
+  if constexpr (LPC >= 64) v = fmaxf(v, __shfl_xor(v, 32, 64));
   return v;
 }
 

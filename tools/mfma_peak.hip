@@ -18,6 +18,14 @@ __global__ __launch_bounds__(256) void mfma_loop(float* out, int iters, float a0
 __global__ void copy4(const float4* __restrict__ a, float4* __restrict__ b, long n) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) b[i] = a[i];
 }
+__global__ void fill4(float4* __restrict__ b, long n, float v) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) b[i] = make_float4(v, v, v, v);
+}
+__global__ void sum4(const float4* __restrict__ a, long n, float* out) {
+  float s = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) { float4 v = a[i]; s += v.x + v.y + v.z + v.w; }
+  if (s == 12345.f) out[0] = s;
+}
 int main() {
   float* out; hipMalloc(&out, 4096 * 256 * 4);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -40,5 +48,16 @@ int main() {
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   printf("float4 copy: %.2f TB/s (read+write)\n", 5.0 * 2 * n * 16 / ms / 1e9);
+  hipLaunchKernelGGL(fill4, dim3(4096), dim3(256), 0, 0, b, n, 1.f); hipDeviceSynchronize();
+  hipEventRecord(e0);
+  for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(fill4, dim3(4096), dim3(256), 0, 0, b, n, 2.f);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  hipEventElapsedTime(&ms, e0, e1);
+  printf("float4 write-only: %.2f TB/s\n", 5.0 * n * 16 / ms / 1e9);
+  hipEventRecord(e0);
+  for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(sum4, dim3(4096), dim3(256), 0, 0, a, n, out);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  hipEventElapsedTime(&ms, e0, e1);
+  printf("float4 read-only: %.2f TB/s\n", 5.0 * n * 16 / ms / 1e9);
   return 0;
 }
