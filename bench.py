@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--prof-steps", type=int, default=3)
     ap.add_argument("--no-infer", action="store_true", help="skip the codec-forward us/frame measurement")
     ap.add_argument("--no-overlap", action="store_true", help="weight-gradient kernels on the main stream (profiling)")
+    ap.add_argument("--wgrad-waves", type=int, default=8)
+    ap.add_argument("--no-split-wgrad", action="store_true")
     ap.add_argument("--fused-bwd", action="store_true", help="debug: whole-block persistent backward kernel")
     ap.add_argument("--unfused-wgrad", action="store_true", help="debug: per-conv weight gradients")
     ap.add_argument("--fused-dgrad", action="store_true", help="debug: one fused data-path backward kernel per gated block")
@@ -110,6 +112,8 @@ def main():
     B = args.batch
     eng = CascadeEngine(B, 2, BKD, [[2], [2]], [32, 32], res_scalar=RES_SCALAR, scale_first=True, lpc=True, device=dev)
     eng.overlap_wgrad = not args.no_overlap
+    eng.wgrad_waves = args.wgrad_waves
+    eng.split_wgrad = not args.no_split_wgrad
     eng.fused_bwd = args.fused_bwd
     eng.fused_wgrad = not args.unfused_wgrad
     eng.fused_dgrad = args.fused_dgrad

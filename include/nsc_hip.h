@@ -105,7 +105,9 @@ int nsc_gated_block_wgrad(const float* x, const float* h, const float* g, const 
                           const float* dz1, float* dw1, float* db1, float* dwl, float* dbl, float* dwr, float* dbr,
                           float* dw9, float* db9, const float* wt1, float* dx, int in_act, int B, int C, int T,
                           int narrow, int k9, int dil, int waves /*8: fastest alone; 4: leaves half the CU's registers and
-                          LDS to kernels running concurrently on another stream*/, float* workspace, void* stream);
+                          LDS to kernels running concurrently on another stream*/,
+                          int part /*0 all gradients; 1 dW9/db9 only; 2 dWl/dWr/dW1 + biases only (light launches that
+                          share a CU with other kernels)*/, float* workspace, void* stream);
 long nsc_gated_block_wgrad_workspace(int C);
 
 /* ---- separable conv pieces (replaces tf.keras.layers.SeparableConv1D behind nn_core_operator.py:17-21) ---- */

@@ -34,7 +34,7 @@ PROTOTYPES = {
     "nsc_weight_flip_transpose": [_P, _P, _I, _I, _I, _P],
     "nsc_gated_block_fwd": [_P] * 14 + [_I] * 7 + [_P],
     "nsc_gated_block_bwd": [_P] * 21 + [_I] * 7 + [_P],
-    "nsc_gated_block_wgrad": [_P] * 16 + [_I] * 8 + [_P, _P],
+    "nsc_gated_block_wgrad": [_P] * 16 + [_I] * 9 + [_P, _P],
     "nsc_glu_bwd_cat": [_P, _P, _P, _P, _I, _I, _I, _P],
     "nsc_gated_block_dgrad": [_P] * 12 + [_I] * 7 + [_P],
     "nsc_depthwise_fwd": [_P, _P, _P, _I, _I, _I, _I, _P],

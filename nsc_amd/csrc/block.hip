@@ -854,17 +854,22 @@ __device__ __forceinline__ void wg_flush(float* p, float v, bool plain) {
 // NW = waves per workgroup.  8: two waves per SIMD (fastest alone, but it fills the register file so nothing can share
 // the CU).  4: one wave per SIMD with <= 256 registers, leaving half of the registers and 76 KB of LDS per CU to the
 // data-gradient kernels that run concurrently on the main stream.
-template <int RT9, int NW>
+// PART selects which gradients the launch produces: 0 = all eight (+ optional 1x1 data gradient); 1 = dW9/db9 only
+// (stages g and dy: 32 KB, ~90 registers); 2 = dWl/dWr/dW1 + biases (stages h, da, x, dz1: 50 KB).  The two light
+// parts leave most of a CU's registers and LDS to the data-gradient kernels running concurrently on the main stream.
+template <int RT9, int NW, int PART>
 __global__ __launch_bounds__(64 * NW, 2) void gated_block_wgrad_kernel(BlockWgradArgs a, int ldn, int ldg, int ldh) {
+  constexpr bool P9 = PART != 2, PLR = PART != 1;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int TT = 64;
   const int C = a.C, T = a.T, d = a.dil;
   const int Hh = 7 * d;
+  // rows C / C+1 of xn are the zero / ones rows used by every part (part 1 keeps only those two rows of xn)
   float* xn = sm;                              // [C + 2][ldn]      rows C = zeros, C+1 = ones
-  float* dys = xn + (C + 2) * ldn;             // [C][ldn]
-  float* gs = dys + C * ldn;                   // [NARROW + 2][ldg] g on [t0-4, t0+68)
-  float* hs = gs + (NARROW + 2) * ldg;         // [NARROW + 2][ldh] h on [t0-Hh, t0+64+Hh)
-  float* dl = hs + (NARROW + 2) * ldh;         // [NARROW][ldn] dlin  (dgate follows: dg_ = dl + NARROW*ldn)
+  float* dys = xn + (C + 2) * ldn;             // [C][ldn]                              (parts 0, 1)
+  float* gs = dys + (P9 ? C * ldn : 0);        // [NARROW + 2][ldg] g on [t0-4, t0+68)  (parts 0, 1)
+  float* hs = gs + (P9 ? (NARROW + 2) * ldg : 0);   // [NARROW + 2][ldh] h on [t0-Hh, t0+64+Hh)   (parts 0, 2)
+  float* dl = hs + (PLR ? (NARROW + 2) * ldh : 0);  // [NARROW][ldn] dlin  (dgate follows: dg_ = dl + NARROW*ldn)
   float* dg_ = dl + NARROW * ldn;              // [NARROW][ldn] dgate
   float* dhs = dg_ + NARROW * ldn;             // [NARROW][ldn] dz1
   const int tid = threadIdx.x, lane = tid & 63;
@@ -874,10 +879,11 @@ __global__ __launch_bounds__(64 * NW, 2) void gated_block_wgrad_kernel(BlockWgra
   // 8 waves (two per SIMD): each owns fewer accumulator tiles (100 registers) and the partner wave hides LDS /
   // global latency that a single wave per SIMD exposed.
   for (int j = tid; j < ldn; j += 64 * NW) { xn[C * ldn + j] = 0.f; xn[(C + 1) * ldn + j] = 1.f; }
-  for (int j = tid; j < ldh; j += 64 * NW) { hs[NARROW * ldh + j] = 0.f; hs[(NARROW + 1) * ldh + j] = 1.f; }
-  for (int j = tid; j < ldg; j += 64 * NW) { gs[NARROW * ldg + j] = 0.f; gs[(NARROW + 1) * ldg + j] = 1.f; }
+  if (PLR) for (int j = tid; j < ldh; j += 64 * NW) { hs[NARROW * ldh + j] = 0.f; hs[(NARROW + 1) * ldh + j] = 1.f; }
+  if (P9) for (int j = tid; j < ldg; j += 64 * NW) { gs[NARROW * ldg + j] = 0.f; gs[(NARROW + 1) * ldg + j] = 1.f; }
 
-  constexpr int R9 = (12 + NW - 1) / NW, RLR = (19 + NW - 1) / NW, R1 = (RT9 + NW - 1) / NW;   // row tiles per wave
+  constexpr int R9 = P9 ? (12 + NW - 1) / NW : 1, RLR = PLR ? (19 + NW - 1) / NW : 1,
+                R1 = PLR ? (RT9 + NW - 1) / NW : 1;   // row tiles per wave (1 = dummy for a disabled part)
   f32x4 g9[R9][RT9], glr[RLR][3], g1[R1][2];   // row tiles {w, w+NW, ...}
 #pragma unroll
   for (int r = 0; r < R9; ++r)
@@ -962,19 +968,21 @@ __global__ __launch_bounds__(64 * NW, 2) void gated_block_wgrad_kernel(BlockWgra
     for (int q = 0; q < QX; ++q) {
       const int r = wave + NW * q;                    // rows >= C read the next frame's data: never stored
       const int so = sbC + r * T * 4;
-      rx[q] = bl(sx, vt, so);
-      ry[q] = bl(sy, vt, so);
+      if (PLR) rx[q] = bl(sx, vt, so);
+      if (P9) ry[q] = bl(sy, vt, so);
     }
+    if (PLR) {
 #pragma unroll
-    for (int q = 0; q < QA; ++q) ra[q] = bl(sa, vt, 2 * sbN + (wave + NW * q) * T * 4);
+      for (int q = 0; q < QA; ++q) ra[q] = bl(sa, vt, 2 * sbN + (wave + NW * q) * T * 4);
+    }
 #pragma unroll
     for (int q = 0; q < QN; ++q) {
       const int so = sbN + (wave + NW * q) * T * 4;   // rows >= 20: never stored
-      rz[q] = bl(sz, vt, so);
+      if (PLR) rz[q] = bl(sz, vt, so);
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
-        rg[q][jj] = bl(sg, vg[jj], so);
-        rh[q][jj] = bl(sh, vh[jj], so);
+        if (P9) rg[q][jj] = bl(sg, vg[jj], so);
+        if (PLR) rh[q][jj] = bl(sh, vh[jj], so);
       }
     }
   };
@@ -982,20 +990,25 @@ __global__ __launch_bounds__(64 * NW, 2) void gated_block_wgrad_kernel(BlockWgra
 #pragma unroll
     for (int q = 0; q < QX; ++q) {
       const int r = wave + NW * q;
-      if (r < C) { xn[r * ldn + lane] = rx[q]; dys[r * ldn + lane] = ry[q]; }
+      if (r < C) {
+        if (PLR) xn[r * ldn + lane] = rx[q];
+        if (P9) dys[r * ldn + lane] = ry[q];
+      }
     }
+    if (PLR) {
 #pragma unroll
-    for (int q = 0; q < QA; ++q) dl[(wave + NW * q) * ldn + lane] = ra[q];
+      for (int q = 0; q < QA; ++q) dl[(wave + NW * q) * ldn + lane] = ra[q];
+    }
 #pragma unroll
     for (int q = 0; q < QN; ++q) {
       const int r = wave + NW * q;
       if (r < NARROW) {
-        dhs[r * ldn + lane] = rz[q];
+        if (PLR) dhs[r * ldn + lane] = rz[q];
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
           const int j = lane + 64 * jj;
-          if (j < ldg) gs[r * ldg + j] = rg[q][jj];
-          if (j < ldh) hs[r * ldh + j] = rh[q][jj];
+          if (P9 && j < ldg) gs[r * ldg + j] = rg[q][jj];
+          if (PLR && j < ldh) hs[r * ldh + j] = rh[q][jj];
         }
       }
     }
@@ -1013,7 +1026,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gated_block_wgrad_kernel(BlockWgra
 #pragma unroll 1
     for (int s = 0; s < TT / 4; ++s) {
       const int tl = 4 * s + kq;
-      {
+      if constexpr (P9) {
         float af[R9], bf[RT9];
 #pragma unroll
         for (int r = 0; r < R9; ++r) af[r] = gs[off9[r] + tl];
@@ -1024,7 +1037,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gated_block_wgrad_kernel(BlockWgra
 #pragma unroll
           for (int c = 0; c < RT9; ++c) g9[r][c] = mfma4(af[r], bf[c], g9[r][c]);
       }
-      {
+      if constexpr (PLR) {
         float af[RLR], bf[3];
 #pragma unroll
         for (int r = 0; r < RLR; ++r) af[r] = hs[offlr[r] + tl];
@@ -1035,7 +1048,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gated_block_wgrad_kernel(BlockWgra
 #pragma unroll
           for (int c = 0; c < 3; ++c) glr[r][c] = mfma4(af[r], bf[c], glr[r][c]);
       }
-      {
+      if constexpr (PLR) {
         const float b0 = dhs[l15 * ldn + tl];
         const float b1 = sm[offb1 + tl];
 #pragma unroll
@@ -1051,7 +1064,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gated_block_wgrad_kernel(BlockWgra
     constexpr int RH = NW == 8 ? (RT9 + 1) / 2 : RT9;  // row tiles per wave in D1 (8 waves: halves [0,RH) and [RH,2RH))
     const int rbase = (wave >> 2) * RH;
     float av[5][RH];
-    if (a.dx) {
+    if (PART == 0 && a.dx) {
 #pragma unroll
       for (int s = 0; s < 5; ++s)
 #pragma unroll
@@ -1060,7 +1073,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gated_block_wgrad_kernel(BlockWgra
           av[s][r] = a.wt1[(s * 4 + kq) * C + (c < C ? c : C - 1)];
         }
     }
-    if (a.dx && !(a.skip & 1)) {
+    if (PART == 0 && a.dx && !(a.skip & 1)) {
       // fused 1x1 data gradient: dx = (W1^T dz1 + dy) * act'(x); wave owns column tile `wave`, all RT9 row tiles, K = 20
       f32x4 acc[RH];
 #pragma unroll
@@ -1095,6 +1108,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gated_block_wgrad_kernel(BlockWgra
   const bool plain = a.slab_stride != 0;
   const long so = (long)blockIdx.x * a.slab_stride;
   if (a.skip & 4) return;
+  if constexpr (P9)
 #pragma unroll
   for (int r = 0; r < R9; ++r)
 #pragma unroll
@@ -1109,6 +1123,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gated_block_wgrad_kernel(BlockWgra
         else wg_flush(a.db9 + so + o, g9[r][cc][reg], plain);
       }
     }
+  if constexpr (PLR)
 #pragma unroll
   for (int r = 0; r < RLR; ++r)
 #pragma unroll
@@ -1124,6 +1139,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gated_block_wgrad_kernel(BlockWgra
         else wg_flush((gate ? a.dbr : a.dbl) + so + c, glr[r][ct][reg], plain);
       }
     }
+  if constexpr (PLR)
 #pragma unroll
   for (int r = 0; r < R1; ++r)
 #pragma unroll
@@ -1169,7 +1185,8 @@ extern "C" long nsc_gated_block_wgrad_workspace(int C) {
 extern "C" int nsc_gated_block_wgrad(const float* x, const float* h, const float* g, const float* dy, const float* da,
                                      const float* dz1, float* dw1, float* db1, float* dwl, float* dbl, float* dwr,
                                      float* dbr, float* dw9, float* db9, const float* wt1, float* dx, int in_act, int B,
-                                     int C, int T, int narrow, int k9, int dil, int waves, float* workspace, void* stream) {
+                                     int C, int T, int narrow, int k9, int dil, int waves, int part, float* workspace,
+                                     void* stream) {
   NSC_REQUIRE(x && h && g && dy && da && dz1 && dw1 && db1 && dwl && dbl && dwr && dbr && dw9 && db9,
               NSC_ERR_BAD_ARG, "nsc_gated_block_wgrad: null pointer");
   NSC_REQUIRE(!dx || wt1, NSC_ERR_BAD_ARG, "nsc_gated_block_wgrad: dx needs wt1");
@@ -1177,8 +1194,10 @@ extern "C" int nsc_gated_block_wgrad(const float* x, const float* h, const float
   NSC_REQUIRE(B > 0 && C > 1 && T > 0 && dil > 0, NSC_ERR_BAD_ARG, "nsc_gated_block_wgrad: bad sizes");
   NSC_REQUIRE(narrow == NARROW && k9 == K9 && dil <= 4 && C <= 112, NSC_ERR_UNSUPPORTED,
               "nsc_gated_block_wgrad: built for narrow=20, k9=9, dil<=4, C<=112 (got %d, %d, %d, %d)", narrow, k9, dil, C);
+  NSC_REQUIRE(part >= 0 && part <= 2 && !(part && dx), NSC_ERR_BAD_ARG, "nsc_gated_block_wgrad: part in 0..2; dx needs part 0");
   const int ldn = ld2(64), ldg = ld2(72), ldh = ld2(64 + 14 * dil);
-  const size_t fl = (size_t)(2 * C + 2) * ldn + (size_t)(NARROW + 2) * (ldg + ldh) + (size_t)3 * NARROW * ldn;
+  const size_t fl = (size_t)(C + 2) * ldn + (part != 2 ? (size_t)C * ldn + (size_t)(NARROW + 2) * ldg : 0) +
+                    (part != 1 ? (size_t)(NARROW + 2) * ldh : 0) + (size_t)3 * NARROW * ldn;
   const size_t smem = fl * sizeof(float);
   NSC_REQUIRE(smem <= 160 * 1024, NSC_ERR_UNSUPPORTED, "nsc_gated_block_wgrad: %zu B LDS", smem);
   BlockWgradArgs a{B, C, T, dil, x, h, g, dy, da, dz1, wt1, dx, in_act, dw1, db1, dwl, dbl, dwr, dbr, dw9, db9, 0, 0, 0, 0};
@@ -1201,7 +1220,8 @@ extern "C" int nsc_gated_block_wgrad(const float* x, const float* h, const float
   hipStream_t st = (hipStream_t)stream;
 #define LAUNCH_WG(RT, NW_)                                                                                          \
   do {                                                                                                              \
-    auto kern = gated_block_wgrad_kernel<RT, NW_>;                                                                  \
+    auto kern = part == 0 ? gated_block_wgrad_kernel<RT, NW_, 0>                                                    \
+                          : (part == 1 ? gated_block_wgrad_kernel<RT, NW_, 1> : gated_block_wgrad_kernel<RT, NW_, 2>); \
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);   \
     NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "gated_block_wgrad: smem attr: %s", hipGetErrorString(e));         \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW_), smem, st, a, ldn, ldg, ldh);                               \
@@ -1212,8 +1232,11 @@ extern "C" int nsc_gated_block_wgrad(const float* x, const float* h, const float
 #undef LAUNCH_WG
   NSC_CHECK_LAUNCH("gated_block_wgrad");
   if (use_slab) {
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(nsc_cdiv(range, 256), 8), dim3(256), 0, st, workspace, a.slab_stride, grid,
-                       gbase, (int)range);
+    // reduce only the sub-range this launch wrote (part 1: dW9 | db9 at the end; part 2: everything before it)
+    const long off9 = (long)C * NARROW + NARROW + 2L * (K15 * NARROW * NARROW + NARROW);
+    const long r0 = part == 1 ? off9 : 0, r1 = part == 2 ? off9 : range;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(nsc_cdiv(r1 - r0, 256), 8), dim3(256), 0, st, workspace + r0, a.slab_stride,
+                       grid, gbase + r0, (int)(r1 - r0));
     NSC_CHECK_LAUNCH("slab_reduce");
   }
   return NSC_OK;

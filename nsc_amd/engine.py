@@ -253,12 +253,17 @@ class _Block:
             fl = self.c1.flops() * (2 if fuse_d1 else 1) + self.cl.flops() + self.cr.flops() + self.c9.flops()
             tok = e.prof_begin("block_wgrad", fl)
             st = e.side_fork()
-            check(e.lib.nsc_gated_block_wgrad(self.x.data_ptr(), self.h.data_ptr(), self.g.data_ptr(), dz.data_ptr(),
-                                              da.data_ptr(), dh.data_ptr(), dw1, db1, dwl, dbl, dwr, dbr, dw9, db9,
-                                              e.wt_ptr + 4 * self.c1.w_off, _lib.ptr(dx) if fuse_d1 else None,
-                                              KIND_ACT[in_kind], B, self.Cin, T, n, 9, self.cl.dil,
-                                              8, e.wgrad_workspace(self.Cin), st),   # 4 waves measured slower even when overlapped
-                  "gated_block_wgrad")
+            args = (self.x.data_ptr(), self.h.data_ptr(), self.g.data_ptr(), dz.data_ptr(), da.data_ptr(), dh.data_ptr(),
+                    dw1, db1, dwl, dbl, dwr, dbr, dw9, db9, e.wt_ptr + 4 * self.c1.w_off)
+            tail = (KIND_ACT[in_kind], B, self.Cin, T, n, 9, self.cl.dil)
+            if e.overlap_wgrad and e.split_wgrad:
+                # two light persistent launches (dW9 | dWl, dWr, dW1) that can share CUs with the main-stream kernels
+                for part in (1, 2):
+                    check(e.lib.nsc_gated_block_wgrad(*args, None, *tail, 4, part, e.wgrad_workspace(self.Cin), st),
+                          "gated_block_wgrad")
+            else:
+                check(e.lib.nsc_gated_block_wgrad(*args, _lib.ptr(dx) if fuse_d1 else None, *tail, e.wgrad_waves, 0,
+                                                  e.wgrad_workspace(self.Cin), st), "gated_block_wgrad")
             e.prof_end(tok)
             if fused_dgrad:
                 return dxf if need_dx else None
@@ -549,6 +554,8 @@ class CascadeEngine:
     # optimizer), and both they and the data-gradient chain are latency- rather than throughput-bound, so running them
     # concurrently on the same CUs is nearly additive.  fork = event on the main stream, join before Adam / all-reduce.
     overlap_wgrad = True
+    wgrad_waves = 8      # waves per workgroup of the persistent block-wgrad kernel (8 fills the register file of a CU)
+    split_wgrad = True   # under overlap: two light 4-wave launches per block instead of one heavy 8-wave launch
 
     def side_fork(self):
         """Returns the stream handle weight-gradient kernels should be launched on (side stream ordered after everything

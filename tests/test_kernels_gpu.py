@@ -494,7 +494,11 @@ def test_block_wgrad_kernel(lib, case):
     da = np.concatenate([dlin, dgate], axis=2)                              # [B,T,40] -> dlin | dgate
     rc = lib.nsc_gated_block_wgrad(tr(x), tr(h), tr(g), tr(dy), tr(da), tr(dz1), dws[0].data_ptr(), dbs[0].data_ptr(),
                                    dws[1].data_ptr(), dbs[1].data_ptr(), dws[2].data_ptr(), dbs[2].data_ptr(),
-                                   dws[3].data_ptr(), dbs[3].data_ptr(), None, None, 0, B, C_, T, 20, 9, dil, 4, None, _st())
+                                   dws[3].data_ptr(), dbs[3].data_ptr(), None, None, 0, B, C_, T, 20, 9, dil, 4, 1, None, _st())
+    assert rc == 0, lib.nsc_last_error()
+    rc = lib.nsc_gated_block_wgrad(tr(x), tr(h), tr(g), tr(dy), tr(da), tr(dz1), dws[0].data_ptr(), dbs[0].data_ptr(),
+                                   dws[1].data_ptr(), dbs[1].data_ptr(), dws[2].data_ptr(), dbs[2].data_ptr(),
+                                   dws[3].data_ptr(), dbs[3].data_ptr(), None, None, 0, B, C_, T, 20, 9, dil, 4, 2, None, _st())
     assert rc == 0, lib.nsc_last_error()
     for i in range(4):
         assert_close(dws[i].cpu().numpy(), ref[i][0], tol=2e-4, what=f"block wgrad dW[{i}] {case}")
@@ -512,7 +516,7 @@ def test_block_wgrad_kernel(lib, case):
     wt1 = np.ascontiguousarray(W1[::-1].transpose(0, 2, 1))                  # [1,20,C]
     dx = torch.full((B, C_, T), float("nan"), device="cuda")
     rc = lib.nsc_gated_block_wgrad(tr(x), tr(h), tr(g), tr(dy), tr(da), tr(dz1), *ptrs, P(wt1), dx.data_ptr(), 2, B, C_, T,
-                                   20, 9, dil, 8, ws.data_ptr(), _st())
+                                   20, 9, dil, 8, 0, ws.data_ptr(), _st())
     assert rc == 0, lib.nsc_last_error()
     got, off = flat.cpu().numpy() - 0.5, 0
     for i, (s_, n_) in enumerate(zip(shapes, sizes)):
@@ -521,6 +525,18 @@ def test_block_wgrad_kernel(lib, case):
         off += n_ + s_[2]
     dx_ref = (dz1.astype(np.float64) @ W1[0].astype(np.float64).T + dy) * np.where(x > 0, 1.0, 0.2)
     assert_close(dx.cpu().numpy().transpose(0, 2, 1), dx_ref, tol=2e-4, what=f"fused 1x1 dgrad {case}")
+    # the two light parts with the slab flush (each must reduce only what it wrote; workspace poisoned first)
+    flat.fill_(0.25)
+    ws.fill_(float("nan"))
+    for part in (1, 2):
+        rc = lib.nsc_gated_block_wgrad(tr(x), tr(h), tr(g), tr(dy), tr(da), tr(dz1), *ptrs, None, None, 0, B, C_, T, 20, 9, dil,
+                                       4, part, ws.data_ptr(), _st())
+        assert rc == 0, lib.nsc_last_error()
+    got, off = flat.cpu().numpy() - 0.25, 0
+    for i, (s_, n_) in enumerate(zip(shapes, sizes)):
+        assert_close(got[off:off + n_].reshape(s_), ref[i][0], tol=2e-4, what=f"split slab flush dW[{i}] {case}")
+        assert_close(got[off + n_:off + n_ + s_[2]], ref[i][1], tol=2e-4, what=f"split slab flush db[{i}] {case}")
+        off += n_ + s_[2]
 
 
 @pytest.mark.parametrize("case", [(2, 100, 512, 2, 2), (2, 100, 256, 1, 0), (3, 50, 512, 2, 2), (2, 50, 512, 1, 2),
