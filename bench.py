@@ -107,8 +107,9 @@ def main():
     assert comm.world == args.gpus or comm.world == 1, f"WORLD_SIZE {comm.world} != --gpus {args.gpus}"
     if args.gpus > 1 and comm.world == 1:
         raise SystemExit("launch with torch.distributed.run for --gpus > 1")
-    torch.cuda.set_device(comm.local_rank)
-    dev = torch.device("cuda", comm.local_rank)
+    ldev = comm.local_rank % torch.cuda.device_count()   # one GPU per rank on a real node; wraps only in single-GPU smoke tests
+    torch.cuda.set_device(ldev)
+    dev = torch.device("cuda", ldev)
     B = args.batch
     eng = CascadeEngine(B, 2, BKD, [[2], [2]], [32, 32], res_scalar=RES_SCALAR, scale_first=True, lpc=True, device=dev)
     eng.overlap_wgrad = not args.no_overlap
@@ -243,7 +244,7 @@ def main():
     # ---- second half of the metric: codec forward us/frame (BASELINE config 5: 2-codec encode+quantise+decode,
     # batch 4096 frames, hipGraph-captured forward), plus the batch-1 latency the reference's eval loop actually pays
     infer = None
-    if comm.rank == 0 and not args.no_infer:
+    if comm.rank == 0 and comm.world == 1 and not args.no_infer:
         def fwd_time(Bi, reps):
             engi = CascadeEngine(Bi, 2, BKD, [[2], [2]], [32, 32], res_scalar=RES_SCALAR, scale_first=True, lpc=True, device=dev)
             engi.params.copy_(eng.params)
@@ -297,7 +298,8 @@ def main():
             "model_tflops": round(fps * MFLOP_PER_FRAME_JOINT * 1e6 / 1e12, 2),
             "roofline": roof, "roofline_quantizer": qroof, "cpu_baseline": cpu, "codec_forward": infer, "kernels": kern_ms,
         }
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    comm.barrier()
     comm.close()
 
 

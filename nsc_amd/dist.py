@@ -21,9 +21,9 @@ class Comm:
         if self.world > 1 and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
-            backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
-            if backend == "nccl":
-                torch.cuda.set_device(self.local_rank)
+            backend = backend or os.environ.get("NSC_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+            if torch.cuda.is_available():
+                torch.cuda.set_device(self.local_rank % torch.cuda.device_count())
             dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
 
     def allreduce(self, t, op=dist.ReduceOp.SUM):
