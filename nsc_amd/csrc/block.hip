@@ -232,6 +232,256 @@ __global__ __launch_bounds__(512) void gated_block_fwd_kernel(BlockArgs a, int l
   }
 }
 
+// -----------------------------------------------------------------------------------------------------
+// v2: the same block, PERSISTENT and weight-stationary.  One workgroup per CU walks (frame, 64-step tile) pairs.
+// v1 fetched every MFMA's A fragment (a weight) from global memory - one vmem instruction, three address VALU ops
+// and a wait per MFMA, used exactly once per workgroup - which held it at ~27 % of the fp32 MFMA rate.  Here the
+// weights are loaded ONCE per workgroup: the 1x1 (50 fragments/lane) and this wave's k9 row tile (45) stay in
+// registers for the life of the kernel, the two k15 gate kernels (row-interleaved as in v1) sit in LDS, and the inner
+// loops are {ds_read with an immediate offset, v_mfma} only.  The next tile's x is prefetched into registers
+// while the current tile computes.  Built for the shapes the codec uses (C = 4*NK1 rounded, dil 1|2); other shapes
+// take v1.
+// -----------------------------------------------------------------------------------------------------
+template <int RT9, int NK1, int DIL>
+__global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int ntiles, int tpf, int skip) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  constexpr int TT = 64, H = 4 + 7 * DIL, WX = TT + 2 * H, WGW = TT + 8, LDX = 112, LDG = 80, CR = 4 * NK1, LDW = 48;
+  constexpr int NCT1 = (WX + 15) / 16;      // column tiles of the h tile (7 at dil 2, 6 at dil 1)
+  constexpr int NQ = (CR + 7) / 8;          // staged x rows per wave
+  static_assert(NCT1 * 16 <= LDX && 79 + 14 * DIL < NCT1 * 16, "h tile must cover every column the k15 taps read");
+  float* xs = sm;                            // [CR][LDX]
+  float* hs = xs + CR * LDX;                 // [20][LDX]
+  float* gs = hs + NARROW * LDX;             // [20][LDG]
+  float* w2s = gs + NARROW * LDG;            // [15*20][48]  k15 gate kernels, rows interleaved lin/tanh (see header)
+  const int C = a.C, T = a.T;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, kq = lane >> 4;
+
+  // ---- once per workgroup: weights -> LDS / registers ----
+  // Every load below uses a CLAMPED index instead of a mask: pad rows of A (output channels >= 20 / >= C) only feed
+  // output rows that are never stored, and pad k-rows (ci >= C) multiply x rows that phase 0 writes as zeros, so any
+  // finite stand-in value is harmless - and without selects all ~125 loads per lane are in flight at once.
+  {
+    constexpr int NE = (K15 * NARROW * LDW + 511) / 512;
+    float tmp[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const int e = min(tid + 512 * i, K15 * NARROW * LDW - 1);
+      const int row = e / LDW, r = e - row * LDW;
+      const int ii = r & 15;
+      const int c = min((r >> 4) * 8 + (ii >> 2) * 2 + (ii & 1), NARROW - 1);
+      const float* src = (ii & 2) ? a.wr : a.wl;
+      tmp[i] = src[row * NARROW + c];
+    }
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const int e = tid + 512 * i;
+      if (e < K15 * NARROW * LDW) w2s[e] = tmp[i];
+    }
+  }
+  float w1r[2][NK1];
+#pragma unroll
+  for (int u = 0; u < NK1; ++u) {
+    const int ci = min(4 * u + kq, C - 1);
+    w1r[0][u] = a.w1[ci * NARROW + l15];
+    w1r[1][u] = a.w1[ci * NARROW + min(16 + l15, NARROW - 1)];
+  }
+  const int rt3 = RT9 == 7 ? (wave < 7 ? wave : 6) : (wave & 3);
+  const int cb3 = RT9 == 7 ? 0 : (wave >> 2) * 32;      // first output column of this wave in phase 3
+  constexpr int NC3 = RT9 == 7 ? 4 : 2;                  // column tiles per wave in phase 3
+  float w9r[K9][5];
+#pragma unroll
+  for (int tap = 0; tap < K9; ++tap)
+#pragma unroll
+    for (int u = 0; u < 5; ++u) w9r[tap][u] = a.w9[(tap * NARROW + 4 * u + kq) * C + min(rt3 * 16 + l15, C - 1)];
+  float b1r[2][4], b9r[4];
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    b1r[0][reg] = a.b1[kq * 4 + reg];
+    b1r[1][reg] = a.b1[min(16 + kq * 4 + reg, NARROW - 1)];
+    b9r[reg] = a.b9[min(rt3 * 16 + kq * 4 + reg, C - 1)];
+  }
+  // phase-2 jobs: q -> (row tile q % 3, column tile q / 3); wave w runs q = w and w + 8 (wave 7: a discarded duplicate)
+  int jrt[2], jct[2];
+  bool jlive[2];
+  float blr[2][2], brr[2][2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int q = wave + 8 * e;
+    jlive[e] = q < 15;
+    const int qq = jlive[e] ? q : wave;
+    jrt[e] = qq % 3;
+    jct[e] = qq / 3;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int c = jrt[e] * 8 + kq * 2 + u;
+      blr[e][u] = a.bl[min(c, NARROW - 1)];
+      brr[e][u] = a.br[min(c, NARROW - 1)];
+    }
+  }
+
+  // x tile prefetch: wave w owns rows w, w+8, ...; lanes along time (two 64-column halves).  Raw buffer loads: scalar row
+  // offset, per-lane time offset, out-of-frame columns pointed past the descriptor so the hardware returns 0 - no
+  // address VALU and no value selects (with selects the compiler serialised the loads under register pressure).
+  float pf[NQ][2];
+  const __amdgpu_buffer_rsrc_t sx =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (unsigned)((long)a.B * C * T * 4), 0x00020000);
+  auto prefetch = [&](int tile) {
+    const int tl = __builtin_amdgcn_readfirstlane(tile < ntiles ? tile : 0);   // past the end: a harmless re-read
+    const int b = tl / tpf, t0 = (tl - b * tpf) * TT;
+    const int OOB = 0x7ffffff0;
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+      const int j = hb * 64 + lane;
+      const int t = t0 - H + j;
+      const int vo = (j < WX && t >= 0 && t < T) ? t * 4 : OOB;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int r = min(wave + 8 * q, C - 1);      // pad rows: stored as zeros below
+        pf[q][hb] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(sx, vo, (b * C + r) * T * 4, 0));
+      }
+    }
+  };
+  prefetch(blockIdx.x);
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int b = tile / tpf, t0 = (tile - b * tpf) * TT;
+    // ---- phase 0: prefetched x tile -> LDS ----
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+      const int j = hb * 64 + lane;
+      if (j < LDX) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const int r = wave + 8 * q;
+          if (r < CR) xs[r * LDX + j] = r < C ? pf[q][hb] : 0.f;
+        }
+      }
+    }
+    __syncthreads();
+    if (!(skip & 8)) prefetch(tile + gridDim.x);   // in flight during the three MFMA phases
+
+    // ---- phase 1: h = lrelu(W1 x + b1); column tile = wave ----
+    if (wave < NCT1 && !(skip & 1)) {
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      const int j = wave * 16 + l15;
+      const float* xcol = xs + kq * LDX + j;
+#pragma unroll
+      for (int u = 0; u < NK1; ++u) {
+        const float bv = xcol[4 * u * LDX];
+        acc0 = mfma4(w1r[0][u], bv, acc0);
+        acc1 = mfma4(w1r[1][u], bv, acc1);
+      }
+      const int t = t0 - H + j;
+      const bool live = j < WX && t >= 0 && t < T;
+      const bool save = a.h_out && live && j >= H && j < H + TT;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int o0 = kq * 4 + reg, o1 = 16 + kq * 4 + reg;
+        float v0 = acc0[reg] + b1r[0][reg];
+        v0 = v0 > 0.f ? v0 : NSC_LRELU_ALPHA * v0;
+        hs[o0 * LDX + j] = live ? v0 : 0.f;
+        if (save) a.h_out[((long)b * NARROW + o0) * T + t] = v0;
+        if (o1 < NARROW) {
+          float v1 = acc1[reg] + b1r[1][reg];
+          v1 = v1 > 0.f ? v1 : NSC_LRELU_ALPHA * v1;
+          hs[o1 * LDX + j] = live ? v1 : 0.f;
+          if (save) a.h_out[((long)b * NARROW + o1) * T + t] = v1;
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- phase 2: both k15 gate convs, A from LDS (w2s), B from LDS (hs) ----
+    if (!(skip & 2)) {
+      f32x4 acc[2];
+      acc[0] = acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const float* ab0 = w2s + kq * LDW + jrt[0] * 16 + l15;
+      const float* ab1 = w2s + kq * LDW + jrt[1] * 16 + l15;
+      const float* hb0 = hs + kq * LDX + jct[0] * 16 + l15;
+      const float* hb1 = hs + kq * LDX + jct[1] * 16 + l15;
+#pragma unroll
+      for (int tap = 0; tap < K15; ++tap)
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+          const int ao = (tap * NARROW + 4 * u) * LDW, ho = 4 * u * LDX + tap * DIL;
+          acc[0] = mfma4(ab0[ao], hb0[ho], acc[0]);
+          acc[1] = mfma4(ab1[ao], hb1[ho], acc[1]);
+        }
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        if (!jlive[e]) continue;
+        const int jj = jct[e] * 16 + l15;
+        const int c0 = jrt[e] * 8 + kq * 2;
+        const int t = t0 - 4 + jj;
+        const bool live = jj < WGW && t >= 0 && t < T;
+        const bool save = a.lin_out && live && jj >= 4 && jj < 4 + TT;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int c = c0 + u;
+          if (c < NARROW) {
+            const float lin = acc[e][u] + blr[e][u];
+            const float th = tanhf(acc[e][2 + u] + brr[e][u]);
+            gs[c * LDG + jj] = live ? lin * th : 0.f;
+            if (save) {
+              const long gi = ((long)b * NARROW + c) * T + t;
+              a.lin_out[gi] = lin;
+              a.th_out[gi] = th;
+              a.g_out[gi] = lin * th;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- phase 3: y = W9 * g + b9 + x; this wave's row tile (weights in registers), NC3 column tiles ----
+    if ((RT9 != 7 || wave < 7) && !(skip & 4)) {
+      f32x4 acc[NC3];
+#pragma unroll
+      for (int c = 0; c < NC3; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const float* gb = gs + kq * LDG + cb3 + l15;
+#pragma unroll
+      for (int tap = 0; tap < K9; ++tap)
+#pragma unroll
+        for (int u = 0; u < 5; ++u)
+#pragma unroll
+          for (int c = 0; c < NC3; ++c) acc[c] = mfma4(w9r[tap][u], gb[4 * u * LDG + c * 16 + tap], acc[c]);
+#pragma unroll
+      for (int c = 0; c < NC3; ++c) {
+        const int tt = cb3 + c * 16 + l15;
+        const int t = t0 + tt;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int o = rt3 * 16 + kq * 4 + reg;
+          if (o < C && t < T) {
+            float v = acc[c][reg] + b9r[reg] + xs[o * LDX + H + tt];
+            if (!a.flat) v = v > 0.f ? v : NSC_LRELU_ALPHA * v;
+            a.out[((long)b * C + o) * T + t] = v;
+          }
+        }
+      }
+    }
+    __syncthreads();   // xs / hs / gs are rewritten by the next tile
+  }
+}
+
+template <int RT9, int NK1, int DIL>
+static int launch_block_fwd2(const BlockArgs& a, hipStream_t st) {
+  constexpr int CR = 4 * NK1;
+  const size_t smem = ((size_t)(CR + NARROW) * 112 + (size_t)NARROW * 80 + (size_t)K15 * NARROW * 48) * sizeof(float);
+  auto kern = gated_block_fwd2_kernel<RT9, NK1, DIL>;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "gated_block_fwd2: smem attr: %s", hipGetErrorString(e));
+  const int tpf = nsc_cdiv(a.T, 64);
+  const int ntiles = a.B * tpf;
+  static const int skip = getenv("NSC_FWD2_SKIP") ? atoi(getenv("NSC_FWD2_SKIP")) : 0;   // timing probe only
+  hipLaunchKernelGGL(kern, dim3(std::min(ntiles, 256)), dim3(512), smem, st, a, ntiles, tpf, skip);
+  NSC_CHECK_LAUNCH("gated_block_fwd2");
+  return NSC_OK;
+}
+
 extern "C" int nsc_gated_block_fwd(const float* x, const float* w1, const float* b1, const float* wl, const float* bl,
                                    const float* wr, const float* br, const float* w9, const float* b9, float* out,
                                    float* h_out, float* lin_out, float* th_out, float* g_out, int B, int C, int T,
@@ -254,6 +504,11 @@ extern "C" int nsc_gated_block_fwd(const float* x, const float* w1, const float*
   BlockArgs a{B, C, T, dil, flat, x, w1, b1, wl, bl, wr, br, w9, b9, out, h_out, lin_out, th_out, g_out};
   dim3 grid(nsc_cdiv(T, 64), B);
   hipStream_t st = (hipStream_t)stream;
+  static const bool v1_only = getenv("NSC_BLOCK_FWD_V1") != nullptr;   // A/B switch for profiling
+  if (!v1_only && (dil == 1 || dil == 2)) {
+    if (C == 100) return dil == 1 ? launch_block_fwd2<7, 25, 1>(a, st) : launch_block_fwd2<7, 25, 2>(a, st);
+    if (C == 50) return dil == 1 ? launch_block_fwd2<4, 13, 1>(a, st) : launch_block_fwd2<4, 13, 2>(a, st);
+  }
   const int nrt = nsc_cdiv(C, 16);
 #define LAUNCH_BLK(RT)                                                                                              \
   do {                                                                                                              \
