@@ -66,6 +66,12 @@ int nsc_conv1d_cout1_fwd(const nsc_conv_desc* d, const float* x, const float* w,
  * flip_taps=1 writes tap k to row K-1-k (used when x/dz roles are swapped for Cout==1 convs). */
 int nsc_conv1d_wgrad(const nsc_conv_desc* d, const float* x, const float* dz, float* dw, float* db,
                      int flip_taps, void* stream);
+/* Same, with caller-owned scratch (floats; size from nsc_conv1d_wgrad_workspace): the partial sums of the (b,t) splits
+ * are stored to private slabs and summed by a second launch instead of being added with same-address float atomics.
+ * workspace NULL or too small -> the atomic path of nsc_conv1d_wgrad. */
+int nsc_conv1d_wgrad_ws(const nsc_conv_desc* d, const float* x, const float* dz, float* dw, float* db,
+                        int flip_taps, float* workspace, long workspace_floats, void* stream);
+long nsc_conv1d_wgrad_workspace(const nsc_conv_desc* d);
 /* wt[K-1-k, o, i] = w[k, i, o] : weights of the data-gradient conv (dgrad == nsc_conv1d_fwd on wt). */
 int nsc_weight_flip_transpose(const float* w, float* wt, int K, int Cin, int Cout, void* stream);
 

@@ -31,6 +31,7 @@ PROTOTYPES = {
     "nsc_conv1d_fwd": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P],
     "nsc_conv1d_cout1_fwd": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P],
     "nsc_conv1d_wgrad": [C.POINTER(ConvDesc), _P, _P, _P, _P, _I, _P],
+    "nsc_conv1d_wgrad_ws": [C.POINTER(ConvDesc), _P, _P, _P, _P, _I, _P, _L, _P],
     "nsc_weight_flip_transpose": [_P, _P, _I, _I, _I, _P],
     "nsc_gated_block_fwd": [_P] * 14 + [_I] * 7 + [_P],
     "nsc_gated_block_bwd": [_P] * 21 + [_I] * 7 + [_P],
@@ -63,7 +64,8 @@ PROTOTYPES = {
     "nsc_frame_utterance": [_P, _L, _P, _P, _I, _P],
     "nsc_overlap_add": [_P, _I, _P, _P, _P],
 }
-EXPORTS = sorted(list(PROTOTYPES) + ["nsc_version", "nsc_last_error", "nsc_gated_block_wgrad_workspace"])
+EXPORTS = sorted(list(PROTOTYPES) + ["nsc_version", "nsc_last_error", "nsc_gated_block_wgrad_workspace",
+                  "nsc_conv1d_wgrad_workspace"])
 
 
 class NscError(RuntimeError):
@@ -88,6 +90,8 @@ def load():
         fn.restype = C.c_int
     lib.nsc_gated_block_wgrad_workspace.argtypes = [C.c_int]
     lib.nsc_gated_block_wgrad_workspace.restype = C.c_long
+    lib.nsc_conv1d_wgrad_workspace.argtypes = [C.POINTER(ConvDesc)]
+    lib.nsc_conv1d_wgrad_workspace.restype = C.c_long
     lib.nsc_version.restype = C.c_int
     lib.nsc_last_error.restype = C.c_char_p
     _lib = lib

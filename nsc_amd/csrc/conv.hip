@@ -368,17 +368,20 @@ extern "C" int nsc_conv1d_cout1_fwd(const nsc_conv_desc* d, const float* x, cons
 }
 
 // ------------------------------------------------------------------------------------------------
-// weight gradient
+// Weight gradient as a GEMM with the (b, t) axis as the reduction:
+//     dW[(tap,ci), o] = sum_{b,t} x[b, ci, t*stride + tap*dil - padL] * dz[b, o, t]      (+ a row of ones -> db)
+// Rows (tap,ci) are split over grid.y (128*RT rows per workgroup: 8 waves x RT row tiles), the (b,t) reduction over
+// grid.x ("K-splits"); every workgroup keeps its RT x CT accumulator tiles in registers across all of its 64-step
+// chunks.  Both operand tiles are staged with 16 row loads in flight per wave (the first version issued one dz row per
+// round trip and spent ~80 % of its time there).  Flush: with a workspace each K-split STORES its partial dW into a
+// private slab and conv_slab_reduce_kernel sums the slabs (192 K-splits x 90k float atomics on the same addresses took
+// 2/3 of the stride-2 conv's 283 us); without one, float atomics straight into dw/db (few K-splits).
 // ------------------------------------------------------------------------------------------------
-// rows = kk = tap*Cin + ci (+1 bias row fed by a row of ones), cols = output channel, reduction = (b, t).
-// Workgroup = 4 waves; wave wv owns row tiles [(blockIdx.y*4 + wv)*RT, +RT) x all CT column tiles.
-// blockIdx.x walks (frame, 64-step time chunk) pairs with stride gridDim.x (split-K); partial sums are
-// added to dw/db with global float atomics (64-B contiguous segments per 16 lanes).
 template <int RT, int CT>
-__global__ __launch_bounds__(256) void conv1d_wgrad_kernel(nsc_conv_desc d, const float* __restrict__ x,
+__global__ __launch_bounds__(512) void conv1d_wgrad_kernel(nsc_conv_desc d, const float* __restrict__ x,
                                                            const float* __restrict__ dz, float* __restrict__ dw,
-                                                           float* __restrict__ db, int flip, int ldx, int win,
-                                                           int nchunk_t) {
+                                                           float* __restrict__ db, float* __restrict__ slab,
+                                                           long slab_stride, int flip, int ldx, int win, int nchunk_t) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int TT = 64, LDZ = 66;  // 66 % 32 == 2: conflict-free B-fragment reads
   float* xs = sm;                          // [Cin + 2][ldx] : rows Cin = zeros, Cin+1 = ones
@@ -386,15 +389,17 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(nsc_conv_desc d, cons
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform (SGPR): selects, not branches
   const int l15 = lane & 15, kq = lane >> 4;
-  const int nrows = d.K * d.Cin + (db ? 1 : 0);
+  const int nW = d.K * d.Cin;
+  const int nrows = nW + (db ? 1 : 0);
   const int Tin_virt = d.in_up ? 2 * d.Tin : d.Tin;
+  const int rt0 = (blockIdx.y * 8 + wave) * RT;   // first row tile of this wave
 
   // per-lane A-row offsets (row = rowtile*16 + l15)
   int rowoff[RT];
 #pragma unroll
   for (int r = 0; r < RT; ++r) {
-    const int kk = ((blockIdx.y * 4 + wave) * RT + r) * 16 + l15;
-    if (kk < d.K * d.Cin) {
+    const int kk = (rt0 + r) * 16 + l15;
+    if (kk < nW) {
       const int tap = kk / d.Cin, ci = kk - tap * d.Cin;
       rowoff[r] = ci * ldx + tap * d.dil;
     } else if (kk < nrows) {
@@ -410,53 +415,55 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(nsc_conv_desc d, cons
     for (int c = 0; c < CT; ++c) acc[r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // constant rows
-  for (int j = tid; j < ldx; j += 256) {
+  for (int j = tid; j < ldx; j += 512) {
     xs[d.Cin * ldx + j] = 0.f;
     xs[(d.Cin + 1) * ldx + j] = 1.f;
   }
+  const bool busy = rt0 * 16 < nrows;   // waves past the last row tile only help staging
   const int nchunks = d.B * nchunk_t;
   for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
     const int b = chunk / nchunk_t, tc = chunk - b * nchunk_t;
     const int t0 = tc * TT;
     __syncthreads();  // previous chunk's reads done
-    {
-      nsc_stage_rows(xs, ldx, d.Cin, d.Cin, win, x + (long)b * d.Cin * d.Tin, d.Tin, t0 * d.stride - d.padL, Tin_virt,
-                     d.in_up, wave, lane);
-      const float* dzb = dz + (long)b * d.Cout * d.Tout;
-      for (int o = wave; o < CT * 16; o += 4) {
-        const int t = t0 + lane;
-        dzs[o * LDZ + lane] = (o < d.Cout && t < d.Tout) ? dzb[(long)o * d.Tout + t] : 0.f;
+    nsc_stage_rows<8, 16>(xs, ldx, d.Cin, d.Cin, win, x + (long)b * d.Cin * d.Tin, d.Tin, t0 * d.stride - d.padL,
+                          Tin_virt, d.in_up, wave, lane);
+    nsc_stage_rows<8, 16>(dzs, LDZ, CT * 16, d.Cout, TT, dz + (long)b * d.Cout * d.Tout, d.Tout, t0, d.Tout, 0, wave,
+                          lane, TT);
+    __syncthreads();
+    if (busy) {
+#pragma unroll 2
+      for (int tt = 0; tt < TT / 4; ++tt) {
+        const int tloc = 4 * tt + kq;
+        float af[RT], bf[CT];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) af[r] = xs[rowoff[r] + tloc * d.stride];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) bf[c] = dzs[(c * 16 + l15) * LDZ + tloc];
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+          for (int c = 0; c < CT; ++c)
+            acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r], bf[c], acc[r][c], 0, 0, 0);
       }
     }
-    __syncthreads();
-#pragma unroll 2
-    for (int tt = 0; tt < TT / 4; ++tt) {
-      const int tloc = 4 * tt + kq;
-      float af[RT], bf[CT];
-#pragma unroll
-      for (int r = 0; r < RT; ++r) af[r] = xs[rowoff[r] + tloc * d.stride];
-#pragma unroll
-      for (int c = 0; c < CT; ++c) bf[c] = dzs[(c * 16 + l15) * LDZ + tloc];
-#pragma unroll
-      for (int r = 0; r < RT; ++r)
-#pragma unroll
-        for (int c = 0; c < CT; ++c)
-          acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r], bf[c], acc[r][c], 0, 0, 0);
-    }
   }
+  if (!busy) return;
   // ---- flush: D col = l15 -> output channel, row = 4*kq + reg -> kk ----
+  float* sl = slab ? slab + (long)blockIdx.x * slab_stride : nullptr;
 #pragma unroll
   for (int r = 0; r < RT; ++r) {
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
-      const int kk = ((blockIdx.y * 4 + wave) * RT + r) * 16 + kq * 4 + reg;
+      const int kk = (rt0 + r) * 16 + kq * 4 + reg;
       if (kk >= nrows) continue;
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
         const int o = c * 16 + l15;
         if (o >= d.Cout) continue;
         const float v = acc[r][c][reg];
-        if (kk < d.K * d.Cin) {
+        if (sl) {
+          sl[(long)kk * d.Cout + o] = v;     // rows in kernel order; the bias row is row nW; flip applied by the reduce
+        } else if (kk < nW) {
           int kko = kk;
           if (flip) {
             const int tap = kk / d.Cin, ci = kk - tap * d.Cin;
@@ -471,48 +478,108 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(nsc_conv_desc d, cons
   }
 }
 
+// dw / db += sum over the K-split slabs (blockIdx.y splits the slabs so enough loads are in flight)
+__global__ void conv_slab_reduce_kernel(const float* __restrict__ slab, long stride, int nslabs, float* __restrict__ dw,
+                                        float* __restrict__ db, int K, int Cin, int Cout, int n, int flip) {
+  const int per = (nslabs + gridDim.y - 1) / gridDim.y;
+  const int w0 = blockIdx.y * per, w1 = min(nslabs, w0 + per);
+  const int nW = K * Cin * Cout;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int w = w0;
+    for (; w + 3 < w1; w += 4) {
+      s0 += slab[(long)w * stride + i];
+      s1 += slab[(long)(w + 1) * stride + i];
+      s2 += slab[(long)(w + 2) * stride + i];
+      s3 += slab[(long)(w + 3) * stride + i];
+    }
+    for (; w < w1; ++w) s0 += slab[(long)w * stride + i];
+    const float v = (s0 + s1) + (s2 + s3);
+    if (i < nW) {
+      int io = i;
+      if (flip) {
+        const int kk = i / Cout, o = i - kk * Cout;
+        const int tap = kk / Cin, ci = kk - tap * Cin;
+        io = ((K - 1 - tap) * Cin + ci) * Cout + o;
+      }
+      atomicAdd(dw + io, v);
+    } else {
+      atomicAdd(db + (i - nW), v);
+    }
+  }
+}
+
+struct WgradPlan { int gx, gy, ldx, win, nchunk_t; size_t smem; long slab_stride; };
+
+template <int RT>
+static WgradPlan wgrad_plan(const nsc_conv_desc* d, int CT, bool bias, bool use_slab) {
+  WgradPlan p;
+  const int TT = 64;
+  p.win = (TT - 1) * d->stride + (d->K - 1) * d->dil + 1;
+  p.ldx = p.win;
+  while ((p.ldx & 31) != 2) ++p.ldx;  // A-fragment rows (consecutive ci) land on distinct even banks, kq on odd
+  p.smem = ((size_t)(d->Cin + 2) * p.ldx + (size_t)CT * 16 * 66) * sizeof(float);
+  const int nrows = d->K * d->Cin + (bias ? 1 : 0);
+  const int nrt = nsc_cdiv(nrows, 16);
+  p.gy = nsc_cdiv(nrt, 8 * RT);
+  p.nchunk_t = nsc_cdiv(d->Tout, TT);
+  const int nchunks = d->B * p.nchunk_t;
+  // K-splits: with slabs ~one workgroup per CU (256 in all) and >= 2 chunks each (the slab traffic grows with gx);
+  // with atomics keep the number of same-address adders small.
+  int gx = use_slab ? 256 / p.gy : 64 / p.gy;
+  if (p.smem <= 76 * 1024 && use_slab) gx *= 2;      // two workgroups fit a CU
+  if (gx > nchunks / 2) gx = nchunks / 2;
+  if (gx < 1) gx = 1;
+  p.gx = gx;
+  p.slab_stride = ((long)nrows * d->Cout + 63) & ~63L;
+  return p;
+}
+
+static bool wgrad_big(const nsc_conv_desc* d, bool bias) { return nsc_cdiv(d->K * d->Cin + (bias ? 1 : 0), 16) > 24; }
+
 template <int RT, int CT>
 static int launch_wgrad(const nsc_conv_desc* d, const float* x, const float* dz, float* dw, float* db, int flip,
-                        hipStream_t st) {
-  const int TT = 64;
-  const int win = (TT - 1) * d->stride + (d->K - 1) * d->dil + 1;
-  int ldx = win;
-  while ((ldx & 31) != 2) ++ldx;  // A-fragment rows (consecutive ci) land on distinct even banks, kq on odd
-  const size_t smem = ((size_t)(d->Cin + 2) * ldx + (size_t)CT * 16 * 66) * sizeof(float);
-  NSC_REQUIRE(smem <= 160 * 1024, NSC_ERR_UNSUPPORTED, "conv1d_wgrad: tiles %zu B exceed LDS", smem);
+                        float* ws, long ws_floats, hipStream_t st) {
+  WgradPlan p = wgrad_plan<RT>(d, CT, db != nullptr, ws != nullptr);
+  if (ws && (p.gx < 4 || (long)p.gx * p.slab_stride > ws_floats)) {   // not worth a slab / does not fit: atomics
+    ws = nullptr;
+    p = wgrad_plan<RT>(d, CT, db != nullptr, false);
+  }
+  NSC_REQUIRE(p.smem <= 160 * 1024, NSC_ERR_UNSUPPORTED, "conv1d_wgrad: tiles %zu B exceed LDS", p.smem);
   auto kern = conv1d_wgrad_kernel<RT, CT>;
-  if (smem > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (p.smem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.smem);
     NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "conv1d_wgrad: set smem attr: %s", hipGetErrorString(e));
   }
-  const int nrows = d->K * d->Cin + (db ? 1 : 0);
-  const int nrt = nsc_cdiv(nrows, 16);
-  const int gy = nsc_cdiv(nrt, 4 * RT);
-  const int nchunk_t = nsc_cdiv(d->Tout, TT);
-  const int nchunks = d->B * nchunk_t;
-  // Parallelism comes from splitting the (tap,ci) ROWS over workgroups first (gy) and the (b,t) reduction second (gx):
-  // every K-split adds the whole dW tile with float atomics to the SAME addresses, which is what bounded the first
-  // version (768 splits).  Aim for ~2.5 workgroups per CU, at least 8 and at most 160 K-splits.
-  int gx = 640 / gy;
-  if (gx < 8) gx = 8;
-  if (gx > 160) gx = 160;
-  if (RT == 4) gx = 768 / gy;   // very tall dW (stride-2 k9 100->100): measured faster with more K-splits (1 WG/CU by LDS)
-  if (gx > nchunks) gx = nchunks;
-  hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(256), smem, st, *d, x, dz, dw, db, flip, ldx, win, nchunk_t);
+  hipLaunchKernelGGL(kern, dim3(p.gx, p.gy), dim3(512), p.smem, st, *d, x, dz, dw, db, ws, p.slab_stride, flip, p.ldx,
+                     p.win, p.nchunk_t);
   NSC_CHECK_LAUNCH("conv1d_wgrad");
+  if (ws) {
+    const int n = (d->K * d->Cin + (db ? 1 : 0)) * d->Cout;
+    const int gy = p.gx >= 64 ? 8 : (p.gx >= 16 ? 4 : 1);
+    hipLaunchKernelGGL(conv_slab_reduce_kernel, dim3(nsc_cdiv(n, 256), gy), dim3(256), 0, st, ws, p.slab_stride, p.gx, dw,
+                       db, d->K, d->Cin, d->Cout, n, flip);
+    NSC_CHECK_LAUNCH("conv_slab_reduce");
+  }
   return NSC_OK;
 }
 
 template <int CT>
 static int dispatch_wgrad_rt(const nsc_conv_desc* d, const float* x, const float* dz, float* dw, float* db, int flip,
-                             hipStream_t st) {
-  const int nrt = nsc_cdiv(d->K * d->Cin + (db ? 1 : 0), 16);
-  if (nrt <= 24) return launch_wgrad<1, CT>(d, x, dz, dw, db, flip, st);   // one row tile per wave: split rows over WGs
-  return launch_wgrad<4, CT>(d, x, dz, dw, db, flip, st);
+                             float* ws, long ws_floats, hipStream_t st) {
+  if (!wgrad_big(d, db != nullptr)) return launch_wgrad<1, CT>(d, x, dz, dw, db, flip, ws, ws_floats, st);
+  return launch_wgrad<2, CT>(d, x, dz, dw, db, flip, ws, ws_floats, st);   // very tall dW (stride-2 k9 100->100)
 }
 
-extern "C" int nsc_conv1d_wgrad(const nsc_conv_desc* d, const float* x, const float* dz, float* dw, float* db,
-                                int flip_taps, void* stream) {
+extern "C" long nsc_conv1d_wgrad_workspace(const nsc_conv_desc* d) {
+  if (!d || d->K <= 0 || d->Cin <= 0 || d->Cout <= 0) return 0;
+  const WgradPlan p = wgrad_big(d, true) ? wgrad_plan<2>(d, nsc_cdiv(d->Cout, 16), true, true)
+                                         : wgrad_plan<1>(d, nsc_cdiv(d->Cout, 16), true, true);
+  return (long)p.gx * p.slab_stride;
+}
+
+extern "C" int nsc_conv1d_wgrad_ws(const nsc_conv_desc* d, const float* x, const float* dz, float* dw, float* db,
+                                   int flip_taps, float* workspace, long workspace_floats, void* stream) {
   int rc = check_desc(d, "nsc_conv1d_wgrad");
   if (rc) return rc;
   NSC_REQUIRE(x && dz && dw, NSC_ERR_BAD_ARG, "nsc_conv1d_wgrad: null x/dz/dw");
@@ -520,12 +587,17 @@ extern "C" int nsc_conv1d_wgrad(const nsc_conv_desc* d, const float* x, const fl
   hipStream_t st = (hipStream_t)stream;
   const int nct = nsc_cdiv(d->Cout, 16);
   switch (nct) {
-    case 1: return dispatch_wgrad_rt<1>(d, x, dz, dw, db, flip_taps, st);
-    case 2: return dispatch_wgrad_rt<2>(d, x, dz, dw, db, flip_taps, st);
-    case 3: return dispatch_wgrad_rt<3>(d, x, dz, dw, db, flip_taps, st);
-    case 4: return dispatch_wgrad_rt<4>(d, x, dz, dw, db, flip_taps, st);
-    default: return dispatch_wgrad_rt<7>(d, x, dz, dw, db, flip_taps, st);
+    case 1: return dispatch_wgrad_rt<1>(d, x, dz, dw, db, flip_taps, workspace, workspace_floats, st);
+    case 2: return dispatch_wgrad_rt<2>(d, x, dz, dw, db, flip_taps, workspace, workspace_floats, st);
+    case 3: return dispatch_wgrad_rt<3>(d, x, dz, dw, db, flip_taps, workspace, workspace_floats, st);
+    case 4: return dispatch_wgrad_rt<4>(d, x, dz, dw, db, flip_taps, workspace, workspace_floats, st);
+    default: return dispatch_wgrad_rt<7>(d, x, dz, dw, db, flip_taps, workspace, workspace_floats, st);
   }
+}
+
+extern "C" int nsc_conv1d_wgrad(const nsc_conv_desc* d, const float* x, const float* dz, float* dw, float* db,
+                                int flip_taps, void* stream) {
+  return nsc_conv1d_wgrad_ws(d, x, dz, dw, db, flip_taps, nullptr, 0, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

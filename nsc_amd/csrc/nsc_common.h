@@ -58,15 +58,17 @@ __device__ __forceinline__ float nsc_ldm(const float* __restrict__ p, int idx, b
 // Stage rows of a [rows, Tin] tensor into LDS: xs[r*ldx + j] = src[r*Tin + u0 + j] for j < width, zero outside the
 // tensor / for pad rows (r >= rows_valid) / for j >= width.  One wave per row, lanes along time (coalesced 256-B reads).
 // in_up: virtual zero-upsampled-by-2 source (u even -> src[u/2], odd -> 0), virtual length Tvirt = 2*Tin.
-template <int NW = 4>   // waves in the workgroup
+template <int NW = 4, int U = 8>   // waves in the workgroup, rows in flight per wave
 __device__ __forceinline__ void nsc_stage_rows(float* __restrict__ xs, int ldx, int rows_total, int rows_valid, int width,
                                                const float* __restrict__ src, int Tin, int u0, int Tvirt, int in_up,
-                                               int wave, int lane) {
+                                               int wave, int lane, int jspan = -1) {
   // U rows per batch: all U loads are issued before the first LDS store, so one memory round trip covers U rows
   // (a load->store pair per loop iteration left every row waiting on its own latency).  Loads are branch-free:
   // clamped address + select on the value.
-  constexpr int U = 8;
-  for (int jb = 0; jb < ldx; jb += 64) {
+  // jspan: columns to write (default: the whole row stride ldx, zero-filling [width, ldx)); pass `width` when the
+  // columns beyond it are never read, to skip the extra pass.
+  if (jspan < 0) jspan = ldx;
+  for (int jb = 0; jb < jspan; jb += 64) {
     const int j = jb + lane;
     const int u = u0 + j;
     const bool cok = j < width && u >= 0 && u < Tvirt && (!in_up || !(u & 1));

@@ -125,21 +125,27 @@ class _Conv:
         self._wgrad(x, dz, dw, db)
         e.prof_end(tok)
 
+    def wgrad_desc(self):
+        """Descriptor of the weight-gradient launch (roles swapped for Cout == 1: "input" = dz, "grad" = x, flipped taps)."""
+        e = self.eng
+        if self.Cout == 1:
+            assert self.stride == 1
+            return ConvDesc(B=e.B, Cin=1, Cout=self.Cin, Tin=self.Tout, Tout=self.Tin, K=self.K, dil=self.dil, stride=1,
+                            padL=(self.K - 1) * self.dil - self.padL, act=0, res_mode=0, mul_mode=0, out_mode=0, in_up=0,
+                            accumulate=0)
+        return self.desc()
+
     def _wgrad(self, x, dz, dw, db):
         e = self.eng
         st = e.side_fork()
+        ws = e.wgrad_workspace(slot=e.side_idx)
+        d = self.wgrad_desc()
         if self.Cout == 1:
-            # swap roles (SURVEY/DESIGN): "input" = dz (1 channel), "grad" = x (Cin channels); flipped taps
-            assert self.stride == 1
-            d = ConvDesc(B=e.B, Cin=1, Cout=self.Cin, Tin=self.Tout, Tout=self.Tin, K=self.K, dil=self.dil, stride=1,
-                         padL=(self.K - 1) * self.dil - self.padL, act=0, res_mode=0, mul_mode=0, out_mode=0, in_up=0,
-                         accumulate=0)
-            check(e.lib.nsc_conv1d_wgrad(C.byref(d), dz.data_ptr(), x.data_ptr(), dw, None, 1, st),
+            check(e.lib.nsc_conv1d_wgrad_ws(C.byref(d), dz.data_ptr(), x.data_ptr(), dw, None, 1, ws, e._ws_floats, st),
                   f"conv wgrad(swapped) {self.name}")
             check(e.lib.nsc_sum_all(dz.data_ptr(), db, dz.numel(), st), "bias grad")
         else:
-            d = self.desc()
-            check(e.lib.nsc_conv1d_wgrad(C.byref(d), x.data_ptr(), dz.data_ptr(), dw, db, 0, st),
+            check(e.lib.nsc_conv1d_wgrad_ws(C.byref(d), x.data_ptr(), dz.data_ptr(), dw, db, 0, ws, e._ws_floats, st),
                   f"conv wgrad {self.name}")
 
     def wt_index(self):
@@ -261,11 +267,11 @@ class _Block:
                 for part in (1, 2):
                     if part == 2:
                         st = e.side_fork()     # the two parts are independent: next side stream
-                    check(e.lib.nsc_gated_block_wgrad(*args, None, *tail, 4, part, e.wgrad_workspace(self.Cin, e.side_idx), st),
+                    check(e.lib.nsc_gated_block_wgrad(*args, None, *tail, 4, part, e.wgrad_workspace(slot=e.side_idx), st),
                           "gated_block_wgrad")
             else:
                 check(e.lib.nsc_gated_block_wgrad(*args, _lib.ptr(dx) if fuse_d1 else None, *tail, e.wgrad_waves, 0,
-                                                  e.wgrad_workspace(self.Cin, e.side_idx), st), "gated_block_wgrad")
+                                                  e.wgrad_workspace(slot=e.side_idx), st), "gated_block_wgrad")
             e.prof_end(tok)
             if fused_dgrad:
                 return dxf if need_dx else None
@@ -589,16 +595,27 @@ class CascadeEngine:
     _side_rr = 0
     side_idx = 0
 
-    def wgrad_workspace(self, C, slot=0):
-        """Scratch for the store+reduce flush of nsc_gated_block_wgrad.  One buffer per slot: launches that may run
-        concurrently (different side streams) must not share a slab; launches on one stream are ordered."""
-        n = int(self.lib.nsc_gated_block_wgrad_workspace(int(C)))
+    def wgrad_workspace(self, slot=0):
+        """Scratch for the store+reduce flush of nsc_gated_block_wgrad / nsc_conv1d_wgrad_ws.  One buffer per slot:
+        launches that may run concurrently (different side streams) must not share a slab; launches on one stream are
+        ordered.  Sized ONCE for the largest user so it is never reallocated under a running kernel."""
+        if self._ws_floats is None:
+            n = 0
+            for c in self.codecs:
+                for blk in c.all_blocks():
+                    if blk.Cin > 1:
+                        n = max(n, int(self.lib.nsc_gated_block_wgrad_workspace(int(blk.Cin))))
+            for cv in self.convs:
+                n = max(n, int(self.lib.nsc_conv1d_wgrad_workspace(C.byref(cv.wgrad_desc()))))
+            self._ws_floats = n
         key = f"wgrad.ws{slot}"
         ws = self._bufs.get(key)
-        if ws is None or ws.numel() < n:
-            ws = torch.empty(n, dtype=torch.float32, device=self.device)
+        if ws is None:
+            ws = torch.empty(self._ws_floats, dtype=torch.float32, device=self.device)
             self._bufs[key] = ws
         return ws.data_ptr()
+
+    _ws_floats = None
 
     def prof_begin(self, tag, flops):
         if self.prof is None:

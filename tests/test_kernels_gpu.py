@@ -138,7 +138,8 @@ def test_conv1d_shuffle_and_mul_epilogues(lib):
 GRAD_CASES = [
     (3, 1, 100, 512, 55, 1, 1), (2, 100, 20, 512, 1, 1, 1), (2, 20, 20, 512, 15, 2, 1), (2, 20, 100, 256, 9, 1, 1),
     (2, 100, 100, 512, 9, 1, 2), (2, 100, 1, 256, 55, 1, 1), (2, 50, 1, 512, 55, 1, 1), (2, 1, 20, 256, 1, 1, 1),
-    (2, 7, 13, 300, 5, 3, 1), (3, 50, 50, 512, 15, 1, 1), (2, 100, 100, 256, 1, 1, 1),
+    (2, 7, 13, 300, 5, 3, 1), (3, 50, 50, 512, 15, 1, 1), (2, 100, 100, 256, 1, 1, 1), (40, 100, 100, 512, 9, 1, 2),
+    (1, 3, 5, 40, 3, 1, 1),
 ]
 
 
@@ -169,6 +170,18 @@ def test_conv1d_dgrad_wgrad(lib, case):
         assert lib.nsc_conv1d_wgrad(C.byref(d), xd.data_ptr(), dzd.data_ptr(), dw.data_ptr(), db.data_ptr(), 0, _st()) == 0, lib.nsc_last_error()
     assert_close(dw.cpu().numpy(), Wt.grad.numpy(), what=f"wgrad {case}")
     assert_close(db.cpu().numpy(), bt.grad.numpy(), what=f"bias grad {case}")
+    # ---- wgrad again through the slab (store + reduce) flush: poisoned workspace, accumulates on top of dw ----
+    lib.nsc_conv1d_wgrad_workspace.restype = C.c_long
+    nws = lib.nsc_conv1d_wgrad_workspace(C.byref(d))
+    assert nws > 0
+    ws = torch.full((nws,), float("nan"), device="cuda")
+    dw2, db2 = dw.clone(), db.clone()
+    if Cout == 1:
+        assert lib.nsc_conv1d_wgrad_ws(C.byref(d), dzd.data_ptr(), xd.data_ptr(), dw2.data_ptr(), None, 1, ws.data_ptr(), nws, _st()) == 0
+    else:
+        assert lib.nsc_conv1d_wgrad_ws(C.byref(d), xd.data_ptr(), dzd.data_ptr(), dw2.data_ptr(), db2.data_ptr(), 0, ws.data_ptr(), nws, _st()) == 0
+        assert_close(db2.cpu().numpy(), 2 * bt.grad.numpy(), what=f"bias grad (slab) {case}")
+    assert_close(dw2.cpu().numpy(), 2 * Wt.grad.numpy(), what=f"wgrad (slab) {case}")
     # ---- dgrad ----
     wt = torch.empty((K, Cout, Cin), device="cuda")
     assert lib.nsc_weight_flip_transpose(wd.data_ptr(), wt.data_ptr(), K, Cin, Cout, _st()) == 0
