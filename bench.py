@@ -97,7 +97,7 @@ def main():
     ap.add_argument("--no-split-wgrad", action="store_true")
     ap.add_argument("--fused-bwd", action="store_true", help="debug: whole-block persistent backward kernel")
     ap.add_argument("--unfused-wgrad", action="store_true", help="debug: per-conv weight gradients")
-    ap.add_argument("--fused-dgrad", action="store_true", help="debug: one fused data-path backward kernel per gated block")
+    ap.add_argument("--unfused-dgrad", action="store_true", help="debug: per-conv data-gradient launches instead of one fused kernel per gated block")
     ap.add_argument("--unfused-fwd", action="store_true", help="debug: per-conv forward/backward (no block fusion)")
     args = ap.parse_args()
 
@@ -117,7 +117,7 @@ def main():
     eng.split_wgrad = not args.no_split_wgrad
     eng.fused_bwd = args.fused_bwd
     eng.fused_wgrad = not args.unfused_wgrad
-    eng.fused_dgrad = args.fused_dgrad
+    eng.fused_dgrad = not args.unfused_dgrad
     eng.fused_fwd = not args.unfused_fwd
     xd, lpcd, x_np, lpc_np = synth_batch(B, comm.rank, dev)
     cfg = step_cfg()

@@ -1722,6 +1722,290 @@ __global__ __launch_bounds__(512) void gated_block_dgrad_kernel(BlockDgradArgs a
   }
 }
 
+// -----------------------------------------------------------------------------------------------------
+// v2 of the fused data-path backward: PERSISTENT and weight-stationary (same idea as gated_block_fwd2_kernel).
+// One workgroup per CU walks (frame, 64-step tile) pairs; weights are fetched once per workgroup.  The data
+// gradients have FEW output rows (20 -> two 16-row MFMA tiles) and LONG reductions (k9: 9*C, k15: 15*40), so the
+// REDUCTIONS are split over the waves: wave w = (row tile w>>2, K-quarter w&3) owns k-steps {kg, kg+4, ...} of the
+// k9 gradient (57 weight fragments, register-resident) and taps {kg, kg+4, kg+8, kg+12} of the k15 gradient (weights
+// in LDS as [tap][40][20], shared by all waves), for ALL column tiles.  The four partial sums per output meet in LDS:
+// plain ds_write of each wave's accumulators to a private slice, summed by the elementwise phase that follows
+// (LDS float atomics measured ~2.4x slower than the MFMA work they were reducing).  Inner loops are {ds_read, v_mfma}.
+// The next tile's dy / lin / tanh / h are prefetched into registers (raw buffer loads; out-of-frame columns come back
+// as 0 from the bounds check) while this tile computes.
+// -----------------------------------------------------------------------------------------------------
+template <int RT9, int NK9, int DIL>
+__global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs a, int ntiles, int tpf, int skip) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  constexpr int TT = 64, Hh = 7 * DIL, W_a = TT + 2 * Hh, W_dy = W_a + 8, NCTA = (W_a + 15) / 16, CR = 4 * NK9;
+  constexpr int LDY = 112, LDA = 112, LDN = 80, WA16 = NCTA * 16;
+  constexpr int NQ = (CR + 7) / 8;                 // dy rows per wave
+  constexpr int NJ9 = (NK9 + 3) / 4;               // channel groups (of 4) per K-quarter of the k9 gradient
+  constexpr int PART1 = 4 * 16 * WA16;             // offset of the row-tile-1 partial sums (rows 16..19 only)
+  static_assert(WA16 + 8 <= LDY && 63 + 15 * DIL < LDA, "tile widths");
+  float* dys = sm;                                 // [CR][LDY]       j  <-> t0 - Hh - 4 + j   (pad rows zero)
+  float* lin = dys + CR * LDY;                     // [20][LDA]       ja <-> t0 - Hh + ja      -> dlin  (rows 0..19 of da)
+  float* th = lin + NARROW * LDA;                  // [20][LDA]                                 -> dgate (rows 20..39 of da)
+  float* dhs = th + NARROW * LDA;                  // [20][LDN]       tt <-> t0 + tt : dz1
+  float* part = dhs + NARROW * LDN;                // [4][16][WA16] + [4][4][WA16]  partial sums of the K-quarters
+  float* w15s = part + 4 * NARROW * WA16;          // [15][40][20]   wt_l | wt_r concatenated along the reduced channel
+  const int C = a.C, T = a.T;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, kq = lane >> 4;
+  const int rt = wave >> 2, kg = (wave + rt) & 3;  // this wave's output row tile and K-quarter (the longer quarter 0
+                                                   // lands on different SIMDs for the two row tiles)
+  const int cic = min(rt * 16 + l15, NARROW - 1);  // A-fragment row (rows >= 20: clamped, never stored)
+
+  // ---- once per workgroup: weights -> registers / LDS (clamped indices: pad k-rows meet zero rows of the staged
+  // tiles; only k-steps / taps past the end need a real zero) ----
+  for (int e = tid; e < K15 * 2 * NARROW * NARROW; e += 512) {
+    const int tp = e / (2 * NARROW * NARROW), r = e - tp * 2 * NARROW * NARROW;
+    const int cp = r / NARROW, ci = r - cp * NARROW;
+    w15s[e] = cp < NARROW ? a.wtl[(tp * NARROW + cp) * NARROW + ci] : a.wtr[(tp * NARROW + cp - NARROW) * NARROW + ci];
+  }
+  // k9 gradient: K-quarter kg owns the channel groups cq = kg + 4j of every tap, so the B-fragment address of step
+  // (tap', j) is lane base + the compile-time offset (16 j LDY + tap'): no per-step address registers.
+  float w9r[K9][NJ9];
+#pragma unroll
+  for (int tp = 0; tp < K9; ++tp)
+#pragma unroll
+    for (int j = 0; j < NJ9; ++j) {
+      const int cq = kg + 4 * j;                       // >= NK9 only for j = NJ9-1 of some kg: that step is skipped
+      w9r[tp][j] = a.wt9[((long)tp * C + min(4 * cq + kq, C - 1)) * NARROW + cic];
+    }
+  const int rt1 = RT9 == 7 ? (wave < 7 ? wave : 6) : (wave & 3);
+  const int cb1 = RT9 == 7 ? 0 : (wave >> 2) * 32;
+  constexpr int NC1 = RT9 == 7 ? 4 : 2;
+  float w1r[5];
+#pragma unroll
+  for (int s5 = 0; s5 < 5; ++s5) w1r[s5] = a.wt1[(s5 * 4 + kq) * C + min(rt1 * 16 + l15, C - 1)];
+
+  // ---- prefetch of the next tile: dy (wave w rows w, w+8, ...), lin / tanh (rows w, w+8, w+16), h (elementwise map) ----
+  const __amdgpu_buffer_rsrc_t sdy =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, (unsigned)((long)a.B * C * T * 4), 0x00020000);
+  const unsigned nbN = (unsigned)((long)a.B * NARROW * T * 4);
+  const __amdgpu_buffer_rsrc_t slin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.lin), 0, nbN, 0x00020000);
+  const __amdgpu_buffer_rsrc_t sth = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.th), 0, nbN, 0x00020000);
+  const __amdgpu_buffer_rsrc_t sh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.h), 0, nbN, 0x00020000);
+  float pfy[NQ][2], pfl[3][2], pft[3][2], pfh[3];
+  auto bld = [](const __amdgpu_buffer_rsrc_t& r, int voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+  };
+  const int OOB = 0x7ffffff0;
+  auto prefetch_dy = [&](int tile) {
+    const int tl = __builtin_amdgcn_readfirstlane(tile < ntiles ? tile : 0);
+    const int b = tl / tpf, t0 = (tl - b * tpf) * TT;
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+      const int j = hb * 64 + lane;
+      const int ty = t0 - Hh - 4 + j;
+      const int vy = (j < W_dy && ty >= 0 && ty < T) ? ty * 4 : OOB;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) pfy[q][hb] = bld(sdy, vy, (b * C + min(wave + 8 * q, C - 1)) * T * 4);
+    }
+  };
+  auto prefetch_a = [&](int tile) {
+    const int tl = __builtin_amdgcn_readfirstlane(tile < ntiles ? tile : 0);
+    const int b = tl / tpf, t0 = (tl - b * tpf) * TT;
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+      const int j = hb * 64 + lane;
+      const int ta = t0 - Hh + j;
+      const int va = (j < W_a && ta >= 0 && ta < T) ? ta * 4 : OOB;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int so = (b * NARROW + min(wave + 8 * q, NARROW - 1)) * T * 4;
+        pfl[q][hb] = bld(slin, va, so);
+        pft[q][hb] = bld(sth, va, so);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {    // h at element e = tid + 512 q of the [20][64] dz1 tile (q = 2: only e < 1280)
+      const int e = tid + 512 * q;
+      const int c = e >> 6, t = t0 + (e & 63);
+      pfh[q] = bld(sh, (c < NARROW && t < T) ? t * 4 : OOB, (b * NARROW + min(c, NARROW - 1)) * T * 4);
+    }
+  };
+  prefetch_dy(blockIdx.x);
+  prefetch_a(blockIdx.x);
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int b = tile / tpf, t0 = (tile - b * tpf) * TT;
+    // ---- phase 0: prefetched tiles -> LDS ----
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+      const int j = hb * 64 + lane;
+      if (j < LDY) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const int r = wave + 8 * q;
+          if (r < CR) dys[r * LDY + j] = r < C ? pfy[q][hb] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const int r = wave + 8 * q;
+          if (r < NARROW) {
+            lin[r * LDA + j] = pfl[q][hb];
+            th[r * LDA + j] = pft[q][hb];
+          }
+        }
+      }
+    }
+    float hv[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) hv[q] = pfh[q];
+    __syncthreads();
+    if (!(skip & 8)) prefetch_dy(tile + gridDim.x);
+
+    // ---- D9: this wave's quarter of dg[ci][ja] = sum_{tap', o} wt9[tap'][o][ci] * dy[o][ja + tap'] ----
+    if (!(skip & 1)) {
+      f32x4 acc[NCTA];
+#pragma unroll
+      for (int ct = 0; ct < NCTA; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const float* yb = dys + (4 * kg + kq) * LDY + l15;
+#pragma unroll
+      for (int tp = 0; tp < K9; ++tp)
+#pragma unroll
+        for (int j = 0; j < NJ9 - 1; ++j)
+#pragma unroll
+          for (int ct = 0; ct < NCTA; ++ct) acc[ct] = mfma4(w9r[tp][j], yb[16 * j * LDY + tp + ct * 16], acc[ct]);
+      if (kg + 4 * (NJ9 - 1) < NK9) {                      // wave-uniform: the quarters that own one more channel group
+#pragma unroll
+        for (int tp = 0; tp < K9; ++tp)
+#pragma unroll
+          for (int ct = 0; ct < NCTA; ++ct)
+            acc[ct] = mfma4(w9r[tp][NJ9 - 1], yb[16 * (NJ9 - 1) * LDY + tp + ct * 16], acc[ct]);
+      }
+      if (rt == 0 || kq == 0) {                            // row tile 1 holds channels 16..19 in its first 4 rows only
+        float* pp = rt == 0 ? part + (kg * 16 + kq * 4) * WA16 : part + PART1 + kg * 4 * WA16;
+#pragma unroll
+        for (int ct = 0; ct < NCTA; ++ct)
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) pp[reg * WA16 + ct * 16 + l15] = acc[ct][reg];
+      }
+    }
+    __syncthreads();
+
+    // ---- GLU backward in place (lin/th are zero outside the frame, so dlin/dgate are too); da -> global ----
+    for (int e = tid; e < NARROW * WA16; e += 512) {
+      const int c = e / WA16, ja = e - c * WA16;
+      const float* pp = c < 16 ? part + c * WA16 + ja : part + PART1 + (c - 16) * WA16 + ja;
+      const int ps = c < 16 ? 16 * WA16 : 4 * WA16;
+      const float gg = (pp[0] + pp[ps]) + (pp[2 * ps] + pp[3 * ps]);
+      const float l = lin[c * LDA + ja], tg = th[c * LDA + ja];
+      const float dl_ = gg * tg, dgt = gg * l * (1.f - tg * tg);
+      lin[c * LDA + ja] = dl_;
+      th[c * LDA + ja] = dgt;
+      const int t = t0 - Hh + ja;
+      if (ja >= Hh && ja < Hh + TT && t < T) {
+        a.da[((long)b * 2 * NARROW + c) * T + t] = dl_;
+        a.da[((long)b * 2 * NARROW + NARROW + c) * T + t] = dgt;
+      }
+    }
+    __syncthreads();
+    if (!(skip & 8)) prefetch_a(tile + gridDim.x);   // lin / tanh / h of the next tile (their LDS tiles are still in use)
+
+    // ---- D15: this wave's taps of dh[ci][tt] = sum wt_lr[tap'][c'][ci] * da[c'][tt + tap' d] ----
+    if (!(skip & 2)) {
+      f32x4 acc[4];
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const float* ab = lin + kq * LDA + l15 + kg * DIL;
+      const float* wb = w15s + (kg * 2 * NARROW + kq) * NARROW + cic;
+#pragma unroll
+      for (int e4 = 0; e4 < 4; ++e4) {
+        if (e4 == 3 && kg == 3) break;                     // tap 15 does not exist (wave-uniform)
+#pragma unroll
+        for (int u = 0; u < 10; ++u) {
+          const float av = wb[(e4 * 4 * 2 * NARROW + 4 * u) * NARROW];
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct) acc[ct] = mfma4(av, ab[4 * u * LDA + e4 * 4 * DIL + ct * 16], acc[ct]);
+        }
+      }
+      if (rt == 0 || kq == 0) {
+        float* pp = rt == 0 ? part + (kg * 16 + kq * 4) * TT : part + 4 * 16 * TT + kg * 4 * TT;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) pp[reg * TT + ct * 16 + l15] = acc[ct][reg];
+      }
+    }
+    // x at this wave's D1 outputs (for act'(x)): issued here, consumed after the next two barriers
+    float xv[NC1][4];
+    if (a.in_act == NSC_ACT_LRELU) {
+#pragma unroll
+      for (int c = 0; c < NC1; ++c)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int co = min(rt1 * 16 + kq * 4 + reg, C - 1), t = min(t0 + cb1 + c * 16 + l15, T - 1);
+          xv[c][reg] = a.x[((long)b * C + co) * T + t];
+        }
+    }
+    __syncthreads();
+
+    // ---- dz1 = (sum of the four partial dh) . lrelu'(h) -> LDS + global ----
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int e = tid + 512 * q;
+      if (e < NARROW * TT) {
+        const int c = e >> 6, tt = e & 63;
+        const int t = t0 + tt;
+        const float* pp = c < 16 ? part + c * TT + tt : part + 4 * 16 * TT + (c - 16) * TT + tt;
+        const int ps = c < 16 ? 16 * TT : 4 * TT;
+        const float dh = (pp[0] + pp[ps]) + (pp[2 * ps] + pp[3 * ps]);
+        const float v = t < T ? dh * (hv[q] > 0.f ? 1.f : NSC_LRELU_ALPHA) : 0.f;
+        dhs[c * LDN + tt] = v;
+        if (t < T) a.dz1[((long)b * NARROW + c) * T + t] = v;
+      }
+    }
+    __syncthreads();
+
+    // ---- D1: dx = (W1^T dz1 + dy) . act'(x); this wave's row tile, NC1 column tiles ----
+    if ((RT9 != 7 || wave < 7) && !(skip & 4)) {
+      f32x4 acc[NC1];
+#pragma unroll
+      for (int c = 0; c < NC1; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const float* zb = dhs + kq * LDN + cb1 + l15;
+#pragma unroll
+      for (int s5 = 0; s5 < 5; ++s5)
+#pragma unroll
+        for (int c = 0; c < NC1; ++c) acc[c] = mfma4(w1r[s5], zb[4 * s5 * LDN + c * 16], acc[c]);
+#pragma unroll
+      for (int c = 0; c < NC1; ++c) {
+        const int tt = cb1 + c * 16 + l15;
+        const int t = t0 + tt;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int co = rt1 * 16 + kq * 4 + reg;
+          if (co < C && t < T) {
+            float v = acc[c][reg] + dys[co * LDY + tt + Hh + 4];
+            if (a.in_act == NSC_ACT_LRELU) v *= (xv[c][reg] > 0.f ? 1.f : NSC_LRELU_ALPHA);
+            a.dx[((long)b * C + co) * T + t] = v;
+          }
+        }
+      }
+    }
+    __syncthreads();   // dys / lin / th / dhs / part are rewritten by the next tile
+  }
+}
+
+template <int RT9, int NK9, int DIL>
+static int launch_block_dgrad2(const BlockDgradArgs& a, hipStream_t st) {
+  constexpr int WA16 = ((64 + 14 * DIL + 15) / 16) * 16;
+  const size_t smem = ((size_t)4 * NK9 * 112 + (size_t)2 * NARROW * 112 + (size_t)NARROW * 80 + (size_t)4 * NARROW * WA16 +
+                       (size_t)K15 * 2 * NARROW * NARROW) * sizeof(float);
+  auto kern = gated_block_dgrad2_kernel<RT9, NK9, DIL>;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "gated_block_dgrad2: smem attr: %s", hipGetErrorString(e));
+  const int tpf = nsc_cdiv(a.T, 64);
+  const int ntiles = a.B * tpf;
+  static const int skip = getenv("NSC_DGRAD2_SKIP") ? atoi(getenv("NSC_DGRAD2_SKIP")) : 0;   // timing probe only
+  hipLaunchKernelGGL(kern, dim3(std::min(ntiles, 256)), dim3(512), smem, st, a, ntiles, tpf, skip);
+  NSC_CHECK_LAUNCH("gated_block_dgrad2");
+  return NSC_OK;
+}
+
 extern "C" int nsc_gated_block_dgrad(const float* x, const float* h, const float* lin, const float* th, const float* dy,
                                      const float* wt1, const float* wtl, const float* wtr, const float* wt9, float* dx,
                                      float* da, float* dz1, int B, int C, int T, int narrow, int k9, int dil, int in_act,
@@ -1742,6 +2026,11 @@ extern "C" int nsc_gated_block_dgrad(const float* x, const float* h, const float
   BlockDgradArgs a{B, C, T, dil, in_act, x, h, lin, th, dy, wt1, wtl, wtr, wt9, dx, da, dz1};
   dim3 grid(nsc_cdiv(T, 64), B);
   hipStream_t st = (hipStream_t)stream;
+  static const bool v1_only = getenv("NSC_BLOCK_DGRAD_V1") != nullptr;   // A/B switch for profiling
+  if (!v1_only) {
+    if (C == 100) return dil == 1 ? launch_block_dgrad2<7, 25, 1>(a, st) : launch_block_dgrad2<7, 25, 2>(a, st);
+    if (C == 50) return dil == 1 ? launch_block_dgrad2<4, 13, 1>(a, st) : launch_block_dgrad2<4, 13, 2>(a, st);
+  }
 #define LAUNCH_DG(RT)                                                                                               \
   do {                                                                                                              \
     auto kern = gated_block_dgrad_kernel<RT>;                                                                       \

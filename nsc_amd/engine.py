@@ -553,8 +553,8 @@ class CascadeEngine:
     fused_bwd = False  # whole-block backward in one persistent kernel (correct, but its conv phases run at one wave
                        # per SIMD and lose to the per-conv kernels: measured 9.0 vs 6.7 ms/step) - kept, off by default
     fused_wgrad = True # all eight parameter gradients of a block in one persistent kernel (csrc/block.hip)
-    fused_dgrad = False  # whole data path of a block (k9 -> GLU -> k15 -> 1x1 data gradients) in one 8-wave kernel:
-                         # correct, but measured slower than the three multi-wave per-conv launches (1.9 vs 1.2 ms/step)
+    fused_dgrad = True   # whole data path of a block (k9 -> GLU -> k15 -> 1x1 data gradients) in one persistent,
+                         # weight-stationary kernel (v2; the per-tile v1 lost to the per-conv launches: 1.9 vs 1.2 ms/step)
     # per-launch HIP-event timing of the conv kernels (bench.py roofline); events sit on the launch stream
     prof = None
 
