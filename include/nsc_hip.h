@@ -115,6 +115,20 @@ int nsc_gated_block_wgrad(const float* x, const float* h, const float* g, const 
                           int part /*0 all gradients; 1 dW9/db9 only; 2 dWl/dWr/dW1 + biases only (light launches that
                           share a CU with other kernels)*/, float* workspace, void* stream);
 long nsc_gated_block_wgrad_workspace(int C);
+/* Batched form: the parameter gradients of njobs gated blocks in ONE persistent launch (+ one slab reduction).  The
+ * reference's tf.gradients has no ordering constraint between a block's weight gradients and the rest of the backward
+ * pass (cmrl.py:106-113 / :369-372 only hand them to the optimizer), so a host can defer all of them to the end.
+ * Each job's eight gradients must be contiguous in creation order starting at `grads`
+ * (dw1 | db1 | dwl | dbl | dwr | dbr | dw9 | db9); they are ACCUMULATED into.  workspace: >=
+ * nsc_gated_block_wgrad_batch_workspace(max C) floats, caller-owned. */
+typedef struct nsc_block_wgrad_job {
+  const float *x, *h, *g, *dy, *da, *dz1;
+  float* grads;
+  int C, T, dil;
+} nsc_block_wgrad_job;
+long nsc_gated_block_wgrad_batch_workspace(int Cmax);
+int nsc_gated_block_wgrad_batch(const nsc_block_wgrad_job* jobs, int njobs, int B, int narrow, int k9,
+                                float* workspace, long workspace_floats, void* stream);
 
 /* ---- separable conv pieces (replaces tf.keras.layers.SeparableConv1D behind nn_core_operator.py:17-21) ---- */
 int nsc_depthwise_fwd(const float* x, const float* wd /*[K,C]*/, float* y, int B, int C, int T, int K, void* stream);

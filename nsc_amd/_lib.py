@@ -64,8 +64,14 @@ PROTOTYPES = {
     "nsc_frame_utterance": [_P, _L, _P, _P, _I, _P],
     "nsc_overlap_add": [_P, _I, _P, _P, _P],
 }
+class BlockWgradJob(C.Structure):
+    """include/nsc_hip.h: struct nsc_block_wgrad_job"""
+    _fields_ = [(n, C.c_void_p) for n in ("x", "h", "g", "dy", "da", "dz1", "grads")] + [(n, C.c_int) for n in ("C", "T", "dil")]
+
+
+PROTOTYPES["nsc_gated_block_wgrad_batch"] = [C.POINTER(BlockWgradJob), _I, _I, _I, _I, _P, _L, _P]
 EXPORTS = sorted(list(PROTOTYPES) + ["nsc_version", "nsc_last_error", "nsc_gated_block_wgrad_workspace",
-                  "nsc_conv1d_wgrad_workspace"])
+                  "nsc_conv1d_wgrad_workspace", "nsc_gated_block_wgrad_batch_workspace"])
 
 
 class NscError(RuntimeError):
@@ -92,6 +98,8 @@ def load():
     lib.nsc_gated_block_wgrad_workspace.restype = C.c_long
     lib.nsc_conv1d_wgrad_workspace.argtypes = [C.POINTER(ConvDesc)]
     lib.nsc_conv1d_wgrad_workspace.restype = C.c_long
+    lib.nsc_gated_block_wgrad_batch_workspace.argtypes = [C.c_int]
+    lib.nsc_gated_block_wgrad_batch_workspace.restype = C.c_long
     lib.nsc_version.restype = C.c_int
     lib.nsc_last_error.restype = C.c_char_p
     _lib = lib

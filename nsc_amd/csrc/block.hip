@@ -1112,8 +1112,10 @@ __device__ __forceinline__ void wg_flush(float* p, float v, bool plain) {
 // PART selects which gradients the launch produces: 0 = all eight (+ optional 1x1 data gradient); 1 = dW9/db9 only
 // (stages g and dy: 32 KB, ~90 registers); 2 = dWl/dWr/dW1 + biases (stages h, da, x, dz1: 50 KB).  The two light
 // parts leave most of a CU's registers and LDS to the data-gradient kernels running concurrently on the main stream.
+// wg / nwg: this workgroup's index among the nwg workgroups that share the block's tiles; slab_id: its slab in the workspace
 template <int RT9, int NW, int PART>
-__global__ __launch_bounds__(64 * NW, 2) void gated_block_wgrad_kernel(BlockWgradArgs a, int ldn, int ldg, int ldh) {
+__device__ __forceinline__ void block_wgrad_body(const BlockWgradArgs& a, int ldn, int ldg, int ldh, int wg, int nwg,
+                                                 int slab_id) {
   constexpr bool P9 = PART != 2, PLR = PART != 1;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int TT = 64;
@@ -1269,14 +1271,14 @@ __global__ __launch_bounds__(64 * NW, 2) void gated_block_wgrad_kernel(BlockWgra
     }
   };
 
-  if ((int)blockIdx.x < a.ntiles) load_tile(blockIdx.x);
-  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+  if (wg < a.ntiles) load_tile(wg);
+  for (int tile = wg; tile < a.ntiles; tile += nwg) {
     const int b = tile / a.tiles_per_frame;
     const int t0 = (tile - b * a.tiles_per_frame) * TT;
     __syncthreads();                       // everyone is done reading the previous tile
     if (!(a.skip & 16)) store_tile();
     __syncthreads();
-    if (tile + (int)gridDim.x < a.ntiles && !(a.skip & 8)) load_tile(tile + gridDim.x);   // in flight during the MFMA loop below
+    if (tile + nwg < a.ntiles && !(a.skip & 8)) load_tile(tile + nwg);   // in flight during the MFMA loop below
     if (!(a.skip & 2))
 #pragma unroll 1
     for (int s = 0; s < TT / 4; ++s) {
@@ -1361,7 +1363,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gated_block_wgrad_kernel(BlockWgra
   // private slab (summed afterwards by slab_reduce_kernel): 256 workgroups x 32k atomics on the same addresses cost
   // ~100 us per block, the store + reduce path ~15 us.
   const bool plain = a.slab_stride != 0;
-  const long so = (long)blockIdx.x * a.slab_stride;
+  const long so = (long)slab_id * a.slab_stride;
   if (a.skip & 4) return;
   if constexpr (P9)
 #pragma unroll
@@ -1409,6 +1411,63 @@ __global__ __launch_bounds__(64 * NW, 2) void gated_block_wgrad_kernel(BlockWgra
         else wg_flush(a.db1 + so + o, g1[r][c][reg], plain);
       }
     }
+}
+
+template <int RT9, int NW, int PART>
+__global__ __launch_bounds__(64 * NW, 2) void gated_block_wgrad_kernel(BlockWgradArgs a, int ldn, int ldg, int ldh) {
+  block_wgrad_body<RT9, NW, PART>(a, ldn, ldg, ldh, blockIdx.x, gridDim.x, blockIdx.x);
+}
+
+// ---- batched form: ONE launch produces the parameter gradients of up to NSC_WG_MAXJ gated blocks.  The weight
+// gradients are off the critical path (only the optimizer reads them), so the engine defers them to the end of the
+// backward pass; a (block, part) pair then gets ~256/njobs persistent workgroups that each walk 20-60 tiles instead
+// of 2-4, which amortises the prologue, the register-resident accumulators' flush and the slab reduction (14x fewer
+// slabs per block), and removes 4 launches per block.  Workgroup w: part = 1 + (w & 1) (two 4-wave workgroups of
+// different parts share a CU); among the workgroups of a part, job j owns [wg0[j], wg0[j+1]).
+#define NSC_WG_MAXJ 12
+struct BlockWgradBatch {
+  BlockWgradArgs a[NSC_WG_MAXJ];
+  int wg0[NSC_WG_MAXJ + 1];
+  int njobs;
+};
+template <int RT9>
+__global__ __launch_bounds__(256, 2) void gated_block_wgrad_batch_kernel(BlockWgradBatch t, int ldn, int ldg) {
+  const int part = 1 + (blockIdx.x & 1), w = blockIdx.x >> 1;
+  int j = 0;
+  while (j + 1 < t.njobs && w >= t.wg0[j + 1]) ++j;
+  j = __builtin_amdgcn_readfirstlane(j);
+  const BlockWgradArgs& a = t.a[j];
+  int ldh = 64 + 14 * a.dil;
+  while ((ldh & 31) != 2) ++ldh;
+  const int wl = w - t.wg0[j], nw = t.wg0[j + 1] - t.wg0[j];
+  if (part == 1) block_wgrad_body<RT9, 4, 1>(a, ldn, ldg, ldh, wl, nw, w);
+  else block_wgrad_body<RT9, 4, 2>(a, ldn, ldg, ldh, wl, nw, w);
+}
+
+// per job: grads[range] += sum of its workgroups' slabs; blockIdx.y = job * 2 + half (half 0: everything before dW9 -
+// written by the part-2 workgroups; half 1: dW9 | db9 - written by the part-1 workgroups; both use slabs wg0[j]..wg0[j+1])
+struct SlabReduceBatch {
+  float* grads[NSC_WG_MAXJ];
+  int off9[NSC_WG_MAXJ], range[NSC_WG_MAXJ];
+  int wg0[NSC_WG_MAXJ + 1];
+};
+__global__ void slab_reduce_batch_kernel(SlabReduceBatch t, const float* __restrict__ slab, long stride) {
+  const int j = blockIdx.y >> 1, half = blockIdx.y & 1;
+  const int i0 = half ? t.off9[j] : 0, i1 = half ? t.range[j] : t.off9[j];
+  const int w0 = t.wg0[j], w1 = t.wg0[j + 1];
+  float* g = t.grads[j];
+  for (int i = i0 + blockIdx.x * blockDim.x + threadIdx.x; i < i1; i += gridDim.x * blockDim.x) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int w = w0;
+    for (; w + 3 < w1; w += 4) {
+      s0 += slab[(long)w * stride + i];
+      s1 += slab[(long)(w + 1) * stride + i];
+      s2 += slab[(long)(w + 2) * stride + i];
+      s3 += slab[(long)(w + 3) * stride + i];
+    }
+    for (; w < w1; ++w) s0 += slab[(long)w * stride + i];
+    g[i] += (s0 + s1) + (s2 + s3);      // one adder per element: no atomics needed
+  }
 }
 
 // grads[i] += sum_w slab[w * stride + i]; blockIdx.y splits the slabs (8 groups) so enough loads are in flight
@@ -1495,6 +1554,122 @@ extern "C" int nsc_gated_block_wgrad(const float* x, const float* h, const float
     NSC_CHECK_LAUNCH("slab_reduce");
   }
   return NSC_OK;
+}
+
+template <int RT9>
+static int launch_wgrad_batch(const nsc_block_wgrad_job* jobs, const int* idx, int n, int B, float* workspace,
+                              long workspace_floats, hipStream_t st) {
+  BlockWgradBatch t;
+  SlabReduceBatch r;
+  memset(&t, 0, sizeof(t));
+  memset(&r, 0, sizeof(r));
+  static int skip_env = -1;
+  if (skip_env < 0) { const char* e = getenv("NSC_WG_SKIP"); skip_env = e ? atoi(e) : 0; }
+  const int ldn = ld2(64), ldg = ld2(72);
+  long stride = 0, total_tiles = 0;
+  size_t smem = 0;
+  for (int q = 0; q < n; ++q) {
+    const nsc_block_wgrad_job& jb = jobs[idx[q]];
+    const int C = jb.C;
+    const long range = (long)C * NARROW + NARROW + 2L * (K15 * NARROW * NARROW + NARROW) + (long)K9 * NARROW * C + C;
+    stride = std::max(stride, (range + 63) & ~63L);
+    BlockWgradArgs& a = t.a[q];
+    a.B = B; a.C = C; a.T = jb.T; a.dil = jb.dil;
+    a.x = jb.x; a.h = jb.h; a.g = jb.g; a.dy = jb.dy; a.da = jb.da; a.dz1 = jb.dz1;
+    a.wt1 = nullptr; a.dx = nullptr; a.in_act = 0;
+    // gradient pointers redirected into slab 0 of the workspace, keeping the block's relative layout
+    float* p = workspace;
+    a.dw1 = p; p += (long)C * NARROW; a.db1 = p; p += NARROW;
+    a.dwl = p; p += K15 * NARROW * NARROW; a.dbl = p; p += NARROW;
+    a.dwr = p; p += K15 * NARROW * NARROW; a.dbr = p; p += NARROW;
+    a.dw9 = p; p += (long)K9 * NARROW * C; a.db9 = p;
+    a.tiles_per_frame = nsc_cdiv(jb.T, 64);
+    a.ntiles = B * a.tiles_per_frame;
+    a.skip = skip_env;
+    total_tiles += a.ntiles;
+    r.grads[q] = jb.grads;
+    r.off9[q] = (int)((long)C * NARROW + NARROW + 2L * (K15 * NARROW * NARROW + NARROW));
+    r.range[q] = (int)range;
+    const int ldh = ld2(64 + 14 * jb.dil);
+    const size_t f1 = (size_t)(C + 2) * ldn + (size_t)C * ldn + (size_t)(NARROW + 2) * ldg + (size_t)3 * NARROW * ldn;
+    const size_t f2 = (size_t)(C + 2) * ldn + (size_t)(NARROW + 2) * ldh + (size_t)3 * NARROW * ldn;
+    smem = std::max(smem, std::max(f1, f2) * sizeof(float));
+  }
+  NSC_REQUIRE(smem <= 80 * 1024, NSC_ERR_UNSUPPORTED, "nsc_gated_block_wgrad_batch: %zu B LDS", smem);
+  // workgroup slots per job ~ its share of the tiles (largest remainder, at least one each, 256 in all)
+  const int slots = 256;
+  NSC_REQUIRE((long)slots * stride <= workspace_floats, NSC_ERR_BAD_ARG,
+              "nsc_gated_block_wgrad_batch: workspace %ld floats < %ld", workspace_floats, (long)slots * stride);
+  int cnt[NSC_WG_MAXJ], used = 0;
+  for (int q = 0; q < n; ++q) {
+    cnt[q] = std::max(1, (int)((long)slots * t.a[q].ntiles / total_tiles));
+    cnt[q] = std::min(cnt[q], t.a[q].ntiles);
+    used += cnt[q];
+  }
+  for (int guard = 0; used < slots && guard < 4 * slots; ++guard) {   // hand out the rest to the most loaded jobs
+    int best = -1;
+    double bl = 0;
+    for (int q = 0; q < n; ++q) {
+      const double l = (double)t.a[q].ntiles / cnt[q];
+      if (cnt[q] < t.a[q].ntiles && l > bl) { bl = l; best = q; }
+    }
+    if (best < 0) break;
+    ++cnt[best];
+    ++used;
+  }
+  while (used > slots) {                                              // (only if njobs > slots; cannot happen for MAXJ)
+    int best = 0;
+    for (int q = 1; q < n; ++q) if (cnt[q] > cnt[best]) best = q;
+    --cnt[best];
+    --used;
+  }
+  t.wg0[0] = 0;
+  for (int q = 0; q < n; ++q) t.wg0[q + 1] = t.wg0[q] + cnt[q];
+  for (int q = 0; q <= n; ++q) r.wg0[q] = t.wg0[q];
+  t.njobs = n;
+  for (int q = 0; q < n; ++q) t.a[q].slab_stride = stride;
+  auto kern = gated_block_wgrad_batch_kernel<RT9>;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "gated_block_wgrad_batch: smem attr: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL(kern, dim3(2 * used), dim3(256), smem, st, t, ldn, ldg);
+  NSC_CHECK_LAUNCH("gated_block_wgrad_batch");
+  hipLaunchKernelGGL(slab_reduce_batch_kernel, dim3(64, 2 * n), dim3(256), 0, st, r, workspace, stride);
+  NSC_CHECK_LAUNCH("slab_reduce_batch");
+  return NSC_OK;
+}
+
+extern "C" long nsc_gated_block_wgrad_batch_workspace(int Cmax) { return nsc_gated_block_wgrad_workspace(Cmax); }
+
+extern "C" int nsc_gated_block_wgrad_batch(const nsc_block_wgrad_job* jobs, int njobs, int B, int narrow, int k9,
+                                           float* workspace, long workspace_floats, void* stream) {
+  NSC_REQUIRE(jobs && njobs > 0 && B > 0 && workspace, NSC_ERR_BAD_ARG, "nsc_gated_block_wgrad_batch: bad arguments");
+  NSC_REQUIRE(narrow == NARROW && k9 == K9, NSC_ERR_UNSUPPORTED, "nsc_gated_block_wgrad_batch: built for narrow=20, k9=9");
+  int small[NSC_WG_MAXJ], big[NSC_WG_MAXJ], ns = 0, nb = 0;
+  hipStream_t st = (hipStream_t)stream;
+  auto flush = [&](bool all) -> int {
+    if (ns && (all || ns == NSC_WG_MAXJ)) {
+      int rc = launch_wgrad_batch<4>(jobs, small, ns, B, workspace, workspace_floats, st);
+      if (rc) return rc;
+      ns = 0;
+    }
+    if (nb && (all || nb == NSC_WG_MAXJ)) {
+      int rc = launch_wgrad_batch<7>(jobs, big, nb, B, workspace, workspace_floats, st);
+      if (rc) return rc;
+      nb = 0;
+    }
+    return NSC_OK;
+  };
+  for (int j = 0; j < njobs; ++j) {
+    const nsc_block_wgrad_job& jb = jobs[j];
+    NSC_REQUIRE(jb.x && jb.h && jb.g && jb.dy && jb.da && jb.dz1 && jb.grads, NSC_ERR_BAD_ARG,
+                "nsc_gated_block_wgrad_batch: job %d has a null pointer", j);
+    NSC_REQUIRE(jb.C > 1 && jb.C <= 112 && jb.T > 0 && jb.dil > 0 && jb.dil <= 4, NSC_ERR_UNSUPPORTED,
+                "nsc_gated_block_wgrad_batch: job %d: C %d, T %d, dil %d unsupported", j, jb.C, jb.T, jb.dil);
+    if (nsc_cdiv(jb.C, 16) <= 4) small[ns++] = j; else big[nb++] = j;
+    int rc = flush(false);
+    if (rc) return rc;
+  }
+  return flush(true);
 }
 
 // =====================================================================================================

@@ -257,6 +257,10 @@ class _Block:
             (dw1, db1), (dwl, dbl), (dwr, dbr), (dw9, db9) = G(self.c1), G(self.cl), G(self.cr), G(self.c9)
             fuse_d1 = need_dx and not e.overlap_wgrad and not fused_dgrad   # with overlap the 1x1 dgrad stays on the critical stream
             fl = self.c1.flops() * (2 if fuse_d1 else 1) + self.cl.flops() + self.cr.flops() + self.c9.flops()
+            if e.batch_wgrad and fused_dgrad:
+                # defer: every buffer the job reads is private to this block and lives until the end of the step
+                e.defer_block_wgrad(self, dz, da, dh, dw1, fl)
+                return dxf if need_dx else None
             tok = e.prof_begin("block_wgrad", fl)
             st = e.side_fork()
             args = (self.x.data_ptr(), self.h.data_ptr(), self.g.data_ptr(), dz.data_ptr(), da.data_ptr(), dh.data_ptr(),
@@ -498,6 +502,7 @@ class CascadeEngine:
         self.layout = ParamLayout()
         self.convs = []
         self._bufs = {}
+        self._wg_jobs, self._wg_keep, self._wg_flops = [], [], 0.0
         if self.lpc:  # 'lpc_quan' scope is created before scope_1 (nsc_module:993-996)
             self.lpc_alpha_off = self.layout.add("lpc_quan/alpha", ())
             self.lpc_bins_off = self.layout.add("lpc_quan/bins", (len(lpc_coeff_lsf_bins),))
@@ -566,6 +571,29 @@ class CascadeEngine:
     split_wgrad = True   # under overlap: two light 4-wave launches per block instead of one heavy 8-wave launch
 
     n_side = 1   # side streams, used round-robin (2 measured no faster: 6.04 vs 5.96 ms/step)
+
+    # ---- block weight gradients deferred to the end of the backward pass and produced by ONE persistent launch per
+    # block width (nsc_gated_block_wgrad_batch): per-block launches walk only 2-4 tiles per workgroup at batch 128, so
+    # their prologue, accumulator flush and slab reduction cost more than the MFMA work itself.
+    batch_wgrad = True
+
+    def defer_block_wgrad(self, blk, dz, da, dz1, dw1_ptr, flops):
+        self._wg_jobs.append(_lib.BlockWgradJob(blk.x.data_ptr(), blk.h.data_ptr(), blk.g.data_ptr(), dz.data_ptr(),
+                                                da.data_ptr(), dz1.data_ptr(), dw1_ptr, blk.Cin, blk.T, blk.cl.dil))
+        self._wg_keep += [blk.x, blk.h, blk.g, dz, da, dz1]
+        self._wg_flops += flops
+
+    def flush_block_wgrads(self):
+        if not self._wg_jobs:
+            return
+        jobs = (_lib.BlockWgradJob * len(self._wg_jobs))(*self._wg_jobs)
+        ws = self.wgrad_workspace(slot="batch")   # private: per-conv wgrads may still be running on the side stream
+        tok = self.prof_begin("block_wgrad", self._wg_flops)
+        # main stream: ordered after every data-gradient kernel, and after nothing else that matters (tail of the step)
+        check(self.lib.nsc_gated_block_wgrad_batch(jobs, len(self._wg_jobs), self.B, 20, 9, ws, self._ws_floats,
+                                                   self.stream()), "gated_block_wgrad_batch")
+        self.prof_end(tok)
+        self._wg_jobs, self._wg_keep, self._wg_flops = [], [], 0.0
 
     def side_fork(self):
         """Returns the stream handle weight-gradient kernels should be launched on (a side stream ordered after everything
@@ -796,6 +824,7 @@ class CascadeEngine:
                                             gh.data_ptr() if c_ent_lpc != 0.0 else None, float(c_ent_lpc) * Bg, 0, None,
                                             self.g_ptr + 4 * self.lpc_alpha_off, self.g_ptr + 4 * self.lpc_bins_off,
                                             self.stream()), "lpc quantize_bwd")
+        self.flush_block_wgrads()
         self.side_join()
         return dict(time=self.time, freq=self.freq, quan=[c.quan for c in self.codecs], ent=ents)
 

@@ -593,3 +593,37 @@ def test_fused_gated_block_dgrad(lib, case):
     assert_close(g(da)[:, :, 20:], rpre.grad.numpy(), tol=2e-4, what=f"dgate {case}")
     assert_close(g(dz1), hpre.grad.numpy(), tol=2e-4, what=f"dz1 {case}")
     assert_close(g(dx), zt.grad.numpy(), tol=2e-4, what=f"dx {case}")
+
+
+def test_block_wgrad_batch_equals_per_block_launches(lib):
+    """nsc_gated_block_wgrad_batch (deferred, one launch for many blocks of mixed shapes) == per-block nsc_gated_block_wgrad."""
+    from nsc_amd._lib import BlockWgradJob
+    rng = np.random.default_rng(77)
+    B = 6
+    shapes = [(100, 256, 2), (100, 512, 1), (50, 512, 2), (100, 256, 1), (50, 512, 1), (36, 128, 2)]
+    keep, jobs, refs, outs = [], [], [], []
+    lib.nsc_gated_block_wgrad_batch_workspace.restype = C.c_long
+    nws = lib.nsc_gated_block_wgrad_batch_workspace(100)
+    ws = torch.full((nws,), float("nan"), device="cuda")
+    for (C_, T, dil) in shapes:
+        t = {k: dev(rng.standard_normal(s_).astype(np.float32)) for k, s_ in
+             dict(x=(B, C_, T), h=(B, 20, T), g=(B, 20, T), dy=(B, C_, T), da=(B, 40, T), dz1=(B, 20, T)).items()}
+        n = C_ * 20 + 20 + 2 * (15 * 20 * 20 + 20) + 9 * 20 * C_ + C_
+        ref = torch.full((n,), 0.5, device="cuda")
+        out = torch.full((n,), 0.5, device="cuda")
+        o = [0, C_ * 20, C_ * 20 + 20, C_ * 20 + 20 + 6000, C_ * 20 + 20 + 6020, C_ * 20 + 20 + 12020, C_ * 20 + 20 + 12040,
+             C_ * 20 + 20 + 12040 + 180 * C_]
+        ptrs = [ref.data_ptr() + 4 * v for v in o]
+        rc = lib.nsc_gated_block_wgrad(t["x"].data_ptr(), t["h"].data_ptr(), t["g"].data_ptr(), t["dy"].data_ptr(),
+                                       t["da"].data_ptr(), t["dz1"].data_ptr(), *ptrs, None, None, 0, B, C_, T, 20, 9, dil, 8, 0,
+                                       None, _st())
+        assert rc == 0, lib.nsc_last_error()
+        jobs.append(BlockWgradJob(t["x"].data_ptr(), t["h"].data_ptr(), t["g"].data_ptr(), t["dy"].data_ptr(), t["da"].data_ptr(),
+                                  t["dz1"].data_ptr(), out.data_ptr(), C_, T, dil))
+        keep.append(t); refs.append(ref); outs.append(out)
+    arr = (BlockWgradJob * len(jobs))(*jobs)
+    rc = lib.nsc_gated_block_wgrad_batch(arr, len(jobs), B, 20, 9, ws.data_ptr(), nws, _st())
+    assert rc == 0, lib.nsc_last_error()
+    torch.cuda.synchronize()
+    for i, (r, o_) in enumerate(zip(refs, outs)):
+        assert_close(o_.cpu().numpy(), r.cpu().numpy(), tol=2e-4, what=f"batched block wgrad job {i} {shapes[i]}")
