@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""HBM-side traffic per launch of each kernel class, from the FETCH_SIZE / WRITE_SIZE passes of tools/pmc_run.sh.
+usage: python tools/pmc_traffic.py gpurun_out/pmc_<tag>  > profiles/pmc_traffic.json
+Units: rocprofv3 reports both counters in KiB.  Correction: the axpby calibration passes (tools/pmc_calib.py, same
+4-byte-per-lane coalesced access as the library's kernels, known byte count) give counter/true-bytes factors; the
+training-step counters are divided by them (MI355X_MICROARCH.md: gfx950's FETCH_SIZE under-reports coalesced reads)."""
+import collections, csv, glob, json, sys
+d = sys.argv[1]
+CLASSES = [("conv1d_fwd_kernel", "conv_mfma"), ("gated_block_fwd", "block_fwd"), ("gated_block_dgrad", "block_dgrad"),
+           ("gated_block_wgrad", "block_wgrad"), ("conv1d_wgrad_kernel", "wgrad_mfma"), ("quantize_fwd_kernel", "quantize_fwd"),
+           ("conv1d_cout1_kernel", "conv_cout1")]
+
+
+def read(sub, counter):
+    tot, cnt = collections.Counter(), collections.Counter()
+    for f in glob.glob(f"{d}/{sub}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            tot[r["Kernel_Name"]] += float(r["Counter_Value"]); cnt[r["Kernel_Name"]] += 1
+    return tot, cnt
+
+
+def calib(sub, counter, true_bytes):
+    tot, cnt = read(sub, counter)
+    k = [n for n in tot if "axpby" in n]
+    if not k:
+        return None
+    return (tot[k[0]] / cnt[k[0]]) * 1024.0 / true_bytes
+
+
+n = 128 * 1024 * 1024
+cf, cw = calib("calib_fetch", "FETCH_SIZE", 8.0 * n), calib("calib_write", "WRITE_SIZE", 4.0 * n)
+ft, fc = read("pass3", "FETCH_SIZE")
+wt, wc = read("pass4", "WRITE_SIZE")
+out = {"_calibration": {"fetch_counter_per_true_byte": cf, "write_counter_per_true_byte": cw,
+                        "how": "nsc_axpby over 128 Mi floats (1 GiB read, 512 MiB written per launch), 4 B/lane coalesced"}}
+for pat, tag in CLASSES:
+    fk = [k for k in ft if pat in k]; wk = [k for k in wt if pat in k]
+    nf, nw = sum(fc[k] for k in fk), sum(wc[k] for k in wk)
+    if not nf or not nw:
+        continue
+    fb = sum(ft[k] for k in fk) * 1024.0 / nf / (cf or 1.0)
+    wb = sum(wt[k] for k in wk) * 1024.0 / nw / (cw or 1.0)
+    out[tag] = {"fetch_bytes_per_launch": round(fb), "write_bytes_per_launch": round(wb), "launches_sampled": int(nf),
+                "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (KiB) in separate passes over bench.py --no-overlap --no-infer "
+                          "(training-step launches only), divided by the axpby calibration factors; averaged over the launches "
+                          "of the kernel family"}
+json.dump(out, sys.stdout, indent=1)
