@@ -9,6 +9,7 @@
 //   wgrad   : rows i = (tap, ci),      cols j = output channel, k = time ; A = x tile (LDS), B = dz tile (LDS)
 // so D's lane index is always the memory-contiguous axis of the output (time for y, Cout for dW).
 #include "nsc_common.h"
+#include <cstdlib>
 #include <cstdarg>
 #include <algorithm>
 
@@ -345,6 +346,124 @@ __global__ __launch_bounds__(256) void conv1d_cout1_kernel(nsc_conv_desc d, cons
   }
 }
 
+// Register-tiled form for the k55 convs of the model (stride 1, dilation 1): the v1 kernel above issues two LDS reads
+// per FMA and runs at ~5 TF/s.  Here a lane owns R consecutive outputs and slides a (R+K-1)-sample window held in
+// registers over the taps, so a channel costs ~(R+K)/4 + K/4 16-byte LDS reads for R*K FMAs (VALU-bound); the weights
+// are read as wave-uniform (broadcast) float4s from a [Cin][K] transposed copy.  8 waves split the channels and meet
+// in LDS.
+template <int K, int R>
+__global__ __launch_bounds__(512) void conv1d_cout1_v2_kernel(nsc_conv_desc d, const float* __restrict__ x,
+                                                              const float* __restrict__ w,
+                                                              const float* __restrict__ bias,
+                                                              const float* __restrict__ res,
+                                                              const float* __restrict__ aux, float* __restrict__ y,
+                                                              int ldx) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  constexpr int TT = 64 * R, KP = (K + 3) & ~3, NWIN = (R + KP - 1 + 3) & ~3;
+  static_assert(NWIN % R == 0, "window is read in R-float vectors");
+  float* xs = sm;                       // [Cin][ldx]   ldx >= TT + NWIN - R, multiple of 4, zero-filled past the tile
+  float* ws = xs + d.Cin * ldx;         // [Cin][KP]    ws[c][k] = w[k][c], zero for k >= K
+  float* part = ws + d.Cin * KP;        // [8][TT]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.y, t0 = blockIdx.x * TT;
+  {
+    // whole x tile in flight at once: wave w owns rows w, w+8, ...; raw buffer loads, out-of-frame columns -> 0 by the
+    // hardware bounds check (a batched-by-8 staging loop spent 5 memory round trips here: 25 of the kernel's 50 us)
+    constexpr int NQ = 13, NJ = (TT + NWIN - R + 63) / 64;      // up to 104 channels
+    const __amdgpu_buffer_rsrc_t sx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0,
+                                                                        (unsigned)((long)d.B * d.Cin * d.Tin * 4), 0x00020000);
+    float v[NQ][NJ];
+#pragma unroll
+    for (int jb = 0; jb < NJ; ++jb) {
+      const int j = jb * 64 + lane;
+      const int u = t0 - d.padL + j;
+      const int vo = (j < TT + K - 1 && u >= 0 && u < d.Tin) ? u * 4 : 0x7ffffff0;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int r = min(wave + 8 * q, d.Cin - 1);
+        v[q][jb] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(sx, vo, (b * d.Cin + r) * d.Tin * 4, 0));
+      }
+    }
+#pragma unroll
+    for (int jb = 0; jb < NJ; ++jb) {
+      const int j = jb * 64 + lane;
+      if (j < ldx) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const int r = wave + 8 * q;
+          if (r < d.Cin) xs[r * ldx + j] = v[q][jb];
+        }
+      }
+    }
+  }
+  for (int e = tid; e < d.Cin * KP; e += 512) {
+    const int c = e / KP, k = e - c * KP;
+    ws[e] = k < K ? w[k * d.Cin + c] : 0.f;
+  }
+  __syncthreads();
+  float acc[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) acc[r] = 0.f;
+  for (int c = wave; c < d.Cin; c += 8) {
+    // the window starts at float R*lane of the row: read it as R-float vectors so consecutive lanes hit consecutive
+    // banks (scalar reads at a 4-float lane stride were 8-way bank conflicts: 44 of this kernel's 51 us)
+    typedef float vecR __attribute__((ext_vector_type(R)));
+    const vecR* xr = reinterpret_cast<const vecR*>(xs) + (c * (ldx / R) + lane);
+    const float* wr = ws + c * KP;
+    float xw[NWIN];
+#pragma unroll
+    for (int i = 0; i < NWIN / R; ++i) {
+      const vecR t = xr[i];
+#pragma unroll
+      for (int e = 0; e < R; ++e) xw[i * R + e] = t[e];
+    }
+#pragma unroll
+    for (int k4 = 0; k4 < KP / 4; ++k4) {
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + 4 * k4);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        if (4 * k4 + kk < K) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) acc[r] = fmaf(xw[4 * k4 + kk + r], wv[kk], acc[r]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) part[wave * TT + R * lane + r] = acc[r];
+  __syncthreads();
+  if (tid < TT) {
+    const int t = t0 + tid;
+    if (t < d.Tout) {
+      float v = bias ? bias[0] : 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v += part[q * TT + tid];
+      const long idx = (long)b * d.Tout + t;
+      if (d.res_mode) v += res[idx];
+      v = nsc_apply_act(v, d.act);
+      if (d.mul_mode) v *= nsc_act_grad_from_out(aux[idx], d.mul_mode);
+      if (d.accumulate) y[idx] += v;
+      else y[idx] = v;
+    }
+  }
+}
+
+template <int K, int R>
+static int launch_cout1_v2(const nsc_conv_desc* d, const float* x, const float* w, const float* bias, const float* res,
+                           const float* aux, float* y, hipStream_t st) {
+  constexpr int TT = 64 * R, KP = (K + 3) & ~3, NWIN = (R + KP - 1 + 3) & ~3;
+  const int ldx = (TT + NWIN - R + 3) & ~3;
+  const size_t smem = ((size_t)d->Cin * ldx + (size_t)d->Cin * KP + 8 * TT) * sizeof(float);
+  if (smem > 160 * 1024) return 1;     // does not fit: caller falls back to v1
+  auto kern = conv1d_cout1_v2_kernel<K, R>;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "conv1d_cout1_v2: set smem attr: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL(kern, dim3(nsc_cdiv(d->Tout, TT), d->B), dim3(512), smem, st, *d, x, w, bias, res, aux, y, ldx);
+  NSC_CHECK_LAUNCH("conv1d_cout1_v2");
+  return NSC_OK;
+}
+
 extern "C" int nsc_conv1d_cout1_fwd(const nsc_conv_desc* d, const float* x, const float* w, const float* bias,
                                     const float* res, const float* aux, float* y, void* stream) {
   int rc = check_desc(d, "nsc_conv1d_cout1_fwd");
@@ -352,6 +471,14 @@ extern "C" int nsc_conv1d_cout1_fwd(const nsc_conv_desc* d, const float* x, cons
   NSC_REQUIRE(d->Cout == 1 && d->out_mode == 0, NSC_ERR_BAD_ARG, "nsc_conv1d_cout1_fwd: needs Cout == 1, plain store");
   NSC_REQUIRE(x && w && y, NSC_ERR_BAD_ARG, "nsc_conv1d_cout1_fwd: null x/w/y");
   NSC_REQUIRE(!(d->res_mode && !res) && !(d->mul_mode && !aux), NSC_ERR_BAD_ARG, "nsc_conv1d_cout1_fwd: null res/aux");
+  static const bool v1_only = getenv("NSC_COUT1_V1") != nullptr;   // A/B switch for profiling
+  if (!v1_only && d->K == 55 && d->dil == 1 && d->stride == 1 && !d->in_up && d->Cin >= 8 && d->Cin <= 104) {
+    // R outputs per lane: 4 when that still gives every CU a workgroup, else 2
+    const bool r4 = (long)d->B * nsc_cdiv(d->Tout, 256) >= 256;
+    const int rc2 = r4 ? launch_cout1_v2<55, 4>(d, x, w, bias, res, aux, y, (hipStream_t)stream)
+                       : launch_cout1_v2<55, 2>(d, x, w, bias, res, aux, y, (hipStream_t)stream);
+    if (rc2 <= 0) return rc2;          // launched (0) or failed (<0); 1 = tile does not fit LDS -> v1 below
+  }
   int ldx = 127 * d->stride + (d->K - 1) * d->dil + 1;
   ldx |= 1;
   const size_t smem = ((size_t)d->Cin * ldx + (size_t)d->K * d->Cin + 128) * sizeof(float);

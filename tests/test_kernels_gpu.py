@@ -59,6 +59,8 @@ CONV_CASES = [
     (2, 1, 20, 256, 1, 1, 1, "lrelu", 0),
     (1, 100, 1, 256, 55, 1, 1, "tanh", 0),
     (2, 50, 1, 512, 55, 1, 1, "none", 0),
+    (130, 12, 1, 500, 55, 1, 1, "tanh", 1),   # Cout = 1, enough tiles for the 4-outputs-per-lane register-tiled kernel
+    (3, 9, 1, 100, 55, 1, 1, "none", 0),      # Cout = 1, T < one tile, channels not a multiple of the 8 waves
     (2, 7, 13, 300, 5, 3, 1, "tanh", 0),      # ragged: odd channels, T not a tile multiple
     (2, 6, 130, 77, 3, 1, 2, "none", 0),      # Cout > 112 (grid.z), odd T with stride 2
     (1, 100, 100, 128, 1, 1, 1, "lrelu", 0),  # pointwise
