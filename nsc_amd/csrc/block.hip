@@ -1917,13 +1917,16 @@ __global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs 
   constexpr int NQ = (CR + 7) / 8;                 // dy rows per wave
   constexpr int NJ9 = (NK9 + 3) / 4;               // channel groups (of 4) per K-quarter of the k9 gradient
   constexpr int PART1 = 4 * 16 * WA16;             // offset of the row-tile-1 partial sums (rows 16..19 only)
+  constexpr int LDD = 68;                          // dxs row stride: == 4 (mod 32), D-fragment stores conflict-free
+  constexpr int PARTSZ = 4 * NARROW * WA16 > CR * LDD ? 4 * NARROW * WA16 : CR * LDD;
   static_assert(WA16 + 8 <= LDY && 63 + 15 * DIL < LDA, "tile widths");
   float* dys = sm;                                 // [CR][LDY]       j  <-> t0 - Hh - 4 + j   (pad rows zero)
   float* lin = dys + CR * LDY;                     // [20][LDA]       ja <-> t0 - Hh + ja      -> dlin  (rows 0..19 of da)
   float* th = lin + NARROW * LDA;                  // [20][LDA]                                 -> dgate (rows 20..39 of da)
   float* dhs = th + NARROW * LDA;                  // [20][LDN]       tt <-> t0 + tt : dz1
-  float* part = dhs + NARROW * LDN;                // [4][16][WA16] + [4][4][WA16]  partial sums of the K-quarters
-  float* w15s = part + 4 * NARROW * WA16;          // [15][40][20]   wt_l | wt_r concatenated along the reduced channel
+  float* part = dhs + NARROW * LDN;                // [4][16][WA16] + [4][4][WA16]  partial sums of the K-quarters;
+  float* dxs = part;                               //   later [CR][LDD]: dx before act'(x), for the row-wise copy-out
+  float* w15s = part + PARTSZ;                     // [15][40][20]   wt_l | wt_r concatenated along the reduced channel
   const int C = a.C, T = a.T;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1963,6 +1966,8 @@ __global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs 
   const __amdgpu_buffer_rsrc_t slin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.lin), 0, nbN, 0x00020000);
   const __amdgpu_buffer_rsrc_t sth = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.th), 0, nbN, 0x00020000);
   const __amdgpu_buffer_rsrc_t sh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.h), 0, nbN, 0x00020000);
+  const __amdgpu_buffer_rsrc_t sxx =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (unsigned)((long)a.B * C * T * 4), 0x00020000);
   float pfy[NQ][2], pfl[3][2], pft[3][2], pfh[3];
   auto bld = [](const __amdgpu_buffer_rsrc_t& r, int voff, int soff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
@@ -2039,18 +2044,39 @@ __global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs 
 #pragma unroll
       for (int ct = 0; ct < NCTA; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
       const float* yb = dys + (4 * kg + kq) * LDY + l15;
+      // explicit two-deep software pipeline with scheduling fences: left alone the scheduler hoists ~30 ds_read2 (60
+      // registers) ahead of the MFMAs, which spills - and a scratch reload waits on vmcnt IN ORDER, i.e. on the whole
+      // prefetch of the next tile.  One step = NCTA B fragments + NCTA MFMAs (>= 160 cycles, covers the LDS latency
+      // together with the partner wave).
+      constexpr int NSTEP = K9 * (NJ9 - 1);
+      float bn[NCTA], bc[NCTA];
 #pragma unroll
-      for (int tp = 0; tp < K9; ++tp)
+      for (int ct = 0; ct < NCTA; ++ct) bn[ct] = yb[ct * 16];
 #pragma unroll
-        for (int j = 0; j < NJ9 - 1; ++j)
+      for (int st = 0; st < NSTEP; ++st) {
+        const int tp = st / (NJ9 - 1), j = st - tp * (NJ9 - 1);
 #pragma unroll
-          for (int ct = 0; ct < NCTA; ++ct) acc[ct] = mfma4(w9r[tp][j], yb[16 * j * LDY + tp + ct * 16], acc[ct]);
+        for (int ct = 0; ct < NCTA; ++ct) bc[ct] = bn[ct];
+        if (st + 1 < NSTEP) {
+          const int tpn = (st + 1) / (NJ9 - 1), jn = (st + 1) - tpn * (NJ9 - 1);
+#pragma unroll
+          for (int ct = 0; ct < NCTA; ++ct) bn[ct] = yb[16 * jn * LDY + tpn + ct * 16];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ct = 0; ct < NCTA; ++ct) acc[ct] = mfma4(w9r[tp][j], bc[ct], acc[ct]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       if (kg + 4 * (NJ9 - 1) < NK9) {                      // wave-uniform: the quarters that own one more channel group
 #pragma unroll
-        for (int tp = 0; tp < K9; ++tp)
+        for (int tp = 0; tp < K9; ++tp) {
 #pragma unroll
-          for (int ct = 0; ct < NCTA; ++ct)
-            acc[ct] = mfma4(w9r[tp][NJ9 - 1], yb[16 * (NJ9 - 1) * LDY + tp + ct * 16], acc[ct]);
+          for (int ct = 0; ct < NCTA; ++ct) bc[ct] = yb[16 * (NJ9 - 1) * LDY + tp + ct * 16];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int ct = 0; ct < NCTA; ++ct) acc[ct] = mfma4(w9r[tp][NJ9 - 1], bc[ct], acc[ct]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
       if (rt == 0 || kq == 0) {                            // row tile 1 holds channels 16..19 in its first 4 rows only
         float* pp = rt == 0 ? part + (kg * 16 + kq * 4) * WA16 : part + PART1 + kg * 4 * WA16;
@@ -2092,10 +2118,20 @@ __global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs 
       for (int e4 = 0; e4 < 4; ++e4) {
         if (e4 == 3 && kg == 3) break;                     // tap 15 does not exist (wave-uniform)
 #pragma unroll
-        for (int u = 0; u < 10; ++u) {
-          const float av = wb[(e4 * 4 * 2 * NARROW + 4 * u) * NARROW];
+        for (int u = 0; u < 10; u += 2) {                  // two k-steps per scheduling group (see D9)
+          float av[2], bv[2][4];
 #pragma unroll
-          for (int ct = 0; ct < 4; ++ct) acc[ct] = mfma4(av, ab[4 * u * LDA + e4 * 4 * DIL + ct * 16], acc[ct]);
+          for (int uu = 0; uu < 2; ++uu) {
+            av[uu] = wb[(e4 * 4 * 2 * NARROW + 4 * (u + uu)) * NARROW];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) bv[uu][ct] = ab[4 * (u + uu) * LDA + e4 * 4 * DIL + ct * 16];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int uu = 0; uu < 2; ++uu)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[ct] = mfma4(av[uu], bv[uu][ct], acc[ct]);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
       if (rt == 0 || kq == 0) {
@@ -2106,16 +2142,12 @@ __global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs 
           for (int reg = 0; reg < 4; ++reg) pp[reg * TT + ct * 16 + l15] = acc[ct][reg];
       }
     }
-    // x at this wave's D1 outputs (for act'(x)): issued here, consumed after the next two barriers
-    float xv[NC1][4];
+    // x rows of the copy-out phase (for act'(x)): wave w rows w, w+8, ...; issued here, consumed three barriers later
+    float xv[NQ];
     if (a.in_act == NSC_ACT_LRELU) {
+      const int vx = (t0 + lane < T) ? (t0 + lane) * 4 : OOB;
 #pragma unroll
-      for (int c = 0; c < NC1; ++c)
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const int co = min(rt1 * 16 + kq * 4 + reg, C - 1), t = min(t0 + cb1 + c * 16 + l15, T - 1);
-          xv[c][reg] = a.x[((long)b * C + co) * T + t];
-        }
+      for (int q = 0; q < NQ; ++q) xv[q] = bld(sxx, vx, (b * C + min(wave + 8 * q, C - 1)) * T * 4);
     }
     __syncthreads();
 
@@ -2149,15 +2181,23 @@ __global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs 
 #pragma unroll
       for (int c = 0; c < NC1; ++c) {
         const int tt = cb1 + c * 16 + l15;
-        const int t = t0 + tt;
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
           const int co = rt1 * 16 + kq * 4 + reg;
-          if (co < C && t < T) {
-            float v = acc[c][reg] + dys[co * LDY + tt + Hh + 4];
-            if (a.in_act == NSC_ACT_LRELU) v *= (xv[c][reg] > 0.f ? 1.f : NSC_LRELU_ALPHA);
-            a.dx[((long)b * C + co) * T + t] = v;
-          }
+          if (co < C) dxs[co * LDD + tt] = acc[c][reg] + dys[co * LDY + tt + Hh + 4];
+        }
+      }
+    }
+    __syncthreads();
+    // ---- copy-out: dx rows as whole 256-B lines (the D-fragment stores were 64-B pieces), . act'(x) ----
+    if (t0 + lane < T) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int r = wave + 8 * q;
+        if (r < C) {
+          float v = dxs[r * LDD + lane];
+          if (a.in_act == NSC_ACT_LRELU) v *= (xv[q] > 0.f ? 1.f : NSC_LRELU_ALPHA);
+          a.dx[((long)b * C + r) * T + t0 + lane] = v;
         }
       }
     }
@@ -2168,7 +2208,8 @@ __global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs 
 template <int RT9, int NK9, int DIL>
 static int launch_block_dgrad2(const BlockDgradArgs& a, hipStream_t st) {
   constexpr int WA16 = ((64 + 14 * DIL + 15) / 16) * 16;
-  const size_t smem = ((size_t)4 * NK9 * 112 + (size_t)2 * NARROW * 112 + (size_t)NARROW * 80 + (size_t)4 * NARROW * WA16 +
+  const size_t partsz = std::max((size_t)4 * NARROW * WA16, (size_t)4 * NK9 * 68);
+  const size_t smem = ((size_t)4 * NK9 * 112 + (size_t)2 * NARROW * 112 + (size_t)NARROW * 80 + partsz +
                        (size_t)K15 * 2 * NARROW * NARROW) * sizeof(float);
   auto kern = gated_block_dgrad2_kernel<RT9, NK9, DIL>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);

@@ -35,6 +35,9 @@ extern "C" int nsc_version(void) { return 100; }
 // k-step ahead so the MFMA chain of step s covers the latency of step s+1's loads.
 // KS = 2: eight waves; waves 4-7 own the same output tiles as waves 0-3 but the ODD taps of the k-loop (intra-workgroup
 // split-K): twice the waves in flight per tile and half the dependent MFMA chain per wave; partial sums meet in LDS.
+#ifndef NSC_CONV_U
+#define NSC_CONV_U 8    // x-tile rows in flight per wave while staging (16 measured no faster: the weight fetch, not staging, bounds these)
+#endif
 template <int RT, int NC, bool CIN1, int KS>
 __global__ __launch_bounds__(256 * KS) void conv1d_fwd_kernel(nsc_conv_desc d, const float* __restrict__ x,
                                                          const float* __restrict__ w,
@@ -55,7 +58,7 @@ __global__ __launch_bounds__(256 * KS) void conv1d_fwd_kernel(nsc_conv_desc d, c
   const int Tin_virt = d.in_up ? 2 * d.Tin : d.Tin;
 
   // ---- stage x tile: xs[ci][j] = xin[b, ci, t0*stride - padL + j], zero outside (wave per row, lanes along time) ----
-  nsc_stage_rows<4 * KS>(xs, ldx, Cin4, d.Cin, win, x + (long)b * d.Cin * d.Tin, d.Tin, t0 * d.stride - d.padL, Tin_virt,
+  nsc_stage_rows<4 * KS, NSC_CONV_U>(xs, ldx, Cin4, d.Cin, win, x + (long)b * d.Cin * d.Tin, d.Tin, t0 * d.stride - d.padL, Tin_virt,
                          d.in_up, wave8, lane);
   __syncthreads();
 
