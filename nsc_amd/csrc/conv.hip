@@ -38,7 +38,10 @@ extern "C" int nsc_version(void) { return 100; }
 #ifndef NSC_CONV_U
 #define NSC_CONV_U 8    // x-tile rows in flight per wave while staging (16 measured no faster: the weight fetch, not staging, bounds these)
 #endif
-template <int RT, int NC, bool CIN1, int KS>
+// NPRE > 0: the k-loop has exactly NPRE k-steps (known shapes: 1x1 100->100, k55 1->C) and ALL of a wave's weight
+// fragments are fetched into registers up front, in flight together with the x-tile staging; the streamed form pays
+// an L2 round trip per group of k-steps, which at one wave per SIMD is most of the kernel for these short reductions.
+template <int RT, int NC, bool CIN1, int KS, int NPRE = 0>
 __global__ __launch_bounds__(256 * KS) void conv1d_fwd_kernel(nsc_conv_desc d, const float* __restrict__ x,
                                                          const float* __restrict__ w,
                                                          const float* __restrict__ bias,
@@ -56,8 +59,30 @@ __global__ __launch_bounds__(256 * KS) void conv1d_fwd_kernel(nsc_conv_desc d, c
   const int rt0 = blockIdx.z * RT;
   const int Cin4 = CIN1 ? 1 : ((d.Cin + 3) & ~3);
   const int Tin_virt = d.in_up ? 2 * d.Tin : d.Tin;
+  const int skip = win >> 20;   // timing probe (NSC_CONV_SKIP): 1 staging, 2 MFMA loop, 4 epilogue
+  win &= 0xfffff;
 
+  float wa[NPRE > 0 ? NPRE : 1][RT];
+  if constexpr (NPRE > 0) {
+    static_assert(NPRE == 0 || KS == 1, "preloaded weights: one wave per (row tile group, column tile)");
+#pragma unroll
+    for (int u = 0; u < NPRE; ++u)
+#pragma unroll
+      for (int r = 0; r < RT; ++r) {
+        const int o = min((rt0 + r) * 16 + l15, d.Cout - 1);       // rows >= Cout: clamped, never stored
+        if constexpr (CIN1) {
+          const int tap = 4 * u + kq;                                // taps >= K (last k-step) need a real zero
+          const float v = w[min(tap, d.K - 1) * d.Cout + o];
+          wa[u][r] = (u == NPRE - 1 && tap >= d.K) ? 0.f : v;
+        } else {
+          const int ncq_ = Cin4 >> 2;
+          const int tap = u / ncq_, ci = min(4 * (u - tap * ncq_) + kq, d.Cin - 1);   // ci >= Cin: zero rows of the x tile
+          wa[u][r] = w[(min(tap, d.K - 1) * d.Cin + ci) * d.Cout + o];
+        }
+      }
+  }
   // ---- stage x tile: xs[ci][j] = xin[b, ci, t0*stride - padL + j], zero outside (wave per row, lanes along time) ----
+  if (!(skip & 1))
   nsc_stage_rows<4 * KS, NSC_CONV_U>(xs, ldx, Cin4, d.Cin, win, x + (long)b * d.Cin * d.Tin, d.Tin, t0 * d.stride - d.padL, Tin_virt,
                          d.in_up, wave8, lane);
   __syncthreads();
@@ -71,7 +96,29 @@ __global__ __launch_bounds__(256 * KS) void conv1d_fwd_kernel(nsc_conv_desc d, c
   const int tcol0 = wave * NC * 16 + l15;  // this lane's first column (time offset inside the tile)
   const int Cout = d.Cout;
 
-  if constexpr (CIN1) {
+  if (skip & 2) {
+  } else if constexpr (NPRE > 0) {
+    const int ncq_ = CIN1 ? 1 : (Cin4 >> 2);
+#pragma unroll
+    for (int u = 0; u < NPRE; ++u) {
+      float bf[NC];
+      if constexpr (CIN1) {
+        const int tap = 4 * u + kq;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) bf[c] = xs[(tcol0 + c * 16) * d.stride + tap * d.dil];
+      } else {
+        const int tap = u / ncq_, cq = u - tap * ncq_;
+        const float* xrow = xs + kq * ldx + tcol0 * d.stride + (cq * 4 * ldx + tap * d.dil);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) bf[c] = xrow[c * 16 * d.stride];
+      }
+#pragma unroll
+      for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+          acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[u][r], bf[c], acc[r][c], 0, 0, 0);
+    }
+  } else if constexpr (CIN1) {
     // K order = tap; k-step s covers taps 4s..4s+3 (lane group kq).  xs has 3*dil zero slack at the end.
     // No control flow inside the MFMA loop (it would make hipcc shuttle the accumulators VGPR<->AGPR every step).
     const int nsteps = (d.K + 3) >> 2;
@@ -178,38 +225,49 @@ __global__ __launch_bounds__(256 * KS) void conv1d_fwd_kernel(nsc_conv_desc d, c
           for (int reg = 0; reg < 4; ++reg) red[((r * NC + c) * 4 + reg) * 64 + lane] = acc[r][c][reg];
     }
     __syncthreads();
-    if (khalf == 1) return;
+    if (khalf == 0) {
+#pragma unroll
+      for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) acc[r][c][reg] += red[((r * NC + c) * 4 + reg) * 64 + lane];
+    }
+  }
+
+  // ---- epilogue through LDS: the accumulators (D col = l15 -> time, row = 4*kq + reg -> channel) are transposed into an
+  // [RT*16][TT] tile over the dead x tile, then written out row-wise: a wave handles whole 256-B rows, so y, the
+  // residual and aux move as full cache lines (the D-fragment form wrote 64-B pieces and spent 16 of the 1x1 conv's
+  // 34 us here) and the per-channel bias is a scalar.
+  constexpr int TTc = 4 * NC * 16, LDO = TTc + 4;     // row stride == 4 (mod 32): fragment stores conflict-free
+  __syncthreads();                                     // every wave is done reading the x tile / the split-K buffer
+  float* os = xs;
+  if (KS == 1 || khalf == 0) {
 #pragma unroll
     for (int r = 0; r < RT; ++r)
 #pragma unroll
-      for (int c = 0; c < NC; ++c)
+      for (int reg = 0; reg < 4; ++reg)
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) acc[r][c][reg] += red[((r * NC + c) * 4 + reg) * 64 + lane];
+        for (int c = 0; c < NC; ++c) os[(r * 16 + kq * 4 + reg) * LDO + tcol0 + c * 16] = acc[r][c][reg];
   }
-
-  // ---- epilogue: D col = l15 -> time, row = 4*kq + reg -> channel ----
+  __syncthreads();
+  const int nrow = min(RT * 16, Cout - rt0 * 16);
+  for (int row = wave8; row < nrow; row += 4 * KS) {
+    const int ch = rt0 * 16 + row;
+    const float bv = bias ? bias[ch] : 0.f;
 #pragma unroll
-  for (int r = 0; r < RT; ++r) {
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int ch = (rt0 + r) * 16 + kq * 4 + reg;
-      if (ch >= Cout) continue;
-      const float bv = bias ? bias[ch] : 0.f;
-#pragma unroll
-      for (int c = 0; c < NC; ++c) {
-        const int t = t0 + tcol0 + c * 16;
-        if (t >= d.Tout) continue;
-        float v = acc[r][c][reg] + bv;
-        const long idx = ((long)b * Cout + ch) * d.Tout + t;
-        if (d.res_mode == 1) v += res[idx];
-        else if (d.res_mode == 2) v += res[(long)b * d.Tout + t];
-        v = nsc_apply_act(v, d.act);
-        if (d.mul_mode) v *= nsc_act_grad_from_out(aux[idx], d.mul_mode);
-        long oidx = idx;
-        if (d.out_mode == 1) oidx = ((long)b * (Cout >> 1) + (ch >> 1)) * (2L * d.Tout) + 2 * t + (ch & 1);
-        if (d.accumulate) y[oidx] += v;
-        else y[oidx] = v;
-      }
+    for (int hb = 0; hb < TTc / 64; ++hb) {
+      const int tl = hb * 64 + lane, t = t0 + tl;
+      if (t >= d.Tout) continue;
+      float v = os[row * LDO + tl] + bv;
+      const long idx = ((long)b * Cout + ch) * d.Tout + t;
+      if (d.res_mode == 1) v += res[idx];
+      else if (d.res_mode == 2) v += res[(long)b * d.Tout + t];
+      v = nsc_apply_act(v, d.act);
+      if (d.mul_mode) v *= nsc_act_grad_from_out(aux[idx], d.mul_mode);
+      const long oidx = d.out_mode == 1 ? ((long)b * (Cout >> 1) + (ch >> 1)) * (2L * d.Tout) + 2 * t + (ch & 1) : idx;
+      if (d.accumulate) y[oidx] += v;
+      else y[oidx] = v;
     }
   }
 }
@@ -224,7 +282,7 @@ static int round_ldx_fwd(int win, int stride) {
   return win | 1;
 }
 
-template <int RT, int NC, bool CIN1, int KS>
+template <int RT, int NC, bool CIN1, int KS, int NPRE = 0>
 static int launch_fwd_ks(const nsc_conv_desc* d, const float* x, const float* w, const float* bias, const float* res,
                          const float* aux, float* y, hipStream_t st) {
   const int TT = 4 * NC * 16;
@@ -234,15 +292,17 @@ static int launch_fwd_ks(const nsc_conv_desc* d, const float* x, const float* w,
   const int Cin4 = CIN1 ? 1 : ((d->Cin + 3) & ~3);
   size_t smem = (size_t)Cin4 * ldx * sizeof(float);
   if (KS == 2) smem = std::max(smem, (size_t)4 * RT * NC * 256 * sizeof(float));
+  smem = std::max(smem, (size_t)RT * 16 * (TT + 4) * sizeof(float));      // output tile of the row-wise epilogue
   NSC_REQUIRE(smem <= 160 * 1024, NSC_ERR_UNSUPPORTED, "conv1d_fwd: x tile %zu B exceeds LDS", smem);
-  auto kern = conv1d_fwd_kernel<RT, NC, CIN1, KS>;
+  auto kern = conv1d_fwd_kernel<RT, NC, CIN1, KS, NPRE>;
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "conv1d_fwd: set smem attr: %s", hipGetErrorString(e));
   }
   const int nrt = nsc_cdiv(d->Cout, 16);
   dim3 grid(nsc_cdiv(d->Tout, TT), d->B, nsc_cdiv(nrt, RT));
-  hipLaunchKernelGGL(kern, grid, dim3(256 * KS), smem, st, *d, x, w, bias, res, aux, y, ldx, win);
+  static const int skip = getenv("NSC_CONV_SKIP") ? atoi(getenv("NSC_CONV_SKIP")) : 0;
+  hipLaunchKernelGGL(kern, grid, dim3(256 * KS), smem, st, *d, x, w, bias, res, aux, y, ldx, win | (skip << 20));
   NSC_CHECK_LAUNCH("conv1d_fwd");
   return NSC_OK;
 }
@@ -250,8 +310,14 @@ static int launch_fwd_ks(const nsc_conv_desc* d, const float* x, const float* w,
 template <int RT, int NC, bool CIN1>
 static int launch_fwd(const nsc_conv_desc* d, const float* x, const float* w, const float* bias, const float* res,
                       const float* aux, float* y, hipStream_t st) {
+  static const bool no_pre = getenv("NSC_CONV_NOPRE") != nullptr;   // A/B switch for profiling
   if constexpr (!CIN1) {
     if (d->K >= 2) return launch_fwd_ks<RT, NC, CIN1, 2>(d, x, w, bias, res, aux, y, st);
+    if constexpr (RT == 7) {
+      if (!no_pre && d->K == 1 && ((d->Cin + 3) >> 2) == 25) return launch_fwd_ks<RT, NC, CIN1, 1, 25>(d, x, w, bias, res, aux, y, st);
+    }
+  } else if constexpr (RT == 7 || RT == 4) {
+    if (!no_pre && d->K > 52 && d->K <= 56) return launch_fwd_ks<RT, NC, CIN1, 1, 14>(d, x, w, bias, res, aux, y, st);
   }
   return launch_fwd_ks<RT, NC, CIN1, 1>(d, x, w, bias, res, aux, y, st);
 }
@@ -297,7 +363,9 @@ extern "C" int nsc_conv1d_fwd(const nsc_conv_desc* d, const float* x, const floa
   const bool cin1 = d->Cin == 1;
   const int Cin4 = cin1 ? 1 : ((d->Cin + 3) & ~3);
   const long smem2 = (long)Cin4 * ((127L) * d->stride + (d->K - 1) * d->dil + 40) * 4;
-  const bool nc2 = smem2 <= 72 * 1024 && d->Tout >= 128;
+  static const int force_nc = getenv("NSC_CONV_NC") ? atoi(getenv("NSC_CONV_NC")) : 0;   // profiling switch
+  bool nc2 = smem2 <= 72 * 1024 && d->Tout >= 128;
+  if (force_nc) nc2 = force_nc == 2;
   if (cin1) return nc2 ? dispatch_rt<2, true>(d, x, w, bias, res, aux, y, st)
                        : dispatch_rt<1, true>(d, x, w, bias, res, aux, y, st);
   return nc2 ? dispatch_rt<2, false>(d, x, w, bias, res, aux, y, st)
