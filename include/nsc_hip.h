@@ -72,6 +72,18 @@ int nsc_conv1d_wgrad(const nsc_conv_desc* d, const float* x, const float* dz, fl
 int nsc_conv1d_wgrad_ws(const nsc_conv_desc* d, const float* x, const float* dz, float* dw, float* db,
                         int flip_taps, float* workspace, long workspace_floats, void* stream);
 long nsc_conv1d_wgrad_workspace(const nsc_conv_desc* d);
+/* Batched form: the weight (+bias) gradients of njobs convs in a few launches (one per kernel class + one slab
+ * reduction each).  Like the block form, it exists because nothing but the optimizer reads these gradients, so a host can
+ * defer them to the end of the backward pass.  Gradients are ACCUMULATED into dw / db (db nullable). */
+typedef struct nsc_conv_wgrad_job {
+  nsc_conv_desc d;
+  const float *x, *dz;
+  float *dw, *db;
+  int flip_taps;
+} nsc_conv_wgrad_job;
+long nsc_conv1d_wgrad_batch_workspace(const nsc_conv_wgrad_job* jobs, int njobs);
+int nsc_conv1d_wgrad_batch(const nsc_conv_wgrad_job* jobs, int njobs, float* workspace, long workspace_floats,
+                           void* stream);
 /* wt[K-1-k, o, i] = w[k, i, o] : weights of the data-gradient conv (dgrad == nsc_conv1d_fwd on wt). */
 int nsc_weight_flip_transpose(const float* w, float* wt, int K, int Cin, int Cout, void* stream);
 

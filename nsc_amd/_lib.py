@@ -69,9 +69,17 @@ class BlockWgradJob(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("x", "h", "g", "dy", "da", "dz1", "grads")] + [(n, C.c_int) for n in ("C", "T", "dil")]
 
 
+class ConvWgradJob(C.Structure):
+    """include/nsc_hip.h: struct nsc_conv_wgrad_job"""
+    _fields_ = [("d", ConvDesc), ("x", C.c_void_p), ("dz", C.c_void_p), ("dw", C.c_void_p), ("db", C.c_void_p),
+                ("flip_taps", C.c_int)]
+
+
 PROTOTYPES["nsc_gated_block_wgrad_batch"] = [C.POINTER(BlockWgradJob), _I, _I, _I, _I, _P, _L, _P]
+PROTOTYPES["nsc_conv1d_wgrad_batch"] = [C.POINTER(ConvWgradJob), _I, _P, _L, _P]
 EXPORTS = sorted(list(PROTOTYPES) + ["nsc_version", "nsc_last_error", "nsc_gated_block_wgrad_workspace",
-                  "nsc_conv1d_wgrad_workspace", "nsc_gated_block_wgrad_batch_workspace"])
+                  "nsc_conv1d_wgrad_workspace", "nsc_gated_block_wgrad_batch_workspace",
+                  "nsc_conv1d_wgrad_batch_workspace"])
 
 
 class NscError(RuntimeError):
@@ -100,6 +108,8 @@ def load():
     lib.nsc_conv1d_wgrad_workspace.restype = C.c_long
     lib.nsc_gated_block_wgrad_batch_workspace.argtypes = [C.c_int]
     lib.nsc_gated_block_wgrad_batch_workspace.restype = C.c_long
+    lib.nsc_conv1d_wgrad_batch_workspace.argtypes = [C.POINTER(ConvWgradJob), C.c_int]
+    lib.nsc_conv1d_wgrad_batch_workspace.restype = C.c_long
     lib.nsc_version.restype = C.c_int
     lib.nsc_last_error.restype = C.c_char_p
     _lib = lib

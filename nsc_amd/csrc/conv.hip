@@ -575,11 +575,12 @@ extern "C" int nsc_conv1d_cout1_fwd(const nsc_conv_desc* d, const float* x, cons
 // private slab and conv_slab_reduce_kernel sums the slabs (192 K-splits x 90k float atomics on the same addresses took
 // 2/3 of the stride-2 conv's 283 us); without one, float atomics straight into dw/db (few K-splits).
 // ------------------------------------------------------------------------------------------------
+// bx / gx: this workgroup's K-split index and the number of K-splits; by: its row group
 template <int RT, int CT>
-__global__ __launch_bounds__(512) void conv1d_wgrad_kernel(nsc_conv_desc d, const float* __restrict__ x,
-                                                           const float* __restrict__ dz, float* __restrict__ dw,
-                                                           float* __restrict__ db, float* __restrict__ slab,
-                                                           long slab_stride, int flip, int ldx, int win, int nchunk_t) {
+__device__ __forceinline__ void conv_wgrad_body(const nsc_conv_desc& d, const float* __restrict__ x,
+                                                const float* __restrict__ dz, float* __restrict__ dw,
+                                                float* __restrict__ db, float* __restrict__ slab, long slab_stride,
+                                                int flip, int ldx, int win, int nchunk_t, int bx, int gx, int by) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int TT = 64, LDZ = 66;  // 66 % 32 == 2: conflict-free B-fragment reads
   float* xs = sm;                          // [Cin + 2][ldx] : rows Cin = zeros, Cin+1 = ones
@@ -590,7 +591,7 @@ __global__ __launch_bounds__(512) void conv1d_wgrad_kernel(nsc_conv_desc d, cons
   const int nW = d.K * d.Cin;
   const int nrows = nW + (db ? 1 : 0);
   const int Tin_virt = d.in_up ? 2 * d.Tin : d.Tin;
-  const int rt0 = (blockIdx.y * 8 + wave) * RT;   // first row tile of this wave
+  const int rt0 = (by * 8 + wave) * RT;   // first row tile of this wave
 
   // per-lane A-row offsets (row = rowtile*16 + l15)
   int rowoff[RT];
@@ -619,35 +620,97 @@ __global__ __launch_bounds__(512) void conv1d_wgrad_kernel(nsc_conv_desc d, cons
   }
   const bool busy = rt0 * 16 < nrows;   // waves past the last row tile only help staging
   const int nchunks = d.B * nchunk_t;
-  for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    const int b = chunk / nchunk_t, tc = chunk - b * nchunk_t;
-    const int t0 = tc * TT;
-    __syncthreads();  // previous chunk's reads done
-    nsc_stage_rows<8, 16>(xs, ldx, d.Cin, d.Cin, win, x + (long)b * d.Cin * d.Tin, d.Tin, t0 * d.stride - d.padL,
-                          Tin_virt, d.in_up, wave, lane);
-    nsc_stage_rows<8, 16>(dzs, LDZ, CT * 16, d.Cout, TT, dz + (long)b * d.Cout * d.Tout, d.Tout, t0, d.Tout, 0, wave,
-                          lane, TT);
-    __syncthreads();
-    if (busy) {
+  auto mfma_chunk = [&]() {
 #pragma unroll 2
-      for (int tt = 0; tt < TT / 4; ++tt) {
-        const int tloc = 4 * tt + kq;
-        float af[RT], bf[CT];
+    for (int tt = 0; tt < TT / 4; ++tt) {
+      const int tloc = 4 * tt + kq;
+      float af[RT], bf[CT];
 #pragma unroll
-        for (int r = 0; r < RT; ++r) af[r] = xs[rowoff[r] + tloc * d.stride];
+      for (int r = 0; r < RT; ++r) af[r] = xs[rowoff[r] + tloc * d.stride];
 #pragma unroll
-        for (int c = 0; c < CT; ++c) bf[c] = dzs[(c * 16 + l15) * LDZ + tloc];
+      for (int c = 0; c < CT; ++c) bf[c] = dzs[(c * 16 + l15) * LDZ + tloc];
 #pragma unroll
-        for (int r = 0; r < RT; ++r)
+      for (int r = 0; r < RT; ++r)
 #pragma unroll
-          for (int c = 0; c < CT; ++c)
-            acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r], bf[c], acc[r][c], 0, 0, 0);
+        for (int c = 0; c < CT; ++c)
+          acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r], bf[c], acc[r][c], 0, 0, 0);
+    }
+  };
+  // Register prefetch of the next chunk's operand tiles (raw buffer loads; out-of-frame columns come back as 0 from the
+  // bounds check) while this chunk's MFMAs run: staging and MFMA time were equal (~7 us per chunk of the stride-2 conv),
+  // serial.  Shapes outside the register budget (Cin > 104, window > 192 columns, zero-upsampled input) stage in place.
+  constexpr int NQX = 13, NH = 3, NQZ = 2 * CT;
+  if (!d.in_up && d.Cin <= 8 * NQX && win <= 64 * NH) {
+    const __amdgpu_buffer_rsrc_t sx =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (unsigned)((long)d.B * d.Cin * d.Tin * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t sz =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dz), 0, (unsigned)((long)d.B * d.Cout * d.Tout * 4), 0x00020000);
+    float px[NQX][NH], pz[NQZ];
+    const int OOB = 0x7ffffff0;
+    auto load_chunk = [&](int chunk) {
+      const int cc = __builtin_amdgcn_readfirstlane(chunk < nchunks ? chunk : bx);
+      const int b = cc / nchunk_t, t0 = (cc - b * nchunk_t) * TT;
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        const int j = h * 64 + lane;
+        const int u = t0 * d.stride - d.padL + j;
+        const int vo = (j < win && u >= 0 && u < d.Tin) ? u * 4 : OOB;
+        if (h * 64 < win) {                         // wave-uniform guards: only the rows / column blocks this shape has
+#pragma unroll
+          for (int q = 0; q < NQX; ++q)
+            if (8 * q < d.Cin)
+              px[q][h] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                       sx, vo, (b * d.Cin + min(wave + 8 * q, d.Cin - 1)) * d.Tin * 4, 0));
+        }
       }
+      const int vz = (t0 + lane < d.Tout) ? (t0 + lane) * 4 : OOB;
+#pragma unroll
+      for (int q = 0; q < NQZ; ++q)
+        pz[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                              sz, vz, (b * d.Cout + min(wave + 8 * q, d.Cout - 1)) * d.Tout * 4, 0));
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        const int j = h * 64 + lane;
+        if (j < ldx) {
+#pragma unroll
+          for (int q = 0; q < NQX; ++q) {
+            const int r = wave + 8 * q;
+            if (r < d.Cin) xs[r * ldx + j] = px[q][h];
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < NQZ; ++q) {
+        const int o = wave + 8 * q;
+        dzs[o * LDZ + lane] = o < d.Cout ? pz[q] : 0.f;
+      }
+    };
+    load_chunk(bx);
+    for (int chunk = bx; chunk < nchunks; chunk += gx) {
+      __syncthreads();  // previous chunk's reads done
+      store_chunk();
+      __syncthreads();
+      load_chunk(chunk + gx);
+      if (busy) mfma_chunk();
+    }
+  } else {
+    for (int chunk = bx; chunk < nchunks; chunk += gx) {
+      const int b = chunk / nchunk_t, tc = chunk - b * nchunk_t;
+      const int t0 = tc * TT;
+      __syncthreads();  // previous chunk's reads done
+      nsc_stage_rows<8, 16>(xs, ldx, d.Cin, d.Cin, win, x + (long)b * d.Cin * d.Tin, d.Tin, t0 * d.stride - d.padL,
+                            Tin_virt, d.in_up, wave, lane);
+      nsc_stage_rows<8, 16>(dzs, LDZ, CT * 16, d.Cout, TT, dz + (long)b * d.Cout * d.Tout, d.Tout, t0, d.Tout, 0, wave,
+                            lane, TT);
+      __syncthreads();
+      if (busy) mfma_chunk();
     }
   }
   if (!busy) return;
   // ---- flush: D col = l15 -> output channel, row = 4*kq + reg -> kk ----
-  float* sl = slab ? slab + (long)blockIdx.x * slab_stride : nullptr;
+  float* sl = slab ? slab + (long)bx * slab_stride : nullptr;
 #pragma unroll
   for (int r = 0; r < RT; ++r) {
 #pragma unroll
@@ -672,6 +735,87 @@ __global__ __launch_bounds__(512) void conv1d_wgrad_kernel(nsc_conv_desc d, cons
           atomicAdd(db + o, v);
         }
       }
+    }
+  }
+}
+
+template <int RT, int CT>
+__global__ __launch_bounds__(512) void conv1d_wgrad_kernel(nsc_conv_desc d, const float* __restrict__ x,
+                                                           const float* __restrict__ dz, float* __restrict__ dw,
+                                                           float* __restrict__ db, float* __restrict__ slab,
+                                                           long slab_stride, int flip, int ldx, int win, int nchunk_t) {
+  conv_wgrad_body<RT, CT>(d, x, dz, dw, db, slab, slab_stride, flip, ldx, win, nchunk_t, blockIdx.x, gridDim.x, blockIdx.y);
+}
+
+// ---- batched form: the weight gradients of up to NSC_CW_MAXJ convs (same RT/CT class) in ONE launch; every job always
+// flushes to its own slabs, summed by one conv_slab_reduce_batch_kernel launch.  The engine defers the per-conv weight
+// gradients to the end of the backward pass: alone, each is a ~30 us launch + a reduce launch for ~5 us of MFMA work.
+#define NSC_CW_MAXJ 10
+struct ConvWgradJobDev {
+  nsc_conv_desc d;
+  const float *x, *dz;
+  float *dw, *db;            // db != null marks "has bias row"
+  float* slab;
+  long slab_stride;
+  int flip, ldx, win, nchunk_t, gx, gy, wg0;
+};
+struct ConvWgradBatch {
+  ConvWgradJobDev j[NSC_CW_MAXJ];
+  int njobs;
+};
+template <int RT, int CT>
+__global__ __launch_bounds__(512) void conv1d_wgrad_batch_kernel(ConvWgradBatch t) {
+  const int w = blockIdx.x;
+  int j = 0;
+#pragma unroll
+  for (int q = 1; q < NSC_CW_MAXJ; ++q)
+    if (q < t.njobs && w >= t.j[q].wg0) j = q;
+  // copy the selected job with wave-uniform selects (a dynamically indexed kernarg array is spilled to scratch)
+  ConvWgradJobDev jb = t.j[0];
+#pragma unroll
+  for (int q = 1; q < NSC_CW_MAXJ; ++q)
+    if (q == j) jb = t.j[q];
+  const int wl = w - jb.wg0;
+  conv_wgrad_body<RT, CT>(jb.d, jb.x, jb.dz, jb.dw, jb.db, jb.slab, jb.slab_stride, jb.flip, jb.ldx, jb.win, jb.nchunk_t,
+                          wl % jb.gx, jb.gx, wl / jb.gx);
+}
+
+struct ConvReduceJob {
+  const float* slab;
+  long stride;
+  float *dw, *db;
+  int nslabs, K, Cin, Cout, n, flip;
+};
+struct ConvReduceBatch {
+  ConvReduceJob j[NSC_CW_MAXJ];
+};
+__global__ void conv_slab_reduce_batch_kernel(ConvReduceBatch t) {
+  ConvReduceJob jb = t.j[0];
+#pragma unroll
+  for (int q = 1; q < NSC_CW_MAXJ; ++q)
+    if (q == (int)blockIdx.y) jb = t.j[q];
+  const int nW = jb.K * jb.Cin * jb.Cout;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < jb.n; i += gridDim.x * blockDim.x) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int w = 0;
+    for (; w + 3 < jb.nslabs; w += 4) {
+      s0 += jb.slab[(long)w * jb.stride + i];
+      s1 += jb.slab[(long)(w + 1) * jb.stride + i];
+      s2 += jb.slab[(long)(w + 2) * jb.stride + i];
+      s3 += jb.slab[(long)(w + 3) * jb.stride + i];
+    }
+    for (; w < jb.nslabs; ++w) s0 += jb.slab[(long)w * jb.stride + i];
+    const float v = (s0 + s1) + (s2 + s3);
+    if (i < nW) {
+      int io = i;
+      if (jb.flip) {
+        const int kk = i / jb.Cout, o = i - kk * jb.Cout;
+        const int tap = kk / jb.Cin, ci = kk - tap * jb.Cin;
+        io = ((jb.K - 1 - tap) * jb.Cin + ci) * jb.Cout + o;
+      }
+      jb.dw[io] += v;          // one adder per element
+    } else {
+      jb.db[i - nW] += v;
     }
   }
 }
@@ -796,6 +940,140 @@ extern "C" int nsc_conv1d_wgrad_ws(const nsc_conv_desc* d, const float* x, const
 extern "C" int nsc_conv1d_wgrad(const nsc_conv_desc* d, const float* x, const float* dz, float* dw, float* db,
                                 int flip_taps, void* stream) {
   return nsc_conv1d_wgrad_ws(d, x, dz, dw, db, flip_taps, nullptr, 0, stream);
+}
+
+// ---- host side of the batched form ----
+struct CwPlan { int rt, ct, gy, nchunks; long stride; size_t smem; double weight; WgradPlan p; };
+
+static CwPlan cw_plan(const nsc_conv_wgrad_job& jb) {
+  CwPlan c;
+  const nsc_conv_desc* d = &jb.d;
+  const bool bias = jb.db != nullptr;
+  c.ct = nsc_cdiv(d->Cout, 16);
+  if (c.ct > 4) c.ct = 7;
+  c.rt = wgrad_big(d, bias) ? 2 : 1;
+  c.p = c.rt == 2 ? wgrad_plan<2>(d, c.ct, bias, true) : wgrad_plan<1>(d, c.ct, bias, true);
+  c.gy = c.p.gy;
+  c.nchunks = d->B * c.p.nchunk_t;
+  c.stride = c.p.slab_stride;
+  c.smem = c.p.smem;
+  c.weight = (double)c.nchunks * c.gy * (d->Cin * nsc_cdiv(c.p.win, 64) + c.ct * 16 + 4.0 * c.rt * c.ct);
+  return c;
+}
+
+// K-splits per job of one class: a budget of workgroups shared in proportion to the jobs' weights
+static void cw_split(const CwPlan* c, int n, int* gx) {
+  size_t smem = 0;
+  double tot = 0;
+  for (int q = 0; q < n; ++q) { smem = std::max(smem, c[q].smem); tot += c[q].weight; }
+  const int budget = smem <= 76 * 1024 ? 512 : 256;
+  for (int q = 0; q < n; ++q) {
+    int g = (int)(budget * c[q].weight / tot / c[q].gy + 0.5);
+    g = std::min(g, std::max(1, c[q].nchunks / 2));
+    gx[q] = std::max(1, g);
+  }
+}
+
+template <int RT, int CT>
+static int launch_cw_class(const nsc_conv_wgrad_job* jobs, const int* idx, const CwPlan* cp, int n, float* workspace,
+                           long workspace_floats, hipStream_t st) {
+  ConvWgradBatch t;
+  ConvReduceBatch r;
+  memset(&t, 0, sizeof(t));
+  memset(&r, 0, sizeof(r));
+  int gx[NSC_CW_MAXJ];
+  cw_split(cp, n, gx);
+  long off = 0;
+  int wg = 0, nmax = 0;
+  size_t smem = 0;
+  for (int q = 0; q < n; ++q) {
+    const nsc_conv_wgrad_job& jb = jobs[idx[q]];
+    ConvWgradJobDev& dv = t.j[q];
+    dv.d = jb.d; dv.x = jb.x; dv.dz = jb.dz; dv.dw = jb.dw; dv.db = jb.db;
+    dv.slab = workspace + off; dv.slab_stride = cp[q].stride;
+    dv.flip = jb.flip_taps; dv.ldx = cp[q].p.ldx; dv.win = cp[q].p.win; dv.nchunk_t = cp[q].p.nchunk_t;
+    dv.gx = gx[q]; dv.gy = cp[q].gy; dv.wg0 = wg;
+    ConvReduceJob& rj = r.j[q];
+    rj.slab = dv.slab; rj.stride = dv.slab_stride; rj.dw = jb.dw; rj.db = jb.db; rj.nslabs = gx[q];
+    rj.K = jb.d.K; rj.Cin = jb.d.Cin; rj.Cout = jb.d.Cout; rj.flip = jb.flip_taps;
+    rj.n = (jb.d.K * jb.d.Cin + (jb.db ? 1 : 0)) * jb.d.Cout;
+    nmax = std::max(nmax, rj.n);
+    off += (long)gx[q] * cp[q].stride;
+    wg += gx[q] * cp[q].gy;
+    smem = std::max(smem, cp[q].smem);
+  }
+  NSC_REQUIRE(off <= workspace_floats, NSC_ERR_BAD_ARG, "nsc_conv1d_wgrad_batch: workspace %ld floats < %ld", workspace_floats, off);
+  NSC_REQUIRE(smem <= 160 * 1024, NSC_ERR_UNSUPPORTED, "nsc_conv1d_wgrad_batch: tiles %zu B exceed LDS", smem);
+  t.njobs = n;
+  auto kern = conv1d_wgrad_batch_kernel<RT, CT>;
+  if (smem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "conv1d_wgrad_batch: set smem attr: %s", hipGetErrorString(e));
+  }
+  hipLaunchKernelGGL(kern, dim3(wg), dim3(512), smem, st, t);
+  NSC_CHECK_LAUNCH("conv1d_wgrad_batch");
+  hipLaunchKernelGGL(conv_slab_reduce_batch_kernel, dim3(std::min(64, nsc_cdiv(nmax, 256)), n), dim3(256), 0, st, r);
+  NSC_CHECK_LAUNCH("conv_slab_reduce_batch");
+  return NSC_OK;
+}
+
+static int cw_dispatch(int rt, int ct, const nsc_conv_wgrad_job* jobs, const int* idx, const CwPlan* cp, int n, float* ws,
+                       long wsf, hipStream_t st) {
+#define CW(RT_, CT_) if (rt == RT_ && ct == CT_) return launch_cw_class<RT_, CT_>(jobs, idx, cp, n, ws, wsf, st)
+  CW(1, 1); CW(1, 2); CW(1, 3); CW(1, 4); CW(1, 7); CW(2, 1); CW(2, 2); CW(2, 3); CW(2, 4); CW(2, 7);
+#undef CW
+  nsc_set_error("nsc_conv1d_wgrad_batch: no kernel for class (%d, %d)", rt, ct);
+  return NSC_ERR_UNSUPPORTED;
+}
+
+// visits the jobs class by class ((RT, CT) template instance), at most NSC_CW_MAXJ per launch; f(rt, ct, idx, plans, n)
+template <typename F>
+static int cw_for_each_class(const nsc_conv_wgrad_job* jobs, int njobs, F f) {
+  bool done[256] = {false};
+  NSC_REQUIRE(njobs <= 256, NSC_ERR_UNSUPPORTED, "nsc_conv1d_wgrad_batch: more than 256 jobs");
+  for (int a = 0; a < njobs; ++a) {
+    if (done[a]) continue;
+    const CwPlan pa = cw_plan(jobs[a]);
+    int idx[NSC_CW_MAXJ], n = 0;
+    CwPlan cp[NSC_CW_MAXJ];
+    for (int b = a; b < njobs && n < NSC_CW_MAXJ; ++b) {
+      if (done[b]) continue;
+      const CwPlan pb = cw_plan(jobs[b]);
+      if (pb.rt == pa.rt && pb.ct == pa.ct) { idx[n] = b; cp[n] = pb; ++n; done[b] = true; }
+    }
+    int rc = f(pa.rt, pa.ct, idx, cp, n);
+    if (rc) return rc;
+  }
+  return NSC_OK;
+}
+
+extern "C" long nsc_conv1d_wgrad_batch_workspace(const nsc_conv_wgrad_job* jobs, int njobs) {
+  if (!jobs || njobs <= 0) return 0;
+  long need = 0;
+  cw_for_each_class(jobs, njobs, [&](int, int, const int*, const CwPlan* cp, int n) {
+    int gx[NSC_CW_MAXJ];
+    cw_split(cp, n, gx);
+    long off = 0;
+    for (int q = 0; q < n; ++q) off += (long)gx[q] * cp[q].stride;
+    need = std::max(need, off);
+    return 0;
+  });
+  return need;
+}
+
+extern "C" int nsc_conv1d_wgrad_batch(const nsc_conv_wgrad_job* jobs, int njobs, float* workspace, long workspace_floats,
+                                      void* stream) {
+  NSC_REQUIRE(jobs && njobs > 0 && workspace, NSC_ERR_BAD_ARG, "nsc_conv1d_wgrad_batch: bad arguments");
+  for (int j = 0; j < njobs; ++j) {
+    int rc = check_desc(&jobs[j].d, "nsc_conv1d_wgrad_batch");
+    if (rc) return rc;
+    NSC_REQUIRE(jobs[j].x && jobs[j].dz && jobs[j].dw, NSC_ERR_BAD_ARG, "nsc_conv1d_wgrad_batch: job %d: null x/dz/dw", j);
+    NSC_REQUIRE(jobs[j].d.Cout <= 112, NSC_ERR_UNSUPPORTED, "nsc_conv1d_wgrad_batch: job %d: Cout %d > 112", j, jobs[j].d.Cout);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  return cw_for_each_class(jobs, njobs, [&](int rt, int ct, const int* idx, const CwPlan* cp, int n) {
+    return cw_dispatch(rt, ct, jobs, idx, cp, n, workspace, workspace_floats, st);
+  });
 }
 
 // ------------------------------------------------------------------------------------------------

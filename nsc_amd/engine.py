@@ -121,6 +121,10 @@ class _Conv:
     def wgrad(self, x, dz):
         e = self.eng
         dw, db = self._p(e.g_ptr, self.w_off), self._p(e.g_ptr, self.b_off)
+        if e.batch_conv_wgrad:
+            e._cw_flops += self.flops()
+            self._wgrad(x, dz, dw, db)
+            return
         tok = e.prof_begin("wgrad_mfma", self.flops())
         self._wgrad(x, dz, dw, db)
         e.prof_end(tok)
@@ -137,6 +141,15 @@ class _Conv:
 
     def _wgrad(self, x, dz, dw, db):
         e = self.eng
+        if e.batch_conv_wgrad:
+            # deferred to the end of the backward pass (x, dz are private to this conv and live until then)
+            d = self.wgrad_desc()
+            if self.Cout == 1:
+                e.defer_conv_wgrad(d, dz, x, dw, None, 1)
+                check(e.lib.nsc_sum_all(dz.data_ptr(), db, dz.numel(), e.stream()), "bias grad")
+            else:
+                e.defer_conv_wgrad(d, x, dz, dw, db, 0)
+            return
         st = e.side_fork()
         ws = e.wgrad_workspace(slot=e.side_idx)
         d = self.wgrad_desc()
@@ -503,6 +516,7 @@ class CascadeEngine:
         self.convs = []
         self._bufs = {}
         self._wg_jobs, self._wg_keep, self._wg_flops = [], [], 0.0
+        self._cw_jobs, self._cw_flops = [], 0.0
         if self.lpc:  # 'lpc_quan' scope is created before scope_1 (nsc_module:993-996)
             self.lpc_alpha_off = self.layout.add("lpc_quan/alpha", ())
             self.lpc_bins_off = self.layout.add("lpc_quan/bins", (len(lpc_coeff_lsf_bins),))
@@ -576,6 +590,9 @@ class CascadeEngine:
     # block width (nsc_gated_block_wgrad_batch): per-block launches walk only 2-4 tiles per workgroup at batch 128, so
     # their prologue, accumulator flush and slab reduction cost more than the MFMA work itself.
     batch_wgrad = True
+    batch_conv_wgrad = False  # the same for the convs outside gated blocks (nsc_conv1d_wgrad_batch; measured 4.20 vs 4.15 ms/step:
+                              # the per-conv launches hide in the gaps of the data-gradient chain); False = one launch per
+                              # conv on the side stream
 
     def defer_block_wgrad(self, blk, dz, da, dz1, dw1_ptr, flops):
         self._wg_jobs.append(_lib.BlockWgradJob(blk.x.data_ptr(), blk.h.data_ptr(), blk.g.data_ptr(), dz.data_ptr(),
@@ -583,8 +600,29 @@ class CascadeEngine:
         self._wg_keep += [blk.x, blk.h, blk.g, dz, da, dz1]
         self._wg_flops += flops
 
+    def defer_conv_wgrad(self, desc, x, dz, dw_ptr, db_ptr, flip):
+        self._cw_jobs.append(_lib.ConvWgradJob(desc, x.data_ptr(), dz.data_ptr(), dw_ptr, db_ptr, flip))
+        self._wg_keep += [x, dz]
+
+    def flush_conv_wgrads(self):
+        if not self._cw_jobs:
+            return
+        n = len(self._cw_jobs)
+        jobs = (_lib.ConvWgradJob * n)(*self._cw_jobs)
+        need = int(self.lib.nsc_conv1d_wgrad_batch_workspace(jobs, n))
+        ws = self._bufs.get("cwgrad.ws")
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.float32, device=self.device)
+            self._bufs["cwgrad.ws"] = ws
+        tok = self.prof_begin("wgrad_mfma", self._cw_flops)
+        check(self.lib.nsc_conv1d_wgrad_batch(jobs, n, ws.data_ptr(), ws.numel(), self.stream()), "conv1d_wgrad_batch")
+        self.prof_end(tok)
+        self._cw_jobs, self._cw_flops = [], 0.0
+
     def flush_block_wgrads(self):
+        self.flush_conv_wgrads()
         if not self._wg_jobs:
+            self._wg_keep = []
             return
         jobs = (_lib.BlockWgradJob * len(self._wg_jobs))(*self._wg_jobs)
         ws = self.wgrad_workspace(slot="batch")   # private: per-conv wgrads may still be running on the side stream

@@ -629,3 +629,43 @@ def test_block_wgrad_batch_equals_per_block_launches(lib):
     torch.cuda.synchronize()
     for i, (r, o_) in enumerate(zip(refs, outs)):
         assert_close(o_.cpu().numpy(), r.cpu().numpy(), tol=2e-4, what=f"batched block wgrad job {i} {shapes[i]}")
+
+
+def test_conv_wgrad_batch_equals_per_conv_launches(lib):
+    """nsc_conv1d_wgrad_batch (deferred; mixed shapes and kernel classes, incl. the role-swapped Cout == 1 form, stride 2 and a
+    bias-less job) == one nsc_conv1d_wgrad per conv."""
+    from nsc_amd._lib import ConvWgradJob
+    rng = np.random.default_rng(99)
+    B = 5
+    # (Cin, Cout, T, K, dil, stride, swapped)
+    shapes = [(1, 100, 512, 55, 1, 1, 0), (100, 100, 256, 1, 1, 1, 0), (20, 100, 256, 9, 1, 1, 0), (20, 20, 256, 15, 2, 1, 0),
+              (1, 20, 256, 1, 1, 1, 0), (100, 100, 512, 9, 1, 2, 0), (100, 1, 256, 55, 1, 1, 1), (50, 1, 512, 55, 1, 1, 1),
+              (20, 20, 256, 15, 1, 1, 0), (1, 100, 256, 55, 1, 1, 0), (7, 13, 300, 5, 3, 1, 0), (100, 100, 256, 1, 1, 1, 0),
+              (20, 100, 256, 9, 1, 1, 0)]
+    jobs, keep, refs, outs = [], [], [], []
+    for (Cin, Cout, T, K, dil, s, sw) in shapes:
+        Tout, padL, _ = O.same_pad(T, K, dil, s)
+        x = dev(rng.standard_normal((B, Cin, T)).astype(np.float32))
+        dz = dev(rng.standard_normal((B, Cout, Tout)).astype(np.float32))
+        dw_ref = torch.full((K, Cin, Cout), 0.25, device="cuda"); db_ref = torch.full((Cout,), 0.25, device="cuda")
+        dw = dw_ref.clone(); db = db_ref.clone()
+        if sw:   # Cout == 1: "input" = dz, "grad" = x, flipped taps, no bias row
+            d = _desc(B=B, Cin=1, Cout=Cin, Tin=Tout, Tout=T, K=K, dil=dil, padL=(K - 1) * dil - padL)
+            assert lib.nsc_conv1d_wgrad(C.byref(d), dz.data_ptr(), x.data_ptr(), dw_ref.data_ptr(), None, 1, _st()) == 0
+            jobs.append(ConvWgradJob(d, dz.data_ptr(), x.data_ptr(), dw.data_ptr(), None, 1))
+        else:
+            d = _desc(B=B, Cin=Cin, Cout=Cout, Tin=T, Tout=Tout, K=K, dil=dil, stride=s, padL=padL)
+            assert lib.nsc_conv1d_wgrad(C.byref(d), x.data_ptr(), dz.data_ptr(), dw_ref.data_ptr(), db_ref.data_ptr(), 0, _st()) == 0
+            jobs.append(ConvWgradJob(d, x.data_ptr(), dz.data_ptr(), dw.data_ptr(), db.data_ptr(), 0))
+        keep += [x, dz]; refs.append((dw_ref, db_ref)); outs.append((dw, db))
+    arr = (ConvWgradJob * len(jobs))(*jobs)
+    lib.nsc_conv1d_wgrad_batch_workspace.restype = C.c_long
+    nws = lib.nsc_conv1d_wgrad_batch_workspace(arr, len(jobs))
+    assert nws > 0
+    ws = torch.full((nws,), float("nan"), device="cuda")
+    rc = lib.nsc_conv1d_wgrad_batch(arr, len(jobs), ws.data_ptr(), nws, _st())
+    assert rc == 0, lib.nsc_last_error()
+    torch.cuda.synchronize()
+    for i, ((rw, rb), (ow, ob)) in enumerate(zip(refs, outs)):
+        assert_close(ow.cpu().numpy() - 0.25, rw.cpu().numpy() - 0.25, tol=2e-4, what=f"batched conv wgrad dW job {i} {shapes[i]}")
+        assert_close(ob.cpu().numpy() - 0.25, rb.cpu().numpy() - 0.25, tol=2e-4, what=f"batched conv wgrad db job {i} {shapes[i]}")
