@@ -185,6 +185,9 @@ int nsc_quantize_fwd(const float* code, const float* alpha, const float* bins, f
 /* entropy from a (possibly all-reduced) histogram: ent[0] = -sum h log2(h+1e-7), h = hist/sum(hist);
  * ghist[k] = d ent / d hist[k]. */
 int nsc_entropy_from_hist(const float* hist, int nb, float* ent, float* ghist, void* stream);
+/* entropy_coding_loss evaluated one frame at a time (the reference's validation loop feeds batches of 1,
+ * neural_speech_coding_module.py:685-722): ent[b] = entropy in bits of frame b's own soft histogram, p [B, L, nb]. */
+int nsc_frame_entropy(const float* p, int B, int L, int nb, float* ent, void* stream);
 /* backward.  Upstream gradients: dout[B*L] (of `out`), dp (nullable, explicit dL/dp [B*L,nb]),
  * plus the analytically fused loss terms  c_quan*quan_loss(p)[b] summed over b  and  ent_scale*entropy(p):
  *   dL/dp += c_quan/L * 0.5/sqrt(p+1e-20) + ent_scale*ghist[k].

@@ -39,6 +39,9 @@ def build_parser():
     parser.add_argument('--lpc_domain', action='store_true', help='LPC-residual (collaborative quantisation) path')
     parser.add_argument('--data_root', type=str, default=None, help='.npy of training frames; synthetic frames if absent')
     parser.add_argument('--max_batches_per_epoch', type=int, default=None, help='default 2500 like the reference')
+    parser.add_argument('--val_data_root', type=str, default=None, help='.npy of validation frames (tau controller); synthetic if absent')
+    parser.add_argument('--tau_from_validation', type=int, default=1,
+                        help='1: tau follows the per-frame entropy of validation frames like the reference; 0: the last training batch')
     parser.add_argument('--out_root', type=str, default='.', help="where ./check and ./doc live")
     parser.add_argument('--model_id', type=str, default=None, help='fix the random model id')
     parser.add_argument('--seed', type=int, default=20200504)

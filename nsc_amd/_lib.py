@@ -31,6 +31,7 @@ PROTOTYPES = {
     "nsc_conv1d_fwd": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P],
     "nsc_conv1d_cout1_fwd": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P],
     "nsc_conv1d_wgrad": [C.POINTER(ConvDesc), _P, _P, _P, _P, _I, _P],
+    "nsc_frame_entropy": [_P, _I, _I, _I, _P, _P],
     "nsc_conv1d_wgrad_ws": [C.POINTER(ConvDesc), _P, _P, _P, _P, _I, _P, _L, _P],
     "nsc_weight_flip_transpose": [_P, _P, _I, _I, _I, _P],
     "nsc_gated_block_fwd": [_P] * 14 + [_I] * 7 + [_P],

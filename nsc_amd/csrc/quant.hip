@@ -397,6 +397,58 @@ __global__ __launch_bounds__(256) void entropy_from_hist_kernel(const float* __r
     }
   }
 }
+// Per-FRAME entropy of the soft assignments: what the reference's validation loop reads when it evaluates
+// entropy_coding_loss one frame at a time (neural_speech_coding_module.py:685-722: batch of 1 => the histogram is that of
+// a single frame).  ent[b] = -sum_k h log2(h + 1e-7), h = sum_l p[b,l,k] / sum_{l,k} p[b,l,k].  One workgroup per frame.
+__global__ __launch_bounds__(256) void frame_entropy_kernel(const float* __restrict__ p, int L, int nb,
+                                                            float* __restrict__ ent) {
+  extern __shared__ float sh[];           // [nb] histogram + [256] reduction scratch
+  float* red = sh + nb;
+  const int tid = threadIdx.x;
+  const float* pb = p + (long)blockIdx.x * L * nb;
+  for (int k = tid; k < nb; k += 256) sh[k] = 0.f;
+  __syncthreads();
+  // thread t owns bin (t % nb) of rows t / nb, t / nb + 256 / nb, ... when nb divides 256; otherwise a plain strided walk
+  const int n = L * nb;
+  if (256 % nb == 0) {
+    const int k = tid % nb, rows = 256 / nb;
+    float s = 0.f;
+    for (int l = tid / nb; l < L; l += rows) s += pb[l * nb + k];
+    atomicAdd(&sh[k], s);
+  } else {
+    for (int e = tid; e < n; e += 256) atomicAdd(&sh[e % nb], pb[e]);
+  }
+  __syncthreads();
+  float s = 0.f;
+  for (int k = tid; k < nb; k += 256) s += sh[k];
+  red[tid] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  const float S = red[0];
+  __syncthreads();
+  float a = 0.f;
+  for (int k = tid; k < nb; k += 256) {
+    const float h = sh[k] / S;
+    a -= h * logf(h + 1e-7f);
+  }
+  red[tid] = a;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) ent[blockIdx.x] = red[0] * 1.4426950408889634f;
+}
+extern "C" int nsc_frame_entropy(const float* p, int B, int L, int nb, float* ent, void* stream) {
+  NSC_REQUIRE(p && ent && B > 0 && L > 0 && nb > 0, NSC_ERR_BAD_ARG, "nsc_frame_entropy: bad args");
+  hipLaunchKernelGGL(frame_entropy_kernel, dim3(B), dim3(256), (nb + 256) * sizeof(float), (hipStream_t)stream, p, L, nb, ent);
+  NSC_CHECK_LAUNCH("frame_entropy");
+  return NSC_OK;
+}
+
 extern "C" int nsc_entropy_from_hist(const float* hist, int nb, float* ent, float* ghist, void* stream) {
   NSC_REQUIRE(hist && nb > 0, NSC_ERR_BAD_ARG, "nsc_entropy_from_hist: bad args");
   hipLaunchKernelGGL(entropy_from_hist_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, hist, nb, ent, ghist);

@@ -866,6 +866,22 @@ class CascadeEngine:
         self.side_join()
         return dict(time=self.time, freq=self.freq, quan=[c.quan for c in self.codecs], ent=ents)
 
+    def frame_entropies(self, x, lpc_x=None):
+        """Per-frame entropy (bits) of every codec's soft assignment, as the reference's validation loop measures it:
+        frames are fed one at a time with the_share=False, is_quan_on=1 (nsc_module:685-722), so entropy_coding_loss sees
+        the histogram of a single frame.  Here the whole batch goes through one forward and nsc_frame_entropy evaluates
+        each frame's own histogram.  Returns a [num_codecs, B] tensor."""
+        self._enter()
+        try:
+            self.forward(x, 1.0, False, lpc_x=lpc_x, want_p=True)
+            out = self.buf("val.frame_ent", (self.N, self.B))
+            for i, c in enumerate(self.codecs):
+                check(self.lib.nsc_frame_entropy(c.p.data_ptr(), self.B, c.L, c.nb, out[i].data_ptr(), self.stream()),
+                      "frame_entropy")
+            return out
+        finally:
+            self._leave()
+
     def adam_step(self, scopes, lr, slot=1, beta1=0.9, beta2=0.999, eps=1e-8):
         """TF1 Adam on the flat ranges of the given scopes (independent state per optimizer slot)."""
         st = self.adam[slot]

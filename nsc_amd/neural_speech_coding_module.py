@@ -55,6 +55,9 @@ class neuralSpeechCodingModule(object):
         self._is_pure_time_domain = not bool(getattr(arg, "lpc_domain", not K.is_pure_time_domain))
         self._max_batches = getattr(arg, "max_batches_per_epoch", None) or 2500     # nsc_module:118
         self._data_root = getattr(arg, "data_root", None)
+        self._val_data_root = getattr(arg, "val_data_root", None)
+        self._tau_from_validation = bool(getattr(arg, "tau_from_validation", 1))   # reference behaviour
+        self._val_data = None
         self._out_root = getattr(arg, "out_root", ".") or "."
         self._seed = int(getattr(arg, "seed", 20200504) or 20200504)
         self._comm = getattr(arg, "comm", None)
@@ -83,6 +86,43 @@ class neuralSpeechCodingModule(object):
                 lsf = np.sort(rng.uniform(0.03, 3.1, (nb, self._lpc_order)), axis=1).astype(np.float32)
                 res = (np.clip(0.03 * rng.standard_normal((nb, K.frame_length)), -1, 1) * training_window()).astype(np.float32)
                 self._tr_data = np.concatenate([frames, lsf, res], 1)
+
+    def _load_validation_data(self):
+        """Frames the tau controller's entropy is measured on (the reference reads it off its validation utterances,
+        nsc_module:462-470 -> end2end_eval :656-740).  A file next to the training data, or synthetic frames from another seed."""
+        root = self._val_data_root
+        n = 4 * self._batch_size
+        if root and os.path.exists(root):
+            self._val_data = np.load(root)[:n].astype(np.float32)
+            return
+        rng = np.random.default_rng(4321)
+        frames = (np.clip(0.03 * rng.standard_normal((n, K.frame_length)), -1, 1) * training_window()).astype(np.float32)
+        if self._is_pure_time_domain:
+            self._val_data = frames
+        else:
+            lsf = np.sort(rng.uniform(0.03, 3.1, (n, self._lpc_order)), axis=1).astype(np.float32)
+            self._val_data = np.concatenate([frames, lsf, frames], 1)
+
+    def validation_entropy(self, eng):
+        """Mean per-frame entropy of each codec over the validation frames (one forward per batch; the per-frame
+        histograms are separated on the GPU by nsc_frame_entropy).  Returns a list, one value per codec."""
+        if getattr(self, "_val_data", None) is None:
+            self._load_validation_data()
+        B, dev = self._batch_size, eng.device
+        tot, cnt = None, 0
+        for k in range(0, self._val_data.shape[0] - B + 1, B):
+            rows = self._val_data[k:k + B]
+            if self._is_pure_time_domain:
+                x = torch.from_numpy(np.ascontiguousarray(rows[:, :K.frame_length].reshape(B, 1, -1))).to(dev)
+                lpc_x = None
+            else:
+                o = K.frame_length + self._lpc_order
+                x = torch.from_numpy(np.ascontiguousarray(rows[:, o:o + K.frame_length].reshape(B, 1, -1))).to(dev)
+                lpc_x = torch.from_numpy(np.ascontiguousarray(rows[:, K.frame_length:o].reshape(B, self._lpc_order, 1))).to(dev)
+            e = eng.frame_entropies(x, lpc_x=lpc_x).sum(dim=1)
+            tot = e if tot is None else tot + e
+            cnt += B
+        return [float(v) / cnt for v in tot.cpu().numpy()] if cnt else None
 
     def _write_to_file_and_update_to_display(self, the_string):
         """nsc_module:73-79."""
@@ -253,6 +293,11 @@ class neuralSpeechCodingModule(object):
             elapsed = time.perf_counter() - start
             np.random.shuffle(self._tr_data)                                       # nsc_module:460
             ents = [float(e.item()) for e in terms["ent"]] if terms else [0.0]
+            if self._tau_from_validation and cfg.get("is_quan_on", 1.0) == 1.0:
+                # the control signal of the reference: per-frame entropy on held-out frames (nsc_module:462-470, 715-733)
+                vents = self.validation_entropy(eng)
+                if vents:
+                    ents = vents
             fully_entropy = ents[-1] if flag != 'finetune' else float(sum(ents))
             tl, fl_ = float(terms["time"].mean().item()), float(terms["freq"].mean().item())
             ql = float(terms["quan"][-1].mean().item())

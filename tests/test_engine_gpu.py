@@ -268,3 +268,20 @@ def test_data_parallel_engine_two_ranks_equals_one_process(tmp_path):
     # reduction-order noise floor may differ (a vanishing fraction)
     assert res["perr"] < 2e-3, res
     assert np.allclose(res["ent"], res["ent_ref"], rtol=1e-5), res   # entropy is that of the GLOBAL batch on every rank
+
+
+def test_validation_frame_entropies_match_batch_of_one_oracle():
+    """engine.frame_entropies (one batched forward + per-frame histograms) == the oracle run one frame at a time with
+    the_share=False, is_quan_on=1, as the reference's validation loop does (nsc_module:685-722)."""
+    B = 3
+    ps = make_store(2, [[2], [2]], [32, 32])
+    for i in (1, 2):                                  # a softer alpha so the per-frame histograms are not one-hot
+        ps.params[f"scope_{i}/alpha"] = np.array(-8.0)
+    x = synth_frames(B)
+    eng = _engine(B, 2, [[2], [2]], [32, 32], ps)
+    got = eng.frame_entropies(dev(x.transpose(0, 2, 1))).cpu().numpy()
+    for b in range(B):
+        ps.begin_replay()
+        outs, _ = O.cascade_forward(x[b:b + 1].astype(np.float64), ps, BKD, [[2], [2]], [32, 32], 1.0, False)
+        ref = [O.entropy_coding_loss(o["p"]) for o in outs]
+        assert np.allclose(got[:, b], ref, rtol=2e-4, atol=2e-4), (b, got[:, b], ref)

@@ -669,3 +669,18 @@ def test_conv_wgrad_batch_equals_per_conv_launches(lib):
     for i, ((rw, rb), (ow, ob)) in enumerate(zip(refs, outs)):
         assert_close(ow.cpu().numpy() - 0.25, rw.cpu().numpy() - 0.25, tol=2e-4, what=f"batched conv wgrad dW job {i} {shapes[i]}")
         assert_close(ob.cpu().numpy() - 0.25, rb.cpu().numpy() - 0.25, tol=2e-4, what=f"batched conv wgrad db job {i} {shapes[i]}")
+
+
+@pytest.mark.parametrize("shape", [(7, 256, 32), (3, 16, 256), (4, 128, 32), (2, 50, 24)])
+def test_frame_entropy(lib, shape):
+    """nsc_frame_entropy == entropy_coding_loss (loss_terms_and_measures.py:262-267) applied to one frame at a time."""
+    B, L, nb = shape
+    rng = np.random.default_rng(B * 1000 + L + nb)
+    z = rng.standard_normal((B, L, nb)) * 3
+    p = np.exp(z - z.max(-1, keepdims=True)); p /= p.sum(-1, keepdims=True)
+    p[0] = 0; p[0, :, 3] = 1.0                      # a frame that uses one bin: entropy ~ 0
+    ent = torch.full((B,), float("nan"), device="cuda")
+    assert lib.nsc_frame_entropy(P(p.astype(np.float32)), B, L, nb, ent.data_ptr(), _st()) == 0
+    ref = np.array([O.entropy_coding_loss(p[b:b + 1]) for b in range(B)])
+    got = ent.cpu().numpy()
+    assert np.all(np.abs(got - ref) <= 1e-4 * np.maximum(1.0, np.abs(ref))), (got, ref)
