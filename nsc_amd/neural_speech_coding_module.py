@@ -298,6 +298,10 @@ class neuralSpeechCodingModule(object):
                 vents = self.validation_entropy(eng)
                 if vents:
                     ents = vents
+                # artefact of the reference's validation pass (nsc_module:740): 'bins<id><epoch>.npy'
+                if not (self._comm and self._comm.rank != 0):
+                    np.save(os.path.join(self._out_root, 'bins' + self._rand_model_id + str(i) + '.npy'),
+                            eng.view(f"scope_{len(eng.codecs)}/bins").detach().cpu().numpy())
             fully_entropy = ents[-1] if flag != 'finetune' else float(sum(ents))
             tl, fl_ = float(terms["time"].mean().item()), float(terms["freq"].mean().item())
             ql = float(terms["quan"][-1].mean().item())

@@ -107,6 +107,9 @@ def test_cli_phases_cascaded_then_finetune_then_feedforward(tmp_path):
     assert "scope_2|conv1d|kernel" in z2.files and "scope_2|conv1d|kernel" not in z1.files
     journal = open(glob.glob(str(tmp_path / "doc" / "*_journal.txt"))[0]).read()
     assert journal.count("Epoch") == 3                        # 2 epochs of codec 1 + 1 follower epoch
+    bins_art = sorted(os.path.basename(p) for p in glob.glob(str(tmp_path / "bins1234567*.npy")))
+    assert bins_art == ["bins12345670.npy", "bins12345671.npy"]   # one per epoch that ran the quantizer (nsc_module:740)
+    assert np.load(tmp_path / bins_art[-1]).shape == (32,)
     a5 = _args(tmp_path, the_strides="2", training_mode="5", base_model_id="1234567")
     m5 = CMRL(a5)
     m5.model("finetune", a5)
