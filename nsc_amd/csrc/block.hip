@@ -258,6 +258,30 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, kq = lane >> 4;
 
+  // the first tile's x goes out before the weights: its HBM round trip is the longest latency of the prologue
+  // x tile prefetch: wave w owns rows w, w+8, ...; lanes along time (two 64-column halves).  Raw buffer loads: scalar row
+  // offset, per-lane time offset, out-of-frame columns pointed past the descriptor so the hardware returns 0 - no
+  // address VALU and no value selects (with selects the compiler serialised the loads under register pressure).
+  float pf[NQ][2];
+  const __amdgpu_buffer_rsrc_t sx =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (unsigned)((long)a.B * C * T * 4), 0x00020000);
+  auto prefetch = [&](int tile) {
+    const int tl = __builtin_amdgcn_readfirstlane(tile < ntiles ? tile : 0);   // past the end: a harmless re-read
+    const int b = tl / tpf, t0 = (tl - b * tpf) * TT;
+    const int OOB = 0x7ffffff0;
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+      const int j = hb * 64 + lane;
+      const int t = t0 - H + j;
+      const int vo = (j < WX && t >= 0 && t < T) ? t * 4 : OOB;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int r = min(wave + 8 * q, C - 1);      // pad rows: stored as zeros below
+        pf[q][hb] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(sx, vo, (b * C + r) * T * 4, 0));
+      }
+    }
+  };
+  prefetch(blockIdx.x);
   // ---- once per workgroup: weights -> LDS / registers ----
   // Every load below uses a CLAMPED index instead of a mask: pad rows of A (output channels >= 20 / >= C) only feed
   // output rows that are never stored, and pad k-rows (ci >= C) multiply x rows that phase 0 writes as zeros, so any
@@ -321,29 +345,6 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
     }
   }
 
-  // x tile prefetch: wave w owns rows w, w+8, ...; lanes along time (two 64-column halves).  Raw buffer loads: scalar row
-  // offset, per-lane time offset, out-of-frame columns pointed past the descriptor so the hardware returns 0 - no
-  // address VALU and no value selects (with selects the compiler serialised the loads under register pressure).
-  float pf[NQ][2];
-  const __amdgpu_buffer_rsrc_t sx =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (unsigned)((long)a.B * C * T * 4), 0x00020000);
-  auto prefetch = [&](int tile) {
-    const int tl = __builtin_amdgcn_readfirstlane(tile < ntiles ? tile : 0);   // past the end: a harmless re-read
-    const int b = tl / tpf, t0 = (tl - b * tpf) * TT;
-    const int OOB = 0x7ffffff0;
-#pragma unroll
-    for (int hb = 0; hb < 2; ++hb) {
-      const int j = hb * 64 + lane;
-      const int t = t0 - H + j;
-      const int vo = (j < WX && t >= 0 && t < T) ? t * 4 : OOB;
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const int r = min(wave + 8 * q, C - 1);      // pad rows: stored as zeros below
-        pf[q][hb] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(sx, vo, (b * C + r) * T * 4, 0));
-      }
-    }
-  };
-  prefetch(blockIdx.x);
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int b = tile / tpf, t0 = (tile - b * tpf) * TT;
@@ -1935,30 +1936,7 @@ __global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs 
                                                    // lands on different SIMDs for the two row tiles)
   const int cic = min(rt * 16 + l15, NARROW - 1);  // A-fragment row (rows >= 20: clamped, never stored)
 
-  // ---- once per workgroup: weights -> registers / LDS (clamped indices: pad k-rows meet zero rows of the staged
-  // tiles; only k-steps / taps past the end need a real zero) ----
-  for (int e = tid; e < K15 * 2 * NARROW * NARROW; e += 512) {
-    const int tp = e / (2 * NARROW * NARROW), r = e - tp * 2 * NARROW * NARROW;
-    const int cp = r / NARROW, ci = r - cp * NARROW;
-    w15s[e] = cp < NARROW ? a.wtl[(tp * NARROW + cp) * NARROW + ci] : a.wtr[(tp * NARROW + cp - NARROW) * NARROW + ci];
-  }
-  // k9 gradient: K-quarter kg owns the channel groups cq = kg + 4j of every tap, so the B-fragment address of step
-  // (tap', j) is lane base + the compile-time offset (16 j LDY + tap'): no per-step address registers.
-  float w9r[K9][NJ9];
-#pragma unroll
-  for (int tp = 0; tp < K9; ++tp)
-#pragma unroll
-    for (int j = 0; j < NJ9; ++j) {
-      const int cq = kg + 4 * j;                       // >= NK9 only for j = NJ9-1 of some kg: that step is skipped
-      w9r[tp][j] = a.wt9[((long)tp * C + min(4 * cq + kq, C - 1)) * NARROW + cic];
-    }
-  const int rt1 = RT9 == 7 ? (wave < 7 ? wave : 6) : (wave & 3);
-  const int cb1 = RT9 == 7 ? 0 : (wave >> 2) * 32;
-  constexpr int NC1 = RT9 == 7 ? 4 : 2;
-  float w1r[5];
-#pragma unroll
-  for (int s5 = 0; s5 < 5; ++s5) w1r[s5] = a.wt1[(s5 * 4 + kq) * C + min(rt1 * 16 + l15, C - 1)];
-
+  // the first tile's x goes out before the weights: its HBM round trip is the longest latency of the prologue
   // ---- prefetch of the next tile: dy (wave w rows w, w+8, ...), lin / tanh (rows w, w+8, w+16), h (elementwise map) ----
   const __amdgpu_buffer_rsrc_t sdy =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, (unsigned)((long)a.B * C * T * 4), 0x00020000);
@@ -2009,6 +1987,34 @@ __global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs 
   };
   prefetch_dy(blockIdx.x);
   prefetch_a(blockIdx.x);
+  // ---- once per workgroup: weights -> registers / LDS (clamped indices: pad k-rows meet zero rows of the staged
+  // tiles; only k-steps / taps past the end need a real zero) ----
+  for (int e = tid; e < K15 * 2 * NARROW * NARROW; e += 512) {
+    const int tp = e / (2 * NARROW * NARROW), r = e - tp * 2 * NARROW * NARROW;
+    const int cp = r / NARROW, ci = r - cp * NARROW;
+    w15s[e] = cp < NARROW ? a.wtl[(tp * NARROW + cp) * NARROW + ci] : a.wtr[(tp * NARROW + cp - NARROW) * NARROW + ci];
+  }
+  // k9 gradient: K-quarter kg owns the channel groups cq = kg + 4j of every tap, so the B-fragment address of step
+  // (tap', j) is lane base + the compile-time offset (16 j LDY + tap'): no per-step address registers.
+  // NK9 = 4 (NJ9-1) + 1 for both shapes: the one left-over channel group (cq = NK9-1) is shared out by TAP (quarter kg takes
+  // taps kg, kg+4, kg+8 < 9), so the quarters carry 57 | 56 | 56 | 56 k-steps instead of 63 | 54 | 54 | 54.
+  static_assert(NK9 == 4 * (NJ9 - 1) + 1, "left-over channel group is shared out by tap");
+  float w9r[K9][NJ9 - 1], w9x[3];
+#pragma unroll
+  for (int tp = 0; tp < K9; ++tp)
+#pragma unroll
+    for (int j = 0; j < NJ9 - 1; ++j)
+      w9r[tp][j] = a.wt9[((long)tp * C + min(4 * (kg + 4 * j) + kq, C - 1)) * NARROW + cic];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    w9x[i] = a.wt9[((long)min(kg + 4 * i, K9 - 1) * C + min(4 * (NK9 - 1) + kq, C - 1)) * NARROW + cic];
+  const int rt1 = RT9 == 7 ? (wave < 7 ? wave : 6) : (wave & 3);
+  const int cb1 = RT9 == 7 ? 0 : (wave >> 2) * 32;
+  constexpr int NC1 = RT9 == 7 ? 4 : 2;
+  float w1r[5];
+#pragma unroll
+  for (int s5 = 0; s5 < 5; ++s5) w1r[s5] = a.wt1[(s5 * 4 + kq) * C + min(rt1 * 16 + l15, C - 1)];
+
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int b = tile / tpf, t0 = (tile - b * tpf) * TT;
@@ -2067,14 +2073,16 @@ __global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs 
         for (int ct = 0; ct < NCTA; ++ct) acc[ct] = mfma4(w9r[tp][j], bc[ct], acc[ct]);
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (kg + 4 * (NJ9 - 1) < NK9) {                      // wave-uniform: the quarters that own one more channel group
+      {                                                    // the left-over channel group: this quarter's taps kg + 4 i
+        const float* yx = dys + (4 * (NK9 - 1) + kq) * LDY + l15 + kg;
 #pragma unroll
-        for (int tp = 0; tp < K9; ++tp) {
+        for (int i = 0; i < 3; ++i) {
+          if (i == 2 && kg != 0) break;                      // tap kg + 8 exists for quarter 0 only (wave-uniform)
 #pragma unroll
-          for (int ct = 0; ct < NCTA; ++ct) bc[ct] = yb[16 * (NJ9 - 1) * LDY + tp + ct * 16];
+          for (int ct = 0; ct < NCTA; ++ct) bc[ct] = yx[4 * i + ct * 16];
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int ct = 0; ct < NCTA; ++ct) acc[ct] = mfma4(w9r[tp][NJ9 - 1], bc[ct], acc[ct]);
+          for (int ct = 0; ct < NCTA; ++ct) acc[ct] = mfma4(w9x[i], bc[ct], acc[ct]);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
