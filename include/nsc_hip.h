@@ -51,7 +51,8 @@ typedef struct nsc_conv_desc {
   int act;        /* nsc_act */
   int res_mode;   /* 0 none, 1 res[B,Cout,Tout], 2 broadcast res[B,1,Tout] */
   int mul_mode;   /* 0 none, 1 v *= lrelu'(aux), 2 v *= tanh'(aux) = 1-aux^2 ; aux[B,Cout,Tout] is an activation OUTPUT */
-  int out_mode;   /* 0 plain y[B,Cout,Tout]; 1 sub-pixel shuffle: y[B,Cout/2,2*Tout], y[b,o>>1,2t+(o&1)] (nsc_module:158-167) */
+  int out_mode;   /* 0 plain y[B,Cout,Tout]; 1 sub-pixel shuffle: y[B,Cout/2,2*Tout], y[b,o>>1,2t+(o&1)] (nsc_module:158-167);
+                     with out_mode 1, res / aux are laid out like the OUTPUT */
   int in_up;      /* 0 plain; 1 virtual input u: x[u/2] if u even else 0, virtual length 2*Tin */
   int accumulate; /* 0 y = v ; 1 y += v */
 } nsc_conv_desc;

@@ -252,6 +252,30 @@ __global__ __launch_bounds__(256 * KS) void conv1d_fwd_kernel(nsc_conv_desc d, c
   }
   __syncthreads();
   const int nrow = min(RT * 16, Cout - rt0 * 16);
+  if (d.out_mode == 1) {
+    // sub-pixel shuffle: output row (ch >> 1) interleaves LDS rows 2c, 2c+1 in time, so a wave still writes whole lines;
+    // residual / aux (if any) are laid out like the OUTPUT [B, Cout/2, 2 Tout]
+    for (int orow = wave8; 2 * orow < nrow; orow += 4 * KS) {
+      const int och = (rt0 * 16 >> 1) + orow;
+      const float b0 = bias ? bias[rt0 * 16 + 2 * orow] : 0.f;
+      const float b1 = (bias && 2 * orow + 1 < nrow) ? bias[rt0 * 16 + 2 * orow + 1] : 0.f;
+#pragma unroll
+      for (int hb = 0; hb < 2 * TTc / 64; ++hb) {
+        const int tl2 = hb * 64 + lane, par = tl2 & 1, tl = tl2 >> 1;
+        const int t2 = 2 * t0 + tl2;
+        if (t2 >= 2 * d.Tout || 2 * orow + par >= nrow) continue;
+        float v = os[(2 * orow + par) * LDO + tl] + (par ? b1 : b0);
+        const long oidx = ((long)b * (Cout >> 1) + och) * (2L * d.Tout) + t2;
+        if (d.res_mode == 1) v += res[oidx];
+        else if (d.res_mode == 2) v += res[(long)b * 2 * d.Tout + t2];
+        v = nsc_apply_act(v, d.act);
+        if (d.mul_mode) v *= nsc_act_grad_from_out(aux[oidx], d.mul_mode);
+        if (d.accumulate) y[oidx] += v;
+        else y[oidx] = v;
+      }
+    }
+    return;
+  }
   for (int row = wave8; row < nrow; row += 4 * KS) {
     const int ch = rt0 * 16 + row;
     const float bv = bias ? bias[ch] : 0.f;

@@ -317,11 +317,12 @@ extern "C" int nsc_overlap_add(const float* frames, int nframes, const float* wi
   return NSC_OK;
 }
 
-// dst[e] = src[idx[e]]  (one launch rebuilds every flipped/transposed dgrad weight from the flat parameter buffer)
+// dst[e] = src[idx[e]], or 0 where idx[e] < 0  (one launch rebuilds every flipped/transposed dgrad weight from the flat
+// parameter buffer; negative entries are the structural zeros of the polyphase stride-2 data-gradient kernels)
 __global__ void gather_kernel(const float* __restrict__ src, const int* __restrict__ idx, float* __restrict__ dst,
                               long n) {
   for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x)
-    dst[e] = src[idx[e]];
+    dst[e] = idx[e] >= 0 ? src[max(idx[e], 0)] : 0.f;
 }
 extern "C" int nsc_gather(const float* src, const int* idx, float* dst, long n, void* stream) {
   NSC_REQUIRE(src && idx && dst && n > 0, NSC_ERR_BAD_ARG, "nsc_gather: bad args");

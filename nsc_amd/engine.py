@@ -105,9 +105,37 @@ class _Conv:
                  _lib.ptr(res), None, y.data_ptr(), e.stream()), f"conv fwd {self.name}")
         e.prof_end(tok)
 
+    def poly_ok(self):
+        """stride-2 k9 SAME conv (padL 3): its data gradient splits into two phases with 4 / 5 taps (see wtpoly_index)."""
+        return self.stride == 2 and self.K == 9 and self.dil == 1 and self.padL == 3 and 2 * self.Cin <= 224 and self.Cin > 1
+
+    def wtpoly_index(self):
+        """Polyphase form of the stride-2 data gradient.  Forward: y[o,m] = sum_k W[k,ci,o] x[ci, 2m+k-3], so
+        dx[ci, 2n+p] = sum_{t'} W[7-2t'+p, ci, o] dy[o, n+t'-2]: a stride-1 conv over dy with 5 taps (4 for p = 0) whose
+        output channels 2ci+p interleave in time (sub-pixel shuffle).  The zero-upsampled form spends half of its MFMAs on
+        zeros.  Returns source offsets for W'[t', o, 2ci+p] (-1 = structural zero)."""
+        K, Ci, Co = self.K, self.Cin, self.Cout
+        src = np.arange(K * Ci * Co, dtype=np.int64).reshape(K, Ci, Co) + self.w_off
+        out = np.full((5, Co, 2 * Ci), -1, dtype=np.int64)
+        for tp in range(5):
+            for par in range(2):
+                k = 7 - 2 * tp + par
+                if 0 <= k < K:
+                    out[tp, :, par::2] = src[k].T          # [Co, Ci]
+        return out.reshape(-1).astype(np.int32)
+
     def dgrad(self, dz, dx, res=None, res_mode=0, mul_kind="none", aux=None):
         """dx = conv^T(dz) (+res) (* act'(aux)); runs the forward kernel on the flipped/transposed weights."""
         e = self.eng
+        if self.poly_ok() and e.poly_dgrad:
+            d = ConvDesc(B=e.B, Cin=self.Cout, Cout=2 * self.Cin, Tin=self.Tout, Tout=self.Tout, K=5, dil=1, stride=1, padL=2,
+                         act=0, res_mode=res_mode, mul_mode=KIND_MUL[mul_kind], out_mode=1, in_up=0, accumulate=0)
+            tok = e.prof_begin("conv_mfma", self.flops())
+            check(e.lib.nsc_conv1d_fwd(C.byref(d), dz.data_ptr(), e.wt_ptr + 4 * self.wtpoly_off, None, _lib.ptr(res),
+                                       _lib.ptr(aux) if mul_kind != "none" else None, dx.data_ptr(), e.stream()),
+                  f"conv dgrad (polyphase) {self.name}")
+            e.prof_end(tok)
+            return
         padl = (self.K - 1) * self.dil - self.padL
         d = ConvDesc(B=e.B, Cin=self.Cout, Cout=self.Cin, Tin=self.Tout, Tout=self.Tin, K=self.K, dil=self.dil,
                      stride=1, padL=padl, act=0, res_mode=res_mode, mul_mode=KIND_MUL[mul_kind], out_mode=0,
@@ -535,6 +563,11 @@ class CascadeEngine:
         for b in blocks:
             b.wtlr_off = n + extra
             extra += b.cl.K * 2 * b.narrow * b.narrow
+        # polyphase data-gradient kernels of the stride-2 k9 convs: W'[t', o, 2 ci + p] (5 taps, structural zero at p=0, t'=4)
+        poly = [c for c in self.convs if c.poly_ok()]
+        for c in poly:
+            c.wtpoly_off = n + extra
+            extra += 5 * c.Cout * 2 * c.Cin
         self.wt = torch.zeros(n + extra, **f32)
         self.p_ptr, self.g_ptr, self.wt_ptr = self.params.data_ptr(), self.grads.data_ptr(), self.wt.data_ptr()
         idx = np.arange(n + extra, dtype=np.int32)
@@ -545,6 +578,8 @@ class CascadeEngine:
             il = b.cl.wt_index().reshape(K, nn, nn)      # [tap', c, ci] source offsets
             ir = b.cr.wt_index().reshape(K, nn, nn)
             idx[b.wtlr_off:b.wtlr_off + K * 2 * nn * nn] = np.concatenate([il, ir], axis=1).reshape(-1)
+        for c in poly:
+            idx[c.wtpoly_off:c.wtpoly_off + 5 * c.Cout * 2 * c.Cin] = c.wtpoly_index()
         self.wt_idx = torch.from_numpy(idx).to(self.device)
         # two Adam slot sets (no-quan op / quan op) with independent state (nsc_module:922-926)
         self.adam = [dict(m=torch.zeros(n, **f32), v=torch.zeros(n, **f32), t=0,
@@ -589,6 +624,7 @@ class CascadeEngine:
     # ---- block weight gradients deferred to the end of the backward pass and produced by ONE persistent launch per
     # block width (nsc_gated_block_wgrad_batch): per-block launches walk only 2-4 tiles per workgroup at batch 128, so
     # their prologue, accumulator flush and slab reduction cost more than the MFMA work itself.
+    poly_dgrad = True    # stride-2 data gradients in polyphase form (half the MFMAs of the zero-upsampled form)
     batch_wgrad = True
     batch_conv_wgrad = False  # the same for the convs outside gated blocks (nsc_conv1d_wgrad_batch; measured 4.20 vs 4.15 ms/step:
                               # the per-conv launches hide in the gaps of the data-gradient chain); False = one launch per

@@ -684,3 +684,31 @@ def test_frame_entropy(lib, shape):
     ref = np.array([O.entropy_coding_loss(p[b:b + 1]) for b in range(B)])
     got = ent.cpu().numpy()
     assert np.all(np.abs(got - ref) <= 1e-4 * np.maximum(1.0, np.abs(ref))), (got, ref)
+
+
+def test_stride2_dgrad_polyphase_equals_autograd(lib):
+    """Data gradient of the stride-2 k9 conv as a 5-tap stride-1 conv over dy with sub-pixel-shuffled output (engine
+    _Conv.wtpoly_index) vs autograd of the oracle conv; also exercises the interleaved row-wise shuffle epilogue with aux."""
+    rng = np.random.default_rng(2024)
+    B, Cin, Cout, T, K = 3, 100, 100, 512, 9
+    x = rng.standard_normal((B, T, Cin)).astype(np.float32)
+    W = (rng.standard_normal((K, Cin, Cout)) / np.sqrt(K * Cin)).astype(np.float32)
+    Tout, padL, _ = O.same_pad(T, K, 1, 2)
+    assert (Tout, padL) == (256, 3)
+    dz = rng.standard_normal((B, Tout, Cout)).astype(np.float32)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    (OT.conv1d(xt, torch.tensor(W, dtype=torch.float64), torch.zeros(Cout, dtype=torch.float64), 1, 2, None)
+     * torch.tensor(dz, dtype=torch.float64)).sum().backward()
+    Wp = np.zeros((5, Cout, 2 * Cin), np.float32)
+    for tp in range(5):
+        for par in range(2):
+            k = 7 - 2 * tp + par
+            if 0 <= k < K:
+                Wp[tp, :, par::2] = W[k].T
+    aux = rng.standard_normal((B, T, Cin)).astype(np.float32)          # laid out like the OUTPUT
+    dx = torch.full((B, Cin, T), float("nan"), device="cuda")
+    d = _desc(B=B, Cin=Cout, Cout=2 * Cin, Tin=Tout, Tout=Tout, K=5, dil=1, stride=1, padL=2, out_mode=1, mul_mode=1)
+    rc = lib.nsc_conv1d_fwd(C.byref(d), P(dz.transpose(0, 2, 1)), P(Wp), None, None, P(aux.transpose(0, 2, 1)), dx.data_ptr(), _st())
+    assert rc == 0, lib.nsc_last_error()
+    ref = xt.grad.numpy() * np.where(aux > 0, 1.0, 0.2)
+    assert_close(dx.cpu().numpy().transpose(0, 2, 1), ref, tol=2e-4, what="polyphase stride-2 dgrad")
