@@ -192,10 +192,10 @@ def main():
     eng.overlap_wgrad = ov
     # dominant kernel = the instrumented kernel class with the largest share of the step
     KERNELS = {"conv_mfma": "conv1d_fwd_kernel (per-conv forward + data-gradient launches)",
-               "block_fwd": "gated_block_fwd_kernel (fused gated block forward)",
-               "block_wgrad": "gated_block_wgrad_kernel (persistent block weight gradients)",
+               "block_fwd": "gated_block_fwd2_kernel (persistent weight-stationary gated block forward)",
+               "block_wgrad": "gated_block_wgrad_batch_kernel (all blocks' weight gradients, one persistent launch per width)",
                "block_bwd": "gated_block_bwd_kernel (fused gated block backward)",
-               "block_dgrad": "gated_block_dgrad_kernel (fused gated block data-path backward)",
+               "block_dgrad": "gated_block_dgrad2_kernel (persistent weight-stationary gated block data-path backward)",
                "wgrad_mfma": "conv1d_wgrad_kernel (per-conv weight gradients)"}
     roof, by_kernel = None, {}
     traffic = {}
