@@ -285,3 +285,27 @@ def test_validation_frame_entropies_match_batch_of_one_oracle():
         outs, _ = O.cascade_forward(x[b:b + 1].astype(np.float64), ps, BKD, [[2], [2]], [32, 32], 1.0, False)
         ref = [O.entropy_coding_loss(o["p"]) for o in outs]
         assert np.allclose(got[:, b], ref, rtol=2e-4, atol=2e-4), (b, got[:, b], ref)
+
+
+def test_three_codec_follower_two_downsamplings():
+    """BASELINE config 4 topology at test size: codecs with TWO down/up-sampling stages ('2 2': L = 128, blocks at C = 100,
+    50 and 25), a third codec trained as follower of two frozen ones (cmrl.py:22-135): decoded sum and the newest codec's
+    gradients vs the oracle; frozen scopes get exactly zero gradient."""
+    B, N = 2, 3
+    st, nb = [[2, 2]] * N, [32] * N
+    ps = make_store(N, st, nb)
+    x = synth_frames(B)
+    coeff = [60.0, 10.0, 10.0, 0.0]
+    outs, dec, loss, grads = _oracle_grads(ps, x, N, st, coeff, [0.4], "quan_last", 1.0, rs=1.0)
+    eng = _engine(B, N, st, nb, ps)
+    xd = dev(x.transpose(0, 2, 1))
+    eng.grads.zero_()
+    d = eng.forward(xd, 1.0, True)
+    eng.loss_backward(xd, coeff[0], coeff[1], [0.0, 0.0, coeff[2]], [0.0, 0.0, 0.4], [False, False, True])
+    torch.cuda.synchronize()
+    assert eng.codecs[-1].L == 128
+    assert_close(d.cpu().numpy()[:, 0], dec, what="3-codec cascade decoded")
+    _check_grads(eng, grads, ["scope_3"])
+    for s in ("scope_1", "scope_2"):
+        a, b = eng.layout.scope_range(s)
+        assert float(eng.grads[a:b].abs().max()) == 0.0
