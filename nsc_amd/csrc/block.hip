@@ -2055,22 +2055,21 @@ __global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs 
       // prefetch of the next tile.  One step = NCTA B fragments + NCTA MFMAs (>= 160 cycles, covers the LDS latency
       // together with the partner wave).
       constexpr int NSTEP = K9 * (NJ9 - 1);
-      float bn[NCTA], bc[NCTA];
+      float bb[2][NCTA];                                   // ping-pong (compile-time index: no register copies)
+      float* bc = bb[0];
 #pragma unroll
-      for (int ct = 0; ct < NCTA; ++ct) bn[ct] = yb[ct * 16];
+      for (int ct = 0; ct < NCTA; ++ct) bb[0][ct] = yb[ct * 16];
 #pragma unroll
       for (int st = 0; st < NSTEP; ++st) {
         const int tp = st / (NJ9 - 1), j = st - tp * (NJ9 - 1);
-#pragma unroll
-        for (int ct = 0; ct < NCTA; ++ct) bc[ct] = bn[ct];
         if (st + 1 < NSTEP) {
           const int tpn = (st + 1) / (NJ9 - 1), jn = (st + 1) - tpn * (NJ9 - 1);
 #pragma unroll
-          for (int ct = 0; ct < NCTA; ++ct) bn[ct] = yb[16 * jn * LDY + tpn + ct * 16];
+          for (int ct = 0; ct < NCTA; ++ct) bb[(st + 1) & 1][ct] = yb[16 * jn * LDY + tpn + ct * 16];
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ct = 0; ct < NCTA; ++ct) acc[ct] = mfma4(w9r[tp][j], bc[ct], acc[ct]);
+        for (int ct = 0; ct < NCTA; ++ct) acc[ct] = mfma4(w9r[tp][j], bb[st & 1][ct], acc[ct]);
         __builtin_amdgcn_sched_barrier(0);
       }
       {                                                    // the left-over channel group: this quarter's taps kg + 4 i
