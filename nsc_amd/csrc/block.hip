@@ -1898,6 +1898,135 @@ __global__ __launch_bounds__(512) void gated_block_dgrad_kernel(BlockDgradArgs a
   }
 }
 
+// ---- helpers of gated_block_dgrad2_kernel's k9 data gradient ----
+// rows 0..15 (channels 0..15): NC column tiles starting at yb, this wave's K-quarter (register-resident fragments)
+template <int NC, int NJ, int LDY_>
+__device__ __forceinline__ void d9_rows0(const float (&w9r)[K9][NJ], const float (&w9x)[3], const float* yb, const float* yx,
+                                         int kg, f32x4 (&acc)[NC]) {
+  constexpr int NSTEP = K9 * NJ;
+  float bb[2][NC];                                       // ping-pong (compile-time index: no register copies)
+#pragma unroll
+  for (int ct = 0; ct < NC; ++ct) bb[0][ct] = yb[ct * 16];
+#pragma unroll
+  for (int st = 0; st < NSTEP; ++st) {
+    const int tp = st / NJ, j = st - tp * NJ;
+    if (st + 1 < NSTEP) {
+      const int tpn = (st + 1) / NJ, jn = (st + 1) - tpn * NJ;
+#pragma unroll
+      for (int ct = 0; ct < NC; ++ct) bb[(st + 1) & 1][ct] = yb[16 * jn * LDY_ + tpn + ct * 16];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ct = 0; ct < NC; ++ct) acc[ct] = mfma4(w9r[tp][j], bb[st & 1][ct], acc[ct]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {                          // the left-over channel group: this quarter's taps kg + 4 i
+    if (i == 2 && kg != 0) break;                        // tap kg + 8 exists for quarter 0 only (wave-uniform)
+#pragma unroll
+    for (int ct = 0; ct < NC; ++ct) bb[0][ct] = yx[4 * i + ct * 16];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ct = 0; ct < NC; ++ct) acc[ct] = mfma4(w9x[i], bb[0][ct], acc[ct]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+// channels 16..19, PACKED: a 16-row tile of [4 time shifts s][4 channels i] instead of 4 useful rows + 12 of padding.
+// Row (s,i), column n  ->  dg[16+i][64 ctp + 4n + s] = sum_{m,o} A[(s,i)][(m,o)] dy[o][64 ctp + 4n + m],
+// A = wt9[m-s][o][16+i] for 0 <= m-s < 9 else 0: 12 "taps" m instead of 9, but one MFMA column tile now spans 64 time steps
+// instead of 16 (2 tiles instead of 6).  A from LDS (w9ps [9][C][4]), lane (4s+i, kq); B lanes walk time with stride 4.
+template <int NJ, int NK9_, int LDY_>
+__device__ __forceinline__ void d9_packed(const float* w9ps, int C, const float* dys, int kg, int kq, int l15,
+                                          f32x4 (&acc)[2]) {
+  const int sft = l15 >> 2, ich = l15 & 3;
+  const float* ypb = dys + (4 * kg + kq) * LDY_ + 4 * l15;
+#pragma unroll
+  for (int m = 0; m < K9 + 3; ++m) {
+    const int tap = m - sft;
+    const bool ok = (unsigned)tap < (unsigned)K9;
+    const float* ap = w9ps + (((ok ? tap : 0) * C + 4 * kg + kq) * 4 + ich);
+    float av[NJ], b0[NJ], b1[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      av[j] = ap[16 * j * 4];
+      b0[j] = ypb[16 * j * LDY_ + m];
+      b1[j] = ypb[16 * j * LDY_ + m + 64];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const float a = ok ? av[j] : 0.f;
+      acc[0] = mfma4(a, b0[j], acc[0]);
+      acc[1] = mfma4(a, b1[j], acc[1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // the left-over channel group (cq = NK9-1): this quarter's m = kg, kg+4, kg+8
+  const float* ypx = dys + (4 * (NK9_ - 1) + kq) * LDY_ + 4 * l15 + kg;
+#pragma unroll
+  for (int e = 0; e < 3; ++e) {
+    const int tap = kg + 4 * e - sft;
+    const bool ok = (unsigned)tap < (unsigned)K9;
+    const float a0 = w9ps[((ok ? tap : 0) * C + 4 * (NK9_ - 1) + kq) * 4 + ich];
+    const float a = ok ? a0 : 0.f;
+    acc[0] = mfma4(a, ypx[4 * e], acc[0]);
+    acc[1] = mfma4(a, ypx[4 * e + 64], acc[1]);
+  }
+}
+
+// ---- helpers of the k15 data gradient (weights from LDS: w15s [15][40][20]) ----
+// rows = channels 0..15, NC column tiles starting at ab; this wave's taps kg, kg+4, kg+8, (kg+12)
+template <int NC, int DIL_, int LDA_>
+__device__ __forceinline__ void d15_rows0(const float* wb, const float* ab, int kg, f32x4 (&acc)[NC]) {
+#pragma unroll
+  for (int e4 = 0; e4 < 4; ++e4) {
+    if (e4 == 3 && kg == 3) break;                       // tap 15 does not exist (wave-uniform)
+#pragma unroll
+    for (int u = 0; u < 10; u += 2) {                    // two k-steps per scheduling group
+      float av[2], bv[2][NC];
+#pragma unroll
+      for (int uu = 0; uu < 2; ++uu) {
+        av[uu] = wb[(e4 * 4 * 2 * NARROW + 4 * (u + uu)) * NARROW];
+#pragma unroll
+        for (int ct = 0; ct < NC; ++ct) bv[uu][ct] = ab[4 * (u + uu) * LDA_ + e4 * 4 * DIL_ + ct * 16];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int uu = 0; uu < 2; ++uu)
+#pragma unroll
+        for (int ct = 0; ct < NC; ++ct) acc[ct] = mfma4(av[uu], bv[uu][ct], acc[ct]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+// channels 16..19 PACKED as in d9_packed: row (s,i), column n -> dh[16+i][4n + s] = sum_{m,c'} A da[c'][4n + m], with
+// m = s + tap*DIL in [0, 4 + 14 DIL) and A = w15s[tap][c'][16+i] where (m - s) is a valid multiple of DIL, else 0.
+// This wave owns the m = kg (mod 4).  One column tile covers the 64 output steps.
+template <int DIL_, int LDA_>
+__device__ __forceinline__ void d15_packed(const float* w15s, const float* da, int kg, int kq, int l15, f32x4& acc) {
+  constexpr int NM = 4 + 14 * DIL_, NQM = (NM + 3) / 4;
+  const int sft = l15 >> 2, ich = l15 & 3;
+  const float* bb = da + kq * LDA_ + 4 * l15 + kg;
+#pragma unroll
+  for (int q = 0; q < NQM; ++q) {
+    if (kg + 4 * q >= NM) break;                         // wave-uniform (NM is not a multiple of 4 at DIL 1)
+    const int dm = kg + 4 * q - sft;
+    const int tap = DIL_ == 1 ? dm : (dm >> 1);
+    const bool ok = dm >= 0 && (DIL_ == 1 || !(dm & 1)) && tap < K15;
+    const float* ap = w15s + ((ok ? tap : 0) * 2 * NARROW + kq) * NARROW + 16 + ich;
+    float av[10], bv[10];
+#pragma unroll
+    for (int u = 0; u < 10; ++u) {
+      av[u] = ap[4 * u * NARROW];
+      bv[u] = bb[4 * u * LDA_ + 4 * q];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 10; ++u) acc = mfma4(ok ? av[u] : 0.f, bv[u], acc);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // -----------------------------------------------------------------------------------------------------
 // v2 of the fused data-path backward: PERSISTENT and weight-stationary (same idea as gated_block_fwd2_kernel).
 // One workgroup per CU walks (frame, 64-step tile) pairs; weights are fetched once per workgroup.  The data
@@ -1928,13 +2057,13 @@ __global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs 
   float* part = dhs + NARROW * LDN;                // [4][16][WA16] + [4][4][WA16]  partial sums of the K-quarters;
   float* dxs = part;                               //   later [CR][LDD]: dx before act'(x), for the row-wise copy-out
   float* w15s = part + PARTSZ;                     // [15][40][20]   wt_l | wt_r concatenated along the reduced channel
+  float* w9ps = w15s + K15 * 2 * NARROW * NARROW;  // [9][C][4]      k9 gradient weights of channels 16..19 (packed tile)
   const int C = a.C, T = a.T;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, kq = lane >> 4;
   const int rt = wave >> 2, kg = (wave + rt) & 3;  // this wave's output row tile and K-quarter (the longer quarter 0
                                                    // lands on different SIMDs for the two row tiles)
-  const int cic = min(rt * 16 + l15, NARROW - 1);  // A-fragment row (rows >= 20: clamped, never stored)
 
   // the first tile's x goes out before the weights: its HBM round trip is the longest latency of the prologue
   // ---- prefetch of the next tile: dy (wave w rows w, w+8, ...), lin / tanh (rows w, w+8, w+16), h (elementwise map) ----
@@ -1996,6 +2125,7 @@ __global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs 
   }
   // k9 gradient: K-quarter kg owns the channel groups cq = kg + 4j of every tap, so the B-fragment address of step
   // (tap', j) is lane base + the compile-time offset (16 j LDY + tap'): no per-step address registers.
+  for (int e = tid; e < K9 * C * 4; e += 512) w9ps[e] = a.wt9[(long)(e >> 2) * NARROW + 16 + (e & 3)];
   // NK9 = 4 (NJ9-1) + 1 for both shapes: the one left-over channel group (cq = NK9-1) is shared out by TAP (quarter kg takes
   // taps kg, kg+4, kg+8 < 9), so the quarters carry 57 | 56 | 56 | 56 k-steps instead of 63 | 54 | 54 | 54.
   static_assert(NK9 == 4 * (NJ9 - 1) + 1, "left-over channel group is shared out by tap");
@@ -2004,10 +2134,10 @@ __global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs 
   for (int tp = 0; tp < K9; ++tp)
 #pragma unroll
     for (int j = 0; j < NJ9 - 1; ++j)
-      w9r[tp][j] = a.wt9[((long)tp * C + min(4 * (kg + 4 * j) + kq, C - 1)) * NARROW + cic];
+      w9r[tp][j] = a.wt9[((long)tp * C + min(4 * (kg + 4 * j) + kq, C - 1)) * NARROW + l15];   // rows = channels 0..15
 #pragma unroll
   for (int i = 0; i < 3; ++i)
-    w9x[i] = a.wt9[((long)min(kg + 4 * i, K9 - 1) * C + min(4 * (NK9 - 1) + kq, C - 1)) * NARROW + cic];
+    w9x[i] = a.wt9[((long)min(kg + 4 * i, K9 - 1) * C + min(4 * (NK9 - 1) + kq, C - 1)) * NARROW + l15];
   const int rt1 = RT9 == 7 ? (wave < 7 ? wave : 6) : (wave & 3);
   const int cb1 = RT9 == 7 ? 0 : (wave >> 2) * 32;
   constexpr int NC1 = RT9 == 7 ? 4 : 2;
@@ -2044,53 +2174,45 @@ __global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs 
     __syncthreads();
     if (!(skip & 8)) prefetch_dy(tile + gridDim.x);
 
-    // ---- D9: this wave's quarter of dg[ci][ja] = sum_{tap', o} wt9[tap'][o][ci] * dy[o][ja + tap'] ----
+    // ---- D9: dg[ci][ja] = sum_{tap', o} wt9[tap'][o][ci] * dy[o][ja + tap'], K split in quarters kg.
+    // Channels 0..15: waves 0-3 take column tiles 0..3, waves 4-7 the rest; channels 16..19: waves 4-7, packed tile.
+    // Software-pipelined loops with scheduling fences: left alone the scheduler hoists ~30 ds_read2 (60 registers) ahead
+    // of the MFMAs, which spills - and a scratch reload waits on vmcnt IN ORDER, i.e. on the next tile's whole prefetch.
     if (!(skip & 1)) {
-      f32x4 acc[NCTA];
-#pragma unroll
-      for (int ct = 0; ct < NCTA; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      constexpr int NCB = NCTA - 4;                        // column tiles of channels 0..15 left to waves 4-7
       const float* yb = dys + (4 * kg + kq) * LDY + l15;
-      // explicit two-deep software pipeline with scheduling fences: left alone the scheduler hoists ~30 ds_read2 (60
-      // registers) ahead of the MFMAs, which spills - and a scratch reload waits on vmcnt IN ORDER, i.e. on the whole
-      // prefetch of the next tile.  One step = NCTA B fragments + NCTA MFMAs (>= 160 cycles, covers the LDS latency
-      // together with the partner wave).
-      constexpr int NSTEP = K9 * (NJ9 - 1);
-      float bb[2][NCTA];                                   // ping-pong (compile-time index: no register copies)
-      float* bc = bb[0];
+      const float* yx = dys + (4 * (NK9 - 1) + kq) * LDY + l15 + kg;
+      float* pp0 = part + (kg * 16 + kq * 4) * WA16 + l15;
+      if (rt == 0) {
+        f32x4 acc[4];
 #pragma unroll
-      for (int ct = 0; ct < NCTA; ++ct) bb[0][ct] = yb[ct * 16];
+        for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        d9_rows0<4, NJ9 - 1, LDY>(w9r, w9x, yb, yx, kg, acc);
 #pragma unroll
-      for (int st = 0; st < NSTEP; ++st) {
-        const int tp = st / (NJ9 - 1), j = st - tp * (NJ9 - 1);
-        if (st + 1 < NSTEP) {
-          const int tpn = (st + 1) / (NJ9 - 1), jn = (st + 1) - tpn * (NJ9 - 1);
+        for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-          for (int ct = 0; ct < NCTA; ++ct) bb[(st + 1) & 1][ct] = yb[16 * jn * LDY + tpn + ct * 16];
+          for (int reg = 0; reg < 4; ++reg) pp0[reg * WA16 + ct * 16] = acc[ct][reg];
+      } else {
+        f32x4 acc[NCB];
+#pragma unroll
+        for (int ct = 0; ct < NCB; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        d9_rows0<NCB, NJ9 - 1, LDY>(w9r, w9x, yb + 64, yx + 64, kg, acc);
+#pragma unroll
+        for (int ct = 0; ct < NCB; ++ct)
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) pp0[reg * WA16 + (4 + ct) * 16] = acc[ct][reg];
+        f32x4 pk[2];
+        pk[0] = pk[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        d9_packed<NJ9 - 1, NK9, LDY>(w9ps, C, dys, kg, kq, l15, pk);
+        // row (s = kq, i = reg), column n = l15  ->  dg[16 + reg][64 ctp + 4 l15 + kq]
+#pragma unroll
+        for (int ctp = 0; ctp < 2; ++ctp) {
+          const int col = 64 * ctp + 4 * l15 + kq;
+          if (col < WA16) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) part[PART1 + (kg * 4 + reg) * WA16 + col] = pk[ctp][reg];
+          }
         }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int ct = 0; ct < NCTA; ++ct) acc[ct] = mfma4(w9r[tp][j], bb[st & 1][ct], acc[ct]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      {                                                    // the left-over channel group: this quarter's taps kg + 4 i
-        const float* yx = dys + (4 * (NK9 - 1) + kq) * LDY + l15 + kg;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          if (i == 2 && kg != 0) break;                      // tap kg + 8 exists for quarter 0 only (wave-uniform)
-#pragma unroll
-          for (int ct = 0; ct < NCTA; ++ct) bc[ct] = yx[4 * i + ct * 16];
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int ct = 0; ct < NCTA; ++ct) acc[ct] = mfma4(w9x[i], bc[ct], acc[ct]);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      if (rt == 0 || kq == 0) {                            // row tile 1 holds channels 16..19 in its first 4 rows only
-        float* pp = rt == 0 ? part + (kg * 16 + kq * 4) * WA16 : part + PART1 + kg * 4 * WA16;
-#pragma unroll
-        for (int ct = 0; ct < NCTA; ++ct)
-#pragma unroll
-          for (int reg = 0; reg < 4; ++reg) pp[reg * WA16 + ct * 16 + l15] = acc[ct][reg];
       }
     }
     __syncthreads();
@@ -2114,39 +2236,32 @@ __global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs 
     __syncthreads();
     if (!(skip & 8)) prefetch_a(tile + gridDim.x);   // lin / tanh / h of the next tile (their LDS tiles are still in use)
 
-    // ---- D15: this wave's taps of dh[ci][tt] = sum wt_lr[tap'][c'][ci] * da[c'][tt + tap' d] ----
+    // ---- D15: dh[ci][tt] = sum wt_lr[tap'][c'][ci] * da[c'][tt + tap' d], taps split in quarters kg.
+    // Channels 0..15: waves 0-3 column tiles 0..2, waves 4-7 tile 3; channels 16..19: waves 4-7, packed tile.
     if (!(skip & 2)) {
-      f32x4 acc[4];
-#pragma unroll
-      for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
       const float* ab = lin + kq * LDA + l15 + kg * DIL;
-      const float* wb = w15s + (kg * 2 * NARROW + kq) * NARROW + cic;
+      const float* wb = w15s + (kg * 2 * NARROW + kq) * NARROW + l15;
+      float* pp0 = part + (kg * 16 + kq * 4) * TT + l15;
+      if (rt == 0) {
+        f32x4 acc[3];
 #pragma unroll
-      for (int e4 = 0; e4 < 4; ++e4) {
-        if (e4 == 3 && kg == 3) break;                     // tap 15 does not exist (wave-uniform)
+        for (int ct = 0; ct < 3; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        d15_rows0<3, DIL, LDA>(wb, ab, kg, acc);
 #pragma unroll
-        for (int u = 0; u < 10; u += 2) {                  // two k-steps per scheduling group (see D9)
-          float av[2], bv[2][4];
+        for (int ct = 0; ct < 3; ++ct)
 #pragma unroll
-          for (int uu = 0; uu < 2; ++uu) {
-            av[uu] = wb[(e4 * 4 * 2 * NARROW + 4 * (u + uu)) * NARROW];
+          for (int reg = 0; reg < 4; ++reg) pp0[reg * TT + ct * 16] = acc[ct][reg];
+      } else {
+        f32x4 acc[1];
+        acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        d15_rows0<1, DIL, LDA>(wb, ab + 48, kg, acc);
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) bv[uu][ct] = ab[4 * (u + uu) * LDA + e4 * 4 * DIL + ct * 16];
-          }
-          __builtin_amdgcn_sched_barrier(0);
+        for (int reg = 0; reg < 4; ++reg) pp0[reg * TT + 48] = acc[0][reg];
+        f32x4 pk = {0.f, 0.f, 0.f, 0.f};
+        d15_packed<DIL, LDA>(w15s, lin, kg, kq, l15, pk);
+        // row (s = kq, i = reg), column n = l15  ->  dh[16 + reg][4 l15 + kq]
 #pragma unroll
-          for (int uu = 0; uu < 2; ++uu)
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) acc[ct] = mfma4(av[uu], bv[uu][ct], acc[ct]);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      if (rt == 0 || kq == 0) {
-        float* pp = rt == 0 ? part + (kg * 16 + kq * 4) * TT : part + 4 * 16 * TT + kg * 4 * TT;
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-          for (int reg = 0; reg < 4; ++reg) pp[reg * TT + ct * 16 + l15] = acc[ct][reg];
+        for (int reg = 0; reg < 4; ++reg) part[4 * 16 * TT + (kg * 4 + reg) * TT + 4 * l15 + kq] = pk[reg];
       }
     }
     // x rows of the copy-out phase (for act'(x)): wave w rows w, w+8, ...; issued here, consumed three barriers later
@@ -2217,7 +2332,8 @@ static int launch_block_dgrad2(const BlockDgradArgs& a, hipStream_t st) {
   constexpr int WA16 = ((64 + 14 * DIL + 15) / 16) * 16;
   const size_t partsz = std::max((size_t)4 * NARROW * WA16, (size_t)4 * NK9 * 68);
   const size_t smem = ((size_t)4 * NK9 * 112 + (size_t)2 * NARROW * 112 + (size_t)NARROW * 80 + partsz +
-                       (size_t)K15 * 2 * NARROW * NARROW) * sizeof(float);
+                       (size_t)K15 * 2 * NARROW * NARROW + (size_t)K9 * a.C * 4) * sizeof(float);
+  NSC_REQUIRE(smem <= 160 * 1024, NSC_ERR_UNSUPPORTED, "gated_block_dgrad2: %zu B LDS", smem);
   auto kern = gated_block_dgrad2_kernel<RT9, NK9, DIL>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "gated_block_dgrad2: smem attr: %s", hipGetErrorString(e));
