@@ -1967,7 +1967,9 @@ __device__ __forceinline__ void d9_packed(const float* w9ps, int C, const float*
   for (int e = 0; e < 3; ++e) {
     const int tap = kg + 4 * e - sft;
     const bool ok = (unsigned)tap < (unsigned)K9;
-    const float a0 = w9ps[((ok ? tap : 0) * C + 4 * (NK9_ - 1) + kq) * 4 + ich];
+    // channel rows >= C (C = 50: rows 50, 51) meet zero rows of the dy tile: clamp the index so the fragment is a finite
+    // stand-in (an unclamped read ran past the table into uninitialised LDS: NaN * 0)
+    const float a0 = w9ps[((ok ? tap : 0) * C + min(4 * (NK9_ - 1) + kq, C - 1)) * 4 + ich];
     const float a = ok ? a0 : 0.f;
     acc[0] = mfma4(a, ypx[4 * e], acc[0]);
     acc[1] = mfma4(a, ypx[4 * e + 64], acc[1]);
