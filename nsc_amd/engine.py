@@ -428,7 +428,7 @@ class _Codec:
         # ---- quantizer + fused quan/entropy partials ----
         self.qcode = e.buf(s + ".qcode", (B, 1, self.L))
         self.quan = e.buf(s + ".quan", (B,))
-        self.hist = e.buf(s + ".hist", (self.nb,))
+        self.hist = e.hist_view(s, self.nb)     # a slice of ONE flat buffer: the data-parallel exchange is a single all-reduce
         self.p = e.buf(s + ".p", (B, self.L, self.nb)) if want_p else None
         self.hist.zero_()
         self.is_quan_on, self.soft = float(is_quan_on), int(bool(soft))
@@ -739,6 +739,22 @@ class CascadeEngine:
             out[tag] = (n + 1, ms + a.elapsed_time(b), f + fl)
         return out
 
+    def hist_view(self, key, nb):
+        """[nb] slice of the flat histogram buffer (codecs' 32-bin and the LSF quantizer's 256-bin histograms side by side)."""
+        if self._hist_flat is None:
+            self._hist_flat = torch.zeros(sum(c.nb for c in self.codecs) + 4 * len(lpc_coeff_lsf_bins), dtype=torch.float32,
+                                          device=self.device)
+            self._hist_slots, self._hist_used = {}, 0
+        if key not in self._hist_slots:
+            assert self._hist_used + nb <= self._hist_flat.numel()
+            self._hist_slots[key] = (self._hist_used, nb)
+            self._hist_used += nb
+        o, n = self._hist_slots[key]
+        assert n == nb
+        return self._hist_flat[o:o + n]
+
+    _hist_flat = None
+
     def buf(self, name, shape):
         t = self._bufs.get(name)
         if t is None or tuple(t.shape) != tuple(shape):
@@ -835,7 +851,7 @@ class CascadeEngine:
             self.lpc_x = lpc_x
             self.lpc_q = self.buf("lpc.q", (B, L, 1))
             self.lpc_quan = self.buf("lpc.quan", (B,))
-            self.lpc_hist = self.buf("lpc.hist", (nb,))
+            self.lpc_hist = self.hist_view("lpc", nb)
             self.lpc_hist.zero_()
             check(self.lib.nsc_quantize_fwd(lpc_x.data_ptr(), self.p_ptr + 4 * self.lpc_alpha_off,
                                             self.p_ptr + 4 * self.lpc_bins_off, float(is_quan_on), int(bool(soft)), B, L,
@@ -858,7 +874,7 @@ class CascadeEngine:
                                       None, self.mel.data_ptr(), self.melT.data_ptr(), self.time.data_ptr(),
                                       self.freq.data_ptr(), G.data_ptr(), self.stream()), "recon_loss")
         if hist_allreduce is not None:
-            hist_allreduce([c.hist for c in self.codecs] + ([self.lpc_hist] if self.lpc and hasattr(self, "lpc_hist") else []))
+            hist_allreduce([self._hist_flat[:self._hist_used]])   # every quantizer's soft histogram in one message
         ents = [c.entropy() for c in self.codecs]
         n = B * frame_length
         dsum = None  # running sum over later codecs of dL/dxin_j
