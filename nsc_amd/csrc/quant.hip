@@ -29,12 +29,16 @@ __device__ __forceinline__ float grp_sum(float v) {
   if constexpr (LPC >= 64) v += __shfl_xor(v, 32, 64);
   return v;
 }
+// max with a DPP source operand in ONE instruction.  fmaxf(v, dpp_f(v)) costs five (mov, nop, mov_dpp, a canonicalising
+// v_max x,x that llvm.maxnum needs for signalling NaNs, max); the values here are never NaN.
+#define NSC_MAX_DPP(v, ctrl)                                                                                   \
+  asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(v) : "0"(v))
 template <int LPC>
 __device__ __forceinline__ float grp_max(float v) {
-  if constexpr (LPC >= 2) v = fmaxf(v, dpp_f<0xB1>(v));
-  if constexpr (LPC >= 4) v = fmaxf(v, dpp_f<0x4E>(v));
-  if constexpr (LPC >= 8) v = fmaxf(v, dpp_f<0x141>(v));
-  if constexpr (LPC >= 16) v = fmaxf(v, dpp_f<0x140>(v));
+  if constexpr (LPC >= 2) NSC_MAX_DPP(v, "quad_perm:[1,0,3,2]");
+  if constexpr (LPC >= 4) NSC_MAX_DPP(v, "quad_perm:[2,3,0,1]");
+  if constexpr (LPC >= 8) NSC_MAX_DPP(v, "row_half_mirror");
+  if constexpr (LPC >= 16) NSC_MAX_DPP(v, "row_mirror");
   if constexpr (LPC >= 32) v = fmaxf(v, __shfl_xor(v, 16, 64));
   if constexpr (LPC >= 64) v = fmaxf(v, __shfl_xor(v, 32, 64));
   return v;
@@ -44,6 +48,9 @@ __device__ __forceinline__ float grp_max(float v) {
 template <int LPC, int ITER>
 __device__ __forceinline__ void softmax_bins(float c, float alpha, const float (&bv)[ITER][4], const bool (&ok)[ITER][4],
                                              float (&dist)[ITER][4], float (&p)[ITER][4]) {
+  // everything in the log2 domain: z = (alpha log2 e) d, p ~ 2^(z - max z): one fma + v_exp_f32 per bin.  |z - m| <= ~30
+  // wherever p matters, so folding log2 e into alpha costs < 2e-6 rel.
+  const float a2 = alpha * 1.4426950408889634f;
   float z[ITER][4];
   float m = -INFINITY;
 #pragma unroll
@@ -51,7 +58,7 @@ __device__ __forceinline__ void softmax_bins(float c, float alpha, const float (
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       dist[i][j] = fabsf(c - bv[i][j]);
-      z[i][j] = ok[i][j] ? alpha * dist[i][j] : -INFINITY;
+      z[i][j] = ok[i][j] ? a2 * dist[i][j] : -INFINITY;
       m = fmaxf(m, z[i][j]);
     }
   m = grp_max<LPC>(m);
@@ -60,12 +67,11 @@ __device__ __forceinline__ void softmax_bins(float c, float alpha, const float (
   for (int i = 0; i < ITER; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      // v_exp_f32 path: exp(x) = 2^(x log2 e); |x| <= ~20 wherever p matters, so the product's rounding costs < 2e-6 rel.
-      p[i][j] = ok[i][j] ? __expf(z[i][j] - m) : 0.f;
+      p[i][j] = ok[i][j] ? __builtin_amdgcn_exp2f(z[i][j] - m) : 0.f;
       s += p[i][j];
     }
   s = grp_sum<LPC>(s);
-  const float inv = __frcp_rn(s);
+  const float inv = __builtin_amdgcn_rcpf(s);     // v_rcp_f32 (1 ulp); __frcp_rn expands to the 11-instruction IEEE division
 #pragma unroll
   for (int i = 0; i < ITER; ++i)
 #pragma unroll
@@ -84,7 +90,9 @@ __device__ __forceinline__ int grp_argmax(float best, int idx) {
   return idx;
 }
 
-template <int LPC, int ITER>
+// FULL: nb == 4*LPC*ITER (32 bins on 8 lanes, 256 on 64): every (lane, slot) holds a real bin, so the masks, selects and
+// scalar-store fallbacks fold away (they made ~2/3 of the pass's VALU instructions)
+template <int LPC, int ITER, bool FULL>
 __global__ __launch_bounds__(256) void quantize_fwd_kernel(const float* __restrict__ code,
                                                            const float* __restrict__ alpha_p,
                                                            const float* __restrict__ bins, float on, int soft, int L,
@@ -105,7 +113,7 @@ __global__ __launch_bounds__(256) void quantize_fwd_kernel(const float* __restri
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int k = (i * LPC + gl) * 4 + j;
-      ok[i][j] = k < nb;
+      ok[i][j] = FULL || k < nb;
       bv[i][j] = ok[i][j] ? bins[k] : 0.f;
     }
   for (int k = tid; k < nbpad + 4; k += 256) sh[k] = 0.f;
@@ -115,17 +123,43 @@ __global__ __launch_bounds__(256) void quantize_fwd_kernel(const float* __restri
   for (int i = 0; i < ITER; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) hacc[i][j] = 0.f;
-  const bool vec_ok = (nb & 3) == 0;
+  const bool vec_ok = FULL || (nb & 3) == 0;
   // A workgroup walks frames b, b + gridDim.x, ... : the histogram is accumulated across ALL its frames before the
   // flush - one atomic per bin per workgroup with <= 1024 workgroups, instead of one per bin per FRAME (4096
   // serialised atomics on each of the 32 addresses bounded the first version at large batch).
+  // The codes of a frame are fetched one frame AHEAD (NPF loads in flight per lane): with the load inside the pass loop
+  // every pass of 64/LPC codes waited a full memory round trip on its own code (8 passes x ~1 us per frame: the kernel
+  // ran at 2.8 TB/s with the VALU half idle).  (Staging them through LDS instead measured slower: 3.4 vs 3.8 TB/s.)
+  constexpr int NPF = 8;
+  float cn[NPF];
+  auto fetch_codes = [&](int bf) {
+    const int bc = bf < B ? bf : blockIdx.x;
+#pragma unroll
+    for (int it = 0; it < NPF; ++it) {
+      const int l = (wave + 4 * it) * CPW + gc;
+      cn[it] = code[(long)bc * L + (l < L ? l : 0)];
+    }
+  };
+  fetch_codes(blockIdx.x);
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
   float qacc = 0.f;
-  for (int l0 = wave * CPW; l0 < L; l0 += 4 * CPW) {
+  float cc[NPF];
+#pragma unroll
+  for (int it = 0; it < NPF; ++it) cc[it] = cn[it];
+  fetch_codes(b + gridDim.x);
+  int it = 0;
+  for (int l0 = wave * CPW; l0 < L; l0 += 4 * CPW, ++it) {
     const int l = l0 + gc;
     const bool live = l < L;
     const long ci = (long)b * L + (live ? l : 0);
-    const float c = code[ci];
+    float c;
+    if (it < NPF) {
+      c = cc[0];
+#pragma unroll
+      for (int q = 1; q < NPF; ++q) c = (it == q) ? cc[q] : c;     // wave-uniform select (it is uniform)
+    } else {
+      c = code[ci];
+    }
     float dist[ITER][4], p[ITER][4];
     softmax_bins<LPC, ITER>(c, alpha, bv, ok, dist, p);
     float q;
@@ -326,9 +360,16 @@ extern "C" int nsc_quantize_fwd(const float* code, const float* alpha, const flo
   NSC_REQUIRE(nb <= 1024, NSC_ERR_UNSUPPORTED, "nsc_quantize_fwd: nb %d > 1024", nb);
   hipStream_t st = (hipStream_t)stream;
 #define CALLF(LPC_, IT_)                                                                                          \
-  hipLaunchKernelGGL((quantize_fwd_kernel<LPC_, IT_>), dim3(std::min(B, 1024)), dim3(256),                        \
-                     (4 * LPC_ * IT_ + 4) * sizeof(float), st, code, alpha, bins, is_quan_on, soft, L, nb, p_out, out,  \
-                     quan_out, hist, B)
+  do {                                                                                                            \
+    if (nb == 4 * LPC_ * IT_)                                                                                     \
+      hipLaunchKernelGGL((quantize_fwd_kernel<LPC_, IT_, true>), dim3(std::min(B, 1024)), dim3(256),               \
+                         (4 * LPC_ * IT_ + 4) * sizeof(float), st, code, alpha, bins, is_quan_on, soft, L, nb, p_out,  \
+                         out, quan_out, hist, B);                                                                  \
+    else                                                                                                          \
+      hipLaunchKernelGGL((quantize_fwd_kernel<LPC_, IT_, false>), dim3(std::min(B, 1024)), dim3(256),              \
+                         (4 * LPC_ * IT_ + 4) * sizeof(float), st, code, alpha, bins, is_quan_on, soft, L, nb, p_out,  \
+                         out, quan_out, hist, B);                                                                  \
+  } while (0)
   QDISPATCH(nb, CALLF);
 #undef CALLF
   NSC_CHECK_LAUNCH("quantize_fwd");
