@@ -10,6 +10,9 @@
 #include <algorithm>
 
 #define QEPS 1e-20f
+#ifndef NSC_QGRID
+#define NSC_QGRID 1024   // workgroups of the forward kernel (measured at B = 4096: 512 -> 3.7, 768 -> 4.05, 1024 -> 4.08, 1280 -> 3.75, 2048 -> 3.3 TB/s)
+#endif
 
 // Cross-lane exchange inside a row of 16 lanes with DPP (VALU data path, no LDS crossbar like ds_bpermute):
 // xor 1 / xor 2 = quad permutes, "xor 4" = row_half_mirror (lane i <-> 7-i inside each 8 lanes), "xor 8" = row_mirror
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(256) void quantize_fwd_kernel(const float* __restri
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           hacc[i][j] += p[i][j];
-          if (ok[i][j]) qacc += __fsqrt_rn(p[i][j] + QEPS);
+          if (ok[i][j]) qacc += __builtin_amdgcn_sqrtf(p[i][j] + QEPS);   // v_sqrt_f32 (1 ulp); p + 1e-20 is never denormal
         }
       if (p_out) {
         float* pr = p_out + ci * nb;
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(256) void quantize_bwd_kernel(
       for (int j = 0; j < 4; ++j) {
         float g = 0.f;
         if (ok[i][j] && live) {
-          g = gh[i][j] + cq * 0.5f / sqrtf(p[i][j] + QEPS);
+          g = gh[i][j] + cq * 0.5f * __builtin_amdgcn_rsqf(p[i][j] + QEPS);   // v_rsq_f32 (1 ulp)
           if (dp) g += dp[ci * nb + (i * LPC + gl) * 4 + j];
           if (soft) g = fmaf(on * go, bv[i][j], g);
         }
@@ -362,11 +365,11 @@ extern "C" int nsc_quantize_fwd(const float* code, const float* alpha, const flo
 #define CALLF(LPC_, IT_)                                                                                          \
   do {                                                                                                            \
     if (nb == 4 * LPC_ * IT_)                                                                                     \
-      hipLaunchKernelGGL((quantize_fwd_kernel<LPC_, IT_, true>), dim3(std::min(B, 1024)), dim3(256),               \
+      hipLaunchKernelGGL((quantize_fwd_kernel<LPC_, IT_, true>), dim3(std::min(B, NSC_QGRID)), dim3(256),          \
                          (4 * LPC_ * IT_ + 4) * sizeof(float), st, code, alpha, bins, is_quan_on, soft, L, nb, p_out,  \
                          out, quan_out, hist, B);                                                                  \
     else                                                                                                          \
-      hipLaunchKernelGGL((quantize_fwd_kernel<LPC_, IT_, false>), dim3(std::min(B, 1024)), dim3(256),              \
+      hipLaunchKernelGGL((quantize_fwd_kernel<LPC_, IT_, false>), dim3(std::min(B, NSC_QGRID)), dim3(256),         \
                          (4 * LPC_ * IT_ + 4) * sizeof(float), st, code, alpha, bins, is_quan_on, soft, L, nb, p_out,  \
                          out, quan_out, hist, B);                                                                  \
   } while (0)
