@@ -244,7 +244,7 @@ def main():
         qroof = dict(bound="hbm", kernel="quantize_fwd_kernel (p materialised, B=4096 frames)", achieved=round(byts / us / 1e3, 1),
                      peak=8000.0, unit="GB/s", frac=round(byts / us / 1e3 / 8000.0, 4), traffic=traffic.get("quantize_fwd"),
                      bytes_per_launch=byts, avg_launch_us=round(us, 2), peak_measured_on_box=5440.0,
-                     note="peak_measured_on_box = write-only stream rate of this box in the kernel's own pattern, 32 KB contiguous per workgroup (tools/write_peak.hip, profiles/r01_onbox_peaks.txt): the kernel writes 32 of every 34 bytes"): the kernel writes 32 of every 34 bytes")
+                     note="peak_measured_on_box = write-only stream rate of this box in the kernel's own pattern, 32 KB contiguous per workgroup (tools/write_peak.hip, profiles/r01_onbox_peaks.txt): the kernel writes 32 of every 34 bytes")
 
     # ---- second half of the metric: codec forward us/frame (BASELINE config 5: 2-codec encode+quantise+decode,
     # batch 4096 frames, hipGraph-captured forward), plus the batch-1 latency the reference's eval loop actually pays
