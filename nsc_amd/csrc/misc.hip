@@ -4,6 +4,35 @@
 #include <algorithm>
 
 // ---------------- depthwise conv (Keras SeparableConv1D depthwise stage; nn_core_operator.py:17-21) ----------------
+// One thread per 4 consecutive outputs: the 12-sample window it needs is three aligned float4 loads (first / last block
+// zero at the frame edges), the taps are unrolled for K <= 9 (generic K takes the scalar kernel).  REV = 1 runs the taps
+// backwards: the data gradient dx[c,t] = sum_k dy[c, t-k+padL] wd[k,c] is the same correlation with the taps flipped.
+template <bool REV>
+__global__ void depthwise_vec4_kernel(const float* __restrict__ x, const float* __restrict__ wd, float* __restrict__ y,
+                                      int C, int T, int K, long n4) {
+  const int padL = (K - 1) / 2;                      // SAME, stride 1 (K odd here: padL == padR)
+  const int T4 = T >> 2;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n4; e += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(e % T4);
+    const long row = e / T4;
+    const int c = (int)(row % C);
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x + row * T);
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 a = q > 0 ? xr[q - 1] : z, m = xr[q], b = q + 1 < T4 ? xr[q + 1] : z;
+    const float w[12] = {a[0], a[1], a[2], a[3], m[0], m[1], m[2], m[3], b[0], b[1], b[2], b[3]};   // window: t-4 .. t+7
+    f32x4 acc = z;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      if (k < K) {
+        const float wk = wd[(REV ? K - 1 - k : k) * C + c];
+        // forward: out[t+i] += wk * x[t+i + k - padL]  -> window index 4 + i + k - padL
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = fmaf(w[4 + i + k - 4 + (4 - padL)], wk, acc[i]);
+      }
+    }
+    reinterpret_cast<f32x4*>(y + row * T)[q] = acc;
+  }
+}
 __global__ void depthwise_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wd, float* __restrict__ y,
                                      int C, int T, int K, long n) {
   const int padL = (K - 1) / 2;  // SAME, stride 1: pad = K-1, padL = (K-1)//2
@@ -19,11 +48,17 @@ __global__ void depthwise_fwd_kernel(const float* __restrict__ x, const float* _
     y[e] = acc;
   }
 }
+static bool depthwise_vec_ok(int T, int K) { return (T & 3) == 0 && (K & 1) && K <= 9; }
 extern "C" int nsc_depthwise_fwd(const float* x, const float* wd, float* y, int B, int C, int T, int K, void* stream) {
   NSC_REQUIRE(x && wd && y && B > 0 && C > 0 && T > 0 && K > 0, NSC_ERR_BAD_ARG, "nsc_depthwise_fwd: bad args");
   const long n = (long)B * C * T;
-  hipLaunchKernelGGL(depthwise_fwd_kernel, dim3(std::min<long>(4096, nsc_cdiv(n, 256))), dim3(256), 0,
-                     (hipStream_t)stream, x, wd, y, C, T, K, n);
+  if (depthwise_vec_ok(T, K)) {
+    hipLaunchKernelGGL(depthwise_vec4_kernel<false>, dim3(std::min<long>(4096, nsc_cdiv(n / 4, 256))), dim3(256), 0,
+                       (hipStream_t)stream, x, wd, y, C, T, K, n / 4);
+  } else {
+    hipLaunchKernelGGL(depthwise_fwd_kernel, dim3(std::min<long>(4096, nsc_cdiv(n, 256))), dim3(256), 0,
+                       (hipStream_t)stream, x, wd, y, C, T, K, n);
+  }
   NSC_CHECK_LAUNCH("depthwise_fwd");
   return NSC_OK;
 }
@@ -88,7 +123,11 @@ extern "C" int nsc_depthwise_bwd(const float* x, const float* wd, const float* d
   NSC_REQUIRE(x && wd && dy && B > 0 && C > 0 && T > 0 && K > 0, NSC_ERR_BAD_ARG, "nsc_depthwise_bwd: bad args");
   NSC_REQUIRE(K <= 16, NSC_ERR_UNSUPPORTED, "nsc_depthwise_bwd: K %d > 16", K);
   const long n = (long)B * C * T;
-  if (dx) {
+  if (dx && depthwise_vec_ok(T, K)) {
+    hipLaunchKernelGGL(depthwise_vec4_kernel<true>, dim3(std::min<long>(4096, nsc_cdiv(n / 4, 256))), dim3(256), 0,
+                       (hipStream_t)stream, dy, wd, dx, C, T, K, n / 4);
+    NSC_CHECK_LAUNCH("depthwise_bwd_dx");
+  } else if (dx) {
     hipLaunchKernelGGL(depthwise_bwd_dx_kernel, dim3(std::min<long>(4096, nsc_cdiv(n, 256))), dim3(256), 0,
                        (hipStream_t)stream, dy, wd, dx, C, T, K, n);
     NSC_CHECK_LAUNCH("depthwise_bwd_dx");
