@@ -892,8 +892,10 @@ static WgradPlan wgrad_plan(const nsc_conv_desc* d, int CT, bool bias, bool use_
   const int nchunks = d->B * p.nchunk_t;
   // K-splits: with slabs ~one workgroup per CU (256 in all) and >= 2 chunks each (the slab traffic grows with gx);
   // with atomics keep the number of same-address adders small.
-  int gx = use_slab ? 256 / p.gy : 64 / p.gy;
-  if (p.smem <= 76 * 1024 && use_slab) gx *= 2;      // two workgroups fit a CU
+  static const int gx_base = getenv("NSC_WGRAD_GX") ? atoi(getenv("NSC_WGRAD_GX")) : 256;   // tuning probe
+  static const int gx_dbl = getenv("NSC_WGRAD_GX2") ? atoi(getenv("NSC_WGRAD_GX2")) : 1;
+  int gx = use_slab ? gx_base / p.gy : 64 / p.gy;
+  if (p.smem <= 76 * 1024 && use_slab && gx_dbl) gx *= 2;      // two workgroups fit a CU
   if (gx > nchunks / 2) gx = nchunks / 2;
   if (gx < 1) gx = 1;
   p.gx = gx;
