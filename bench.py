@@ -253,6 +253,7 @@ def main():
         def fwd_time(Bi, reps):
             engi = CascadeEngine(Bi, 2, BKD, [[2], [2]], [32, 32], res_scalar=RES_SCALAR, scale_first=True, lpc=True, device=dev)
             engi.params.copy_(eng.params)
+            engi.keep_activations = False        # encode + quantise + decode only: nothing is kept for a backward pass
             xi = torch.from_numpy(np.tile(x_np, (max(1, Bi // B + 1), 1, 1))[:Bi].copy()).to(dev)
             for _ in range(2):
                 engi.forward(xi, 1.0, False)

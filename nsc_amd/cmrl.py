@@ -77,6 +77,7 @@ class CMRL(neuralSpeechCodingModule):
         if frames is None:
             frames = self._tr_data[:B, :512]
         x = torch.from_numpy(np.ascontiguousarray(frames[:B].reshape(B, 1, 512).astype(np.float32))).to(eng.device)
+        eng.keep_activations = False         # inference: nothing is kept for a backward pass
         eng.forward(x, 1.0, True)            # cmrl_eval feeds the_share: 1.0 => soft codes (cmrl.py:592)
         torch.cuda.synchronize()
         t0 = time.time()

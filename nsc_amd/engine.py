@@ -220,7 +220,8 @@ class _Block:
             P = lambda c, base=e.p_ptr: (base + 4 * c.w_off, base + 4 * c.b_off)
             (w1, b1), (wl, bl), (wr, br), (w9, b9) = P(self.c1), P(self.cl), P(self.cr), P(self.c9)
             tok = e.prof_begin("block_fwd", self.c1.flops() + self.cl.flops() + self.cr.flops() + self.c9.flops())
-            save = not self.fused_bwd_ok()   # the fused backward recomputes the intermediates from x
+            # the fused backward recomputes the intermediates from x; an inference-only engine never reads them
+            save = e.keep_activations and not self.fused_bwd_ok()
             check(e.lib.nsc_gated_block_fwd(x.data_ptr(), w1, b1, wl, bl, wr, br, w9, b9, self.out.data_ptr(),
                                             self.h.data_ptr() if save else None, self.lin.data_ptr() if save else None,
                                             self.th.data_ptr() if save else None, self.g.data_ptr() if save else None,
@@ -603,6 +604,7 @@ class CascadeEngine:
     def _leave(self):
         self._st = None
 
+    keep_activations = True   # False for inference-only use: the block forward then skips its 4 saved [B,20,T] tensors
     fused_fwd = True   # gated blocks run as one kernel (csrc/block.hip); False = one launch per conv
     fused_bwd = False  # whole-block backward in one persistent kernel (correct, but its conv phases run at one wave
                        # per SIMD and lose to the per-conv kernels: measured 9.0 vs 6.7 ms/step) - kept, off by default
