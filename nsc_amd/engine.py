@@ -431,7 +431,7 @@ class _Codec:
         self.quan = e.buf(s + ".quan", (B,))
         self.hist = e.hist_view(s, self.nb)     # a slice of ONE flat buffer: the data-parallel exchange is a single all-reduce
         self.p = e.buf(s + ".p", (B, self.L, self.nb)) if want_p else None
-        self.hist.zero_()
+        e.zero_hists_once()
         self.is_quan_on, self.soft = float(is_quan_on), int(bool(soft))
         check(e.lib.nsc_quantize_fwd(self.code.data_ptr(), e.p_ptr + 4 * self.alpha_off, e.p_ptr + 4 * self.bins_off,
                                      self.is_quan_on, self.soft, B, self.L, self.nb, _lib.ptr(self.p),
@@ -756,6 +756,13 @@ class CascadeEngine:
         return self._hist_flat[o:o + n]
 
     _hist_flat = None
+    _hist_clean = False
+
+    def zero_hists_once(self):
+        """All quantizers' histograms live in one flat buffer: zero it once per forward (first quantizer to ask)."""
+        if not self._hist_clean and self._hist_flat is not None:
+            self._hist_flat.zero_()
+            self._hist_clean = True
 
     def buf(self, name, shape):
         t = self._bufs.get(name)
@@ -823,6 +830,7 @@ class CascadeEngine:
         e = self
         B, rs = self.B, self.res_scalar
         assert tuple(x.shape) == (B, 1, frame_length) and x.dtype == torch.float32 and x.is_contiguous()
+        self._hist_clean = False
         self.x = x
         n = B * frame_length
         self.decoded = self.buf("decoded", (B, 1, frame_length))
@@ -854,7 +862,7 @@ class CascadeEngine:
             self.lpc_q = self.buf("lpc.q", (B, L, 1))
             self.lpc_quan = self.buf("lpc.quan", (B,))
             self.lpc_hist = self.hist_view("lpc", nb)
-            self.lpc_hist.zero_()
+            self.zero_hists_once()
             check(self.lib.nsc_quantize_fwd(lpc_x.data_ptr(), self.p_ptr + 4 * self.lpc_alpha_off,
                                             self.p_ptr + 4 * self.lpc_bins_off, float(is_quan_on), int(bool(soft)), B, L,
                                             nb, None, self.lpc_q.data_ptr(), self.lpc_quan.data_ptr(),
@@ -941,8 +949,15 @@ class CascadeEngine:
         st = self.adam[slot]
         st["t"] += 1   # host mirror; the kernel reads the device counter so a captured graph stays valid
         check(self.lib.nsc_increment(st["t_dev"].data_ptr(), self.stream()), "increment")
+        # adjacent scopes are adjacent ranges of the flat buffers: merge them (one launch for the joint step)
+        ranges = []
         for sc in scopes:
             a, b = self.layout.scope_range(sc)
+            if ranges and ranges[-1][1] == a:
+                ranges[-1][1] = b
+            else:
+                ranges.append([a, b])
+        for a, b in ranges:
             check(self.lib.nsc_adam_tf1_step(self.p_ptr + 4 * a, self.g_ptr + 4 * a, st["m"].data_ptr() + 4 * a,
                                              st["v"].data_ptr() + 4 * a, b - a, float(lr), beta1, beta2, eps, st["t"],
                                              st["t_dev"].data_ptr(), self.stream()), "adam")
