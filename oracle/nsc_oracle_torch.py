@@ -213,26 +213,36 @@ def cascade_forward(x, tp, bkd, strides_per_codec, is_quan_on, the_share, res_sc
     return outs, torch.stack(yhat, 0).sum(0)
 
 
-def total_loss_sum(decoded, target, p_list, coeff, tau, mode, p_extra=()):
-    """Scalar minimised by the reference's optimizers (sum over the [B] loss vector).  See
-    nsc_oracle.total_loss_sum.  p_extra: additional soft assignments that only enter the quan term
-    (the LSF quantizer in finetune_lpc, cmrl.py:463-468)."""
-    B = decoded.shape[0]
-    tot = (coeff[0] * mse_loss(decoded, target) + coeff[1] * mfcc_loss(decoded, target)).sum()
+def phase_loss(decoded, target, p_list, coeff, tau, mode, p_extra=(), code_lens=(16.0, 256.0)):
+    """The [B] loss vector a phase minimises (see nsc_oracle.phase_loss for the reference lines).
+    p_extra: (p_lpc,) - the LSF quantizer's soft assignment for the two LPC modes."""
+    base = coeff[0] * mse_loss(decoded, target) + coeff[1] * mfcc_loss(decoded, target)
     tau = np.ravel(np.asarray(tau, dtype=np.float64))
     if mode == "no_quan":
-        return tot
+        return base
     if mode == "quan_last":
-        return tot + (coeff[2] * quan_loss(p_list[-1])).sum() + B * float(tau[0]) * entropy_coding_loss(p_list[-1])
+        return base + coeff[2] * quan_loss(p_list[-1]) + float(tau[0]) * entropy_coding_loss(p_list[-1])
     if mode == "finetune":
+        out = base + coeff[2] * torch.stack([quan_loss(p) for p in p_list], 0).sum()   # scalar (cmrl.py:355)
         for i, p in enumerate(p_list):
-            tot = tot + (coeff[2] * quan_loss(p)).sum() + B * float(tau[i]) * entropy_coding_loss(p)
-        return tot
+            out = out + float(tau[i]) * entropy_coding_loss(p)
+        return out
+    if mode == "one_ae_lpc":
+        a, b = code_lens[0] / sum(code_lens), code_lens[1] / sum(code_lens)
+        pl = p_extra[0]
+        return base + coeff[2] * (quan_loss(pl) * a + quan_loss(p_list[0]) * b) + \
+            float(tau[0]) * (a * entropy_coding_loss(pl) + b * entropy_coding_loss(p_list[0]))
     if mode == "finetune_lpc":
+        out = base
         for p in list(p_extra) + list(p_list):
-            tot = tot + (coeff[2] * quan_loss(p)).sum()
-        return tot
+            out = out + coeff[2] * quan_loss(p)
+        return out
     raise ValueError(mode)
+
+
+def total_loss_sum(decoded, target, p_list, coeff, tau, mode, p_extra=(), code_lens=(16.0, 256.0)):
+    """Scalar minimised by the reference's optimizers: the SUM of the [B] loss vector [TF-semantics]."""
+    return phase_loss(decoded, target, p_list, coeff, tau, mode, p_extra, code_lens).sum()
 
 
 def adam_tf1_step_(params, grads, ms, vs, t, lr, beta1=0.9, beta2=0.999, eps=1e-8):
