@@ -15,6 +15,22 @@ import torch
 from .neural_speech_coding_module import neuralSpeechCodingModule, _split
 
 
+def encode_decode_utterance(eng, utt, soft=True, lpc_x=None):
+    """Utterance-level inference of cmrl_eval (cmrl.py:566-597) without host round trips: a 1-D float32 CUDA signal is
+    cut into hop-480 frames by the framing kernel (`utterance_to_segment(per_sig, True)`, :566), the frames go through
+    the cascade as ONE batch (the reference feeds them one per sess.run, :585-593 - frames are independent, so the
+    batch is the same arithmetic), and the decoded frames are Hann-windowed (first / middle / last variants) and
+    overlap-added by the OLA kernel (:595-597).  `soft=True` is what cmrl_eval actually feeds (`the_share: 1.0`, :592);
+    end2end_eval feeds hard codes (nsc_module:697).  The engine's batch must equal the utterance's frame count."""
+    from .utilities import frames_on_gpu, num_frames, overlap_add_on_gpu
+    nf = num_frames(int(utt.numel()))
+    if nf != eng.B:
+        raise ValueError(f"utterance has {nf} frames but the engine was built for a batch of {eng.B}")
+    frames = frames_on_gpu(utt, post_window=True)
+    dec = eng.forward(frames.view(nf, 1, -1), 1.0, soft, lpc_x=lpc_x)
+    return overlap_add_on_gpu(dec.view(nf, -1))
+
+
 class CMRL(neuralSpeechCodingModule):
     def __init__(self, arg):
         super(CMRL, self).__init__(arg)
@@ -30,10 +46,10 @@ class CMRL(neuralSpeechCodingModule):
         prev = '' if num_res == 1 else 'follower_' + str(num_res - 1) + self._suffix
         self.restore(eng, prev, scopes=[f"scope_{i + 1}" for i in range(num_res)] + ["lpc_quan"])
         eng.reset_adam()
-        no_quan, quan, tau_slots = self._loss_cfgs(n, "follower")
+        no_quan, quan, tau_map = self._loss_cfgs(n, "follower")
         self.model_training(eng, no_quan, quan, self._learning_rate_greedy_followers[-2], self._epoch_greedy_followers[-2],
                             'the_follower', save_id='follower_' + str(num_res) + self._suffix,
-                            the_tau_val=self._coeff_term[3], tau_slots=tau_slots)
+                            the_tau_val=self._coeff_term[3], tau_map=tau_map)
         self._engine = eng
         return eng
 
@@ -50,20 +66,17 @@ class CMRL(neuralSpeechCodingModule):
         else:
             self.restore(eng, 'follower_' + str(num_res - 1) + 'end2endcascade')
         eng.reset_adam()
-        no_quan, quan, tau_slots = self._loss_cfgs(num_res, "finetune")
+        no_quan, quan, tau_map = self._loss_cfgs(num_res, "finetune")
         self.model_training(eng, no_quan, quan, self._learning_rate_greedy_followers[-1], self._epoch_greedy_followers[-1],
                             'finetune', save_id='finetune_' + str(num_res) + self._suffix + self._save_unique_mark,
-                            the_tau_val=self._coeff_term[3], tau_slots=tau_slots)
+                            the_tau_val=self._coeff_term[3], tau_map=tau_map)
         self._engine = eng
         return eng
 
     _finetuning_lpc = _finetuning
 
-    def _feedforward(self, num_res, frames=None):
-        """cmrl.py:876-907 + cmrl_eval :545-644 restricted to the in-scope part: restore, run encode+quantise+decode
-        over frames and report wall time per frame (the reference prints wall time / real-time factor :608-611).
-        NOTE the reference feeds one frame per sess.run; here frames are batched."""
-        eng = self._make_engine(num_res, per_codec_list_semantics=True)
+    def _restore_for_inference(self, eng, num_res):
+        """Checkpoint choice of _feedforward (cmrl.py:887-902)."""
         try:
             if num_res == 1:
                 self.restore(eng, '')
@@ -73,21 +86,53 @@ class CMRL(neuralSpeechCodingModule):
                 self.restore(eng, 'finetune_' + str(num_res) + 'end2endcascade')
         except FileNotFoundError as e:
             print('no checkpoint found (%s): running with freshly initialised weights' % e)
-        B = self._batch_size
-        if frames is None:
-            frames = self._tr_data[:B, :512]
-        x = torch.from_numpy(np.ascontiguousarray(frames[:B].reshape(B, 1, 512).astype(np.float32))).to(eng.device)
-        eng.keep_activations = False         # inference: nothing is kept for a backward pass
-        eng.forward(x, 1.0, True)            # cmrl_eval feeds the_share: 1.0 => soft codes (cmrl.py:592)
-        torch.cuda.synchronize()
-        t0 = time.time()
-        dec = eng.forward(x, 1.0, True)
-        torch.cuda.synchronize()
-        dt = time.time() - t0
-        print('feedforward: %d frames in %.3f ms -> %.2f us/frame, real-time factor %.1f' %
-              (B, 1e3 * dt, 1e6 * dt / B, (B * 480 / 16000.0) / dt))
-        self._engine = eng
-        return dec
+
+    def _feedforward(self, num_res, utterances=None):
+        """Mode '0' (cmrl.py:876-907 -> cmrl_eval :545-644), the in-scope part: restore, then per utterance
+        frames -> cascade -> Hann overlap-add on the GPU (`encode_decode_utterance`), print wall time / real-time factor
+        (:608-611), entropy and bit rate (:621-625), and the journal line (:626-628; PESQ needs the external binary: nan).
+        `utterances`: list of 1-D float arrays (already normalised like _load_sig does); default: synthetic ones.
+        Returns the list of decoded signals (NumPy)."""
+        from .loss_terms_and_measures import entropy_to_bitrate, snr
+        if utterances is None:
+            rng = np.random.default_rng(99)
+            utterances = [(0.03 * rng.standard_normal(n)).astype(np.float32) for n in (16000, 24000)]
+        outs, engines = [], {}
+        for i, sig in enumerate(utterances):
+            sig = np.asarray(sig, np.float32)
+            nf = len(range(0, len(sig) - 512, 480))
+            if nf == 0:
+                outs.append(np.zeros(0, np.float32))
+                continue
+            if nf not in engines:       # one engine per frame count (buffers are sized by the batch)
+                strides = [list(self._the_strides)] * num_res
+                bins = (self._num_bins_for_follower + [self._num_bins_for_follower[-1]] * num_res)[:num_res]
+                from .engine import CascadeEngine
+                eng = CascadeEngine(nf, num_res, self._bottleneck_kernel_and_dilation, strides, bins,
+                                    res_scalar=self._res_scalar, device=self._device, seed=self._seed)
+                eng.keep_activations = False     # inference: nothing is kept for a backward pass
+                self._restore_for_inference(eng, num_res)
+                engines[nf] = eng
+            eng = engines[nf]
+            u = torch.from_numpy(sig).to(eng.device)
+            encode_decode_utterance(eng, u, soft=True)            # warm-up (first-use allocations)
+            torch.cuda.synchronize()
+            t0 = time.time()
+            dec = encode_decode_utterance(eng, u, soft=True)
+            ent = sum(float(c.entropy().item()) for c in eng.codecs)    # interested_var = [reduce_sum(ent_loss_arr)], :882
+            torch.cuda.synchronize()
+            exec_time = time.time() - t0
+            sig_duration = len(sig) / 16000.0
+            print('Execute time for the neural codec:', exec_time, sig_duration, exec_time / sig_duration)
+            d = dec.cpu().numpy()
+            the_snr = float(snr(sig.astype(np.float64), d.astype(np.float64))[1])
+            print('Test Utterance %1d: SNR: %7.5f dB  PESQ-WB: %6.5f  Entropy: %6.5f  Bit rate: %6.5f  ID: %s' % (
+                i, the_snr, float('nan'), ent, entropy_to_bitrate(ent, self._the_strides[0]), self._rand_model_id))
+            self._write_to_file_and_update_to_display(
+                'Test Utterance %1d: SNR: %7.5f dB  PESQ-WB: %6.5f   Entropy: %6.5f \n' % (i, the_snr, float('nan'), ent))
+            outs.append(d)
+            self._engine = eng
+        return outs
 
     _feedforward_lpc = _feedforward
 

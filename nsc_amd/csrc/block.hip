@@ -477,7 +477,7 @@ static int launch_block_fwd2(const BlockArgs& a, hipStream_t st) {
   NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "gated_block_fwd2: smem attr: %s", hipGetErrorString(e));
   const int tpf = nsc_cdiv(a.T, 64);
   const int ntiles = a.B * tpf;
-  static const int skip = getenv("NSC_FWD2_SKIP") ? atoi(getenv("NSC_FWD2_SKIP")) : 0;   // timing probe only
+  static const int skip = NSC_PROBE_INT("NSC_FWD2_SKIP", 0);   // timing probe only
   hipLaunchKernelGGL(kern, dim3(std::min(ntiles, 256)), dim3(512), smem, st, a, ntiles, tpf, skip);
   NSC_CHECK_LAUNCH("gated_block_fwd2");
   return NSC_OK;
@@ -505,7 +505,7 @@ extern "C" int nsc_gated_block_fwd(const float* x, const float* w1, const float*
   BlockArgs a{B, C, T, dil, flat, x, w1, b1, wl, bl, wr, br, w9, b9, out, h_out, lin_out, th_out, g_out};
   dim3 grid(nsc_cdiv(T, 64), B);
   hipStream_t st = (hipStream_t)stream;
-  static const bool v1_only = getenv("NSC_BLOCK_FWD_V1") != nullptr;   // A/B switch for profiling
+  static const bool v1_only = NSC_PROBE_SET("NSC_BLOCK_FWD_V1");   // A/B switch for profiling
   if (!v1_only && (dil == 1 || dil == 2)) {
     if (C == 100) return dil == 1 ? launch_block_fwd2<7, 25, 1>(a, st) : launch_block_fwd2<7, 25, 2>(a, st);
     if (C == 50) return dil == 1 ? launch_block_fwd2<4, 13, 1>(a, st) : launch_block_fwd2<4, 13, 2>(a, st);
@@ -1062,7 +1062,7 @@ extern "C" int nsc_gated_block_bwd(const float* x, const float* dy, const float*
   NSC_REQUIRE(smem <= 160 * 1024, NSC_ERR_UNSUPPORTED, "nsc_gated_block_bwd: %zu B LDS", smem);
   BlockBwdArgs a{B, C, T, dil, in_act, x, dy, w1, b1, wl, bl, wr, br, wt1, wtl, wtr, wt9, dx,
                  dw1, db1, dwl, dbl, dwr, dbr, dw9, db9, 0, 0, 0};
-  { static int skip_env = -1; if (skip_env < 0) { const char* e = getenv("NSC_BWD_SKIP"); skip_env = e ? atoi(e) : 0; } a.skip = skip_env; }
+  { static int skip_env = -1; if (skip_env < 0) { skip_env = NSC_PROBE_INT("NSC_BWD_SKIP", 0); } a.skip = skip_env; }
   a.tiles_per_frame = nsc_cdiv(T, 64);
   a.ntiles = B * a.tiles_per_frame;
   const int grid = std::min(a.ntiles, 256);
@@ -1516,7 +1516,7 @@ extern "C" int nsc_gated_block_wgrad(const float* x, const float* h, const float
   const size_t smem = fl * sizeof(float);
   NSC_REQUIRE(smem <= 160 * 1024, NSC_ERR_UNSUPPORTED, "nsc_gated_block_wgrad: %zu B LDS", smem);
   BlockWgradArgs a{B, C, T, dil, x, h, g, dy, da, dz1, wt1, dx, in_act, dw1, db1, dwl, dbl, dwr, dbr, dw9, db9, 0, 0, 0, 0};
-  { static int skip_env = -1; if (skip_env < 0) { const char* e = getenv("NSC_WG_SKIP"); skip_env = e ? atoi(e) : 0; } a.skip = skip_env; }
+  { static int skip_env = -1; if (skip_env < 0) { skip_env = NSC_PROBE_INT("NSC_WG_SKIP", 0); } a.skip = skip_env; }
   a.tiles_per_frame = nsc_cdiv(T, 64);
   a.ntiles = B * a.tiles_per_frame;
   const int grid = std::min(a.ntiles, 256);
@@ -1565,7 +1565,7 @@ static int launch_wgrad_batch(const nsc_block_wgrad_job* jobs, const int* idx, i
   memset(&t, 0, sizeof(t));
   memset(&r, 0, sizeof(r));
   static int skip_env = -1;
-  if (skip_env < 0) { const char* e = getenv("NSC_WG_SKIP"); skip_env = e ? atoi(e) : 0; }
+  if (skip_env < 0) { skip_env = NSC_PROBE_INT("NSC_WG_SKIP", 0); }
   const int ldn = ld2(64), ldg = ld2(72);
   long stride = 0, total_tiles = 0;
   size_t smem = 0;
@@ -2341,7 +2341,7 @@ static int launch_block_dgrad2(const BlockDgradArgs& a, hipStream_t st) {
   NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "gated_block_dgrad2: smem attr: %s", hipGetErrorString(e));
   const int tpf = nsc_cdiv(a.T, 64);
   const int ntiles = a.B * tpf;
-  static const int skip = getenv("NSC_DGRAD2_SKIP") ? atoi(getenv("NSC_DGRAD2_SKIP")) : 0;   // timing probe only
+  static const int skip = NSC_PROBE_INT("NSC_DGRAD2_SKIP", 0);   // timing probe only
   hipLaunchKernelGGL(kern, dim3(std::min(ntiles, 256)), dim3(512), smem, st, a, ntiles, tpf, skip);
   NSC_CHECK_LAUNCH("gated_block_dgrad2");
   return NSC_OK;
@@ -2367,7 +2367,7 @@ extern "C" int nsc_gated_block_dgrad(const float* x, const float* h, const float
   BlockDgradArgs a{B, C, T, dil, in_act, x, h, lin, th, dy, wt1, wtl, wtr, wt9, dx, da, dz1};
   dim3 grid(nsc_cdiv(T, 64), B);
   hipStream_t st = (hipStream_t)stream;
-  static const bool v1_only = getenv("NSC_BLOCK_DGRAD_V1") != nullptr;   // A/B switch for profiling
+  static const bool v1_only = NSC_PROBE_SET("NSC_BLOCK_DGRAD_V1");   // A/B switch for profiling
   if (!v1_only) {
     if (C == 100) return dil == 1 ? launch_block_dgrad2<7, 25, 1>(a, st) : launch_block_dgrad2<7, 25, 2>(a, st);
     if (C == 50) return dil == 1 ? launch_block_dgrad2<4, 13, 1>(a, st) : launch_block_dgrad2<4, 13, 2>(a, st);

@@ -325,7 +325,7 @@ static int launch_fwd_ks(const nsc_conv_desc* d, const float* x, const float* w,
   }
   const int nrt = nsc_cdiv(d->Cout, 16);
   dim3 grid(nsc_cdiv(d->Tout, TT), d->B, nsc_cdiv(nrt, RT));
-  static const int skip = getenv("NSC_CONV_SKIP") ? atoi(getenv("NSC_CONV_SKIP")) : 0;
+  static const int skip = NSC_PROBE_INT("NSC_CONV_SKIP", 0);
   hipLaunchKernelGGL(kern, grid, dim3(256 * KS), smem, st, *d, x, w, bias, res, aux, y, ldx, win | (skip << 20));
   NSC_CHECK_LAUNCH("conv1d_fwd");
   return NSC_OK;
@@ -334,7 +334,7 @@ static int launch_fwd_ks(const nsc_conv_desc* d, const float* x, const float* w,
 template <int RT, int NC, bool CIN1>
 static int launch_fwd(const nsc_conv_desc* d, const float* x, const float* w, const float* bias, const float* res,
                       const float* aux, float* y, hipStream_t st) {
-  static const bool no_pre = getenv("NSC_CONV_NOPRE") != nullptr;   // A/B switch for profiling
+  static const bool no_pre = NSC_PROBE_SET("NSC_CONV_NOPRE");   // A/B switch for profiling
   if constexpr (!CIN1) {
     if (d->K >= 2) return launch_fwd_ks<RT, NC, CIN1, 2>(d, x, w, bias, res, aux, y, st);
     if constexpr (RT == 7) {
@@ -387,7 +387,7 @@ extern "C" int nsc_conv1d_fwd(const nsc_conv_desc* d, const float* x, const floa
   const bool cin1 = d->Cin == 1;
   const int Cin4 = cin1 ? 1 : ((d->Cin + 3) & ~3);
   const long smem2 = (long)Cin4 * ((127L) * d->stride + (d->K - 1) * d->dil + 40) * 4;
-  static const int force_nc = getenv("NSC_CONV_NC") ? atoi(getenv("NSC_CONV_NC")) : 0;   // profiling switch
+  static const int force_nc = NSC_PROBE_INT("NSC_CONV_NC", 0);   // profiling switch
   bool nc2 = smem2 <= 72 * 1024 && d->Tout >= 128;
   if (force_nc) nc2 = force_nc == 2;
   if (cin1) return nc2 ? dispatch_rt<2, true>(d, x, w, bias, res, aux, y, st)
@@ -566,7 +566,7 @@ extern "C" int nsc_conv1d_cout1_fwd(const nsc_conv_desc* d, const float* x, cons
   NSC_REQUIRE(d->Cout == 1 && d->out_mode == 0, NSC_ERR_BAD_ARG, "nsc_conv1d_cout1_fwd: needs Cout == 1, plain store");
   NSC_REQUIRE(x && w && y, NSC_ERR_BAD_ARG, "nsc_conv1d_cout1_fwd: null x/w/y");
   NSC_REQUIRE(!(d->res_mode && !res) && !(d->mul_mode && !aux), NSC_ERR_BAD_ARG, "nsc_conv1d_cout1_fwd: null res/aux");
-  static const bool v1_only = getenv("NSC_COUT1_V1") != nullptr;   // A/B switch for profiling
+  static const bool v1_only = NSC_PROBE_SET("NSC_COUT1_V1");   // A/B switch for profiling
   if (!v1_only && d->K == 55 && d->dil == 1 && d->stride == 1 && !d->in_up && d->Cin >= 8 && d->Cin <= 104) {
     // R outputs per lane: 4 when that still gives every CU a workgroup, else 2
     const bool r4 = (long)d->B * nsc_cdiv(d->Tout, 256) >= 256;
@@ -892,8 +892,8 @@ static WgradPlan wgrad_plan(const nsc_conv_desc* d, int CT, bool bias, bool use_
   const int nchunks = d->B * p.nchunk_t;
   // K-splits: with slabs ~one workgroup per CU (256 in all) and >= 2 chunks each (the slab traffic grows with gx);
   // with atomics keep the number of same-address adders small.
-  static const int gx_base = getenv("NSC_WGRAD_GX") ? atoi(getenv("NSC_WGRAD_GX")) : 256;   // tuning probe
-  static const int gx_dbl = getenv("NSC_WGRAD_GX2") ? atoi(getenv("NSC_WGRAD_GX2")) : 1;
+  static const int gx_base = NSC_PROBE_INT("NSC_WGRAD_GX", 256);   // tuning probe
+  static const int gx_dbl = NSC_PROBE_INT("NSC_WGRAD_GX2", 1);
   int gx = use_slab ? gx_base / p.gy : 64 / p.gy;
   if (p.smem <= 76 * 1024 && use_slab && gx_dbl) gx *= 2;      // two workgroups fit a CU
   if (gx > nchunks / 2) gx = nchunks / 2;

@@ -9,6 +9,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define NSC_LRELU_ALPHA 0.2f
 
+// Profiling / A-B switches read from the environment exist only in a -DNSC_PROBES build (`make PROBES=1`).  The
+// shipped library has no environment-dependent behaviour: the macros fold to their defaults at compile time.
+#ifdef NSC_PROBES
+#include <cstdlib>
+#define NSC_PROBE_INT(name, dflt) (getenv(name) ? atoi(getenv(name)) : (dflt))
+#define NSC_PROBE_SET(name) (getenv(name) != nullptr)
+#else
+#define NSC_PROBE_INT(name, dflt) (dflt)
+#define NSC_PROBE_SET(name) (false)
+#endif
+
 void nsc_set_error(const char* fmt, ...);
 
 #define NSC_REQUIRE(cond, code, ...)          \

@@ -35,6 +35,13 @@ class Comm:
         for t in tensors:
             self.allreduce(t)
 
+    def broadcast_object(self, obj, src=0):
+        if self.world > 1:
+            box = [obj]
+            dist.broadcast_object_list(box, src=src)
+            return box[0]
+        return obj
+
     def barrier(self):
         if self.world > 1:
             dist.barrier()

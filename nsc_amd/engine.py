@@ -216,7 +216,8 @@ class _Block:
         self.th = e.buf(u + ".th", (B, n, T))
         self.g = e.buf(u + ".g", (B, n, T))
         self.out = e.buf(u + ".out", (B, self.wide, T))
-        if e.fused_fwd and self.Cin > 1 and n == 20 and self.c9.K == 9:
+        if e.fused_fwd and self.Cin > 1 and n == 20 and self.c9.K == 9 and self.wide <= 112 and self.cl.dil <= 4:
+            # (other reference-legal shapes, e.g. wide 128 or dilation 8, take the per-conv path below)
             P = lambda c, base=e.p_ptr: (base + 4 * c.w_off, base + 4 * c.b_off)
             (w1, b1), (wl, bl), (wr, br), (w9, b9) = P(self.c1), P(self.cl), P(self.cr), P(self.c9)
             tok = e.prof_begin("block_fwd", self.c1.flops() + self.cl.flops() + self.cr.flops() + self.c9.flops())
@@ -682,7 +683,10 @@ class CascadeEngine:
         self.side_idx = self._side_rr % len(self._side)    # also selects the slab workspace of launches on this stream
         s = self._side[self.side_idx]
         self._side_rr += 1
-        ev = torch.cuda.Event()
+        if self._fork_ev_i == len(self._fork_evs):
+            self._fork_evs.append(torch.cuda.Event())      # created once, reused every step
+        ev = self._fork_evs[self._fork_ev_i]
+        self._fork_ev_i += 1
         ev.record(torch.cuda.current_stream())
         s.wait_event(ev)
         self._side_used = True
@@ -695,6 +699,8 @@ class CascadeEngine:
             self._side_used = False
 
     _side = None
+    _fork_evs = ()
+    _fork_ev_i = 0
     _side_used = False
     _side_rr = 0
     side_idx = 0
@@ -863,15 +869,16 @@ class CascadeEngine:
             self.lpc_quan = self.buf("lpc.quan", (B,))
             self.lpc_hist = self.hist_view("lpc", nb)
             self.zero_hists_once()
+            self.lpc_p = self.buf("lpc.p", (B, L, nb)) if want_p else None
             check(self.lib.nsc_quantize_fwd(lpc_x.data_ptr(), self.p_ptr + 4 * self.lpc_alpha_off,
                                             self.p_ptr + 4 * self.lpc_bins_off, float(is_quan_on), int(bool(soft)), B, L,
-                                            nb, None, self.lpc_q.data_ptr(), self.lpc_quan.data_ptr(),
+                                            nb, _lib.ptr(self.lpc_p), self.lpc_q.data_ptr(), self.lpc_quan.data_ptr(),
                                             self.lpc_hist.data_ptr(), self.stream()), "lpc quantize_fwd")
         return self.decoded
 
     # ---- losses + backward ----
     def loss_backward(self, target, c_time, c_freq, c_quan, c_ent, trainable, c_quan_lpc=0.0, c_ent_lpc=0.0,
-                      global_batch=None, hist_allreduce=None):
+                      global_batch=None, hist_allreduce=None, train_lpc=None):
         """loss = sum_b [c_time*time + c_freq*freq + sum_i c_quan[i]*quan_i[b]] + Bglobal * sum_i c_ent[i]*ent_i
         (vector loss => implicit sum over the batch).  trainable: list of bool per codec.
         Returns dict of loss terms (device tensors)."""
@@ -913,9 +920,12 @@ class CascadeEngine:
                     acc = self.buf("dsum", (B, 1, frame_length))
                     check(self.lib.nsc_axpby(dx.data_ptr(), dsum.data_ptr(), acc.data_ptr(), 1.0, 1.0, n, self.stream()), "axpby")
                     dsum = acc
-        if self.lpc and (c_quan_lpc != 0.0 or c_ent_lpc != 0.0) and hasattr(self, "lpc_x"):
+        ent_lpc = None
+        if train_lpc is None:
+            train_lpc = c_quan_lpc != 0.0 or c_ent_lpc != 0.0
+        if self.lpc and train_lpc and hasattr(self, "lpc_x"):
             L, nb = self.lpc_x.shape[1], len(lpc_coeff_lsf_bins)
-            ent = self.buf("lpc.ent", (1,))
+            ent = ent_lpc = self.buf("lpc.ent", (1,))
             gh = self.buf("lpc.ghist", (nb,))
             check(self.lib.nsc_entropy_from_hist(self.lpc_hist.data_ptr(), nb, ent.data_ptr(), gh.data_ptr(), self.stream()), "lpc ent")
             check(self.lib.nsc_quantize_bwd(self.lpc_x.data_ptr(), self.p_ptr + 4 * self.lpc_alpha_off,
@@ -926,7 +936,8 @@ class CascadeEngine:
                                             self.stream()), "lpc quantize_bwd")
         self.flush_block_wgrads()
         self.side_join()
-        return dict(time=self.time, freq=self.freq, quan=[c.quan for c in self.codecs], ent=ents)
+        return dict(time=self.time, freq=self.freq, quan=[c.quan for c in self.codecs], ent=ents, ent_lpc=ent_lpc,
+                    quan_lpc=getattr(self, "lpc_quan", None))
 
     def frame_entropies(self, x, lpc_x=None):
         """Per-frame entropy (bits) of every codec's soft assignment, as the reference's validation loop measures it:
@@ -940,6 +951,11 @@ class CascadeEngine:
             for i, c in enumerate(self.codecs):
                 check(self.lib.nsc_frame_entropy(c.p.data_ptr(), self.B, c.L, c.nb, out[i].data_ptr(), self.stream()),
                       "frame_entropy")
+            if self.lpc and lpc_x is not None:
+                # the LSF quantizer's per-frame entropy (end2end_eval_lpc's ent_loss_list[0], nsc_module:1040-1041)
+                self.lpc_frame_ent = self.buf("val.lpc_frame_ent", (self.B,))
+                check(self.lib.nsc_frame_entropy(self.lpc_p.data_ptr(), self.B, lpc_x.shape[1], len(lpc_coeff_lsf_bins),
+                                                 self.lpc_frame_ent.data_ptr(), self.stream()), "frame_entropy lpc")
             return out
         finally:
             self._leave()
@@ -977,19 +993,27 @@ class CascadeEngine:
             self._leave()
 
     def _train_step(self, x, target, cfg, lpc_x, comm):
+        if not isinstance(self._fork_evs, list):
+            self._fork_evs = []
+        self._fork_ev_i = 0
         self.grads.zero_()
         self.refresh_wt()
         self.forward(x, cfg["is_quan_on"], True, lpc_x=lpc_x)
         gb = self.B * (comm.world if comm else 1)
         terms = self.loss_backward(target, cfg["c_time"], cfg["c_freq"], cfg["c_quan"], cfg["c_ent"], cfg["trainable"],
                                    c_quan_lpc=cfg.get("c_quan_lpc", 0.0), c_ent_lpc=cfg.get("c_ent_lpc", 0.0),
-                                   global_batch=gb,
+                                   global_batch=gb, train_lpc=cfg.get("train_lpc"),
+                                   # the decision must not depend on a host value that can differ between ranks (tau):
+                                   # every quan-op step exchanges the (tiny) histograms, no-quan steps never do
                                    hist_allreduce=(comm.allreduce_list if comm and cfg.get("global_entropy", True) and
-                                                   any(c != 0.0 for c in cfg["c_ent"]) else None))
+                                                   cfg.get("quan_op", cfg.get("slot", 1) == 1) else None))
         if comm:
             comm.allreduce(self.grads)   # SUM, not mean: the reference's vector loss sums over the batch (a18)
         scopes = [f"scope_{i + 1}" for i, t in enumerate(cfg["trainable"]) if t]
-        if self.lpc and (cfg.get("c_quan_lpc", 0.0) != 0.0 or cfg.get("c_ent_lpc", 0.0) != 0.0):
+        train_lpc = cfg.get("train_lpc")
+        if train_lpc is None:
+            train_lpc = cfg.get("c_quan_lpc", 0.0) != 0.0 or cfg.get("c_ent_lpc", 0.0) != 0.0
+        if self.lpc and train_lpc:
             scopes = ["lpc_quan"] + scopes
         self.adam_step(scopes, cfg["lr"], cfg.get("slot", 1))
         return terms

@@ -4,10 +4,19 @@
 main.py:6-27), its graph-builder method names (they now build the op-surface graph on HIP kernels) and its training
 loop (`model_training`, nsc_module:424-549) - the inner `sess.run(trainop)` is `CascadeEngine.train_step`.
 
-Out of scope here: wav loading, PESQ/STOI evaluation, LPC analysis/synthesis.  Consequences:
+Out of scope here: wav loading, PESQ/STOI evaluation, LPC analysis of raw audio.  Consequences:
   * data comes from `--data_root` (.npy frames, the reference's format) or a synthetic generator (SURVEY 8d);
-  * the tau controller (nsc_module:494-517) is driven by the entropy of the last training batches of the epoch
-    (soft assignment, global batch) instead of the out-of-scope validation utterances ("next" row N2).
+  * the tau controller (nsc_module:494-517, 630-639) is driven, like the reference's, by the per-frame (batch-of-1,
+    hard assignment) entropy of held-out frames (`validation_entropy`); `--tau_from_validation 0`
+    falls back to the entropy of the epoch's last training batch;
+  * journal lines keep the reference's format strings (nsc_module:520-530, 623-628); STOI / PESQ, which need the
+    out-of-scope tools, are written as nan.
+
+Two behaviours of the shipped reference that this module does NOT reproduce (both found by executing it, see
+tests/golden/make_reference_exec.py): `model_training` feeds `tau` as a (1,2) array built from tau_1/tau_2 even when
+the graph's tau is a scalar (one_ae / followers), which only broadcasts against the [B] loss for B in {1,2} and never
+feeds the value its controller updates; and `end2end_eval` raises for every flag but 'finetune'.  Here the controller's
+tau is the tau that is fed (what nsc_module:494-517 plainly intends and what the finetune / LPC loops do).
 """
 from __future__ import annotations
 
@@ -28,6 +37,55 @@ from .utilities import training_window
 
 def _split(s, typ):
     return [typ(v) for v in str(s).split()]
+
+
+ENT_CHANGE = 0.015     # nsc_module:494, 630
+
+
+def tau_controller(flag, lpc, is_quan_on_val, taus, fully_entropy, ents, target_entropy):
+    """One epoch of the reference's entropy controller.  taus = (tau, tau_1, tau_2) -> new (tau, tau_1, tau_2).
+    time domain (nsc_module:494-517): flag 'finetune' moves tau_1 / tau_2 by 0.015 toward the hard-coded per-codec
+    targets 1.5 / 2.5; any other flag moves tau by 0.015 toward --target_entropy.
+    LPC (nsc_module:630-639): only while is_quan_on == 1: +0.015 above target + 0.05, -0.045 below target."""
+    tau, t1, t2 = taus
+    if lpc:
+        if is_quan_on_val == 1.0:
+            if fully_entropy > target_entropy + 0.05:
+                tau += ENT_CHANGE
+            elif fully_entropy < target_entropy:
+                tau -= ENT_CHANGE * 3
+        return tau, t1, t2
+    if flag == 'finetune':
+        target_1, target_2 = 1.5, 2.5
+        e1, e2 = ents[0], (ents[1] if len(ents) > 1 else ents[0])
+        if e1 > target_1:
+            t1 += ENT_CHANGE
+        if e1 < target_1:
+            t1 -= ENT_CHANGE
+        if e2 > target_2:
+            t2 += ENT_CHANGE
+        if e2 < target_2:
+            t2 -= ENT_CHANGE
+    else:
+        if fully_entropy > target_entropy:
+            tau += ENT_CHANGE
+        elif fully_entropy < target_entropy:
+            tau -= ENT_CHANGE
+    return tau, t1, t2
+
+
+def journal_line(i, ave_snr, ave_si_snr, ave_stoi, ave_pesq, _quan_loss, init_tau, fully_entropy):
+    """The per-epoch journal line of model_training (nsc_module:520-530), format string kept verbatim."""
+    return ('Epoch %3d: SNR: %7.5f dB Si-SNR: %7.5f dB STOI: '
+            '%6.5f PESQ: %6.5f _quan_loss: %6.5f'
+            'tau: %6.5f   '
+            'fully_entropy: %6.5f \n' % (i, ave_snr, ave_si_snr, ave_stoi, ave_pesq, _quan_loss, init_tau, fully_entropy))
+
+
+def journal_line_lpc(i, ave_snr, ave_stoi, ave_pesq, _quan_loss, fully_snr, fully_pesq, fully_entropy):
+    """The per-epoch journal line of model_training_lpc (nsc_module:623-628), format string kept verbatim."""
+    return ('Epoch %3d: SNR: %7.5f dB    STOI: %6.5f   PESQ: %6.5f   _quan_loss: %6.5f  fully_snr: %6.5f   fully_pesq: %6.5f  '
+            'fully_entropy: %6.5f \n' % (i, ave_snr, ave_stoi, ave_pesq, _quan_loss, fully_snr, fully_pesq, fully_entropy))
 
 
 class neuralSpeechCodingModule(object):
@@ -64,10 +122,14 @@ class neuralSpeechCodingModule(object):
         self._device = getattr(arg, "device", "cuda")
         seed_id = getattr(arg, "model_id", None)
         self._rand_model_id = str(seed_id) if seed_id else str(np.random.randint(1000000, 2000000))   # nsc_module:65
+        if self._comm is not None and self._comm.world > 1:
+            # one id for the whole job: checkpoints / journal are written by rank 0 and read back by every rank
+            self._rand_model_id = self._comm.broadcast_object(self._rand_model_id)
         self._load_training_data()
         for d in ("check", "doc"):
             os.makedirs(os.path.join(self._out_root, d), exist_ok=True)
-        self._write_to_file_and_update_to_display(str(arg) + '\n\n')
+        shown = {k: v for k, v in vars(arg).items() if k != "comm"} if hasattr(arg, "__dict__") else arg
+        self._write_to_file_and_update_to_display(str(shown) + '\n\n')
         self._engine = None
 
     # ------------------------------------------------------------------ data
@@ -103,29 +165,50 @@ class neuralSpeechCodingModule(object):
             lsf = np.sort(rng.uniform(0.03, 3.1, (n, self._lpc_order)), axis=1).astype(np.float32)
             self._val_data = np.concatenate([frames, lsf, frames], 1)
 
-    def validation_entropy(self, eng):
-        """Mean per-frame entropy of each codec over the validation frames (one forward per batch; the per-frame
-        histograms are separated on the GPU by nsc_frame_entropy).  Returns a list, one value per codec."""
+    def validation_pass(self, eng):
+        """The in-scope part of the reference's validation (end2end_eval / end2end_eval_lpc, nsc_module:657-758,
+        760-889): every held-out frame goes through the cascade with the HARD assignment and is_quan_on = 1, and
+        entropy_coding_loss is evaluated on each frame's OWN histogram (the reference feeds one frame per sess.run).
+        Here a whole batch goes through one forward and nsc_frame_entropy separates the per-frame histograms.
+        Returns dict(ent=[per codec], ent_lpc=float|None, snr, si_snr, quan=[per codec])."""
+        from .loss_terms_and_measures import si_snr, snr
         if getattr(self, "_val_data", None) is None:
             self._load_validation_data()
         B, dev = self._batch_size, eng.device
-        tot, cnt = None, 0
+        tot, tot_lpc, cnt = None, 0.0, 0
+        ori, dec = [], []
+        fl, lo = K.frame_length, self._lpc_order
         for k in range(0, self._val_data.shape[0] - B + 1, B):
             rows = self._val_data[k:k + B]
             if self._is_pure_time_domain:
-                x = torch.from_numpy(np.ascontiguousarray(rows[:, :K.frame_length].reshape(B, 1, -1))).to(dev)
+                x = torch.from_numpy(np.ascontiguousarray(rows[:, :fl].reshape(B, 1, -1))).to(dev)
                 lpc_x = None
             else:
-                o = K.frame_length + self._lpc_order
-                x = torch.from_numpy(np.ascontiguousarray(rows[:, o:o + K.frame_length].reshape(B, 1, -1))).to(dev)
-                lpc_x = torch.from_numpy(np.ascontiguousarray(rows[:, K.frame_length:o].reshape(B, self._lpc_order, 1))).to(dev)
-            e = eng.frame_entropies(x, lpc_x=lpc_x).sum(dim=1)
-            tot = e if tot is None else tot + e
+                x = torch.from_numpy(np.ascontiguousarray(rows[:, fl + lo:fl + lo + fl].reshape(B, 1, -1))).to(dev)
+                lpc_x = torch.from_numpy(np.ascontiguousarray(rows[:, fl:fl + lo].reshape(B, lo, 1))).to(dev)
+            e = eng.frame_entropies(x, lpc_x=lpc_x)
+            tot = e.sum(dim=1) if tot is None else tot + e.sum(dim=1)
+            if lpc_x is not None:
+                tot_lpc += float(eng.lpc_frame_ent.sum().item())
+            ori.append(x.reshape(-1).cpu().numpy())
+            dec.append(eng.decoded.reshape(-1).cpu().numpy())
             cnt += B
-        return [float(v) / cnt for v in tot.cpu().numpy()] if cnt else None
+        if not cnt:
+            return None
+        o, d = np.concatenate(ori).astype(np.float64), np.concatenate(dec).astype(np.float64)
+        return dict(ent=[float(v) / cnt for v in tot.cpu().numpy()],
+                    ent_lpc=(tot_lpc / cnt if not self._is_pure_time_domain else None),
+                    snr=float(snr(o, d)[1]), si_snr=float(si_snr(d, o)))
+
+    def validation_entropy(self, eng):
+        """Mean per-frame entropy of each codec over the validation frames.  Returns a list, one value per codec."""
+        r = self.validation_pass(eng)
+        return r["ent"] if r else None
 
     def _write_to_file_and_update_to_display(self, the_string):
         """nsc_module:73-79."""
+        if self._comm is not None and self._comm.rank != 0:
+            return                      # one writer per job
         path = os.path.join(self._out_root, 'doc', self._rand_model_id + self._suffix + self._save_unique_mark + '_journal.txt')
         with open(path, 'a') as f:
             f.write(the_string)
@@ -219,6 +302,21 @@ class neuralSpeechCodingModule(object):
             hidden_2, expand_back = self._the_decoder_in_each_module(the_final_code, the_strides, the_share)
             return soft_assignment_3d, -1, -1, the_final_code[0, :, 0], expand_back[:, :, 0], alpha, bins, soft_assignment_3d
 
+    def computational_graph_end2end_quan_on_lpc(self, encoded, quan_lpc_coeff, the_share, is_quan_on, number_bins,
+                                                the_scope, the_strides):
+        """nsc_module:297-335.  Same graph as the time-domain builder; bins span +-beta_boundary (:308), the quantised LPC
+        polynomial argument is unused by the graph (its only use is commented out, :329-331).  Returns the 7-tuple."""
+        st = current_store()
+        with variable_scope(the_scope):
+            alpha = st.get(the_scope + "/alpha", (), lambda s: np.float32(K.init_alpha))
+            bins = st.get(the_scope + "/bins", (number_bins,),
+                          lambda s: np.linspace(-K.beta_boundary, K.beta_boundary, number_bins))
+            _, floating_code = self._the_encoder_in_each_module(encoded, the_strides, the_share)
+            soft_assignment_3d, the_final_code = nn.scalar_softmax_quantization(
+                floating_code, alpha, bins, is_quan_on, the_share, K.frame_length // (2 ** len(the_strides)), number_bins)
+            _, expand_back = self._the_decoder_in_each_module(the_final_code, the_strides, the_share)
+            return soft_assignment_3d, -1, -1, the_final_code[0, :, 0], expand_back[:, :, 0], alpha, bins
+
     # ------------------------------------------------------------------ engine-backed training
     def _strides_for(self, code):
         """`--the_strides` read as one code per codec, 4 => [2,2] else [2] (cmrl.py:32; SURVEY §5 ambiguity)."""
@@ -252,33 +350,50 @@ class neuralSpeechCodingModule(object):
         eng.load_named(named)
         print('model ' + self.ckpt_path(save_id) + ' is restored!')
 
+    def _barrier(self):
+        if self._comm is not None:
+            self._comm.barrier()
+
+    def _is_writer(self):
+        return self._comm is None or self._comm.rank == 0
+
     def model_training(self, eng, cfg_no_quan, cfg_quan, the_learning_rate, epoch, flag, save_id='', the_tau_val=1.0,
-                       tau_slots=None):
-        """nsc_module:424-549 (time domain) / :551-655 (LPC).  Epoch loop, op switch at pretrain_step, tau controller.
-        cfg_*: engine step configs for trainop_no_quan / trainop_quan.  tau_slots: indices into cfg_quan['c_ent'] that
-        are driven by tau (one per controlled codec)."""
+                       tau_map=None):
+        """nsc_module:424-549 (time domain) / :551-655 (LPC).  Epoch loop, op switch at pretrain_step, tau controller,
+        journal line, checkpoint.  cfg_*: engine step configs of trainop_no_quan / trainop_quan.
+        tau_map: [(cfg key, index or None, scale, which tau)] - where the controlled tau(s) enter the quan op's loss:
+        cfg[key][index] = scale * tau (``which`` = 0: the single tau; j >= 1: tau_j of the finetune phase)."""
         dev = eng.device
         init_tau = the_tau_val
-        taus = [the_tau_val] * max(1, len(tau_slots or [0]))
+        init_tau_1 = the_tau_val
+        init_tau_2 = the_tau_val
         lpc = not self._is_pure_time_domain
-        frames = 0
+        tau_map = tau_map or []
+        nan = float('nan')
         for i in range(epoch):
+            print('-----------------------')
             if flag == 'pretrain' and i < self._pretrain_step:
                 cfg = dict(cfg_no_quan)
+                is_quan_on_val = 0.0
                 print('no quan op is used')
             else:
                 cfg = dict(cfg_quan)
-                c_ent = list(cfg["c_ent"])
-                for j, slot in enumerate(tau_slots or []):
-                    c_ent[slot] = taus[j] if flag == 'finetune' else init_tau
-                cfg["c_ent"] = c_ent
-                print((flag if flag != 'pretrain' else 'quan op'), init_tau)
+                is_quan_on_val = 1.0
+                for key, idx, scale, which in tau_map:
+                    t = (init_tau, init_tau_1, init_tau_2)[which]
+                    if idx is None:
+                        cfg[key] = scale * t
+                    else:
+                        lst = list(cfg[key])
+                        lst[idx] = scale * t
+                        cfg[key] = lst
+                print(('quan op' if flag == 'pretrain' else flag + ' is working.'), init_tau)
             cfg["lr"] = the_learning_rate
             print('Epoch ----------------------- ', i)
             start = time.perf_counter()
             gen = (self._generate_one_epoch_end2end_lpc_fast if lpc else self._generate_one_epoch_end2end)(
                 self._tr_data, self._tr_data, self._batch_size)
-            terms = None
+            terms, nsteps = None, 0
             for batch in gen:
                 if lpc:
                     _, _, b_lpc, b_res = batch
@@ -288,57 +403,73 @@ class neuralSpeechCodingModule(object):
                     x = torch.from_numpy(np.ascontiguousarray(batch[0].reshape(self._batch_size, 1, -1))).to(dev)
                     lpc_x = None
                 terms = eng.train_step(x, x, cfg, lpc_x=lpc_x, comm=self._comm)
-                frames += self._batch_size
+                nsteps += 1
             torch.cuda.synchronize()
             elapsed = time.perf_counter() - start
             np.random.shuffle(self._tr_data)                                       # nsc_module:460
-            ents = [float(e.item()) for e in terms["ent"]] if terms else [0.0]
-            if self._tau_from_validation and cfg.get("is_quan_on", 1.0) == 1.0:
-                # the control signal of the reference: per-frame entropy on held-out frames (nsc_module:462-470, 715-733)
-                vents = self.validation_entropy(eng)
-                if vents:
-                    ents = vents
-                # artefact of the reference's validation pass (nsc_module:740): 'bins<id><epoch>.npy'
-                if not (self._comm and self._comm.rank != 0):
+            # ---- validation signal (nsc_module:462-470; the loops themselves are out of scope) ----
+            ents = [float(e.item()) for e in terms["ent"]] if terms else [0.0] * len(eng.codecs)
+            ent_lpc = float(terms["ent_lpc"].item()) if (terms and terms.get("ent_lpc") is not None) else 0.0
+            ave_snr = ave_si_snr = nan
+            if self._tau_from_validation:
+                v = self.validation_pass(eng)
+                if v:
+                    ents, ave_snr, ave_si_snr = v["ent"], v["snr"], v["si_snr"]
+                    ent_lpc = v["ent_lpc"] if v["ent_lpc"] is not None else 0.0
+                if self._is_writer():   # artefacts of the reference's validation pass (nsc_module:740, 839)
                     np.save(os.path.join(self._out_root, 'bins' + self._rand_model_id + str(i) + '.npy'),
                             eng.view(f"scope_{len(eng.codecs)}/bins").detach().cpu().numpy())
-            fully_entropy = ents[-1] if flag != 'finetune' else float(sum(ents))
-            tl, fl_ = float(terms["time"].mean().item()), float(terms["freq"].mean().item())
-            ql = float(terms["quan"][-1].mean().item())
-            print('Epoch %3d: time_loss: %7.5f freq_loss: %7.5f modelid: %s _quan_loss: %6.5f,  fully_entropy: %6.5f , '
-                  'time: %.3f, tau: %.3f, frames/s: %.1f' % (i, tl, fl_, self._rand_model_id, ql, fully_entropy, elapsed,
-                                                             init_tau, frames / max(elapsed, 1e-9) if i == 0 else
-                                                             self._batch_size * min(self._max_batches, (self._tr_data.shape[0] - 1) // self._batch_size) / elapsed))
+                    if lpc:
+                        np.save(os.path.join(self._out_root, 'lpc_coeff_lsf_bins_updated_' + self._rand_model_id + '.npy'),
+                                eng.view("lpc_quan/bins").detach().cpu().numpy())
+            _quan_loss = float(terms["quan"][-1].mean().item()) if terms else nan
+            if lpc:
+                # end2end_eval_lpc :826-833: code-length weighted mean over [LSF, codec...] (16 : L : L)
+                w = np.array([16.0] + [float(c.L) for c in eng.codecs])
+                fully_entropy = float(np.sum(w / w.sum() * np.array([ent_lpc] + list(ents))))
+            elif flag == 'finetune':
+                fully_entropy = float(sum(ents))            # interested_var[5] = reduce_sum(ent_loss_arr), cmrl.py:357
+            else:
+                fully_entropy = ents[-1]                    # the newest codec's entropy (nsc_module:912; cmrl.py:98)
+            fps = self._batch_size * (self._comm.world if self._comm else 1) * nsteps / max(elapsed, 1e-9)
+            if lpc:
+                print('Epoch %3d: SNR: %7.5f dB    STOI: %6.5f    PESQ: %6.5f   linearity: %6.5f  modelid: %s  _quan_loss: '
+                      '%6.5f,  fully_entropy: %6.5f , time: %.3f, tau: %.3f' % (
+                          i, ave_snr, nan, nan, nan, self._rand_model_id, _quan_loss, fully_entropy, elapsed, init_tau))
+                self._write_to_file_and_update_to_display(
+                    journal_line_lpc(i, ave_snr, nan, nan, _quan_loss, 0.0, 0.0, fully_entropy))
+            else:
+                print('Epoch %3d: SNR: %7.5f dB  Si-SNR: %7.5f dB  STOI: %6.5f    PESQ: %6.5f   linearity: %6.5f  modelid: %s  '
+                      '_quan_loss: %6.5f,  fully_entropy: %6.5f , time: %.3f, tau: %.3f, tau_1: %.3f, tau_2: %.3f' % (
+                          i, ave_snr, ave_si_snr, nan, nan, nan, self._rand_model_id, _quan_loss, fully_entropy, elapsed,
+                          init_tau, init_tau_1, init_tau_2))
+            print('frames/s: %.1f' % fps)
             # ---- tau controller (nsc_module:494-517; LPC variant :630-639) ----
-            ent_change = 0.015
-            if cfg.get("is_quan_on", 1.0) == 1.0 and cfg is not cfg_no_quan:
-                if flag == 'finetune' and len(taus) >= 2 and len(ents) >= 2:
-                    for j, target in enumerate((1.5, 2.5)):                        # hard-coded targets :495-512
-                        if ents[j] > target:
-                            taus[j] += ent_change
-                        if ents[j] < target:
-                            taus[j] -= ent_change
-                elif lpc:
-                    if fully_entropy > self._target_entropy + 0.05:
-                        init_tau += ent_change
-                    elif fully_entropy < self._target_entropy:
-                        init_tau -= ent_change * 3
-                else:
-                    if fully_entropy > self._target_entropy:
-                        init_tau += ent_change
-                    elif fully_entropy < self._target_entropy:
-                        init_tau -= ent_change
-            print('Tau: %7.5f' % init_tau, taus)
-            self._write_to_file_and_update_to_display(
-                'Epoch %3d: time_loss: %7.5f freq_loss: %7.5f _quan_loss: %6.5ftau: %6.5f   fully_entropy: %6.5f  '
-                'bitrate_kbps: %6.3f \n' % (i, tl, fl_, ql, init_tau, fully_entropy,
-                                            entropy_to_bitrate(fully_entropy, 4 if eng.codecs[-1].L == 128 else 2)))
-        if not (self._comm and self._comm.rank != 0):
+            init_tau, init_tau_1, init_tau_2 = tau_controller(flag, lpc, is_quan_on_val, (init_tau, init_tau_1, init_tau_2),
+                                                              fully_entropy, ents, self._target_entropy)
+            if lpc:
+                if is_quan_on_val == 1.0:
+                    print('tau:', init_tau)
+            else:
+                if flag == 'finetune':
+                    self._write_to_file_and_update_to_display('codec-1: ' + str(np.array(ents[:1])))
+                    self._write_to_file_and_update_to_display('codec-2: ' + str(np.array(ents[1:2] or ents[:1])))
+                print('Tau: %7.5f, Tau_1: %7.5f, Tau_2: %7.5f' % (init_tau, init_tau_1, init_tau_2))
+                self._write_to_file_and_update_to_display(
+                    journal_line(i, ave_snr, ave_si_snr, nan, nan, _quan_loss, init_tau, fully_entropy))
+            if lpc and flag == 'finetuning_follower_all' and fully_entropy < self._target_entropy:   # nsc_module:641
+                break
+        if self._is_writer():
             self.save(eng, save_id)
+        self._barrier()       # no rank restores the checkpoint before rank 0 has finished writing it
+        self._last_taus = (init_tau, init_tau_1, init_tau_2)
         return init_tau
 
     def _loss_cfgs(self, num_codecs, mode):
-        """Step configs for the two optimizers (nsc_module:914-926; cmrl.py:101-113, 355-372, 483-485)."""
+        """Step configs of the two optimizers and where tau enters (nsc_module:914-926, 1032-1050; cmrl.py:95-113,
+        348-372, 463-485) - checked against the reference's own loss vectors in tests/test_reference_exec.py.
+        The engine minimises  sum_b [c_time*time + c_freq*freq + sum_i c_quan[i]*quan_i[b] + c_quan_lpc*quan_lpc[b]]
+                              + Bglobal * (sum_i c_ent[i]*ent_i + c_ent_lpc*ent_lpc)."""
         c = self._coeff_term
         lpc = not self._is_pure_time_domain
         zeros = [0.0] * num_codecs
@@ -349,35 +480,46 @@ class neuralSpeechCodingModule(object):
         else:                           # finetune: all
             train = [True] * num_codecs
         no_quan = dict(is_quan_on=0.0 if mode == "single" else 1.0, c_time=c[0], c_freq=c[1], c_quan=zeros, c_ent=zeros,
-                       trainable=train, slot=0)
+                       trainable=train, slot=0, quan_op=False)
         cq = list(zeros)
-        ce = list(zeros)
-        tau_slots = []
+        tau_map = []
         extra = {}
-        if mode in ("single", "follower"):
-            cq[-1 if mode == "follower" else 0] = c[2]
-            tau_slots = [num_codecs - 1 if mode == "follower" else 0]
-            if lpc and mode == "single" and self._is_cq:
-                # nsc_module:1036-1046: quan/entropy terms blended by code lengths 16 : L
-                L = 128.0 if self._the_strides[0] == 4 else 256.0
-                cq[0] = c[2] * L / (16.0 + L)
-                extra = dict(c_quan_lpc=c[2] * 16.0 / (16.0 + L))
-        else:
+        if mode == "single" and lpc:
+            # nsc_module:1032-1050: quan and entropy terms of the LSF quantizer and the codec are ALWAYS blended by
+            # their code lengths 16 : L; is_cq only decides whether the LSF quantizer's variables train (:993-995)
+            L = 128.0 if self._the_strides[0] == 4 else 256.0
+            a, b = 16.0 / (16.0 + L), L / (16.0 + L)
+            cq[0] = c[2] * b
+            tau_map = [("c_ent", 0, b, 0)]
+            if self._is_cq:
+                extra = dict(c_quan_lpc=c[2] * a, c_ent_lpc=0.0, train_lpc=True)
+                tau_map.append(("c_ent_lpc", None, a, 0))
+        elif mode in ("single", "follower"):
+            k = num_codecs - 1 if mode == "follower" else 0
+            cq[k] = c[2]
+            tau_map = [("c_ent", k, 1.0, 0)]
+        elif lpc:
+            # cmrl.py:463-485: quan_loss(LSF) + sum_i quan_loss(codec i), every one times coeff[2]; NO entropy term;
+            # lpc_quan/alpha, bins are created without `trainable=` (:398-401) -> always trained here
             cq = [c[2]] * num_codecs
-            if lpc:
-                extra = dict(c_quan_lpc=c[2] if self._is_cq else 0.0)   # no entropy term (cmrl.py:483-485)
-            else:
-                tau_slots = list(range(num_codecs))
-        quan = dict(is_quan_on=1.0, c_time=c[0], c_freq=c[1], c_quan=cq, c_ent=ce, trainable=train, slot=1, **extra)
-        return no_quan, quan, tau_slots
+            extra = dict(c_quan_lpc=c[2], train_lpc=True)
+        else:
+            # cmrl.py:355: quantization_loss = tf.reduce_sum([quan_0, quan_1]) is a SCALAR (summed over the batch too)
+            # that :361-365 broadcasts back into the [B] loss vector => its weight is coeff[2] * (global batch)
+            gb = self._batch_size * (self._comm.world if self._comm else 1)
+            cq = [c[2] * gb] * num_codecs
+            tau_map = [("c_ent", i, 1.0, min(i + 1, 2)) for i in range(num_codecs)]
+        quan = dict(is_quan_on=1.0, c_time=c[0], c_freq=c[1], c_quan=cq, c_ent=list(zeros), trainable=train, slot=1,
+                    quan_op=True, **extra)
+        return no_quan, quan, tau_map
 
     def one_ae(self):
         """nsc_module:891-939 (time domain) / :989-1073 (LPC): train codec 1, pretrain then quantised."""
         eng = self._make_engine(1, per_codec_list_semantics=self._is_pure_time_domain)
         self._engine = eng
-        no_quan, quan, tau_slots = self._loss_cfgs(1, "single")
+        no_quan, quan, tau_map = self._loss_cfgs(1, "single")
         self.model_training(eng, no_quan, quan, self._learning_rate_tanh, self._epoch_tanh, 'pretrain', save_id='',
-                            the_tau_val=self._coeff_term[3], tau_slots=tau_slots)
+                            the_tau_val=self._coeff_term[3], tau_map=tau_map)
         return eng
 
     one_ae_lpc = one_ae

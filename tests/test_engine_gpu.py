@@ -140,7 +140,8 @@ def test_two_codec_finetune_and_follower(rs):
     xd = dev(x.transpose(0, 2, 1))
     eng.grads.zero_()
     d = eng.forward(xd, 1.0, True)
-    eng.loss_backward(xd, coeff[0], coeff[1], [coeff[2]] * 2, tau, [True, True])
+    # cmrl.py:355: the finetune quan term is a batch-summed scalar broadcast into the [B] loss => weight coeff[2] * B
+    eng.loss_backward(xd, coeff[0], coeff[1], [coeff[2] * B] * 2, tau, [True, True])
     torch.cuda.synchronize()
     assert_close(d.cpu().numpy()[:, 0], dec, what="cascade decoded")
     _check_grads(eng, grads, ["scope_1", "scope_2"])

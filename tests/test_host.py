@@ -202,3 +202,74 @@ def test_data_parallel_two_ranks_gloo_equals_single_process(tmp_path):
     res = json.loads(line)
     assert res["err"] < 1e-9, res
     assert res["max"] == 4.0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# host logic of the trainer against what the reference's own code printed / wrote (tests/golden/reference_exec.npz)
+# ---------------------------------------------------------------------------------------------------------------------
+def _fx():
+    import numpy as np
+    return np.load(os.path.join(ROOT, "tests", "golden", "reference_exec.npz"))
+
+
+def test_tau_controller_values_match_reference_stdout():
+    """nsc_amd tau_controller == the 'Tau:' / 'tau:' lines the reference's model_training[_lpc] printed for scripted and
+    real validation entropies: +-0.015 toward target (2.5 -> up, 2.0 -> down, 2.2 -> hold), finetune tau_1/tau_2 toward
+    1.5 / 2.5, LPC +0.015 above target+0.05 and -0.045 below target, nothing while is_quan_on == 0."""
+    from nsc_amd.neural_speech_coding_module import tau_controller
+    fx = _fx()
+    for ph in ("one_ae", "follower", "finetune"):
+        taus = (0.3, 0.3, 0.3)
+        lines = json.loads(str(fx[f"td_{ph}_stdout_tau_lines"]))
+        assert len(lines) == len(fx[f"td_{ph}_evals"]) > 0
+        for e, line in zip(fx[f"td_{ph}_evals"], lines):
+            taus = tau_controller('finetune' if ph == "finetune" else 'pretrain', False, 1.0, taus, e[8], list(e[6:8]), 2.2)
+            assert line == 'Tau: %7.5f, Tau_1: %7.5f, Tau_2: %7.5f' % taus
+    for ph, qons in (("one_ae", [0.0, 1.0]), ("follower", [1.0, 1.0]), ("finetune", [1.0, 1.0])):
+        tau, got = 0.3, []
+        for e, q in zip(fx[f"lp_{ph}_evals"], qons):
+            tau = tau_controller('x', True, q, (tau, 0.0, 0.0), e[7], None, 2.2)[0]
+            if q == 1.0:
+                got.append("tau: " + str(tau))
+        assert got == json.loads(str(fx[f"lp_{ph}_stdout_tau_lines"]))
+
+
+def test_journal_lines_match_reference_format():
+    """Given the reference's numbers, journal_line / journal_line_lpc reproduce the reference's journal text byte for byte."""
+    from nsc_amd.neural_speech_coding_module import journal_line, journal_line_lpc
+    fx = _fx()
+    j = str(fx["td_journal"])
+    e = fx["td_one_ae_evals"][0]          # (snr, si_snr, stoi, pesq, linearity, quan, ent1, ent2, fully_entropy)
+    assert journal_line(0, e[0], e[1], e[2], e[3], e[5], 0.315, e[8]) in j
+    e = fx["td_finetune_evals"][1]
+    assert journal_line(1, e[0], e[1], e[2], e[3], e[5], 0.3, e[8]) in j
+    jl = str(fx["lp_journal"])
+    e = fx["lp_one_ae_evals"][0]          # (snr, stoi, pesq, linearity, quan, fully_snr, fully_pesq, fully_entropy)
+    assert journal_line_lpc(0, e[0], e[1], e[2], e[4], e[5], e[6], e[7]) in jl
+
+
+def test_loss_configs_of_the_cli_follow_the_reference():
+    """_loss_cfgs: finetune quan weight is coeff[2] x global batch (cmrl.py:355 sums over the batch before broadcasting);
+    one_ae_lpc always blends 16 : L incl. the tau slot (nsc_module:1032-1050); finetune_lpc always trains the LSF
+    quantizer (cmrl.py:398-401, 464-466) - and it is the step bench.py times."""
+    from nsc_amd.neural_speech_coding_module import neuralSpeechCodingModule
+    import bench
+
+    def mod(lpc, is_cq, B=128):
+        m = neuralSpeechCodingModule.__new__(neuralSpeechCodingModule)
+        m._coeff_term, m._is_pure_time_domain, m._is_cq, m._the_strides = [60.0, 10.0, 10.0, 0.0], not lpc, is_cq, [2, 2]
+        m._batch_size, m._comm = B, None
+        return m
+
+    _, quan, tau_map = mod(False, 0)._loss_cfgs(2, "finetune")
+    assert quan["c_quan"] == [10.0 * 128, 10.0 * 128] and [t[3] for t in tau_map] == [1, 2]
+    for is_cq in (0, 1):
+        _, quan, tau_map = mod(True, is_cq)._loss_cfgs(1, "single")
+        assert abs(quan["c_quan"][0] - 10.0 * 256 / 272) < 1e-12
+        assert ("c_ent", 0, 256.0 / 272.0, 0) in tau_map
+        assert (quan.get("c_quan_lpc", 0.0) != 0.0) == bool(is_cq) and bool(quan.get("train_lpc")) == bool(is_cq)
+        _, quan, tau_map = mod(True, is_cq)._loss_cfgs(2, "finetune")
+        assert quan["c_quan"] == [10.0, 10.0] and quan["c_quan_lpc"] == 10.0 and quan["train_lpc"] and tau_map == []
+        ref = bench.step_cfg()
+        for k in ("is_quan_on", "c_time", "c_freq", "c_quan", "c_ent", "trainable", "slot", "c_quan_lpc"):
+            assert quan[k] == ref[k], k

@@ -107,6 +107,9 @@ def test_cli_phases_cascaded_then_finetune_then_feedforward(tmp_path):
     assert "scope_2|conv1d|kernel" in z2.files and "scope_2|conv1d|kernel" not in z1.files
     journal = open(glob.glob(str(tmp_path / "doc" / "*_journal.txt"))[0]).read()
     assert journal.count("Epoch") == 3                        # 2 epochs of codec 1 + 1 follower epoch
+    import re                                                 # the reference's line format (nsc_module:520-530)
+    assert re.search(r"Epoch   0: SNR: [-\d.]+ dB Si-SNR: [-\d.]+ dB STOI: +nan PESQ: +nan _quan_loss: [\d.]+tau: [-\d.]+   "
+                     r"fully_entropy: [\d.]+ \n", journal), journal
     bins_art = sorted(os.path.basename(p) for p in glob.glob(str(tmp_path / "bins1234567*.npy")))
     assert bins_art == ["bins12345670.npy", "bins12345671.npy"]   # one per epoch that ran the quantizer (nsc_module:740)
     assert np.load(tmp_path / bins_art[-1]).shape == (32,)
@@ -117,8 +120,14 @@ def test_cli_phases_cascaded_then_finetune_then_feedforward(tmp_path):
     assert not np.array_equal(z3[k], z2[k])                   # joint phase trains codec 1 again
     assert np.all(np.isfinite(z3[k]))
     a0 = _args(tmp_path, the_strides="2", training_mode="0", base_model_id="1234567")
-    dec = CMRL(a0)._feedforward(2)
-    assert tuple(dec.shape) == (8, 1, 512) and bool(torch.isfinite(dec).all())
+    rng = np.random.default_rng(3)
+    utts = [(0.03 * rng.standard_normal(n)).astype(np.float32) for n in (4000, 993, 513, 512)]
+    m0 = CMRL(a0)
+    outs = m0._feedforward(2, utterances=utts)
+    assert [len(o) for o in outs] == [512 + 480 * 7, 992, 512, 0]      # frame counts of utilities.py:26
+    assert all(np.all(np.isfinite(o)) for o in outs)
+    journal = open(glob.glob(str(tmp_path / "doc" / "*_journal.txt"))[0]).read()
+    assert journal.count("Test Utterance") == 3 and "PESQ-WB:" in journal
 
 
 def test_cli_lpc_collaborative_quantisation_phase(tmp_path):
