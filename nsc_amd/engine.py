@@ -683,6 +683,8 @@ class CascadeEngine:
         self.side_idx = self._side_rr % len(self._side)    # also selects the slab workspace of launches on this stream
         s = self._side[self.side_idx]
         self._side_rr += 1
+        if not isinstance(self._fork_evs, list):
+            self._fork_evs = []
         if self._fork_ev_i == len(self._fork_evs):
             self._fork_evs.append(torch.cuda.Event())      # created once, reused every step
         ev = self._fork_evs[self._fork_ev_i]
@@ -884,6 +886,7 @@ class CascadeEngine:
         Returns dict of loss terms (device tensors)."""
         B, rs = self.B, self.res_scalar
         Bg = float(global_batch or B)
+        self._fork_ev_i = 0          # the fork events are reused from the start of every backward pass
         self.time = self.buf("loss.time", (B,))
         self.freq = self.buf("loss.freq", (B,))
         G = self.buf("loss.G", (B, 1, frame_length))
@@ -993,9 +996,6 @@ class CascadeEngine:
             self._leave()
 
     def _train_step(self, x, target, cfg, lpc_x, comm):
-        if not isinstance(self._fork_evs, list):
-            self._fork_evs = []
-        self._fork_ev_i = 0
         self.grads.zero_()
         self.refresh_wt()
         self.forward(x, cfg["is_quan_on"], True, lpc_x=lpc_x)
