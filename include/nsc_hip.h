@@ -216,6 +216,20 @@ int nsc_adam_tf1_step(float* p, const float* g, float* m, float* v, long n, floa
                       float eps, int t, const int* t_dev, void* stream);
 int nsc_increment(int* counter, void* stream);
 
+/* ---- LPC front / back end of the collaborative-quantisation path (replaces the tf.py_func bodies of
+ *      lpc_utilities.py: `lsf2poly_after_quan` :28-33, `lpc_analysis_get_residual` :37-77, `lpc_synthesizer_tr` :137-156;
+ *      call sites nsc_module:1012-1013, 1029, 1100-1101, cmrl.py:161-162, 239, 414-415, 451).  float32 in / out like the
+ *      reference's arrays, double-precision accumulation like its Python floats. ----
+ * lsf [B,order] (radians, ascending) -> poly [B,order+1] (a[0] = 1): spectrum.lsf2poly per frame. */
+int nsc_lsf2poly(const float* lsf, float* poly, int B, int order, void* stream);
+/* x [B,512], poly [B,order+1] -> res [B,512]: seven 128-sample sub-frames at hop 64, each filtered from rest by A(z)
+ * and cross-faded with hanning(128) (first sub-frame: flat then falling half, last: rising half then flat). */
+int nsc_lpc_residual(const float* x, const float* poly, float* res, int B, int order, void* stream);
+/* out = res / A(z) per frame, from rest (order 16). */
+int nsc_lpc_synthesis(const float* poly, const float* res, float* out, int B, int order, void* stream);
+/* p[0..n) = 0 on the stream (a memset node under hipGraph capture). */
+int nsc_zero(float* p, long n, void* stream);
+
 /* ---- framing (utilities.py:7-39): frames[i,:] = utt[480 i : 480 i + 512] * window; overlap-add back ---- */
 int nsc_frame_utterance(const float* utt, long n, const float* window /*nullable [512]*/, float* frames, int nframes, void* stream);
 int nsc_overlap_add(const float* frames, int nframes, const float* win3 /*[3,512]: first, middle, last Hann variants*/,

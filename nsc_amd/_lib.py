@@ -64,6 +64,10 @@ PROTOTYPES = {
     "nsc_increment": [_P, _P],
     "nsc_frame_utterance": [_P, _L, _P, _P, _I, _P],
     "nsc_overlap_add": [_P, _I, _P, _P, _P],
+    "nsc_lsf2poly": [_P, _P, _I, _I, _P],
+    "nsc_lpc_residual": [_P, _P, _P, _I, _I, _P],
+    "nsc_lpc_synthesis": [_P, _P, _P, _I, _I, _P],
+    "nsc_zero": [_P, _L, _P],
 }
 class BlockWgradJob(C.Structure):
     """include/nsc_hip.h: struct nsc_block_wgrad_job"""

@@ -513,3 +513,11 @@ extern "C" int nsc_glu_bwd_cat(const float* lin, const float* th, const float* d
   NSC_CHECK_LAUNCH("glu_bwd_cat");
   return NSC_OK;
 }
+
+// zero a device range on the stream (gradient buffers, histograms): a memset node when captured into a hipGraph
+extern "C" int nsc_zero(float* p, long n, void* stream) {
+  NSC_REQUIRE(p && n > 0, NSC_ERR_BAD_ARG, "nsc_zero: bad args");
+  hipError_t e = hipMemsetAsync(p, 0, (size_t)n * sizeof(float), (hipStream_t)stream);
+  NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "nsc_zero: %s", hipGetErrorString(e));
+  return NSC_OK;
+}

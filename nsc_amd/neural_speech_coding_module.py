@@ -350,6 +350,18 @@ class neuralSpeechCodingModule(object):
         eng.load_named(named)
         print('model ' + self.ckpt_path(save_id) + ' is restored!')
 
+    def _update_lpc_residual(self, eng):
+        """nsc_module:1075-1121: hard-quantise every stored LSF vector with the current (sorted) LSF codebook, rebuild
+        A(z) and re-filter the raw frames; the residual columns of the training matrix are replaced.  The three
+        py_func bodies run as HIP kernels (nsc_amd/lpc_utilities.py)."""
+        from .lpc_utilities import residual_from_lsf
+        fl, lo = K.frame_length, self._lpc_order
+        frames = torch.from_numpy(np.ascontiguousarray(self._tr_data[:, :fl]))
+        lsf = torch.from_numpy(np.ascontiguousarray(self._tr_data[:, fl:fl + lo]))
+        alpha = torch.full((1,), float(K.init_alpha), dtype=torch.float32, device=eng.device)   # a fresh alpha, :1084
+        res = residual_from_lsf(frames, lsf, alpha, eng.view("lpc_quan/bins"))
+        self._tr_data = np.concatenate([self._tr_data[:, :fl + lo], res.cpu().numpy()], 1).astype(np.float32)
+
     def _barrier(self):
         if self._comm is not None:
             self._comm.barrier()
@@ -391,7 +403,15 @@ class neuralSpeechCodingModule(object):
             cfg["lr"] = the_learning_rate
             print('Epoch ----------------------- ', i)
             start = time.perf_counter()
-            gen = (self._generate_one_epoch_end2end_lpc_fast if lpc else self._generate_one_epoch_end2end)(
+            refresh = lpc and self._is_cq and ((i % 30 == 0 and i != 0) or i == epoch - 3)    # nsc_module:578
+            if refresh:
+                # the reference spends this epoch recomputing the residuals with the current LSF codebook and saves
+                print('=============Recalculating the residuals...=============')
+                self._update_lpc_residual(eng)
+                if self._is_writer():
+                    self.save(eng, save_id)
+                self._barrier()
+            gen = () if refresh else (self._generate_one_epoch_end2end_lpc_fast if lpc else self._generate_one_epoch_end2end)(
                 self._tr_data, self._tr_data, self._batch_size)
             terms, nsteps = None, 0
             for batch in gen:
