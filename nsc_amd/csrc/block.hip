@@ -16,6 +16,17 @@
 #define K15 15
 #define K9 9
 
+#ifdef NSC_PROBES
+// phase stamps of workgroup 0 / wave 0 (s_memtime), read back with nsc_probe_read: profiling builds only
+__device__ unsigned long long nsc_dbg_stamps[64];
+#define NSC_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) nsc_dbg_stamps[i] = __builtin_readcyclecounter(); } while (0)
+extern "C" int nsc_probe_read(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(nsc_dbg_stamps), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -3;
+}
+#else
+#define NSC_STAMP(i) do { } while (0)
+#endif
+
 struct BlockArgs {
   int B, C, T, dil, flat;
   const float *x, *w1, *b1, *wl, *bl, *wr, *br, *w9, *b9;
@@ -281,6 +292,7 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
       }
     }
   };
+  NSC_STAMP(32);
   prefetch(blockIdx.x);
   // ---- once per workgroup: weights -> LDS / registers ----
   // Every load below uses a CLAMPED index instead of a mask: pad rows of A (output channels >= 20 / >= C) only feed
@@ -346,8 +358,10 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
   }
 
 
+  NSC_STAMP(33);
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int b = tile / tpf, t0 = (tile - b * tpf) * TT;
+    NSC_STAMP(34);
     // ---- phase 0: prefetched x tile -> LDS ----
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb) {
@@ -360,7 +374,9 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
         }
       }
     }
-    __syncthreads();
+    NSC_STAMP(35);
+    nsc_lds_barrier();
+    NSC_STAMP(36);
     if (!(skip & 8)) prefetch(tile + gridDim.x);   // in flight during the three MFMA phases
 
     // ---- phase 1: h = lrelu(W1 x + b1); column tile = wave ----
@@ -392,7 +408,9 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
         }
       }
     }
-    __syncthreads();
+    NSC_STAMP(37);
+    nsc_lds_barrier();
+    NSC_STAMP(38);
 
     // ---- phase 2: both k15 gate convs, A from LDS (w2s), B from LDS (hs) ----
     if (!(skip & 2)) {
@@ -435,7 +453,9 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
         }
       }
     }
-    __syncthreads();
+    NSC_STAMP(39);
+    nsc_lds_barrier();
+    NSC_STAMP(40);
 
     // ---- phase 3: y = W9 * g + b9 + x; this wave's row tile (weights in registers), NC3 column tiles ----
     if ((RT9 != 7 || wave < 7) && !(skip & 4)) {
@@ -464,8 +484,11 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
         }
       }
     }
-    __syncthreads();   // xs / hs / gs are rewritten by the next tile
+    NSC_STAMP(41);
+    nsc_lds_barrier();   // xs / hs / gs are rewritten by the next tile
+    NSC_STAMP(42);
   }
+  NSC_STAMP(43);
 }
 
 template <int RT9, int NK1, int DIL>
@@ -1935,29 +1958,35 @@ __device__ __forceinline__ void d9_rows0(const float (&w9r)[K9][NJ], const float
 // Row (s,i), column n  ->  dg[16+i][64 ctp + 4n + s] = sum_{m,o} A[(s,i)][(m,o)] dy[o][64 ctp + 4n + m],
 // A = wt9[m-s][o][16+i] for 0 <= m-s < 9 else 0: 12 "taps" m instead of 9, but one MFMA column tile now spans 64 time steps
 // instead of 16 (2 tiles instead of 6).  A from LDS (w9ps [9][C][4]), lane (4s+i, kq); B lanes walk time with stride 4.
-template <int NJ, int NK9_, int LDY_>
-__device__ __forceinline__ void d9_packed(const float* w9ps, int C, const float* dys, int kg, int kq, int l15,
+template <int NJ, int NK9_, int LDY_, int NT = 2>
+__device__ __forceinline__ void d9_packed(const float* w9ps, int C, int w9t, const float* dys, int kg, int kq, int l15,
                                           f32x4 (&acc)[2]) {
+  // NT = 2: acc[0] / acc[1] are the column tiles at +0 / +64.  NT = 1: one column tile; acc[0] / acc[1] take alternate
+  // k-steps (independent MFMA chains) and the caller adds them.
   const int sft = l15 >> 2, ich = l15 & 3;
   const float* ypb = dys + (4 * kg + kq) * LDY_ + 4 * l15;
 #pragma unroll
   for (int m = 0; m < K9 + 3; ++m) {
     const int tap = m - sft;
     const bool ok = (unsigned)tap < (unsigned)K9;
-    const float* ap = w9ps + (((ok ? tap : 0) * C + 4 * kg + kq) * 4 + ich);
-    float av[NJ], b0[NJ], b1[NJ];
+    const float* ap = w9ps + (ok ? tap : 0) * w9t + (4 * kg + kq) * 4 + ich;
+    float av[NJ], b0[NJ], b1[NT == 2 ? NJ : 1];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       av[j] = ap[16 * j * 4];
       b0[j] = ypb[16 * j * LDY_ + m];
-      b1[j] = ypb[16 * j * LDY_ + m + 64];
+      if (NT == 2) b1[j] = ypb[16 * j * LDY_ + m + 64];
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const float a = ok ? av[j] : 0.f;
-      acc[0] = mfma4(a, b0[j], acc[0]);
-      acc[1] = mfma4(a, b1[j], acc[1]);
+      if (NT == 2) {
+        acc[0] = mfma4(a, b0[j], acc[0]);
+        acc[1] = mfma4(a, b1[j], acc[1]);
+      } else {
+        acc[(j + m) & 1] = mfma4(a, b0[j], acc[(j + m) & 1]);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -1969,64 +1998,98 @@ __device__ __forceinline__ void d9_packed(const float* w9ps, int C, const float*
     const bool ok = (unsigned)tap < (unsigned)K9;
     // channel rows >= C (C = 50: rows 50, 51) meet zero rows of the dy tile: clamp the index so the fragment is a finite
     // stand-in (an unclamped read ran past the table into uninitialised LDS: NaN * 0)
-    const float a0 = w9ps[((ok ? tap : 0) * C + min(4 * (NK9_ - 1) + kq, C - 1)) * 4 + ich];
+    const float a0 = w9ps[(ok ? tap : 0) * w9t + min(4 * (NK9_ - 1) + kq, C - 1) * 4 + ich];
     const float a = ok ? a0 : 0.f;
-    acc[0] = mfma4(a, ypx[4 * e], acc[0]);
-    acc[1] = mfma4(a, ypx[4 * e + 64], acc[1]);
+    if (NT == 2) {
+      acc[0] = mfma4(a, ypx[4 * e], acc[0]);
+      acc[1] = mfma4(a, ypx[4 * e + 64], acc[1]);
+    } else {
+      acc[e & 1] = mfma4(a, ypx[4 * e], acc[e & 1]);
+    }
   }
 }
 
-// ---- helpers of the k15 data gradient (weights from LDS: w15s [15][40][20]) ----
+// ---- helpers of the k15 data gradient (weights from LDS: w15s [15][40][20], tap stride W15T) ----
+// W15T = 808: == 8 (mod 32), so the four time shifts of the packed tile (four different taps per lane group) read four
+// different bank groups (at the natural stride 800 == 0 they were a 4-way conflict).
+constexpr int W15T = 2 * NARROW * NARROW + 8;
 // rows = channels 0..15, NC column tiles starting at ab; this wave's taps kg, kg+4, kg+8, (kg+12)
 template <int NC, int DIL_, int LDA_>
 __device__ __forceinline__ void d15_rows0(const float* wb, const float* ab, int kg, f32x4 (&acc)[NC]) {
+  // groups of two k-steps, software-pipelined like d9_rows0: the operands of group g+1 are requested before the MFMAs of
+  // group g issue (unpipelined, every group exposed a full LDS round trip: the phase ran at 2/3 of its MFMA rate)
+  constexpr int NG = 4 * 5;                              // (tap quarter e4, channel-group pair u/2)
+  float av[2][2], bv[2][2][NC];
+  auto fetch = [&](int g, int slot) {
+    const int e4 = g / 5, u = 2 * (g - 5 * e4);
 #pragma unroll
-  for (int e4 = 0; e4 < 4; ++e4) {
-    if (e4 == 3 && kg == 3) break;                       // tap 15 does not exist (wave-uniform)
+    for (int uu = 0; uu < 2; ++uu) {
+      av[slot][uu] = wb[e4 * 4 * W15T + 4 * (u + uu) * NARROW];
 #pragma unroll
-    for (int u = 0; u < 10; u += 2) {                    // two k-steps per scheduling group
-      float av[2], bv[2][NC];
+      for (int ct = 0; ct < NC; ++ct) bv[slot][uu][ct] = ab[4 * (u + uu) * LDA_ + e4 * 4 * DIL_ + ct * 16];
+    }
+  };
+  const bool last_q = kg != 3;                           // tap 15 (groups 15..19 of quarter 3) does not exist: wave-uniform
+  fetch(0, 0);
 #pragma unroll
-      for (int uu = 0; uu < 2; ++uu) {
-        av[uu] = wb[(e4 * 4 * 2 * NARROW + 4 * (u + uu)) * NARROW];
-#pragma unroll
-        for (int ct = 0; ct < NC; ++ct) bv[uu][ct] = ab[4 * (u + uu) * LDA_ + e4 * 4 * DIL_ + ct * 16];
-      }
+  for (int g = 0; g < NG; ++g) {
+    if (g < 15 || last_q) {
+      if (g + 1 < NG && (g + 1 < 15 || last_q)) fetch(g + 1, (g + 1) & 1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int uu = 0; uu < 2; ++uu)
 #pragma unroll
-        for (int ct = 0; ct < NC; ++ct) acc[ct] = mfma4(av[uu], bv[uu][ct], acc[ct]);
+        for (int ct = 0; ct < NC; ++ct) acc[ct] = mfma4(av[g & 1][uu], bv[g & 1][uu][ct], acc[ct]);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
 }
 // channels 16..19 PACKED as in d9_packed: row (s,i), column n -> dh[16+i][4n + s] = sum_{m,c'} A da[c'][4n + m], with
 // m = s + tap*DIL in [0, 4 + 14 DIL) and A = w15s[tap][c'][16+i] where (m - s) is a valid multiple of DIL, else 0.
-// This wave owns the m = kg (mod 4).  One column tile covers the 64 output steps.
+// This wave owns the m = kg (mod 4).  One column tile covers the 64 output steps.  Two accumulators (even / odd
+// k-steps, summed at the end) so that consecutive MFMAs are independent; half-groups of five are pipelined.
 template <int DIL_, int LDA_>
 __device__ __forceinline__ void d15_packed(const float* w15s, const float* da, int kg, int kq, int l15, f32x4& acc) {
-  constexpr int NM = 4 + 14 * DIL_, NQM = (NM + 3) / 4;
+  constexpr int NM = 4 + 14 * DIL_, NQM = (NM + 3) / 4, NH = 2 * NQM;
   const int sft = l15 >> 2, ich = l15 & 3;
   const float* bb = da + kq * LDA_ + 4 * l15 + kg;
-#pragma unroll
-  for (int q = 0; q < NQM; ++q) {
-    if (kg + 4 * q >= NM) break;                         // wave-uniform (NM is not a multiple of 4 at DIL 1)
+  float av[2][5], bv[2][5];
+  bool okv[2];
+  auto fetch = [&](int hgrp, int slot) {
+    const int q = hgrp >> 1, u0 = 5 * (hgrp & 1);
     const int dm = kg + 4 * q - sft;
     const int tap = DIL_ == 1 ? dm : (dm >> 1);
     const bool ok = dm >= 0 && (DIL_ == 1 || !(dm & 1)) && tap < K15;
-    const float* ap = w15s + ((ok ? tap : 0) * 2 * NARROW + kq) * NARROW + 16 + ich;
-    float av[10], bv[10];
+    okv[slot] = ok;
+    const float* ap = w15s + (ok ? tap : 0) * W15T + kq * NARROW + 16 + ich;
 #pragma unroll
-    for (int u = 0; u < 10; ++u) {
-      av[u] = ap[4 * u * NARROW];
-      bv[u] = bb[4 * u * LDA_ + 4 * q];
+    for (int u = 0; u < 5; ++u) {
+      av[slot][u] = ap[4 * (u0 + u) * NARROW];
+      bv[slot][u] = bb[4 * (u0 + u) * LDA_ + 4 * q];
     }
-    __builtin_amdgcn_sched_barrier(0);
+  };
+  f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+  // only the LAST q can fall off the end (NM is not a multiple of 4 at DIL 1): live(q) is true for q < NQM - 1
+  const bool last_live = kg + 4 * (NQM - 1) < NM;        // wave-uniform
+  fetch(0, 0);
 #pragma unroll
-    for (int u = 0; u < 10; ++u) acc = mfma4(ok ? av[u] : 0.f, bv[u], acc);
-    __builtin_amdgcn_sched_barrier(0);
+  for (int hgrp = 0; hgrp < NH; ++hgrp) {
+    const bool live = (hgrp >> 1) < NQM - 1 || last_live;
+    if (live) {
+      if (hgrp + 1 < NH && (((hgrp + 1) >> 1) < NQM - 1 || last_live)) fetch(hgrp + 1, (hgrp + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      const bool ok = okv[hgrp & 1];
+#pragma unroll
+      for (int u = 0; u < 5; ++u) {
+        const float a = ok ? av[hgrp & 1][u] : 0.f;
+        if ((u + hgrp) & 1) acc2 = mfma4(a, bv[hgrp & 1][u], acc2);
+        else acc = mfma4(a, bv[hgrp & 1][u], acc);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] += acc2[r];
 }
 
 // -----------------------------------------------------------------------------------------------------
@@ -2045,12 +2108,17 @@ template <int RT9, int NK9, int DIL>
 __global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs a, int ntiles, int tpf, int skip) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int TT = 64, Hh = 7 * DIL, W_a = TT + 2 * Hh, W_dy = W_a + 8, NCTA = (W_a + 15) / 16, CR = 4 * NK9;
-  constexpr int LDY = 112, LDA = 112, LDN = 80, WA16 = NCTA * 16;
+  // LDY / LDA == 14 (mod 32): the two channel rows a 32-lane group reads sit 14 banks apart.  The packed tiles walk time
+  // with stride 4 (banks {0,4,..,28}): an offset that is not a multiple of 4 keeps the second row off the first row's
+  // banks (at 112 == 16 they were the same banks: 4-way); the 16-consecutive-column reads of rows 0..15 overlap on 2 banks.
+  constexpr int LDY = 110, LDA = 110, LDN = 80, WA16 = NCTA * 16;
+  constexpr int PSW = WA16 + 4, PST = TT + 4;      // row strides of the partial-sum slices: == 4 (mod 8), so the four
+                                                   // D-fragment rows a wave stores (4 rows apart) hit four bank groups
   constexpr int NQ = (CR + 7) / 8;                 // dy rows per wave
   constexpr int NJ9 = (NK9 + 3) / 4;               // channel groups (of 4) per K-quarter of the k9 gradient
-  constexpr int PART1 = 4 * 16 * WA16;             // offset of the row-tile-1 partial sums (rows 16..19 only)
+  constexpr int PART1 = 4 * 16 * PSW;              // offset of the row-tile-1 partial sums (rows 16..19 only)
   constexpr int LDD = 68;                          // dxs row stride: == 4 (mod 32), D-fragment stores conflict-free
-  constexpr int PARTSZ = 4 * NARROW * WA16 > CR * LDD ? 4 * NARROW * WA16 : CR * LDD;
+  constexpr int PARTSZ = 4 * NARROW * PSW > CR * LDD ? 4 * NARROW * PSW : CR * LDD;
   static_assert(WA16 + 8 <= LDY && 63 + 15 * DIL < LDA, "tile widths");
   float* dys = sm;                                 // [CR][LDY]       j  <-> t0 - Hh - 4 + j   (pad rows zero)
   float* lin = dys + CR * LDY;                     // [20][LDA]       ja <-> t0 - Hh + ja      -> dlin  (rows 0..19 of da)
@@ -2059,8 +2127,9 @@ __global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs 
   float* part = dhs + NARROW * LDN;                // [4][16][WA16] + [4][4][WA16]  partial sums of the K-quarters;
   float* dxs = part;                               //   later [CR][LDD]: dx before act'(x), for the row-wise copy-out
   float* w15s = part + PARTSZ;                     // [15][40][20]   wt_l | wt_r concatenated along the reduced channel
-  float* w9ps = w15s + K15 * 2 * NARROW * NARROW;  // [9][C][4]      k9 gradient weights of channels 16..19 (packed tile)
+  float* w9ps = w15s + K15 * W15T;                 // [9][C][4] (tap stride w9t)  k9 gradient weights of channels 16..19
   const int C = a.C, T = a.T;
+  const int w9t = C * 4 + (((C * 4) & 15) == 8 ? 0 : 8);   // == 8 or 24 (mod 32): see W15T
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, kq = lane >> 4;
@@ -2116,18 +2185,53 @@ __global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs 
       pfh[q] = bld(sh, (c < NARROW && t < T) ? t * 4 : OOB, (b * NARROW + min(c, NARROW - 1)) * T * 4);
     }
   };
-  prefetch_dy(blockIdx.x);
-  prefetch_a(blockIdx.x);
+  // CHAIN: a workgroup walks CONSECUTIVE tiles [first, last).  Consecutive tiles of one frame overlap in the 2*Hh columns of
+  // da (= dlin | dgate) that the k15 gradient reads on either side: from the second tile of a chain on, those columns are
+  // carried over in LDS and the k9 gradient + GLU run on the TT new columns only (4 column tiles instead of 6: the halo was
+  // 1.44x of the k9 gradient's MFMAs).  A tile is "fresh" (full width) at the start of a chain and at the start of a frame.
+  const int first = (int)((long)blockIdx.x * ntiles / gridDim.x), last = (int)((long)(blockIdx.x + 1) * ntiles / gridDim.x);
+  NSC_STAMP(0);
+  prefetch_dy(first);
+  prefetch_a(first);
   // ---- once per workgroup: weights -> registers / LDS (clamped indices: pad k-rows meet zero rows of the staged
   // tiles; only k-steps / taps past the end need a real zero) ----
-  for (int e = tid; e < K15 * 2 * NARROW * NARROW; e += 512) {
-    const int tp = e / (2 * NARROW * NARROW), r = e - tp * 2 * NARROW * NARROW;
-    const int cp = r / NARROW, ci = r - cp * NARROW;
-    w15s[e] = cp < NARROW ? a.wtl[(tp * NARROW + cp) * NARROW + ci] : a.wtr[(tp * NARROW + cp - NARROW) * NARROW + ci];
+  // (all loads of a table are issued before its first LDS store: a plain load->store loop serialises ~24 L2 round
+  // trips per lane, which was ~9 us of every launch)
+  {
+    constexpr int N15 = K15 * 2 * NARROW * NARROW, NE = (N15 + 511) / 512;
+    float tmp[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const int e = min(tid + 512 * i, N15 - 1);
+      const int tp = e / (2 * NARROW * NARROW), r = e - tp * 2 * NARROW * NARROW;
+      const int cp = r / NARROW, ci = r - cp * NARROW;
+      const float* src = cp < NARROW ? a.wtl : a.wtr;
+      tmp[i] = src[(tp * NARROW + (cp < NARROW ? cp : cp - NARROW)) * NARROW + ci];
+    }
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const int e = tid + 512 * i;
+      const int tp = e / (2 * NARROW * NARROW);
+      if (e < N15) w15s[e + 8 * tp] = tmp[i];
+    }
   }
   // k9 gradient: K-quarter kg owns the channel groups cq = kg + 4j of every tap, so the B-fragment address of step
   // (tap', j) is lane base + the compile-time offset (16 j LDY + tap'): no per-step address registers.
-  for (int e = tid; e < K9 * C * 4; e += 512) w9ps[e] = a.wt9[(long)(e >> 2) * NARROW + 16 + (e & 3)];
+  {
+    constexpr int NE9 = (K9 * 4 * 4 * NK9 + 511) / 512;
+    const int n9 = K9 * C * 4;
+    float tmp[NE9];
+#pragma unroll
+    for (int i = 0; i < NE9; ++i) {
+      const int e = min(tid + 512 * i, n9 - 1);
+      tmp[i] = a.wt9[(long)(e >> 2) * NARROW + 16 + (e & 3)];
+    }
+#pragma unroll
+    for (int i = 0; i < NE9; ++i) {
+      const int e = tid + 512 * i;
+      if (e < n9) w9ps[(e / (4 * C)) * w9t + (e % (4 * C))] = tmp[i];
+    }
+  }
   // NK9 = 4 (NJ9-1) + 1 for both shapes: the one left-over channel group (cq = NK9-1) is shared out by TAP (quarter kg takes
   // taps kg, kg+4, kg+8 < 9), so the quarters carry 57 | 56 | 56 | 56 k-steps instead of 63 | 54 | 54 | 54.
   static_assert(NK9 == 4 * (NJ9 - 1) + 1, "left-over channel group is shared out by tap");
@@ -2148,8 +2252,12 @@ __global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs 
   for (int s5 = 0; s5 < 5; ++s5) w1r[s5] = a.wt1[(s5 * 4 + kq) * C + min(rt1 * 16 + l15, C - 1)];
 
 
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  NSC_STAMP(1);
+  for (int tile = first; tile < last; ++tile) {
     const int b = tile / tpf, t0 = (tile - b * tpf) * TT;
+    const bool fresh = tile == first || t0 == 0;                                   // workgroup-uniform
+    const bool next_steady = tile + 1 < last && (tile + 1) - ((tile + 1) / tpf) * tpf != 0;
+    NSC_STAMP(2);
     // ---- phase 0: prefetched tiles -> LDS ----
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb) {
@@ -2163,7 +2271,7 @@ __global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs 
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
           const int r = wave + 8 * q;
-          if (r < NARROW) {
+          if (r < NARROW && (fresh || j >= 2 * Hh)) {       // steady tile: columns [0, 2 Hh) hold the carried dlin / dgate
             lin[r * LDA + j] = pfl[q][hb];
             th[r * LDA + j] = pft[q][hb];
           }
@@ -2173,8 +2281,12 @@ __global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs 
     float hv[3];
 #pragma unroll
     for (int q = 0; q < 3; ++q) hv[q] = pfh[q];
-    __syncthreads();
-    if (!(skip & 8)) prefetch_dy(tile + gridDim.x);
+    NSC_STAMP(3);
+    nsc_lds_barrier();
+    NSC_STAMP(4);
+    // the next tile's dy goes out now: all workgroups prefetch at the same moment (a ~17 MB burst), so it needs the two long
+    // MFMA phases to arrive; lin / tanh / h (a third of the bytes) go out after the k15 gradient, when their registers are free
+    if (!(skip & 8)) prefetch_dy(tile + 1 < last ? tile + 1 : tile);
 
     // ---- D9: dg[ci][ja] = sum_{tap', o} wt9[tap'][o][ci] * dy[o][ja + tap'], K split in quarters kg.
     // Channels 0..15: waves 0-3 take column tiles 0..3, waves 4-7 the rest; channels 16..19: waves 4-7, packed tile.
@@ -2184,8 +2296,34 @@ __global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs 
       constexpr int NCB = NCTA - 4;                        // column tiles of channels 0..15 left to waves 4-7
       const float* yb = dys + (4 * kg + kq) * LDY + l15;
       const float* yx = dys + (4 * (NK9 - 1) + kq) * LDY + l15 + kg;
-      float* pp0 = part + (kg * 16 + kq * 4) * WA16 + l15;
-      if (rt == 0) {
+      float* pp0 = part + (kg * 16 + kq * 4) * PSW + l15;
+      if (!fresh) {
+        // steady tile: the TT new columns [J0, J0 + TT) only.  Channels 0..15: waves 0-3 column tiles 0..2, waves 4-7 tile 3;
+        // channels 16..19: waves 4-7, ONE packed tile (it spans 64 time steps).
+        constexpr int J0 = 2 * Hh;
+        if (rt == 0) {
+          f32x4 acc[3];
+#pragma unroll
+          for (int ct = 0; ct < 3; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          d9_rows0<3, NJ9 - 1, LDY>(w9r, w9x, yb + J0, yx + J0, kg, acc);
+#pragma unroll
+          for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) pp0[reg * PSW + J0 + ct * 16] = acc[ct][reg];
+        } else {
+          f32x4 acc[1];
+          acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          d9_rows0<1, NJ9 - 1, LDY>(w9r, w9x, yb + J0 + 48, yx + J0 + 48, kg, acc);
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) pp0[reg * PSW + J0 + 48] = acc[0][reg];
+          f32x4 pk[2];
+          pk[0] = pk[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          d9_packed<NJ9 - 1, NK9, LDY, 1>(w9ps, C, w9t, dys + J0, kg, kq, l15, pk);
+          const int col = J0 + 4 * l15 + kq;
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) part[PART1 + (kg * 4 + reg) * PSW + col] = pk[0][reg] + pk[1][reg];
+        }
+      } else if (rt == 0) {
         f32x4 acc[4];
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -2193,7 +2331,7 @@ __global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs 
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-          for (int reg = 0; reg < 4; ++reg) pp0[reg * WA16 + ct * 16] = acc[ct][reg];
+          for (int reg = 0; reg < 4; ++reg) pp0[reg * PSW + ct * 16] = acc[ct][reg];
       } else {
         f32x4 acc[NCB];
 #pragma unroll
@@ -2202,28 +2340,40 @@ __global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs 
 #pragma unroll
         for (int ct = 0; ct < NCB; ++ct)
 #pragma unroll
-          for (int reg = 0; reg < 4; ++reg) pp0[reg * WA16 + (4 + ct) * 16] = acc[ct][reg];
+          for (int reg = 0; reg < 4; ++reg) pp0[reg * PSW + (4 + ct) * 16] = acc[ct][reg];
         f32x4 pk[2];
         pk[0] = pk[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        d9_packed<NJ9 - 1, NK9, LDY>(w9ps, C, dys, kg, kq, l15, pk);
+        d9_packed<NJ9 - 1, NK9, LDY>(w9ps, C, w9t, dys, kg, kq, l15, pk);
         // row (s = kq, i = reg), column n = l15  ->  dg[16 + reg][64 ctp + 4 l15 + kq]
 #pragma unroll
         for (int ctp = 0; ctp < 2; ++ctp) {
           const int col = 64 * ctp + 4 * l15 + kq;
           if (col < WA16) {
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) part[PART1 + (kg * 4 + reg) * WA16 + col] = pk[ctp][reg];
+            for (int reg = 0; reg < 4; ++reg) part[PART1 + (kg * 4 + reg) * PSW + col] = pk[ctp][reg];
           }
         }
       }
     }
-    __syncthreads();
+    NSC_STAMP(5);
+    nsc_lds_barrier();
+    NSC_STAMP(6);
 
     // ---- GLU backward in place (lin/th are zero outside the frame, so dlin/dgate are too); da -> global ----
     for (int e = tid; e < NARROW * WA16; e += 512) {
       const int c = e / WA16, ja = e - c * WA16;
-      const float* pp = c < 16 ? part + c * WA16 + ja : part + PART1 + (c - 16) * WA16 + ja;
-      const int ps = c < 16 ? 16 * WA16 : 4 * WA16;
+      if (!fresh && ja < 2 * Hh) {
+        // carried column: dlin / dgate are already in LDS (moved there at the end of the previous tile); the columns of
+        // it that belong to THIS tile's output range have not been stored yet
+        const int t = t0 - Hh + ja;
+        if (ja >= Hh && t < T) {
+          a.da[((long)b * 2 * NARROW + c) * T + t] = lin[c * LDA + ja];
+          a.da[((long)b * 2 * NARROW + NARROW + c) * T + t] = th[c * LDA + ja];
+        }
+        continue;
+      }
+      const float* pp = c < 16 ? part + c * PSW + ja : part + PART1 + (c - 16) * PSW + ja;
+      const int ps = c < 16 ? 16 * PSW : 4 * PSW;
       const float gg = (pp[0] + pp[ps]) + (pp[2 * ps] + pp[3 * ps]);
       const float l = lin[c * LDA + ja], tg = th[c * LDA + ja];
       const float dl_ = gg * tg, dgt = gg * l * (1.f - tg * tg);
@@ -2235,15 +2385,16 @@ __global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs 
         a.da[((long)b * 2 * NARROW + NARROW + c) * T + t] = dgt;
       }
     }
-    __syncthreads();
-    if (!(skip & 8)) prefetch_a(tile + gridDim.x);   // lin / tanh / h of the next tile (their LDS tiles are still in use)
+    NSC_STAMP(7);
+    nsc_lds_barrier();
+    NSC_STAMP(8);
 
     // ---- D15: dh[ci][tt] = sum wt_lr[tap'][c'][ci] * da[c'][tt + tap' d], taps split in quarters kg.
     // Channels 0..15: waves 0-3 column tiles 0..2, waves 4-7 tile 3; channels 16..19: waves 4-7, packed tile.
     if (!(skip & 2)) {
       const float* ab = lin + kq * LDA + l15 + kg * DIL;
-      const float* wb = w15s + (kg * 2 * NARROW + kq) * NARROW + l15;
-      float* pp0 = part + (kg * 16 + kq * 4) * TT + l15;
+      const float* wb = w15s + kg * W15T + kq * NARROW + l15;
+      float* pp0 = part + (kg * 16 + kq * 4) * PST + l15;
       if (rt == 0) {
         f32x4 acc[3];
 #pragma unroll
@@ -2252,18 +2403,18 @@ __global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs 
 #pragma unroll
         for (int ct = 0; ct < 3; ++ct)
 #pragma unroll
-          for (int reg = 0; reg < 4; ++reg) pp0[reg * TT + ct * 16] = acc[ct][reg];
+          for (int reg = 0; reg < 4; ++reg) pp0[reg * PST + ct * 16] = acc[ct][reg];
       } else {
         f32x4 acc[1];
         acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
         d15_rows0<1, DIL, LDA>(wb, ab + 48, kg, acc);
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) pp0[reg * TT + 48] = acc[0][reg];
+        for (int reg = 0; reg < 4; ++reg) pp0[reg * PST + 48] = acc[0][reg];
         f32x4 pk = {0.f, 0.f, 0.f, 0.f};
         d15_packed<DIL, LDA>(w15s, lin, kg, kq, l15, pk);
         // row (s = kq, i = reg), column n = l15  ->  dh[16 + reg][4 l15 + kq]
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) part[4 * 16 * TT + (kg * 4 + reg) * TT + 4 * l15 + kq] = pk[reg];
+        for (int reg = 0; reg < 4; ++reg) part[4 * 16 * PST + (kg * 4 + reg) * PST + 4 * l15 + kq] = pk[reg];
       }
     }
     // x rows of the copy-out phase (for act'(x)): wave w rows w, w+8, ...; issued here, consumed three barriers later
@@ -2273,7 +2424,24 @@ __global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs 
 #pragma unroll
       for (int q = 0; q < NQ; ++q) xv[q] = bld(sxx, vx, (b * C + min(wave + 8 * q, C - 1)) * T * 4);
     }
-    __syncthreads();
+    NSC_STAMP(9);
+    nsc_lds_barrier();
+    NSC_STAMP(10);
+    // the next tile's dy / lin / tanh / h go out HERE, not before the two long MFMA phases: their ~40 destination registers
+    // are then free during D9 / D15 (which need them for operand double-buffering), and the three short phases that
+    // follow (~6k cycles) still cover the HBM round trip
+    if (!(skip & 8)) {
+      prefetch_a(tile + 1 < last ? tile + 1 : tile);
+    }
+    if (next_steady) {
+      // carry: the last 2 Hh columns of dlin / dgate (columns [TT, TT + 2 Hh) of this tile) are columns [0, 2 Hh) of the next
+      // tile.  The k15 gradient is done with them (barrier above) and source / destination ranges are disjoint.
+      for (int e = tid; e < 2 * NARROW * 2 * Hh; e += 512) {
+        const int r = e / (2 * Hh), cidx = e - r * (2 * Hh);
+        float* buf = r < NARROW ? lin + r * LDA : th + (r - NARROW) * LDA;
+        buf[cidx] = buf[cidx + TT];
+      }
+    }
 
     // ---- dz1 = (sum of the four partial dh) . lrelu'(h) -> LDS + global ----
 #pragma unroll
@@ -2282,15 +2450,17 @@ __global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs 
       if (e < NARROW * TT) {
         const int c = e >> 6, tt = e & 63;
         const int t = t0 + tt;
-        const float* pp = c < 16 ? part + c * TT + tt : part + 4 * 16 * TT + (c - 16) * TT + tt;
-        const int ps = c < 16 ? 16 * TT : 4 * TT;
+        const float* pp = c < 16 ? part + c * PST + tt : part + 4 * 16 * PST + (c - 16) * PST + tt;
+        const int ps = c < 16 ? 16 * PST : 4 * PST;
         const float dh = (pp[0] + pp[ps]) + (pp[2 * ps] + pp[3 * ps]);
         const float v = t < T ? dh * (hv[q] > 0.f ? 1.f : NSC_LRELU_ALPHA) : 0.f;
         dhs[c * LDN + tt] = v;
         if (t < T) a.dz1[((long)b * NARROW + c) * T + t] = v;
       }
     }
-    __syncthreads();
+    NSC_STAMP(11);
+    nsc_lds_barrier();
+    NSC_STAMP(12);
 
     // ---- D1: dx = (W1^T dz1 + dy) . act'(x); this wave's row tile, NC1 column tiles ----
     if ((RT9 != 7 || wave < 7) && !(skip & 4)) {
@@ -2312,7 +2482,9 @@ __global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs 
         }
       }
     }
-    __syncthreads();
+    NSC_STAMP(13);
+    nsc_lds_barrier();
+    NSC_STAMP(14);
     // ---- copy-out: dx rows as whole 256-B lines (the D-fragment stores were 64-B pieces), . act'(x) ----
     if (t0 + lane < T) {
 #pragma unroll
@@ -2325,16 +2497,20 @@ __global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs 
         }
       }
     }
-    __syncthreads();   // dys / lin / th / dhs / part are rewritten by the next tile
+    NSC_STAMP(15);
+    nsc_lds_barrier();   // dys / lin / th / dhs / part are rewritten by the next tile
+    NSC_STAMP(16);
   }
+  NSC_STAMP(17);
 }
 
 template <int RT9, int NK9, int DIL>
 static int launch_block_dgrad2(const BlockDgradArgs& a, hipStream_t st) {
   constexpr int WA16 = ((64 + 14 * DIL + 15) / 16) * 16;
-  const size_t partsz = std::max((size_t)4 * NARROW * WA16, (size_t)4 * NK9 * 68);
-  const size_t smem = ((size_t)4 * NK9 * 112 + (size_t)2 * NARROW * 112 + (size_t)NARROW * 80 + partsz +
-                       (size_t)K15 * 2 * NARROW * NARROW + (size_t)K9 * a.C * 4) * sizeof(float);
+  const size_t partsz = std::max((size_t)4 * NARROW * (WA16 + 4), (size_t)4 * NK9 * 68);
+  const int w9t = a.C * 4 + (((a.C * 4) & 15) == 8 ? 0 : 8);
+  const size_t smem = ((size_t)4 * NK9 * 110 + (size_t)2 * NARROW * 110 + (size_t)NARROW * 80 + partsz +
+                       (size_t)K15 * W15T + (size_t)K9 * w9t) * sizeof(float);
   NSC_REQUIRE(smem <= 160 * 1024, NSC_ERR_UNSUPPORTED, "gated_block_dgrad2: %zu B LDS", smem);
   auto kern = gated_block_dgrad2_kernel<RT9, NK9, DIL>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);

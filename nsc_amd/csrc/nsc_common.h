@@ -22,6 +22,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 void nsc_set_error(const char* fmt, ...);
 
+// Workgroup barrier that orders LDS traffic ONLY.  __syncthreads() also drains vmcnt, i.e. every wave waits for the
+// write acknowledgements of all its global stores (and for its prefetch loads) at every phase boundary - in the
+// persistent block kernels that was 3 store round trips per tile.  Use where the phases communicate through LDS only.
+__device__ __forceinline__ void nsc_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 #define NSC_REQUIRE(cond, code, ...)          \
   do {                                        \
     if (!(cond)) {                            \

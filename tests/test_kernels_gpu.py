@@ -555,7 +555,10 @@ def test_block_wgrad_kernel(lib, case):
 
 
 @pytest.mark.parametrize("case", [(2, 100, 512, 2, 2), (2, 100, 256, 1, 0), (3, 50, 512, 2, 2), (2, 50, 512, 1, 2),
-                                  (1, 100, 200, 2, 0), (5, 36, 70, 1, 2)])
+                                  (1, 100, 200, 2, 0), (5, 36, 70, 1, 2),
+                                  # more tiles than workgroups: chains of consecutive tiles with the carried da halo, chains
+                                  # that cross frame boundaries, a ragged last tile
+                                  (40, 100, 512, 2, 2), (72, 100, 256, 1, 2), (150, 50, 512, 2, 2), (61, 100, 300, 1, 0)])
 def test_fused_gated_block_dgrad(lib, case):
     """8-wave data-path backward (dx, dlin|dgate, dz1) vs autograd of the oracle block with its saved intermediates."""
     B, C_, T, dil, in_act = case

@@ -1,0 +1,28 @@
+"""PROBES build only: per-phase s_memtime stamps of workgroup 0 / wave 0 of gated_block_dgrad2 (last tile)."""
+import ctypes as C, os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from nsc_amd import _lib
+lib = _lib.load()
+lib.nsc_probe_read.argtypes = [C.c_void_p]
+dev = "cuda"
+st = torch.cuda.current_stream().cuda_stream
+names = ["start", "prologue done", "tile start", "staged", "bar0", "D9 done", "bar1", "GLU done", "bar2", "D15 done", "bar3",
+         "dz1 done", "bar4", "D1 done", "bar5", "copyout done", "bar6", "end"]
+for (B, C_, T, dil) in [(128, 100, 512, 1), (128, 100, 256, 2)]:
+    x = torch.randn(B, C_, T, device=dev); dy = torch.randn(B, C_, T, device=dev)
+    h, lin, th = (torch.randn(B, 20, T, device=dev) for _ in range(3)); th = torch.tanh(th)
+    wt1 = torch.randn(1, 20, C_, device=dev) * 0.1
+    wtl = torch.randn(15, 20, 20, device=dev) * 0.05; wtr = torch.randn(15, 20, 20, device=dev) * 0.05
+    wt9 = torch.randn(9, C_, 20, device=dev) * 0.05
+    dx = torch.empty_like(x); da = torch.empty(B, 40, T, device=dev); dz1 = torch.empty(B, 20, T, device=dev)
+    p = lambda t: t.data_ptr()
+    for _ in range(5):
+        _lib.check(lib.nsc_gated_block_dgrad(p(x), p(h), p(lin), p(th), p(dy), p(wt1), p(wtl), p(wtr), p(wt9), p(dx), p(da), p(dz1),
+                                             B, C_, T, 20, 9, dil, 2, st), "dgrad")
+    torch.cuda.synchronize()
+    buf = (C.c_ulonglong * 64)()
+    assert lib.nsc_probe_read(buf) == 0
+    v = list(buf)[:18]
+    print(f"B={B} C={C_} T={T} dil={dil}: total {v[17]-v[0]} ticks")
+    for i in range(1, 18):
+        print(f"  {names[i]:>14}: +{v[i]-v[i-1]}")
