@@ -97,16 +97,6 @@ int nsc_gated_block_fwd(const float* x, const float* w1, const float* b1, const 
                         float* h_out, float* lin_out, float* th_out, float* g_out, int B, int C, int T,
                         int narrow, int k9, int dil, int flat, void* stream);
 
-/* Fused backward of the same block (persistent, recompute-in-LDS): given x and dy = dL/d(pre-activation of out),
- * writes dx = (conv1^T(dz1) + dy) * act'(x) (in_act = activation that produced x: NSC_ACT_NONE | NSC_ACT_LRELU) and
- * ACCUMULATES all eight parameter gradients.  wt1/wtl/wtr/wt9 are the nsc_weight_flip_transpose'd kernels.
- * Supported: narrow 20, k9 9, dil in {1,2}, C <= 112 (else NSC_ERR_UNSUPPORTED: use the per-conv entry points). */
-int nsc_gated_block_bwd(const float* x, const float* dy, const float* w1, const float* b1, const float* wl,
-                        const float* bl, const float* wr, const float* br, const float* wt1, const float* wtl,
-                        const float* wtr, const float* wt9, float* dx, float* dw1, float* db1, float* dwl, float* dbl,
-                        float* dwr, float* dbr, float* dw9, float* db9, int B, int C, int T, int narrow, int k9,
-                        int dil, int in_act, void* stream);
-
 /* Fused DATA-PATH backward of the same block (8 waves, two workgroups per CU): from the saved h, lin, th (tanh branch)
  * [B,20,T], x and dy [B,C,T] it writes dx = (conv1^T(dz1) + dy) * act'(x), da [B,40,T] (= dlin | dgate) and
  * dz1 [B,20,T] - exactly the inputs of nsc_gated_block_wgrad.  dil in {1,2}, narrow 20, k9 9, C <= 112. */

@@ -496,7 +496,7 @@ static int launch_block_fwd2(const BlockArgs& a, hipStream_t st) {
   constexpr int CR = 4 * NK1;
   const size_t smem = ((size_t)(CR + NARROW) * 112 + (size_t)NARROW * 80 + (size_t)K15 * NARROW * 48) * sizeof(float);
   auto kern = gated_block_fwd2_kernel<RT9, NK1, DIL>;
-  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  static const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);   // once per instantiation
   NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "gated_block_fwd2: smem attr: %s", hipGetErrorString(e));
   const int tpf = nsc_cdiv(a.T, 64);
   const int ntiles = a.B * tpf;
@@ -550,559 +550,6 @@ extern "C" int nsc_gated_block_fwd(const float* x, const float* w1, const float*
   return NSC_OK;
 }
 
-// =====================================================================================================
-// Fused backward of the gated bottleneck block, persistent: one workgroup per CU walks (frame, 64-step tile)
-// pairs; everything between "dy arrives" and "dx leaves" stays on the CU:
-//   recompute  h (1x1), lin / tanh / g (k15 gates)            from the staged x tile           [P1, P2]
-//   dg   = W9^T * dy                                          (k9 data gradient)               [D9]
-//   dlin = dg.th ; dgate = dg.lin.(1-th^2)                    (GLU backward, LDS elementwise)
-//   dz1  = (Wl^T * dlin + Wr^T * dgate) . lrelu'(h)           (k15 data gradients, one pass)   [D15]
-//   dx   = (W1^T * dz1 + dy) . act'(x)                        (1x1 data gradient + residual)   [D1]
-//   dW9 += g (x) dy ; dWl,dWr += h (x) dlin,dgate ; dW1 += x (x) dz1 ; bias grads via a row of ones
-// The weight-gradient accumulators (160 fp32 registers per lane) live in the 512-entry register file of the
-// one-wave-per-SIMD workgroup across ALL its tiles and are flushed once with float atomics: 256 partial sums per
-// layer instead of one per (tile, split).  Column conventions (tile origin t0, Hh = 7*dil):
-//   xs/hs : j <-> t0 - 2Hh + j      (W_h = 64 + 4Hh)      lin/th/g/dg : j <-> t0 - Hh + j   (W_a = 64 + 2Hh)
-//   dys   : j <-> t0 - Hh - 4 + j   (W_a + 8)             xn/dhs      : j <-> t0 + j        (64)
-// Row strides are == 18 (mod 32): conflict-free when lanes walk rows (wgrad operands), 2 of 32 lanes 2-way when
-// lanes walk time (conv operands).
-// =====================================================================================================
-struct BlockBwdArgs {
-  int B, C, T, dil, in_act;     // in_act: activation that produced x (0 none, 2 lrelu): dx is multiplied by act'(x)
-  const float *x, *dy;
-  const float *w1, *b1, *wl, *bl, *wr, *br;             // forward weights (recompute)
-  const float *wt1, *wtl, *wtr, *wt9;                   // flipped/transposed weights (data gradients)
-  float *dx;
-  float *dw1, *db1, *dwl, *dbl, *dwr, *dbr, *dw9, *db9; // accumulated (atomics)
-  int ntiles, tiles_per_frame;
-  int skip;   // timing-only debug mask (NSC_BWD_SKIP): 1 P1, 2 P2, 4 D9, 8 D15, 16 D1, 32 wgrad, 64 staging
-};
-
-template <int RT9>   // row tiles of C (7 for C=100, 4 for C=50)
-__global__ __launch_bounds__(256, 1) void gated_block_bwd_kernel(BlockBwdArgs a, int ldh, int lda, int ldy, int ldn) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  constexpr int TT = 64;
-  const int C = a.C, T = a.T, d = a.dil;
-  const int Hh = 7 * d;
-  const int W_h = TT + 4 * Hh, W_a = TT + 2 * Hh, W_dy = W_a + 8;
-  const int C4 = (C + 3) & ~3;
-  const int nct_h = (W_h + 15) >> 4;         // 8 (d=2) / 6 (d=1)
-  const int nct_a = (W_a + 15) >> 4;         // 6 (d=2) / 5 (d=1)
-  // ---- LDS carve ----
-  const int szA = max(C4 * ldh, C * ldy);
-  float* regA = sm;                          // xs_wide [C4][ldh]  then  dys [C][ldy]
-  float* xn = regA + szA;                    // [C + 2][ldn]  rows C = zeros, C+1 = ones
-  float* hs = xn + (C + 2) * ldn;            // [NARROW + 2][ldh] rows 20 = zeros, 21 = ones
-  float* lin = hs + (NARROW + 2) * ldh;      // [NARROW][lda]   (becomes dlin)
-  float* th = lin + NARROW * lda;            // [NARROW][lda]   (becomes dgate)
-  float* gs = th + NARROW * lda;             // [NARROW + 2][lda] rows 20 = zeros, 21 = ones
-  float* dg = gs + (NARROW + 2) * lda;       // [NARROW][lda]
-  float* dhs = dg + NARROW * lda;            // [NARROW][ldn]
-  float* xs = regA;
-  float* dys = regA;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform (SGPR): selects, not branches
-  const int l15 = lane & 15, kq = lane >> 4;
-
-  // ---- constant rows ----
-  for (int j = tid; j < ldn; j += 256) { xn[C * ldn + j] = 0.f; xn[(C + 1) * ldn + j] = 1.f; }
-  for (int j = tid; j < ldh; j += 256) { hs[NARROW * ldh + j] = 0.f; hs[(NARROW + 1) * ldh + j] = 1.f; }
-  for (int j = tid; j < lda; j += 256) { gs[NARROW * lda + j] = 0.f; gs[(NARROW + 1) * lda + j] = 1.f; }
-
-  // ---- weight-gradient accumulators, owned for the whole kernel ----
-  // dW9 : rows kk = tap*20+ci (180) + bias row 180 -> 12 row tiles; wave owns row tiles {w, w+4, w+8}; RT9 col tiles
-  // dWlr: rows kk = tap*20+ci (300) + bias row 300 -> 19 row tiles; wave owns {w, w+4, w+8, w+12, w+16}; 3 col tiles
-  //       (columns interleaved like the forward: j -> branch (j&2), channel ct*8 + (j>>2)*2 + (j&1))
-  // dW1 : rows ci (C) + bias row C -> RT9 row tiles; wave owns {w, w+4}; 2 col tiles
-  f32x4 g9[3][RT9], glr[5][3], g1[2][2];
-#pragma unroll
-  for (int r = 0; r < 3; ++r)
-#pragma unroll
-    for (int c = 0; c < RT9; ++c) g9[r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int r = 0; r < 5; ++r)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) glr[r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int r = 0; r < 2; ++r)
-#pragma unroll
-    for (int c = 0; c < 2; ++c) g1[r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  // per-lane A-row offsets of the wgrad operands (lane = row l15 of the tile)
-  int off9[3], offlr[5], off1[2];
-#pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    const int kk = (wave + 4 * r) * 16 + l15;
-    if (kk < K9 * NARROW) { const int tap = kk / NARROW, ci = kk - tap * NARROW; off9[r] = ci * lda + tap - 4 + Hh; }
-    else off9[r] = (kk == K9 * NARROW ? (NARROW + 1) : NARROW) * lda;
-  }
-#pragma unroll
-  for (int r = 0; r < 5; ++r) {
-    const int kk = (wave + 4 * r) * 16 + l15;
-    if (kk < K15 * NARROW) { const int tap = kk / NARROW, ci = kk - tap * NARROW; offlr[r] = ci * ldh + Hh + tap * d; }
-    else offlr[r] = (kk == K15 * NARROW ? (NARROW + 1) : NARROW) * ldh;
-  }
-#pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const int ci = (wave + 4 * r) * 16 + l15;
-    off1[r] = (ci < C ? ci : (ci == C ? C + 1 : C)) * ldn;
-  }
-  // B-operand column offsets for dWlr: lane l15 = column j of col tile ct
-  int offb_lr[3];
-  bool okb_lr[3];
-#pragma unroll
-  for (int ct = 0; ct < 3; ++ct) {
-    const int c = ct * 8 + (l15 >> 2) * 2 + (l15 & 1);
-    okb_lr[ct] = c < NARROW;
-    offb_lr[ct] = ((l15 & 2) ? (int)(th - lin) : 0) + (okb_lr[ct] ? c : 0) * lda + Hh;
-  }
-
-  // P2 / D9 job tables (wave-uniform): main column tile = wave; extra jobs (row tile, col tile)
-  // nct_a == 5: extras (rt,4) for waves 0..2.   nct_a == 6: w0: (0,4),(1,5)  w1: (1,4),(2,5)  w2: (2,4)  w3: (0,5)
-  int ex_rt[2] = {-1, -1}, ex_ct[2] = {0, 0};
-  if (nct_a == 5) { if (wave < 3) { ex_rt[0] = wave; ex_ct[0] = 4; } }
-  else {
-    if (wave == 0) { ex_rt[0] = 0; ex_ct[0] = 4; ex_rt[1] = 1; ex_ct[1] = 5; }
-    if (wave == 1) { ex_rt[0] = 1; ex_ct[0] = 4; ex_rt[1] = 2; ex_ct[1] = 5; }
-    if (wave == 2) { ex_rt[0] = 2; ex_ct[0] = 4; }
-    if (wave == 3) { ex_rt[0] = 0; ex_ct[0] = 5; }
-  }
-
-  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-    const int b = tile / a.tiles_per_frame;
-    const int t0 = (tile - b * a.tiles_per_frame) * TT;
-    __syncthreads();   // previous tile fully consumed
-    // ---- S0: x wide (for the recompute) and x narrow (wgrad1 + act') ----
-    if (!(a.skip & 64)) {
-    nsc_stage_rows(xs, ldh, C4, C, W_h, a.x + (long)b * C * T, T, t0 - 2 * Hh, T, 0, wave, lane);
-    nsc_stage_rows(xn, ldn, C, C, TT, a.x + (long)b * C * T, T, t0, T, 0, wave, lane);
-    }
-    __syncthreads();
-
-    // ---- P1: h on all W_h columns ----
-    if (!(a.skip & 1)) {
-      const int ncq = C4 >> 2;
-      for (int ct = wave; ct < nct_h; ct += 4) {
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        const int j = ct * 16 + l15;
-        const float* xcol = xs + j;
-        constexpr int G1 = 8;
-        float an0[G1], an1[G1];
-        auto fetch1 = [&](int cq0) {
-#pragma unroll
-          for (int u = 0; u < G1; ++u) {
-            const int ci = (cq0 + u) * 4 + kq;
-            const bool ok = (cq0 + u) < ncq && ci < C;
-            an0[u] = nsc_ldm(a.w1, ci * NARROW + l15, ok);
-            an1[u] = nsc_ldm(a.w1, ci * NARROW + 16 + l15, ok && 16 + l15 < NARROW);
-          }
-        };
-        fetch1(0);
-        for (int cq0 = 0; cq0 < ncq; cq0 += G1) {
-          float c0[G1], c1[G1];
-#pragma unroll
-          for (int u = 0; u < G1; ++u) { c0[u] = an0[u]; c1[u] = an1[u]; }
-          fetch1(cq0 + G1);
-#pragma unroll
-          for (int u = 0; u < G1; ++u) {
-            const int cqc = (cq0 + u < ncq) ? cq0 + u : 0;
-            const float bv = xcol[(cqc * 4 + kq) * ldh];
-            acc0 = mfma4(c0[u], bv, acc0);
-            acc1 = mfma4(c1[u], bv, acc1);
-          }
-        }
-        const int t = t0 - 2 * Hh + j;
-        const bool live = j < W_h && t >= 0 && t < T;
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const int o0 = kq * 4 + reg, o1 = 16 + kq * 4 + reg;
-          float v0 = acc0[reg] + a.b1[o0];
-          v0 = v0 > 0.f ? v0 : NSC_LRELU_ALPHA * v0;
-          hs[o0 * ldh + j] = live ? v0 : 0.f;
-          if (o1 < NARROW) {
-            float v1 = acc1[reg] + a.b1[o1];
-            v1 = v1 > 0.f ? v1 : NSC_LRELU_ALPHA * v1;
-            hs[o1 * ldh + j] = live ? v1 : 0.f;
-          }
-        }
-      }
-    }
-    __syncthreads();   // hs complete, xs_wide dead
-    // ---- S1: dy tile over region A ----
-    if (!(a.skip & 64)) nsc_stage_rows(dys, ldy, C, C, W_dy, a.dy + (long)b * C * T, T, t0 - Hh - 4, T, 0, wave, lane);
-
-    // ---- P2: lin / th / g on W_a columns (reads hs only) ----
-    if (!(a.skip & 2)) {
-      const int i = l15;
-      const float* wsel = (i & 2) ? a.wr : a.wl;
-      int crow[3];
-#pragma unroll
-      for (int rt = 0; rt < 3; ++rt) crow[rt] = rt * 8 + (i >> 2) * 2 + (i & 1);
-      f32x4 acc[3], accx[2];
-#pragma unroll
-      for (int rt = 0; rt < 3; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      accx[0] = accx[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      const int jm = wave * 16 + l15;
-      const int jx0 = ex_ct[0] * 16 + l15, jx1 = ex_ct[1] * 16 + l15;
-      constexpr int G2 = 5;
-      // 5 weight fragments per k-step: the 3 row tiles of the main column + one per extra job (their row tile is a
-      // wave-uniform index folded into the ADDRESS: selecting among registers made hipcc branch inside the loop)
-      float an[G2][5];
-      const int xr0 = ex_rt[0] < 0 ? 0 : ex_rt[0], xr1 = ex_rt[1] < 0 ? 0 : ex_rt[1];
-      const int crx0 = xr0 * 8 + (i >> 2) * 2 + (i & 1), crx1 = xr1 * 8 + (i >> 2) * 2 + (i & 1);
-      auto fetch2 = [&](int tapf) {
-#pragma unroll
-        for (int u = 0; u < G2; ++u) {
-          const int ci = u * 4 + kq;
-          const int rowb = (tapf * NARROW + ci) * NARROW;
-#pragma unroll
-          for (int rt = 0; rt < 3; ++rt) an[u][rt] = nsc_ldm(wsel, rowb + crow[rt], tapf < K15 && crow[rt] < NARROW);
-          an[u][3] = nsc_ldm(wsel, rowb + crx0, tapf < K15 && crx0 < NARROW);
-          an[u][4] = nsc_ldm(wsel, rowb + crx1, tapf < K15 && crx1 < NARROW);
-        }
-      };
-      fetch2(0);
-      for (int tap = 0; tap < K15; ++tap) {
-        float ac[G2][5];
-#pragma unroll
-        for (int u = 0; u < G2; ++u)
-#pragma unroll
-          for (int rt = 0; rt < 5; ++rt) ac[u][rt] = an[u][rt];
-        fetch2(tap + 1);
-#pragma unroll
-        for (int u = 0; u < G2; ++u) {
-          const float* hrow = hs + (u * 4 + kq) * ldh + tap * d;
-          const float bm = hrow[jm];
-#pragma unroll
-          for (int rt = 0; rt < 3; ++rt) acc[rt] = mfma4(ac[u][rt], bm, acc[rt]);
-          accx[0] = mfma4(ac[u][3], hrow[jx0], accx[0]);   // unused extras: discarded duplicates (no control flow here)
-          accx[1] = mfma4(ac[u][4], hrow[jx1], accx[1]);
-        }
-      }
-      auto emit = [&](const f32x4& v, int rt, int ja) {
-        const int c0 = rt * 8 + kq * 2;
-        const int t = t0 - Hh + ja;
-        const bool live = ja < W_a && t >= 0 && t < T;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int c = c0 + u;
-          if (c < NARROW && ja < lda) {
-            const float l = v[u] + a.bl[c];
-            const float tg = tanhf(v[2 + u] + a.br[c]);
-            lin[c * lda + ja] = live ? l : 0.f;
-            th[c * lda + ja] = live ? tg : 0.f;
-            gs[c * lda + ja] = live ? l * tg : 0.f;
-          }
-        }
-      };
-#pragma unroll
-      for (int rt = 0; rt < 3; ++rt) emit(acc[rt], rt, jm);
-      if (ex_rt[0] >= 0) emit(accx[0], ex_rt[0], jx0);
-      if (ex_rt[1] >= 0) emit(accx[1], ex_rt[1], jx1);
-    }
-    __syncthreads();   // dys, lin, th, gs complete
-
-    // ---- D9: dg[ci][ja] = sum_{tap', o} wt9[tap'][o][ci] * dy[o][ja + tap'] ; 2 row tiles x nct_a col tiles ----
-    // jobs are dealt linearly: job q -> (rt = q & 1, ct = q >> 1); wave owns jobs [q0, q0 + nj)
-    if (!(a.skip & 4)) {
-      const int njobs = 2 * nct_a;                       // 12 (d=2) or 10 (d=1)
-      const int base = njobs / 4, rem = njobs - base * 4;
-      const int nj = base + (wave < rem ? 1 : 0);
-      const int q0 = wave * base + min(wave, rem);
-      f32x4 acc[3];
-      int jrt[3], jcol[3];
-#pragma unroll
-      for (int e = 0; e < 3; ++e) {
-        acc[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const int q = q0 + (e < nj ? e : 0);
-        jrt[e] = q & 1;
-        jcol[e] = (q >> 1) * 16 + l15;
-      }
-      const int ncq = C4 >> 2;                           // k-steps per tap (o in groups of 4)
-      constexpr int G9 = 5;
-      float an[G9][2];
-      int tp = 0, cp = 0;                                // prefetch cursor (tap', cq)
-      auto fetch9 = [&]() {
-        if (a.skip & 128) {   // timing probe: no weight loads
-#pragma unroll
-          for (int u = 0; u < G9; ++u) { an[u][0] = 1.f; an[u][1] = 0.5f; }
-          return;
-        }
-#pragma unroll
-        for (int u = 0; u < G9; ++u) {
-          const int o = cp * 4 + kq;
-          const bool ok = tp < K9 && o < C;
-          const int row = (tp * C + o) * NARROW;
-          an[u][0] = nsc_ldm(a.wt9, row + l15, ok);
-          an[u][1] = nsc_ldm(a.wt9, row + 16 + l15, ok && 16 + l15 < NARROW);
-          const bool wrapp = (cp + 1 == ncq);
-          cp = wrapp ? 0 : cp + 1;
-          tp += wrapp ? 1 : 0;
-        }
-      };
-      fetch9();
-      const int nsteps = K9 * ncq;
-      const int ngroups = (nsteps + G9 - 1) / G9;        // padded steps: zero weights, cursor clamped to a valid tap
-      int tap = 0, cq = 0;
-      for (int g = 0; g < ngroups; ++g) {
-        float ac[G9][2];
-#pragma unroll
-        for (int u = 0; u < G9; ++u) { ac[u][0] = an[u][0]; ac[u][1] = an[u][1]; }
-        fetch9();
-#pragma unroll
-        for (int u = 0; u < G9; ++u) {
-          const int tapc = tap < K9 ? tap : K9 - 1;
-          const float* yrow = dys + (cq * 4 + kq) * ldy + tapc;
-#pragma unroll
-          for (int e = 0; e < 3; ++e)
-            acc[e] = mfma4(jrt[e] ? ac[u][1] : ac[u][0], yrow[jcol[e]], acc[e]);   // e >= nj: harmless duplicate of job q0
-          const bool wrap = (cq + 1 == ncq);
-          cq = wrap ? 0 : cq + 1;
-          tap += wrap ? 1 : 0;
-        }
-      }
-      // GLU backward fused into the epilogue: this lane holds dg for 4 channels at one time step
-#pragma unroll
-      for (int e = 0; e < 3; ++e) {
-        if (e < nj) {
-          const int ja = jcol[e];
-          const int t = t0 - Hh + ja;
-          const bool live = ja < W_a && t >= 0 && t < T;
-#pragma unroll
-          for (int reg = 0; reg < 4; ++reg) {
-            const int ci = jrt[e] * 16 + kq * 4 + reg;
-            if (ci < NARROW && ja < lda) dg[ci * lda + ja] = live ? acc[e][reg] : 0.f;
-          }
-        }
-      }
-    }
-    __syncthreads();
-    // GLU backward in place: lin <- dlin = dg*th ; th <- dgate = dg*lin*(1-th^2)   (zero outside the frame already)
-    for (int e = tid; e < NARROW * lda; e += 256) {
-      const float l = lin[e], tg = th[e], gg = dg[e];
-      lin[e] = gg * tg;
-      th[e] = gg * l * (1.f - tg * tg);
-    }
-    __syncthreads();
-
-    // ---- D15: dz1[ci][tt] = (sum_{tap',br,c} wt{l,r}[tap'][c][ci] * d{lin,gate}[c][tt + tap'*d]) * lrelu'(h) ----
-    if (!(a.skip & 8)) {
-      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-      const int tt = wave * 16 + l15;
-      constexpr int G15 = 10;                             // one tap = 2 branches x 5 k-steps
-      float an[G15][2];
-      auto fetch15 = [&](int tapf) {
-#pragma unroll
-        for (int u = 0; u < G15; ++u) {
-          const float* wsrc = (u < 5) ? a.wtl : a.wtr;
-          const int c = (u % 5) * 4 + kq;
-          const int row = (tapf * NARROW + c) * NARROW;
-          an[u][0] = nsc_ldm(wsrc, row + l15, tapf < K15);
-          an[u][1] = nsc_ldm(wsrc, row + 16 + l15, tapf < K15 && 16 + l15 < NARROW);
-        }
-      };
-      fetch15(0);
-      for (int tap = 0; tap < K15; ++tap) {
-        float ac[G15][2];
-#pragma unroll
-        for (int u = 0; u < G15; ++u) { ac[u][0] = an[u][0]; ac[u][1] = an[u][1]; }
-        fetch15(tap + 1);
-#pragma unroll
-        for (int u = 0; u < G15; ++u) {
-          const float* src = (u < 5) ? lin : th;
-          const float bv = src[((u % 5) * 4 + kq) * lda + tt + tap * d];
-          acc0 = mfma4(ac[u][0], bv, acc0);
-          acc1 = mfma4(ac[u][1], bv, acc1);
-        }
-      }
-      const int t = t0 + tt;
-      const bool live = t < T;
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int c0 = kq * 4 + reg, c1 = 16 + kq * 4 + reg;
-        const float h0 = hs[c0 * ldh + tt + 2 * Hh];
-        dhs[c0 * ldn + tt] = live ? acc0[reg] * (h0 > 0.f ? 1.f : NSC_LRELU_ALPHA) : 0.f;
-        if (c1 < NARROW) {
-          const float h1 = hs[c1 * ldh + tt + 2 * Hh];
-          dhs[c1 * ldn + tt] = live ? acc1[reg] * (h1 > 0.f ? 1.f : NSC_LRELU_ALPHA) : 0.f;
-        }
-      }
-    }
-    __syncthreads();
-
-    // ---- D1: dx = (W1^T dz1 + dy) * act'(x) ; wave owns column tile `wave`, all RT9 row tiles, K = 20 ----
-    if (!(a.skip & 16)) {
-      f32x4 acc[RT9];
-#pragma unroll
-      for (int r = 0; r < RT9; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      const int tt = wave * 16 + l15;
-      float av[5][RT9];
-#pragma unroll
-      for (int s = 0; s < 5; ++s)
-#pragma unroll
-        for (int r = 0; r < RT9; ++r) {
-          const int c = r * 16 + l15;
-          av[s][r] = nsc_ldm(a.wt1, (s * 4 + kq) * C + c, c < C);
-        }
-#pragma unroll
-      for (int s = 0; s < 5; ++s) {
-        const float bv = dhs[(s * 4 + kq) * ldn + tt];
-#pragma unroll
-        for (int r = 0; r < RT9; ++r) acc[r] = mfma4(av[s][r], bv, acc[r]);
-      }
-      const int t = t0 + tt;
-      if (t < T) {
-#pragma unroll
-        for (int r = 0; r < RT9; ++r)
-#pragma unroll
-          for (int reg = 0; reg < 4; ++reg) {
-            const int c = r * 16 + kq * 4 + reg;
-            if (c < C) {
-              float v = acc[r][reg] + dys[c * ldy + tt + Hh + 4];
-              if (a.in_act == NSC_ACT_LRELU) v *= (xn[c * ldn + tt] > 0.f ? 1.f : NSC_LRELU_ALPHA);
-              a.dx[((long)b * C + c) * T + t] = v;
-            }
-          }
-      }
-    }
-
-    // ---- weight gradients over the tile's own 64 columns (k = time), accumulators stay in registers ----
-    if (!(a.skip & 32))
-#pragma unroll 2
-    for (int s = 0; s < TT / 4; ++s) {
-      const int tl = 4 * s + kq;
-      // dW9: A = g rows (tap,ci) ; B = dy[o]
-      {
-        float af[3], bf[RT9];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) af[r] = gs[off9[r] + tl];
-#pragma unroll
-        for (int c = 0; c < RT9; ++c) {
-          const int o = c * 16 + l15;
-          const float yv = dys[(o < C ? o : 0) * ldy + tl + Hh + 4];
-          bf[c] = (o < C) ? yv : 0.f;
-        }
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-          for (int c = 0; c < RT9; ++c) g9[r][c] = mfma4(af[r], bf[c], g9[r][c]);
-      }
-      // dWl / dWr: A = h rows (tap,ci) ; B = dlin | dgate (interleaved columns)
-      {
-        float af[5], bf[3];
-#pragma unroll
-        for (int r = 0; r < 5; ++r) af[r] = hs[offlr[r] + tl];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { const float lv = lin[offb_lr[c] + tl]; bf[c] = okb_lr[c] ? lv : 0.f; }
-#pragma unroll
-        for (int r = 0; r < 5; ++r)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) glr[r][c] = mfma4(af[r], bf[c], glr[r][c]);
-      }
-      // dW1: A = x rows ci ; B = dz1[o]
-      {
-        float af[2], bf[2];
-#pragma unroll
-        for (int r = 0; r < 2; ++r) af[r] = xn[off1[r] + tl];
-        bf[0] = dhs[l15 * ldn + tl];
-        { const float dv = dhs[(16 + l15 < NARROW ? 16 + l15 : 0) * ldn + tl]; bf[1] = (16 + l15 < NARROW) ? dv : 0.f; }
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-          g1[r][0] = mfma4(af[r], bf[0], g1[r][0]);
-          g1[r][1] = mfma4(af[r], bf[1], g1[r][1]);
-        }
-      }
-    }
-  }
-
-  // ---- flush the weight gradients: D col = l15, row = 4*kq + reg ----
-#pragma unroll
-  for (int r = 0; r < 3; ++r)
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int kk = (wave + 4 * r) * 16 + kq * 4 + reg;
-      if (kk > K9 * NARROW) continue;
-#pragma unroll
-      for (int c = 0; c < RT9; ++c) {
-        const int o = c * 16 + l15;
-        if (o >= C) continue;
-        if (kk < K9 * NARROW) atomicAdd(a.dw9 + (long)kk * C + o, g9[r][c][reg]);
-        else atomicAdd(a.db9 + o, g9[r][c][reg]);
-      }
-    }
-#pragma unroll
-  for (int r = 0; r < 5; ++r)
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int kk = (wave + 4 * r) * 16 + kq * 4 + reg;
-      if (kk > K15 * NARROW) continue;
-#pragma unroll
-      for (int ct = 0; ct < 3; ++ct) {
-        const int c = ct * 8 + (l15 >> 2) * 2 + (l15 & 1);
-        if (c >= NARROW) continue;
-        const bool gate = (l15 & 2) != 0;
-        if (kk < K15 * NARROW) atomicAdd((gate ? a.dwr : a.dwl) + kk * NARROW + c, glr[r][ct][reg]);
-        else atomicAdd((gate ? a.dbr : a.dbl) + c, glr[r][ct][reg]);
-      }
-    }
-#pragma unroll
-  for (int r = 0; r < 2; ++r)
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int ci = (wave + 4 * r) * 16 + kq * 4 + reg;
-      if (ci > C) continue;
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const int o = c * 16 + l15;
-        if (o >= NARROW) continue;
-        if (ci < C) atomicAdd(a.dw1 + ci * NARROW + o, g1[r][c][reg]);
-        else atomicAdd(a.db1 + o, g1[r][c][reg]);
-      }
-    }
-}
-
-static int ld18(int w) { int l = w; while ((l & 31) != 18) ++l; return l; }
-
-extern "C" int nsc_gated_block_bwd(const float* x, const float* dy, const float* w1, const float* b1, const float* wl,
-                                   const float* bl, const float* wr, const float* br, const float* wt1,
-                                   const float* wtl, const float* wtr, const float* wt9, float* dx, float* dw1,
-                                   float* db1, float* dwl, float* dbl, float* dwr, float* dbr, float* dw9, float* db9,
-                                   int B, int C, int T, int narrow, int k9, int dil, int in_act, void* stream) {
-  NSC_REQUIRE(x && dy && w1 && b1 && wl && bl && wr && br && wt1 && wtl && wtr && wt9 && dx && dw1 && db1 && dwl && dbl &&
-                  dwr && dbr && dw9 && db9, NSC_ERR_BAD_ARG, "nsc_gated_block_bwd: null pointer");
-  NSC_REQUIRE(B > 0 && C > 1 && T > 0, NSC_ERR_BAD_ARG, "nsc_gated_block_bwd: bad sizes");
-  NSC_REQUIRE(narrow == NARROW && k9 == K9 && (dil == 1 || dil == 2) && C <= 112, NSC_ERR_UNSUPPORTED,
-              "nsc_gated_block_bwd: built for narrow=20, k9=9, dil in {1,2}, C<=112 (got %d, %d, %d, %d)", narrow, k9, dil, C);
-  NSC_REQUIRE(in_act == NSC_ACT_NONE || in_act == NSC_ACT_LRELU, NSC_ERR_BAD_ARG, "nsc_gated_block_bwd: in_act must be none|lrelu");
-  const int Hh = 7 * dil, W_h = 64 + 4 * Hh, W_a = 64 + 2 * Hh, W_dy = W_a + 8;
-  const int nct_h = (W_h + 15) / 16, nct_a = (W_a + 15) / 16;
-  const int ldh = ld18(std::max(W_h, nct_h * 16)), lda = ld18(std::max(W_a, nct_a * 16));
-  const int ldy = ld18(std::max(W_dy, nct_a * 16 + 8)), ldn = ld18(64);
-  const int C4 = (C + 3) & ~3;
-  const size_t fl = (size_t)std::max(C4 * ldh, C * ldy) + (size_t)(C + 2) * ldn + (size_t)(NARROW + 2) * ldh +
-                    (size_t)(4 * NARROW + 2) * lda + (size_t)NARROW * ldn;
-  const size_t smem = fl * sizeof(float);
-  NSC_REQUIRE(smem <= 160 * 1024, NSC_ERR_UNSUPPORTED, "nsc_gated_block_bwd: %zu B LDS", smem);
-  BlockBwdArgs a{B, C, T, dil, in_act, x, dy, w1, b1, wl, bl, wr, br, wt1, wtl, wtr, wt9, dx,
-                 dw1, db1, dwl, dbl, dwr, dbr, dw9, db9, 0, 0, 0};
-  { static int skip_env = -1; if (skip_env < 0) { skip_env = NSC_PROBE_INT("NSC_BWD_SKIP", 0); } a.skip = skip_env; }
-  a.tiles_per_frame = nsc_cdiv(T, 64);
-  a.ntiles = B * a.tiles_per_frame;
-  const int grid = std::min(a.ntiles, 256);
-  hipStream_t st = (hipStream_t)stream;
-#define LAUNCH_BWD(RT)                                                                                              \
-  do {                                                                                                              \
-    auto kern = gated_block_bwd_kernel<RT>;                                                                         \
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);   \
-    NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "gated_block_bwd: smem attr: %s", hipGetErrorString(e));           \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, a, ldh, lda, ldy, ldn);                               \
-  } while (0)
-  if (nsc_cdiv(C, 16) <= 4) LAUNCH_BWD(4);
-  else LAUNCH_BWD(7);
-#undef LAUNCH_BWD
-  NSC_CHECK_LAUNCH("gated_block_bwd");
-  return NSC_OK;
-}
 
 // =====================================================================================================
 // Persistent weight-gradient kernel of one gated block: all eight parameter gradients from the SAVED
@@ -2513,7 +1960,7 @@ static int launch_block_dgrad2(const BlockDgradArgs& a, hipStream_t st) {
                        (size_t)K15 * W15T + (size_t)K9 * w9t) * sizeof(float);
   NSC_REQUIRE(smem <= 160 * 1024, NSC_ERR_UNSUPPORTED, "gated_block_dgrad2: %zu B LDS", smem);
   auto kern = gated_block_dgrad2_kernel<RT9, NK9, DIL>;
-  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  static const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);   // once per instantiation
   NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "gated_block_dgrad2: smem attr: %s", hipGetErrorString(e));
   const int tpf = nsc_cdiv(a.T, 64);
   const int ntiles = a.B * tpf;

@@ -222,7 +222,7 @@ class _Block:
             (w1, b1), (wl, bl), (wr, br), (w9, b9) = P(self.c1), P(self.cl), P(self.cr), P(self.c9)
             tok = e.prof_begin("block_fwd", self.c1.flops() + self.cl.flops() + self.cr.flops() + self.c9.flops())
             # the fused backward recomputes the intermediates from x; an inference-only engine never reads them
-            save = e.keep_activations and not self.fused_bwd_ok()
+            save = e.keep_activations
             check(e.lib.nsc_gated_block_fwd(x.data_ptr(), w1, b1, wl, bl, wr, br, w9, b9, self.out.data_ptr(),
                                             self.h.data_ptr() if save else None, self.lin.data_ptr() if save else None,
                                             self.th.data_ptr() if save else None, self.g.data_ptr() if save else None,
@@ -237,30 +237,10 @@ class _Block:
         self.c9.fwd(self.g, self.out, self.out_kind, res=x, res_mode=2 if self.Cin == 1 else 1)
         return self.out
 
-    def fused_bwd_ok(self):
-        e = self.eng
-        return (e.fused_fwd and e.fused_bwd and self.Cin > 1 and self.narrow == 20 and self.c9.K == 9
-                and self.cl.dil in (1, 2) and self.wide <= 112)
-
     def bwd(self, dz, in_kind, need_dx=True):
         """dz = dL/d(pre-activation of out).  Returns dL/d(pre-activation of the producer of x)."""
         e, u = self.eng, self.uid
         B, n, T = e.B, self.narrow, self.T
-        if self.fused_bwd_ok():
-            dx = e.buf(u + ".dx", (B, self.Cin, T))
-            P = lambda c: (e.p_ptr + 4 * c.w_off, e.p_ptr + 4 * c.b_off)
-            G = lambda c: (e.g_ptr + 4 * c.w_off, e.g_ptr + 4 * c.b_off)
-            WT = lambda c: e.wt_ptr + 4 * c.w_off
-            (w1, b1), (wl, bl), (wr, br) = P(self.c1), P(self.cl), P(self.cr)
-            (dw1, db1), (dwl, dbl), (dwr, dbr), (dw9, db9) = G(self.c1), G(self.cl), G(self.cr), G(self.c9)
-            fl = 2.0 * (self.c1.flops() + self.cl.flops() + self.cr.flops() + self.c9.flops())
-            tok = e.prof_begin("block_bwd", fl)
-            check(e.lib.nsc_gated_block_bwd(self.x.data_ptr(), dz.data_ptr(), w1, b1, wl, bl, wr, br, WT(self.c1),
-                                            WT(self.cl), WT(self.cr), WT(self.c9), dx.data_ptr(), dw1, db1, dwl, dbl,
-                                            dwr, dbr, dw9, db9, B, self.Cin, T, n, 9, self.cl.dil,
-                                            KIND_ACT[in_kind], e.stream()), "gated_block_bwd")
-            e.prof_end(tok)
-            return dx
         dg = e.buf(u + ".dg", (B, n, T))
         dlin = e.buf(u + ".dlin", (B, n, T))
         dgate = e.buf(u + ".dgate", (B, n, T))
@@ -607,8 +587,6 @@ class CascadeEngine:
 
     keep_activations = True   # False for inference-only use: the block forward then skips its 4 saved [B,20,T] tensors
     fused_fwd = True   # gated blocks run as one kernel (csrc/block.hip); False = one launch per conv
-    fused_bwd = False  # whole-block backward in one persistent kernel (correct, but its conv phases run at one wave
-                       # per SIMD and lose to the per-conv kernels: measured 9.0 vs 6.7 ms/step) - kept, off by default
     fused_wgrad = True # all eight parameter gradients of a block in one persistent kernel (csrc/block.hip)
     fused_dgrad = True   # whole data path of a block (k9 -> GLU -> k15 -> 1x1 data gradients) in one persistent,
                          # weight-stationary kernel (v2; the per-tile v1 lost to the per-conv launches: 1.9 vs 1.2 ms/step)
@@ -769,7 +747,7 @@ class CascadeEngine:
     def zero_hists_once(self):
         """All quantizers' histograms live in one flat buffer: zero it once per forward (first quantizer to ask)."""
         if not self._hist_clean and self._hist_flat is not None:
-            self._hist_flat.zero_()
+            check(self.lib.nsc_zero(self._hist_flat.data_ptr(), self._hist_flat.numel(), self.stream()), "zero hists")
             self._hist_clean = True
 
     def buf(self, name, shape):
@@ -996,7 +974,7 @@ class CascadeEngine:
             self._leave()
 
     def _train_step(self, x, target, cfg, lpc_x, comm):
-        self.grads.zero_()
+        check(self.lib.nsc_zero(self.g_ptr, self.grads.numel(), self.stream()), "zero grads")   # a memset node, no torch kernel
         self.refresh_wt()
         self.forward(x, cfg["is_quan_on"], True, lpc_x=lpc_x)
         gb = self.B * (comm.world if comm else 1)

@@ -446,47 +446,6 @@ def test_fused_gated_block_fwd(lib, case):
     assert torch.equal(out, out2)
 
 
-@pytest.mark.parametrize("case", [(2, 100, 512, 2, 2), (2, 100, 256, 1, 0), (3, 50, 512, 2, 2), (2, 50, 512, 1, 2),
-                                  (1, 100, 200, 2, 0), (5, 36, 70, 1, 2)])
-def test_fused_gated_block_bwd(lib, case):
-    """csrc/block.hip persistent backward vs autograd of the oracle block: dx and all eight parameter gradients."""
-    B, C_, T, dil, in_act = case
-    rng = np.random.default_rng(300 + C_ + T + dil)
-    names = ["s/conv1d", "s/conv1d_1", "s/conv1d_2", "s/conv1d_3"]
-    ps = O.ParamStore(rng)
-    x = rng.standard_normal((B, T, C_)).astype(np.float32)
-    O.gated_bottleneck(x, ps, "s", C_, 20, 9, dil, True)
-    for n in names:
-        ps.params[n + "/bias"] = (0.1 * rng.standard_normal(ps.params[n + "/bias"].shape)).astype(np.float32).astype(np.float64)
-    dy = rng.standard_normal((B, T, C_)).astype(np.float32)
-    tp = OT.TorchParams(ps)
-    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
-    # x is itself the output of an activation when in_act == lrelu: emulate with a pre-activation leaf
-    zt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
-    xin = torch.nn.functional.leaky_relu(zt, 0.2) if in_act == 2 else zt
-    y = OT.gated_bottleneck(xin, tp, "s", dil, True)          # flat: y is the pre-activation output
-    (y * torch.tensor(dy, dtype=torch.float64)).sum().backward()
-    xin_np = xin.detach().numpy().astype(np.float32)
-    W = {n: ps.params[n + "/kernel"].astype(np.float32) for n in names}
-    wt = {n: np.ascontiguousarray(W[n][::-1].transpose(0, 2, 1)) for n in names}
-    Pw = [P(W[n]) for n in names]
-    Pb = [P(ps.params[n + "/bias"]) for n in names]
-    Pt = [P(wt[n]) for n in names]
-    dws = [torch.zeros(W[n].shape, device="cuda") for n in names]
-    dbs = [torch.zeros(ps.params[n + "/bias"].shape, device="cuda") for n in names]
-    dx = torch.full((B, C_, T), float("nan"), device="cuda")
-    rc = lib.nsc_gated_block_bwd(P(xin_np.transpose(0, 2, 1)), P(dy.transpose(0, 2, 1)), Pw[0], Pb[0], Pw[1], Pb[1], Pw[2],
-                                 Pb[2], Pt[0], Pt[1], Pt[2], Pt[3], dx.data_ptr(), dws[0].data_ptr(), dbs[0].data_ptr(),
-                                 dws[1].data_ptr(), dbs[1].data_ptr(), dws[2].data_ptr(), dbs[2].data_ptr(),
-                                 dws[3].data_ptr(), dbs[3].data_ptr(), B, C_, T, 20, 9, dil, in_act, _st())
-    assert rc == 0, lib.nsc_last_error()
-    torch.cuda.synchronize()
-    assert_close(dx.cpu().numpy().transpose(0, 2, 1), zt.grad.numpy(), tol=2e-4, what=f"fused bwd dx {case}")
-    for i, n in enumerate(names):
-        assert_close(dws[i].cpu().numpy(), tp.t[n + "/kernel"].grad.numpy(), tol=2e-4, what=f"fused bwd dW {n} {case}")
-        assert_close(dbs[i].cpu().numpy(), tp.t[n + "/bias"].grad.numpy(), tol=2e-4, what=f"fused bwd db {n} {case}")
-
-
 @pytest.mark.parametrize("case", [(2, 100, 512, 2), (2, 100, 256, 1), (3, 50, 512, 2), (5, 36, 70, 1)])
 def test_block_wgrad_kernel(lib, case):
     """Persistent block weight-gradient kernel vs per-conv oracle gradients (inputs are arbitrary tensors)."""

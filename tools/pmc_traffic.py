@@ -11,13 +11,20 @@ CLASSES = [("conv1d_fwd_kernel", "conv_mfma"), ("gated_block_fwd", "block_fwd"),
            ("conv1d_cout1_kernel", "conv_cout1")]
 
 
-def read(sub, counter):
+def read(sub, counter, by_grid=False):
+    """kernel name [@grid<workgroups>] -> (sum of counter, launches).  by_grid buckets the launches of one kernel by
+    their grid size, so that a record describes ONE launch shape (the quantizer runs at the training batch - 128
+    workgroups - and at the config-5 batch - 1024 - in the same profile)."""
     tot, cnt = collections.Counter(), collections.Counter()
     for f in glob.glob(f"{d}/{sub}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter:
                 continue
-            tot[r["Kernel_Name"]] += float(r["Counter_Value"]); cnt[r["Kernel_Name"]] += 1
+            k = r["Kernel_Name"]
+            if by_grid:
+                wg = int(r.get("Grid_Size", 0)) // max(int(r.get("Workgroup_Size", 1)), 1)
+                k = f"{k}@grid{wg}"
+            tot[k] += float(r["Counter_Value"]); cnt[k] += 1
     return tot, cnt
 
 
@@ -46,4 +53,17 @@ for pat, tag in CLASSES:
                 "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (KiB) in separate passes over bench.py --no-overlap --no-infer "
                           "(training-step launches only), divided by the axpby calibration factors; averaged over the launches "
                           "of the kernel family"}
+# per launch SHAPE for the kernels that run at more than one grid size in the profiled command
+ftg, fcg = read("pass3", "FETCH_SIZE", True)
+wtg, wcg = read("pass4", "WRITE_SIZE", True)
+for pat, tag in (("quantize_fwd_kernel", "quantize_fwd"), ("gated_block_dgrad2", "block_dgrad"), ("gated_block_fwd2", "block_fwd")):
+    grids = sorted({k.split("@grid")[1] for k in ftg if pat in k})
+    for g in grids:
+        fk = [k for k in ftg if pat in k and k.endswith("@grid" + g)]
+        wk = [k for k in wtg if pat in k and k.endswith("@grid" + g)]
+        nf, nw = sum(fcg[k] for k in fk), sum(wcg[k] for k in wk)
+        if nf and nw:
+            out[f"{tag}@grid{g}"] = {"fetch_bytes_per_launch": round(sum(ftg[k] for k in fk) * 1024.0 / nf / (cf or 1.0)),
+                                     "write_bytes_per_launch": round(sum(wtg[k] for k in wk) * 1024.0 / nw / (cw or 1.0)),
+                                     "launches_sampled": int(nf), "workgroups": int(g)}
 json.dump(out, sys.stdout, indent=1)
