@@ -292,8 +292,13 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
       }
     }
   };
+  // CHAIN (same idea as gated_block_dgrad2_kernel): a workgroup walks CONSECUTIVE tiles [first, last).  From the second tile
+  // of a chain on ("steady"), the 14*DIL columns of h and the 8 columns of g that the previous tile already computed are
+  // carried over in LDS: phase 1 runs on 4 column tiles instead of 7 (6 at dil 1) and phase 2 on 4 instead of 5.  Every
+  // element is produced by the same instruction sequence in both modes, so the output bits do not depend on the mode.
+  const int first = (int)((long)blockIdx.x * ntiles / gridDim.x), last = (int)((long)(blockIdx.x + 1) * ntiles / gridDim.x);
   NSC_STAMP(32);
-  prefetch(blockIdx.x);
+  prefetch(first);
   // ---- once per workgroup: weights -> LDS / registers ----
   // Every load below uses a CLAMPED index instead of a mask: pad rows of A (output channels >= 20 / >= C) only feed
   // output rows that are never stored, and pad k-rows (ci >= C) multiply x rows that phase 0 writes as zeros, so any
@@ -316,13 +321,12 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
       if (e < K15 * NARROW * LDW) w2s[e] = tmp[i];
     }
   }
-  float w1r[2][NK1];
+  // phase 1: a wave owns ONE of the two row tiles of h (waves 0-3: channels 0..15, waves 4-7: 16..19 + padding), so it
+  // keeps NK1 fragments of W1, not 2 NK1 (the second set cost 25 registers and pushed the C = 100 kernel into scratch)
+  const int r1 = wave >> 2;
+  float w1r[NK1];
 #pragma unroll
-  for (int u = 0; u < NK1; ++u) {
-    const int ci = min(4 * u + kq, C - 1);
-    w1r[0][u] = a.w1[ci * NARROW + l15];
-    w1r[1][u] = a.w1[ci * NARROW + min(16 + l15, NARROW - 1)];
-  }
+  for (int u = 0; u < NK1; ++u) w1r[u] = a.w1[min(4 * u + kq, C - 1) * NARROW + min(r1 * 16 + l15, NARROW - 1)];
   const int rt3 = RT9 == 7 ? (wave < 7 ? wave : 6) : (wave & 3);
   const int cb3 = RT9 == 7 ? 0 : (wave >> 2) * 32;      // first output column of this wave in phase 3
   constexpr int NC3 = RT9 == 7 ? 4 : 2;                  // column tiles per wave in phase 3
@@ -331,11 +335,10 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
   for (int tap = 0; tap < K9; ++tap)
 #pragma unroll
     for (int u = 0; u < 5; ++u) w9r[tap][u] = a.w9[(tap * NARROW + 4 * u + kq) * C + min(rt3 * 16 + l15, C - 1)];
-  float b1r[2][4], b9r[4];
+  float b1r[4], b9r[4];
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) {
-    b1r[0][reg] = a.b1[kq * 4 + reg];
-    b1r[1][reg] = a.b1[min(16 + kq * 4 + reg, NARROW - 1)];
+    b1r[reg] = a.b1[min(r1 * 16 + kq * 4 + reg, NARROW - 1)];
     b9r[reg] = a.b9[min(rt3 * 16 + kq * 4 + reg, C - 1)];
   }
   // phase-2 jobs: q -> (row tile q % 3, column tile q / 3); wave w runs q = w and w + 8 (wave 7: a discarded duplicate)
@@ -359,9 +362,17 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
 
 
   NSC_STAMP(33);
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  for (int tile = first; tile < last; ++tile) {
     const int b = tile / tpf, t0 = (tile - b * tpf) * TT;
+    const bool fresh = tile == first || t0 == 0;                                   // workgroup-uniform
+    const bool next_steady = tile + 1 < last && (tile + 1) - ((tile + 1) / tpf) * tpf != 0;
     NSC_STAMP(34);
+    if (!fresh && tid < NARROW * 8) {
+      // carried g: columns [64, 72) of the previous tile are columns [0, 8) of this one (phase 3 of the previous tile is
+      // behind the loop-end barrier; phase 2 of this tile writes columns >= 8 only)
+      const int r = tid >> 3, cidx = tid & 7;
+      gs[r * LDG + cidx] = gs[r * LDG + cidx + TT];
+    }
     // ---- phase 0: prefetched x tile -> LDS ----
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb) {
@@ -377,34 +388,44 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
     NSC_STAMP(35);
     nsc_lds_barrier();
     NSC_STAMP(36);
-    if (!(skip & 8)) prefetch(tile + gridDim.x);   // in flight during the three MFMA phases
+    if (!(skip & 8)) prefetch(tile + 1 < last ? tile + 1 : tile);   // in flight during the three MFMA phases
 
     // ---- phase 1: h = lrelu(W1 x + b1); column tile = wave ----
-    if (wave < NCT1 && !(skip & 1)) {
+    if (!(skip & 1)) {
+      // column tiles of this wave: steady - the TT new columns [2H, 2H + TT), one tile per wave; fresh - all NCT1 tiles from
+      // column 0, two per wave (the 8th job of a row tile duplicates the 7th: same values, harmless)
+      const int jb0 = fresh ? (wave & 3) * 16 : 2 * H + (wave & 3) * 16;
+      const int jb1 = min((wave & 3) + 4, NCT1 - 1) * 16;
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-      const int j = wave * 16 + l15;
-      const float* xcol = xs + kq * LDX + j;
+      const float* xc0 = xs + kq * LDX + jb0 + l15;
+      const float* xc1 = xs + kq * LDX + jb1 + l15;
+      if (fresh) {
 #pragma unroll
-      for (int u = 0; u < NK1; ++u) {
-        const float bv = xcol[4 * u * LDX];
-        acc0 = mfma4(w1r[0][u], bv, acc0);
-        acc1 = mfma4(w1r[1][u], bv, acc1);
+        for (int u = 0; u < NK1; ++u) {
+          acc0 = mfma4(w1r[u], xc0[4 * u * LDX], acc0);
+          acc1 = mfma4(w1r[u], xc1[4 * u * LDX], acc1);
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < NK1; ++u) acc0 = mfma4(w1r[u], xc0[4 * u * LDX], acc0);
       }
-      const int t = t0 - H + j;
-      const bool live = j < WX && t >= 0 && t < T;
-      const bool save = a.h_out && live && j >= H && j < H + TT;
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int o0 = kq * 4 + reg, o1 = 16 + kq * 4 + reg;
-        float v0 = acc0[reg] + b1r[0][reg];
-        v0 = v0 > 0.f ? v0 : NSC_LRELU_ALPHA * v0;
-        hs[o0 * LDX + j] = live ? v0 : 0.f;
-        if (save) a.h_out[((long)b * NARROW + o0) * T + t] = v0;
-        if (o1 < NARROW) {
-          float v1 = acc1[reg] + b1r[1][reg];
-          v1 = v1 > 0.f ? v1 : NSC_LRELU_ALPHA * v1;
-          hs[o1 * LDX + j] = live ? v1 : 0.f;
-          if (save) a.h_out[((long)b * NARROW + o1) * T + t] = v1;
+      for (int e = 0; e < 2; ++e) {
+        if (e == 1 && !fresh) break;
+        const int j = (e ? jb1 : jb0) + l15;
+        const int t = t0 - H + j;
+        const bool live = j < WX && t >= 0 && t < T;
+        // (when the next tile is steady it never recomputes this tile's right halo: those columns leave for HBM now)
+        const bool save = a.h_out && live && j >= (fresh ? H : 2 * H) && j < (next_steady ? WX : H + TT);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int o = r1 * 16 + kq * 4 + reg;
+          if (o < NARROW) {
+            float v = (e ? acc1[reg] : acc0[reg]) + b1r[reg];
+            v = v > 0.f ? v : NSC_LRELU_ALPHA * v;
+            hs[o * LDX + j] = live ? v : 0.f;
+            if (save) a.h_out[((long)b * NARROW + o) * T + t] = v;
+          }
         }
       }
     }
@@ -414,28 +435,42 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
 
     // ---- phase 2: both k15 gate convs, A from LDS (w2s), B from LDS (hs) ----
     if (!(skip & 2)) {
+      // fresh: 15 jobs (3 row tiles x 5 column tiles from column 0); steady: 12 jobs (4 column tiles from column 8: the
+      // first 8 columns of g are carried) - waves 4-7 then run ONE job
+      const int joff = fresh ? 0 : 8;
+      const bool two = fresh || wave < 4;                 // wave-uniform: does this wave run a second job?
       f32x4 acc[2];
       acc[0] = acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
       const float* ab0 = w2s + kq * LDW + jrt[0] * 16 + l15;
       const float* ab1 = w2s + kq * LDW + jrt[1] * 16 + l15;
-      const float* hb0 = hs + kq * LDX + jct[0] * 16 + l15;
-      const float* hb1 = hs + kq * LDX + jct[1] * 16 + l15;
+      const float* hb0 = hs + kq * LDX + jct[0] * 16 + l15 + joff;
+      const float* hb1 = hs + kq * LDX + jct[1] * 16 + l15 + joff;
+      if (two) {
 #pragma unroll
-      for (int tap = 0; tap < K15; ++tap)
+        for (int tap = 0; tap < K15; ++tap)
 #pragma unroll
-        for (int u = 0; u < 5; ++u) {
-          const int ao = (tap * NARROW + 4 * u) * LDW, ho = 4 * u * LDX + tap * DIL;
-          acc[0] = mfma4(ab0[ao], hb0[ho], acc[0]);
-          acc[1] = mfma4(ab1[ao], hb1[ho], acc[1]);
-        }
+          for (int u = 0; u < 5; ++u) {
+            const int ao = (tap * NARROW + 4 * u) * LDW, ho = 4 * u * LDX + tap * DIL;
+            acc[0] = mfma4(ab0[ao], hb0[ho], acc[0]);
+            acc[1] = mfma4(ab1[ao], hb1[ho], acc[1]);
+          }
+      } else {
+#pragma unroll
+        for (int tap = 0; tap < K15; ++tap)
+#pragma unroll
+          for (int u = 0; u < 5; ++u) {
+            const int ao = (tap * NARROW + 4 * u) * LDW, ho = 4 * u * LDX + tap * DIL;
+            acc[0] = mfma4(ab0[ao], hb0[ho], acc[0]);
+          }
+      }
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        if (!jlive[e]) continue;
-        const int jj = jct[e] * 16 + l15;
+        if (!jlive[e] || (e == 1 && !two)) continue;
+        const int jj = jct[e] * 16 + l15 + joff;
         const int c0 = jrt[e] * 8 + kq * 2;
         const int t = t0 - 4 + jj;
         const bool live = jj < WGW && t >= 0 && t < T;
-        const bool save = a.lin_out && live && jj >= 4 && jj < 4 + TT;
+        const bool save = a.lin_out && live && jj >= (fresh ? 4 : 8) && jj < (next_steady ? WGW : 4 + TT);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const int c = c0 + u;
@@ -456,6 +491,14 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
     NSC_STAMP(39);
     nsc_lds_barrier();
     NSC_STAMP(40);
+    if (next_steady) {
+      // carried h: the k15 convs of the next tile read h from column 8 on; its columns [8, 2H) are this tile's [72, 2H + 64)
+      // (phase 2 is done with hs; source and destination ranges are disjoint)
+      for (int e = tid; e < NARROW * 14 * DIL; e += 512) {
+        const int r = e / (14 * DIL), cidx = 8 + (e - r * (14 * DIL));
+        hs[r * LDX + cidx] = hs[r * LDX + cidx + TT];
+      }
+    }
 
     // ---- phase 3: y = W9 * g + b9 + x; this wave's row tile (weights in registers), NC3 column tiles ----
     if ((RT9 != 7 || wave < 7) && !(skip & 4)) {
@@ -1807,29 +1850,26 @@ __global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs 
     NSC_STAMP(6);
 
     // ---- GLU backward in place (lin/th are zero outside the frame, so dlin/dgate are too); da -> global ----
-    for (int e = tid; e < NARROW * WA16; e += 512) {
-      const int c = e / WA16, ja = e - c * WA16;
-      if (!fresh && ja < 2 * Hh) {
-        // carried column: dlin / dgate are already in LDS (moved there at the end of the previous tile); the columns of
-        // it that belong to THIS tile's output range have not been stored yet
+    // Columns: a fresh tile has all WA16 columns of partial sums, a steady one the TT new columns [2 Hh, W_a).  da leaves for
+    // HBM for this tile's own range [Hh, Hh + TT) - and, when the next tile is steady, for the right halo too: those values
+    // are final (the next tile would recompute exactly them) and the next tile then never touches its carried columns.
+    {
+      const int j_lo = fresh ? 0 : 2 * Hh, ncol = fresh ? WA16 : TT;
+      const int st_lo = fresh ? Hh : 2 * Hh, st_hi = next_steady ? W_a : Hh + TT;
+      for (int e = tid; e < NARROW * ncol; e += 512) {
+        const int c = e / ncol, ja = j_lo + (e - c * ncol);
+        const float* pp = c < 16 ? part + c * PSW + ja : part + PART1 + (c - 16) * PSW + ja;
+        const int ps = c < 16 ? 16 * PSW : 4 * PSW;
+        const float gg = (pp[0] + pp[ps]) + (pp[2 * ps] + pp[3 * ps]);
+        const float l = lin[c * LDA + ja], tg = th[c * LDA + ja];
+        const float dl_ = gg * tg, dgt = gg * l * (1.f - tg * tg);
+        lin[c * LDA + ja] = dl_;
+        th[c * LDA + ja] = dgt;
         const int t = t0 - Hh + ja;
-        if (ja >= Hh && t < T) {
-          a.da[((long)b * 2 * NARROW + c) * T + t] = lin[c * LDA + ja];
-          a.da[((long)b * 2 * NARROW + NARROW + c) * T + t] = th[c * LDA + ja];
+        if (ja >= st_lo && ja < st_hi && t < T) {
+          a.da[((long)b * 2 * NARROW + c) * T + t] = dl_;
+          a.da[((long)b * 2 * NARROW + NARROW + c) * T + t] = dgt;
         }
-        continue;
-      }
-      const float* pp = c < 16 ? part + c * PSW + ja : part + PART1 + (c - 16) * PSW + ja;
-      const int ps = c < 16 ? 16 * PSW : 4 * PSW;
-      const float gg = (pp[0] + pp[ps]) + (pp[2 * ps] + pp[3 * ps]);
-      const float l = lin[c * LDA + ja], tg = th[c * LDA + ja];
-      const float dl_ = gg * tg, dgt = gg * l * (1.f - tg * tg);
-      lin[c * LDA + ja] = dl_;
-      th[c * LDA + ja] = dgt;
-      const int t = t0 - Hh + ja;
-      if (ja >= Hh && ja < Hh + TT && t < T) {
-        a.da[((long)b * 2 * NARROW + c) * T + t] = dl_;
-        a.da[((long)b * 2 * NARROW + NARROW + c) * T + t] = dgt;
       }
     }
     NSC_STAMP(7);

@@ -409,7 +409,9 @@ def test_bad_arguments_return_status(lib):
 
 
 @pytest.mark.parametrize("case", [(2, 100, 512, 2, 0), (2, 100, 256, 1, 1), (3, 50, 512, 2, 0), (2, 50, 512, 1, 1),
-                                  (1, 100, 200, 2, 0), (2, 36, 70, 1, 0), (70, 100, 300, 2, 0), (40, 50, 512, 1, 1)])
+                                  (1, 100, 200, 2, 0), (2, 36, 70, 1, 0), (70, 100, 300, 2, 0), (40, 50, 512, 1, 1),
+                                  # long chains of consecutive tiles (carried h / g columns), crossing frame boundaries
+                                  (150, 100, 512, 1, 0), (150, 50, 512, 2, 1), (72, 100, 256, 2, 0)])
 def test_fused_gated_block_fwd(lib, case):
     """csrc/block.hip vs the oracle's gated_bottleneck (nn_core_operator.py:82-112), incl. saved intermediates."""
     B, C_, T, dil, flat = case
