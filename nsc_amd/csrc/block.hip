@@ -361,6 +361,7 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
   }
 
 
+  nsc_wait_vmem();   // weights (and the first tile) are in: no vmcnt guards on register operands inside the loop
   NSC_STAMP(33);
   for (int tile = first; tile < last; ++tile) {
     const int b = tile / tpf, t0 = (tile - b * tpf) * TT;
@@ -1742,6 +1743,7 @@ __global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs 
   for (int s5 = 0; s5 < 5; ++s5) w1r[s5] = a.wt1[(s5 * 4 + kq) * C + min(rt1 * 16 + l15, C - 1)];
 
 
+  nsc_wait_vmem();   // weights (and the first tile) are in: no vmcnt guards on register operands inside the loop
   NSC_STAMP(1);
   for (int tile = first; tile < last; ++tile) {
     const int b = tile / tpf, t0 = (tile - b * tpf) * TT;
@@ -1791,21 +1793,18 @@ __global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs 
         // steady tile: the TT new columns [J0, J0 + TT) only.  Channels 0..15: waves 0-3 column tiles 0..2, waves 4-7 tile 3;
         // channels 16..19: waves 4-7, ONE packed tile (it spans 64 time steps).
         constexpr int J0 = 2 * Hh;
+        // Measured with per-wave s_memtime stamps (tools/dgrad_stamps.py): the packed tile is operand-bound (~150 cycles per
+        // MFMA whoever shares the SIMD), so waves 4-7 run ONLY it and waves 0-3 take all four column tiles.
         if (rt == 0) {
-          f32x4 acc[3];
+          f32x4 acc[4];
 #pragma unroll
-          for (int ct = 0; ct < 3; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          d9_rows0<3, NJ9 - 1, LDY>(w9r, w9x, yb + J0, yx + J0, kg, acc);
+          for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          d9_rows0<4, NJ9 - 1, LDY>(w9r, w9x, yb + J0, yx + J0, kg, acc);
 #pragma unroll
-          for (int ct = 0; ct < 3; ++ct)
+          for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) pp0[reg * PSW + J0 + ct * 16] = acc[ct][reg];
         } else {
-          f32x4 acc[1];
-          acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          d9_rows0<1, NJ9 - 1, LDY>(w9r, w9x, yb + J0 + 48, yx + J0 + 48, kg, acc);
-#pragma unroll
-          for (int reg = 0; reg < 4; ++reg) pp0[reg * PSW + J0 + 48] = acc[0][reg];
           f32x4 pk[2];
           pk[0] = pk[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
           d9_packed<NJ9 - 1, NK9, LDY, 1>(w9ps, C, w9t, dys + J0, kg, kq, l15, pk);
@@ -1883,20 +1882,15 @@ __global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs 
       const float* wb = w15s + kg * W15T + kq * NARROW + l15;
       float* pp0 = part + (kg * 16 + kq * 4) * PST + l15;
       if (rt == 0) {
-        f32x4 acc[3];
+        f32x4 acc[4];
 #pragma unroll
-        for (int ct = 0; ct < 3; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        d15_rows0<3, DIL, LDA>(wb, ab, kg, acc);
+        for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        d15_rows0<4, DIL, LDA>(wb, ab, kg, acc);
 #pragma unroll
-        for (int ct = 0; ct < 3; ++ct)
+        for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
           for (int reg = 0; reg < 4; ++reg) pp0[reg * PST + ct * 16] = acc[ct][reg];
       } else {
-        f32x4 acc[1];
-        acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        d15_rows0<1, DIL, LDA>(wb, ab + 48, kg, acc);
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) pp0[reg * PST + 48] = acc[0][reg];
         f32x4 pk = {0.f, 0.f, 0.f, 0.f};
         d15_packed<DIL, LDA>(w15s, lin, kg, kq, l15, pk);
         // row (s = kq, i = reg), column n = l15  ->  dh[16 + reg][4 l15 + kq]

@@ -25,6 +25,11 @@ void nsc_set_error(const char* fmt, ...);
 // Workgroup barrier that orders LDS traffic ONLY.  __syncthreads() also drains vmcnt, i.e. every wave waits for the
 // write acknowledgements of all its global stores (and for its prefetch loads) at every phase boundary - in the
 // persistent block kernels that was 3 store round trips per tile.  Use where the phases communicate through LDS only.
+// "Every VMEM load issued so far has landed" as an s_waitcnt the COMPILER sees (vmcnt(0), expcnt / lgkmcnt untouched).
+// Put once between the prologue of a persistent kernel and its tile loop when MFMA operands live in registers that the
+// prologue loaded: otherwise the waitcnt pass must guard their first use INSIDE the loop with counted vmcnt waits, and
+// because vmcnt retires in order those waits also cover the next tile's prefetch - MFMAs stalled on HBM latency every tile.
+__device__ __forceinline__ void nsc_wait_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 __device__ __forceinline__ void nsc_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 #define NSC_REQUIRE(cond, code, ...)          \
