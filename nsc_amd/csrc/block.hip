@@ -273,24 +273,24 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
   // x tile prefetch: wave w owns rows w, w+8, ...; lanes along time (two 64-column halves).  Raw buffer loads: scalar row
   // offset, per-lane time offset, out-of-frame columns pointed past the descriptor so the hardware returns 0 - no
   // address VALU and no value selects (with selects the compiler serialised the loads under register pressure).
-  float pf[NQ][2];
+  // The x tile travels as float4: lane = (row half lane >> 5, float4 index lane & 31 of the LDX / 4 = 28 per row); a wave
+  // instruction covers two rows, wave w owns rows 2w + half + 16 q: 7 x buffer_load_dwordx4 + 7 x ds_write_b128 per lane
+  // instead of 26 + 26 dword operations (a VMEM instruction costs the issuing wave ~60 cycles whatever its width).
+  constexpr int NQ4 = (CR + 15) / 16;
+  f32x4 pf4[NQ4];
   const __amdgpu_buffer_rsrc_t sx =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (unsigned)((long)a.B * C * T * 4), 0x00020000);
+  const int pi4 = lane & 31, phalf = lane >> 5;
   auto prefetch = [&](int tile) {
     const int tl = __builtin_amdgcn_readfirstlane(tile < ntiles ? tile : 0);   // past the end: a harmless re-read
     const int b = tl / tpf, t0 = (tl - b * tpf) * TT;
     const int OOB = 0x7ffffff0;
+    // byte offset of (row 2 wave + half, time t0 - H + 4 i4).  A negative time reads the previous row's tail; the staging
+    // step masks per element.  Only row 0 of frame 0 can start before the tensor: clamped to 0, shifted when staged.
+    const int vo = pi4 < LDX / 4 ? max(((b * C + 2 * wave + phalf) * T + t0 - H + 4 * pi4) * 4, 0) : OOB;
 #pragma unroll
-    for (int hb = 0; hb < 2; ++hb) {
-      const int j = hb * 64 + lane;
-      const int t = t0 - H + j;
-      const int vo = (j < WX && t >= 0 && t < T) ? t * 4 : OOB;
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const int r = min(wave + 8 * q, C - 1);      // pad rows: stored as zeros below
-        pf[q][hb] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(sx, vo, (b * C + r) * T * 4, 0));
-      }
-    }
+    for (int q = 0; q < NQ4; ++q)
+      pf4[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(sx, vo, q * 16 * T * 4, 0));
   };
   // CHAIN (same idea as gated_block_dgrad2_kernel): a workgroup walks CONSECUTIVE tiles [first, last).  From the second tile
   // of a chain on ("steady"), the 14*DIL columns of h and the 8 columns of g that the previous tile already computed are
@@ -374,15 +374,32 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
       const int r = tid >> 3, cidx = tid & 7;
       gs[r * LDG + cidx] = gs[r * LDG + cidx + TT];
     }
-    // ---- phase 0: prefetched x tile -> LDS ----
+    // ---- phase 0: prefetched x tile -> LDS (out-of-frame elements are the conv's zero padding) ----
+    if (pi4 < LDX / 4) {
+      const int tb = t0 - H + 4 * pi4;
+      const bool m0 = (unsigned)tb < (unsigned)T, m1 = (unsigned)(tb + 1) < (unsigned)T;
+      const bool m2 = (unsigned)(tb + 2) < (unsigned)T, m3 = (unsigned)(tb + 3) < (unsigned)T;
+      const bool clamped = b == 0 && wave == 0 && phalf == 0 && tb < 0 && tb > -4;
 #pragma unroll
-    for (int hb = 0; hb < 2; ++hb) {
-      const int j = hb * 64 + lane;
-      if (j < LDX) {
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          const int r = wave + 8 * q;
-          if (r < CR) xs[r * LDX + j] = r < C ? pf[q][hb] : 0.f;
+      for (int q = 0; q < NQ4; ++q) {
+        const int r = 2 * wave + phalf + 16 * q;
+        if (r < CR) {
+          f32x4 v = pf4[q];
+          if (clamped) {
+            // these lanes' offset for the very first row of the tensor was negative and was clamped to time 0 (the clamp
+            // holds for all their rows: the row enters through the scalar offset): element e holds time e, wanted tb + e
+            const f32x4 w = v;
+            const int sh = -tb;
+            v[1] = sh == 1 ? w[0] : 0.f;
+            v[2] = sh == 1 ? w[1] : (sh == 2 ? w[0] : 0.f);
+            v[3] = sh == 1 ? w[2] : (sh == 2 ? w[1] : w[0]);
+          }
+          const bool live = r < C;                           // pad rows of the last k-step are zeros
+          v[0] = live && m0 ? v[0] : 0.f;
+          v[1] = live && m1 ? v[1] : 0.f;
+          v[2] = live && m2 ? v[2] : 0.f;
+          v[3] = live && m3 ? v[3] : 0.f;
+          *reinterpret_cast<f32x4*>(xs + r * LDX + 4 * pi4) = v;
         }
       }
     }
