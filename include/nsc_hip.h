@@ -96,6 +96,13 @@ int nsc_gated_block_fwd(const float* x, const float* w1, const float* b1, const 
                         const float* wr, const float* br, const float* w9, const float* b9, float* out,
                         float* h_out, float* lin_out, float* th_out, float* g_out, int B, int C, int T,
                         int narrow, int k9, int dil, int flat, void* stream);
+/* The same block with ONE input channel (first block of a decoder stage, `_the_decoder_in_each_module`
+ * neural_speech_coding_module.py:246-251 -> gated_bottleneck on the [B,T,1] code): x [B,1,T], w1 [1,1,20]; the residual add
+ * broadcasts x over the C output channels.  C in {100, 50}, dil in {1, 2}; other shapes: NSC_ERR_UNSUPPORTED (per-conv path). */
+int nsc_gated_block_fwd_cin1(const float* x, const float* w1, const float* b1, const float* wl, const float* bl,
+                        const float* wr, const float* br, const float* w9, const float* b9, float* out,
+                        float* h_out, float* lin_out, float* th_out, float* g_out, int B, int C, int T,
+                        int narrow, int k9, int dil, int flat, void* stream);
 
 /* Fused DATA-PATH backward of the same block (8 waves, two workgroups per CU): from the saved h, lin, th (tanh branch)
  * [B,20,T], x and dy [B,C,T] it writes dx = (conv1^T(dz1) + dy) * act'(x), da [B,40,T] (= dlin | dgate) and

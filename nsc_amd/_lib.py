@@ -35,6 +35,7 @@ PROTOTYPES = {
     "nsc_conv1d_wgrad_ws": [C.POINTER(ConvDesc), _P, _P, _P, _P, _I, _P, _L, _P],
     "nsc_weight_flip_transpose": [_P, _P, _I, _I, _I, _P],
     "nsc_gated_block_fwd": [_P] * 14 + [_I] * 7 + [_P],
+    "nsc_gated_block_fwd_cin1": [_P] * 14 + [_I] * 7 + [_P],
     "nsc_gated_block_wgrad": [_P] * 16 + [_I] * 9 + [_P, _P],
     "nsc_glu_bwd_cat": [_P, _P, _P, _P, _I, _I, _I, _P],
     "nsc_gated_block_dgrad": [_P] * 12 + [_I] * 7 + [_P],

@@ -31,6 +31,7 @@ struct BlockArgs {
   int B, C, T, dil, flat;
   const float *x, *w1, *b1, *wl, *bl, *wr, *br, *w9, *b9;
   float *out, *h_out, *lin_out, *th_out, *g_out;  // *_out optional: saved for the unfused backward
+  int Cin;   // input channels: C (residual block) or 1 (the first decoder block: x [B,1,T] is broadcast into the residual add)
 };
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
@@ -265,6 +266,7 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
   float* gs = hs + NARROW * LDX;             // [20][LDG]
   float* w2s = gs + NARROW * LDG;            // [15*20][48]  k15 gate kernels, rows interleaved lin/tanh (see header)
   const int C = a.C, T = a.T;
+  const int Cin = a.Cin;                      // 1 with NK1 == 1: rows 1..3 of the only k-step are zero rows
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, kq = lane >> 4;
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
   constexpr int NQ4 = (CR + 15) / 16;
   f32x4 pf4[NQ4];
   const __amdgpu_buffer_rsrc_t sx =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (unsigned)((long)a.B * C * T * 4), 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (unsigned)((long)a.B * Cin * T * 4), 0x00020000);
   const int pi4 = lane & 31, phalf = lane >> 5;
   auto prefetch = [&](int tile) {
     const int tl = __builtin_amdgcn_readfirstlane(tile < ntiles ? tile : 0);   // past the end: a harmless re-read
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
     const int OOB = 0x7ffffff0;
     // byte offset of (row 2 wave + half, time t0 - H + 4 i4).  A negative time reads the previous row's tail; the staging
     // step masks per element.  Only row 0 of frame 0 can start before the tensor: clamped to 0, shifted when staged.
-    const int vo = pi4 < LDX / 4 ? max(((b * C + 2 * wave + phalf) * T + t0 - H + 4 * pi4) * 4, 0) : OOB;
+    const int vo = pi4 < LDX / 4 ? max(((b * Cin + 2 * wave + phalf) * T + t0 - H + 4 * pi4) * 4, 0) : OOB;
 #pragma unroll
     for (int q = 0; q < NQ4; ++q)
       pf4[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(sx, vo, q * 16 * T * 4, 0));
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
   const int r1 = wave >> 2;
   float w1r[NK1];
 #pragma unroll
-  for (int u = 0; u < NK1; ++u) w1r[u] = a.w1[min(4 * u + kq, C - 1) * NARROW + min(r1 * 16 + l15, NARROW - 1)];
+  for (int u = 0; u < NK1; ++u) w1r[u] = a.w1[min(4 * u + kq, Cin - 1) * NARROW + min(r1 * 16 + l15, NARROW - 1)];
   const int rt3 = RT9 == 7 ? (wave < 7 ? wave : 6) : (wave & 3);
   const int cb3 = RT9 == 7 ? 0 : (wave >> 2) * 32;      // first output column of this wave in phase 3
   constexpr int NC3 = RT9 == 7 ? 4 : 2;                  // column tiles per wave in phase 3
@@ -394,7 +396,7 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
             v[2] = sh == 1 ? w[1] : (sh == 2 ? w[0] : 0.f);
             v[3] = sh == 1 ? w[2] : (sh == 2 ? w[1] : w[0]);
           }
-          const bool live = r < C;                           // pad rows of the last k-step are zeros
+          const bool live = r < Cin;                         // pad rows of the last k-step are zeros
           v[0] = live && m0 ? v[0] : 0.f;
           v[1] = live && m1 ? v[1] : 0.f;
           v[2] = live && m2 ? v[2] : 0.f;
@@ -538,7 +540,7 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
         for (int reg = 0; reg < 4; ++reg) {
           const int o = rt3 * 16 + kq * 4 + reg;
           if (o < C && t < T) {
-            float v = acc[c][reg] + b9r[reg] + xs[o * LDX + H + tt];
+            float v = acc[c][reg] + b9r[reg] + xs[(NK1 == 1 ? 0 : o) * LDX + H + tt];   // Cin = 1: broadcast residual
             if (!a.flat) v = v > 0.f ? v : NSC_LRELU_ALPHA * v;
             a.out[((long)b * C + o) * T + t] = v;
           }
@@ -586,7 +588,7 @@ extern "C" int nsc_gated_block_fwd(const float* x, const float* w1, const float*
   const int C4 = (C + 3) & ~3;
   const size_t smem = ((size_t)(C4 + NARROW) * ldx + (size_t)NARROW * ldg) * sizeof(float);
   NSC_REQUIRE(smem <= 160 * 1024, NSC_ERR_UNSUPPORTED, "nsc_gated_block_fwd: %zu B LDS", smem);
-  BlockArgs a{B, C, T, dil, flat, x, w1, b1, wl, bl, wr, br, w9, b9, out, h_out, lin_out, th_out, g_out};
+  BlockArgs a{B, C, T, dil, flat, x, w1, b1, wl, bl, wr, br, w9, b9, out, h_out, lin_out, th_out, g_out, C};
   dim3 grid(nsc_cdiv(T, 64), B);
   hipStream_t st = (hipStream_t)stream;
   static const bool v1_only = NSC_PROBE_SET("NSC_BLOCK_FWD_V1");   // A/B switch for profiling
@@ -611,6 +613,25 @@ extern "C" int nsc_gated_block_fwd(const float* x, const float* w1, const float*
   return NSC_OK;
 }
 
+
+// The first block of each decoder stage has ONE input channel (the quantised code): its 1x1 conv is 1 -> 20 and the
+// residual add broadcasts x [B,1,T] over the `C` output channels (nn_core_operator.py:110-112 with a [B,T,1] input).
+// Same persistent kernel with a single k-step in phase 1 (rows 1..3 of the staged x tile are zero rows).
+extern "C" int nsc_gated_block_fwd_cin1(const float* x, const float* w1, const float* b1, const float* wl, const float* bl,
+                                        const float* wr, const float* br, const float* w9, const float* b9, float* out,
+                                        float* h_out, float* lin_out, float* th_out, float* g_out, int B, int C, int T,
+                                        int narrow, int k9, int dil, int flat, void* stream) {
+  NSC_REQUIRE(x && w1 && b1 && wl && bl && wr && br && w9 && b9 && out, NSC_ERR_BAD_ARG, "nsc_gated_block_fwd_cin1: null pointer");
+  NSC_REQUIRE(B > 0 && T > 0, NSC_ERR_BAD_ARG, "nsc_gated_block_fwd_cin1: bad sizes");
+  NSC_REQUIRE(narrow == NARROW && k9 == K9 && (C == 100 || C == 50) && (dil == 1 || dil == 2), NSC_ERR_UNSUPPORTED,
+              "nsc_gated_block_fwd_cin1: built for narrow=20, k9=9, C in {100, 50}, dil in {1, 2} (got %d, %d, %d, %d)", narrow, k9, C, dil);
+  NSC_REQUIRE(!(lin_out || th_out || g_out) || (lin_out && th_out && g_out), NSC_ERR_BAD_ARG,
+              "nsc_gated_block_fwd_cin1: lin/th/g outputs must be given together");
+  BlockArgs a{B, C, T, dil, flat, x, w1, b1, wl, bl, wr, br, w9, b9, out, h_out, lin_out, th_out, g_out, 1};
+  hipStream_t st = (hipStream_t)stream;
+  if (C == 100) return dil == 1 ? launch_block_fwd2<7, 1, 1>(a, st) : launch_block_fwd2<7, 1, 2>(a, st);
+  return dil == 1 ? launch_block_fwd2<4, 1, 1>(a, st) : launch_block_fwd2<4, 1, 2>(a, st);
+}
 
 // =====================================================================================================
 // Persistent weight-gradient kernel of one gated block: all eight parameter gradients from the SAVED

@@ -216,17 +216,19 @@ class _Block:
         self.th = e.buf(u + ".th", (B, n, T))
         self.g = e.buf(u + ".g", (B, n, T))
         self.out = e.buf(u + ".out", (B, self.wide, T))
-        if e.fused_fwd and self.Cin > 1 and n == 20 and self.c9.K == 9 and self.wide <= 112 and self.cl.dil <= 4:
+        cin1 = self.Cin == 1 and self.wide in (100, 50) and self.cl.dil in (1, 2)   # first block of a decoder stage
+        if e.fused_fwd and (self.Cin > 1 or cin1) and n == 20 and self.c9.K == 9 and self.wide <= 112 and self.cl.dil <= 4:
             # (other reference-legal shapes, e.g. wide 128 or dilation 8, take the per-conv path below)
             P = lambda c, base=e.p_ptr: (base + 4 * c.w_off, base + 4 * c.b_off)
             (w1, b1), (wl, bl), (wr, br), (w9, b9) = P(self.c1), P(self.cl), P(self.cr), P(self.c9)
             tok = e.prof_begin("block_fwd", self.c1.flops() + self.cl.flops() + self.cr.flops() + self.c9.flops())
             # the fused backward recomputes the intermediates from x; an inference-only engine never reads them
             save = e.keep_activations
-            check(e.lib.nsc_gated_block_fwd(x.data_ptr(), w1, b1, wl, bl, wr, br, w9, b9, self.out.data_ptr(),
+            fn = e.lib.nsc_gated_block_fwd_cin1 if cin1 else e.lib.nsc_gated_block_fwd
+            check(fn(x.data_ptr(), w1, b1, wl, bl, wr, br, w9, b9, self.out.data_ptr(),
                                             self.h.data_ptr() if save else None, self.lin.data_ptr() if save else None,
                                             self.th.data_ptr() if save else None, self.g.data_ptr() if save else None,
-                                            B, self.Cin, T, n, 9, self.cl.dil, int(self.flat),
+                                            B, self.wide, T, n, 9, self.cl.dil, int(self.flat),
                                             e.stream()), "gated_block_fwd")
             e.prof_end(tok)
             return self.out

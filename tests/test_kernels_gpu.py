@@ -515,6 +515,40 @@ def test_block_wgrad_kernel(lib, case):
         off += n_ + s_[2]
 
 
+@pytest.mark.parametrize("case", [(2, 100, 256, 1, 0), (3, 100, 256, 2, 1), (2, 50, 512, 1, 0), (150, 100, 256, 2, 0), (70, 100, 300, 1, 0)])
+def test_fused_gated_block_fwd_one_input_channel(lib, case):
+    """nsc_gated_block_fwd_cin1 vs the oracle's gated_bottleneck on a [B,T,1] input (broadcast residual), incl. the saved
+    intermediates and chains of tiles."""
+    B, C_, T, dil, flat = case
+    rng = np.random.default_rng(900 + C_ + T + dil)
+    ps = O.ParamStore(rng)
+    x = rng.standard_normal((B, T, 1)).astype(np.float32)
+    O.gated_bottleneck(x, ps, "s", C_, 20, 9, dil, bool(flat))
+    names = ["s/conv1d", "s/conv1d_1", "s/conv1d_2", "s/conv1d_3"]
+    for n in names:
+        ps.params[n + "/bias"] = (0.1 * rng.standard_normal(ps.params[n + "/bias"].shape)).astype(np.float32).astype(np.float64)
+    ps.begin_replay()
+    tape = []
+    ref = O.gated_bottleneck(x, ps, "s", C_, 20, 9, dil, bool(flat), tape)
+    t = tape[0][1]
+    W = [P(ps.params[n + "/kernel"]) for n in names]
+    Bv = [P(ps.params[n + "/bias"]) for n in names]
+    out = torch.full((B, C_, T), float("nan"), device="cuda")
+    h, lin, th, g = (torch.full((B, 20, T), float("nan"), device="cuda") for _ in range(4))
+    rc = lib.nsc_gated_block_fwd_cin1(P(x.transpose(0, 2, 1)), W[0], Bv[0], W[1], Bv[1], W[2], Bv[2], W[3], Bv[3],
+                                      out.data_ptr(), h.data_ptr(), lin.data_ptr(), th.data_ptr(), g.data_ptr(), B, C_, T,
+                                      20, 9, dil, flat, _st())
+    assert rc == 0, lib.nsc_last_error()
+    tr = lambda v: v.cpu().numpy().transpose(0, 2, 1)
+    assert_close(tr(h), t["h"], what="cin1 h")
+    assert_close(tr(lin), t["left"], what="cin1 lin")
+    assert_close(tr(th), t["right"], what="cin1 tanh branch")
+    assert_close(tr(g), t["g"], what="cin1 g")
+    assert_close(tr(out), ref, what=f"cin1 block out {case}")
+    assert lib.nsc_gated_block_fwd_cin1(P(x.transpose(0, 2, 1)), W[0], Bv[0], W[1], Bv[1], W[2], Bv[2], W[3], Bv[3],
+                                        out.data_ptr(), None, None, None, None, B, 36, T, 20, 9, dil, flat, _st()) == -2
+
+
 @pytest.mark.parametrize("case", [(2, 100, 512, 2, 2), (2, 100, 256, 1, 0), (3, 50, 512, 2, 2), (2, 50, 512, 1, 2),
                                   (1, 100, 200, 2, 0), (5, 36, 70, 1, 2),
                                   # more tiles than workgroups: chains of consecutive tiles with the carried da halo, chains
