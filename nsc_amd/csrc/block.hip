@@ -1240,6 +1240,8 @@ struct BlockDgradArgs {
   const float *x, *h, *lin, *th, *dy;
   const float *wt1, *wtl, *wtr, *wt9;
   float *dx, *da, *dz1;
+  float* dgate;   // where the second half of da goes and the rows per frame of both halves: da + 20 T / 40 for the joint
+  int da_rows;    // [B,40,T] tensor the block weight-gradient kernel reads; a separate [B,20,T] tensor / 20 for per-conv wgrads
 };
 
 template <int RT9>
@@ -1633,7 +1635,10 @@ __device__ __forceinline__ void d15_packed(const float* w15s, const float* da, i
 // The next tile's dy / lin / tanh / h are prefetched into registers (raw buffer loads; out-of-frame columns come back
 // as 0 from the bounds check) while this tile computes.
 // -----------------------------------------------------------------------------------------------------
-template <int RT9, int NK9, int DIL>
+// CIN1: the block's INPUT has one channel (first block of a decoder stage): dy / dg / dh are as usual, but the 1x1 data
+// gradient is a 20-term dot product per step and the residual branch sums dy over its C channels (the forward broadcast
+// x over them); dx is one row and its producer is the quantizer (no activation gradient).
+template <int RT9, int NK9, int DIL, bool CIN1 = false>
 __global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs a, int ntiles, int tpf, int skip) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int TT = 64, Hh = 7 * DIL, W_a = TT + 2 * Hh, W_dy = W_a + 8, NCTA = (W_a + 15) / 16, CR = 4 * NK9;
@@ -1778,7 +1783,13 @@ __global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs 
   constexpr int NC1 = RT9 == 7 ? 4 : 2;
   float w1r[5];
 #pragma unroll
-  for (int s5 = 0; s5 < 5; ++s5) w1r[s5] = a.wt1[(s5 * 4 + kq) * C + min(rt1 * 16 + l15, C - 1)];
+  for (int s5 = 0; s5 < 5; ++s5) w1r[s5] = CIN1 ? 0.f : a.wt1[(s5 * 4 + kq) * C + min(rt1 * 16 + l15, C - 1)];
+  // CIN1: wt1 is [20] (the flipped / transposed [1,1,20] kernel); lane tt of wave 0 needs all of it
+  float w1c[CIN1 ? NARROW : 1];
+  if (CIN1) {
+#pragma unroll
+    for (int c = 0; c < NARROW; ++c) w1c[c] = a.wt1[c];
+  }
 
 
   nsc_wait_vmem();   // weights (and the first tile) are in: no vmcnt guards on register operands inside the loop
@@ -1904,8 +1915,8 @@ __global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs 
         th[c * LDA + ja] = dgt;
         const int t = t0 - Hh + ja;
         if (ja >= st_lo && ja < st_hi && t < T) {
-          a.da[((long)b * 2 * NARROW + c) * T + t] = dl_;
-          a.da[((long)b * 2 * NARROW + NARROW + c) * T + t] = dgt;
+          a.da[((long)b * a.da_rows + c) * T + t] = dl_;
+          a.dgate[((long)b * a.da_rows + c) * T + t] = dgt;
         }
       }
     }
@@ -1938,7 +1949,7 @@ __global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs 
     }
     // x rows of the copy-out phase (for act'(x)): wave w rows w, w+8, ...; issued here, consumed three barriers later
     float xv[NQ];
-    if (a.in_act == NSC_ACT_LRELU) {
+    if (!CIN1 && a.in_act == NSC_ACT_LRELU) {
       const int vx = (t0 + lane < T) ? (t0 + lane) * 4 : OOB;
 #pragma unroll
       for (int q = 0; q < NQ; ++q) xv[q] = bld(sxx, vx, (b * C + min(wave + 8 * q, C - 1)) * T * 4);
@@ -1981,38 +1992,60 @@ __global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs 
     nsc_lds_barrier();
     NSC_STAMP(12);
 
+    if (CIN1) {
+      // ---- D1, one input channel: dx[t] = sum_c w1[c] dz1[c][t] + sum_o dy[o][t].  Wave w sums the dy rows w, w+8, ...
+      // (wave 0 adds the 20-term dot product) into dxs[w][.]; after the barrier wave 0 adds the eight partial rows.
+      const int tt = lane;
+      float s_ = 0.f;
+      for (int o = wave; o < C; o += 8) s_ += dys[o * LDY + tt + Hh + 4];
+      if (wave == 0) {
+#pragma unroll
+        for (int c = 0; c < NARROW; ++c) s_ = fmaf(w1c[c], dhs[c * LDN + tt], s_);
+      }
+      dxs[wave * LDD + tt] = s_;
+      NSC_STAMP(13);
+      nsc_lds_barrier();
+      NSC_STAMP(14);
+      if (wave == 0 && t0 + tt < T) {
+        float v = 0.f;
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8) v += dxs[w8 * LDD + tt];
+        a.dx[(long)b * T + t0 + tt] = v;
+      }
+    } else {
     // ---- D1: dx = (W1^T dz1 + dy) . act'(x); this wave's row tile, NC1 column tiles ----
-    if ((RT9 != 7 || wave < 7) && !(skip & 4)) {
-      f32x4 acc[NC1];
-#pragma unroll
-      for (int c = 0; c < NC1; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      const float* zb = dhs + kq * LDN + cb1 + l15;
-#pragma unroll
-      for (int s5 = 0; s5 < 5; ++s5)
-#pragma unroll
-        for (int c = 0; c < NC1; ++c) acc[c] = mfma4(w1r[s5], zb[4 * s5 * LDN + c * 16], acc[c]);
-#pragma unroll
-      for (int c = 0; c < NC1; ++c) {
-        const int tt = cb1 + c * 16 + l15;
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const int co = rt1 * 16 + kq * 4 + reg;
-          if (co < C) dxs[co * LDD + tt] = acc[c][reg] + dys[co * LDY + tt + Hh + 4];
+      if ((RT9 != 7 || wave < 7) && !(skip & 4)) {
+        f32x4 acc[NC1];
+  #pragma unroll
+        for (int c = 0; c < NC1; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float* zb = dhs + kq * LDN + cb1 + l15;
+  #pragma unroll
+        for (int s5 = 0; s5 < 5; ++s5)
+  #pragma unroll
+          for (int c = 0; c < NC1; ++c) acc[c] = mfma4(w1r[s5], zb[4 * s5 * LDN + c * 16], acc[c]);
+  #pragma unroll
+        for (int c = 0; c < NC1; ++c) {
+          const int tt = cb1 + c * 16 + l15;
+  #pragma unroll
+          for (int reg = 0; reg < 4; ++reg) {
+            const int co = rt1 * 16 + kq * 4 + reg;
+            if (co < C) dxs[co * LDD + tt] = acc[c][reg] + dys[co * LDY + tt + Hh + 4];
+          }
         }
       }
-    }
-    NSC_STAMP(13);
-    nsc_lds_barrier();
-    NSC_STAMP(14);
-    // ---- copy-out: dx rows as whole 256-B lines (the D-fragment stores were 64-B pieces), . act'(x) ----
-    if (t0 + lane < T) {
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const int r = wave + 8 * q;
-        if (r < C) {
-          float v = dxs[r * LDD + lane];
-          if (a.in_act == NSC_ACT_LRELU) v *= (xv[q] > 0.f ? 1.f : NSC_LRELU_ALPHA);
-          a.dx[((long)b * C + r) * T + t0 + lane] = v;
+      NSC_STAMP(13);
+      nsc_lds_barrier();
+      NSC_STAMP(14);
+      // ---- copy-out: dx rows as whole 256-B lines (the D-fragment stores were 64-B pieces), . act'(x) ----
+      if (t0 + lane < T) {
+  #pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const int r = wave + 8 * q;
+          if (r < C) {
+            float v = dxs[r * LDD + lane];
+            if (a.in_act == NSC_ACT_LRELU) v *= (xv[q] > 0.f ? 1.f : NSC_LRELU_ALPHA);
+            a.dx[((long)b * C + r) * T + t0 + lane] = v;
+          }
         }
       }
     }
@@ -2023,7 +2056,7 @@ __global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs 
   NSC_STAMP(17);
 }
 
-template <int RT9, int NK9, int DIL>
+template <int RT9, int NK9, int DIL, bool CIN1 = false>
 static int launch_block_dgrad2(const BlockDgradArgs& a, hipStream_t st) {
   constexpr int WA16 = ((64 + 14 * DIL + 15) / 16) * 16;
   const size_t partsz = std::max((size_t)4 * NARROW * (WA16 + 4), (size_t)4 * NK9 * 68);
@@ -2031,7 +2064,7 @@ static int launch_block_dgrad2(const BlockDgradArgs& a, hipStream_t st) {
   const size_t smem = ((size_t)4 * NK9 * 110 + (size_t)2 * NARROW * 110 + (size_t)NARROW * 80 + partsz +
                        (size_t)K15 * W15T + (size_t)K9 * w9t) * sizeof(float);
   NSC_REQUIRE(smem <= 160 * 1024, NSC_ERR_UNSUPPORTED, "gated_block_dgrad2: %zu B LDS", smem);
-  auto kern = gated_block_dgrad2_kernel<RT9, NK9, DIL>;
+  auto kern = gated_block_dgrad2_kernel<RT9, NK9, DIL, CIN1>;
   static const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);   // once per instantiation
   NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "gated_block_dgrad2: smem attr: %s", hipGetErrorString(e));
   const int tpf = nsc_cdiv(a.T, 64);
@@ -2059,7 +2092,7 @@ extern "C" int nsc_gated_block_dgrad(const float* x, const float* h, const float
   const int C4 = (C + 3) & ~3;
   const size_t smem = ((size_t)C4 * ldy + (size_t)3 * NARROW * lda + (size_t)NARROW * ldn) * sizeof(float);
   NSC_REQUIRE(smem <= 160 * 1024, NSC_ERR_UNSUPPORTED, "nsc_gated_block_dgrad: %zu B LDS", smem);
-  BlockDgradArgs a{B, C, T, dil, in_act, x, h, lin, th, dy, wt1, wtl, wtr, wt9, dx, da, dz1};
+  BlockDgradArgs a{B, C, T, dil, in_act, x, h, lin, th, dy, wt1, wtl, wtr, wt9, dx, da, dz1, da + (long)NARROW * T, 2 * NARROW};
   dim3 grid(nsc_cdiv(T, 64), B);
   hipStream_t st = (hipStream_t)stream;
   static const bool v1_only = NSC_PROBE_SET("NSC_BLOCK_DGRAD_V1");   // A/B switch for profiling
@@ -2079,4 +2112,21 @@ extern "C" int nsc_gated_block_dgrad(const float* x, const float* h, const float
 #undef LAUNCH_DG
   NSC_CHECK_LAUNCH("gated_block_dgrad");
   return NSC_OK;
+}
+
+// One input channel (first block of a decoder stage): dy [B,C,T] as usual, dx [B,1,T]; wt1 = the [20] taps of the 1 -> 20
+// 1x1 conv; dlin / dgate leave as two [B,20,T] tensors (what the per-conv weight-gradient launches of this block read).
+extern "C" int nsc_gated_block_dgrad_cin1(const float* h, const float* lin, const float* th, const float* dy,
+                                          const float* wt1, const float* wtl, const float* wtr, const float* wt9, float* dx,
+                                          float* dlin, float* dgate, float* dz1, int B, int C, int T, int narrow, int k9,
+                                          int dil, void* stream) {
+  NSC_REQUIRE(h && lin && th && dy && wt1 && wtl && wtr && wt9 && dx && dlin && dgate && dz1, NSC_ERR_BAD_ARG,
+              "nsc_gated_block_dgrad_cin1: null pointer");
+  NSC_REQUIRE(B > 0 && T > 0, NSC_ERR_BAD_ARG, "nsc_gated_block_dgrad_cin1: bad sizes");
+  NSC_REQUIRE(narrow == NARROW && k9 == K9 && (dil == 1 || dil == 2) && (C == 100 || C == 50), NSC_ERR_UNSUPPORTED,
+              "nsc_gated_block_dgrad_cin1: built for narrow=20, k9=9, dil in {1,2}, C in {100, 50} (got %d, %d, %d, %d)", narrow, k9, dil, C);
+  BlockDgradArgs a{B, C, T, dil, NSC_ACT_NONE, dy /* x: unused */, h, lin, th, dy, wt1, wtl, wtr, wt9, dx, dlin, dz1, dgate, NARROW};
+  hipStream_t st = (hipStream_t)stream;
+  if (C == 100) return dil == 1 ? launch_block_dgrad2<7, 25, 1, true>(a, st) : launch_block_dgrad2<7, 25, 2, true>(a, st);
+  return dil == 1 ? launch_block_dgrad2<4, 13, 1, true>(a, st) : launch_block_dgrad2<4, 13, 2, true>(a, st);
 }

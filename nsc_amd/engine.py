@@ -307,6 +307,25 @@ class _Block:
             if need_dx and not fuse_d1:
                 self.c1.dgrad(dh, dx, res=dz, res_mode=1, mul_kind=in_kind, aux=self.x)
             return dx
+        if (self.Cin == 1 and e.fused_fwd and e.fused_dgrad and n == 20 and self.c9.K == 9 and self.wide in (100, 50)
+                and self.cl.dil in (1, 2)):
+            # first block of a decoder stage: the whole data path in one persistent kernel (one input channel: the 1x1
+            # gradient is a dot product, the residual branch sums dy over its channels); its four weight gradients stay
+            # per-conv launches on the side stream (the batched block kernel assumes Cin == Cout)
+            assert in_kind == "none"
+            dx = e.buf(u + ".dx", (B, 1, T))
+            WT = lambda c: e.wt_ptr + 4 * c.w_off
+            tok = e.prof_begin("block_dgrad", self.c1.flops() + self.cl.flops() + self.cr.flops() + self.c9.flops())
+            check(e.lib.nsc_gated_block_dgrad_cin1(self.h.data_ptr(), self.lin.data_ptr(), self.th.data_ptr(), dz.data_ptr(),
+                                                   WT(self.c1), WT(self.cl), WT(self.cr), WT(self.c9), dx.data_ptr(),
+                                                   dlin.data_ptr(), dgate.data_ptr(), dh.data_ptr(), B, self.wide, T, n, 9,
+                                                   self.cl.dil, e.stream()), "gated_block_dgrad_cin1")
+            e.prof_end(tok)
+            self.c9.wgrad(self.g, dz)
+            self.cl.wgrad(self.h, dlin)
+            self.cr.wgrad(self.h, dgate)
+            self.c1.wgrad(self.x, dh)
+            return dx if need_dx else None
         self.c9.wgrad(self.g, dz)
         self.c9.dgrad(dz, dg)
         check(e.lib.nsc_glu_bwd(self.lin.data_ptr(), self.th.data_ptr(), dg.data_ptr(), dlin.data_ptr(),

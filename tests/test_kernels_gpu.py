@@ -595,6 +595,45 @@ def test_fused_gated_block_dgrad(lib, case):
     assert_close(g(dx), zt.grad.numpy(), tol=2e-4, what=f"dx {case}")
 
 
+@pytest.mark.parametrize("case", [(2, 100, 256, 1), (3, 100, 256, 2), (2, 50, 512, 2), (150, 100, 256, 2), (70, 100, 300, 1)])
+def test_fused_gated_block_dgrad_one_input_channel(lib, case):
+    """nsc_gated_block_dgrad_cin1 vs autograd of the oracle block on a [B,T,1] input: dx (incl. the channel-summed residual
+    branch), dlin, dgate, dz1 - with chains of tiles."""
+    B, C_, T, dil = case
+    rng = np.random.default_rng(1100 + C_ + T + dil)
+    names = ["s/conv1d", "s/conv1d_1", "s/conv1d_2", "s/conv1d_3"]
+    ps = O.ParamStore(rng)
+    x = rng.standard_normal((B, T, 1)).astype(np.float32)
+    O.gated_bottleneck(x, ps, "s", C_, 20, 9, dil, True)
+    for n in names:
+        ps.params[n + "/bias"] = (0.1 * rng.standard_normal(ps.params[n + "/bias"].shape)).astype(np.float32).astype(np.float64)
+    dy = rng.standard_normal((B, T, C_)).astype(np.float32)
+    tp = OT.TorchParams(ps)
+    xin = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    W1, b1 = tp.conv("s"); Wl, bl = tp.conv("s"); Wr, br = tp.conv("s"); W9, b9 = tp.conv("s")
+    hpre = OT.conv1d(xin, W1, b1, activation=None); hpre.retain_grad()
+    h = OT.act(hpre, "lrelu")
+    left = OT.conv1d(h, Wl, bl, dilation_rate=dil, activation=None); left.retain_grad()
+    rpre = OT.conv1d(h, Wr, br, dilation_rate=dil, activation=None); rpre.retain_grad()
+    right = torch.tanh(rpre)
+    y = OT.conv1d(left * right, W9, b9, activation=None) + xin          # [B,T,C] + [B,T,1]: broadcast
+    (y * torch.tensor(dy, dtype=torch.float64)).sum().backward()
+    wt = {n: np.array(ps.params[n + "/kernel"].astype(np.float32)[::-1].transpose(0, 2, 1), order="C", copy=True) for n in names}
+    tr = lambda v: P(np.ascontiguousarray(np.asarray(v, np.float32).transpose(0, 2, 1)))
+    dx = torch.full((B, 1, T), float("nan"), device="cuda")
+    dlin, dgate, dz1 = (torch.full((B, 20, T), float("nan"), device="cuda") for _ in range(3))
+    rc = lib.nsc_gated_block_dgrad_cin1(tr(h.detach().numpy()), tr(left.detach().numpy()), tr(right.detach().numpy()), tr(dy),
+                                        P(wt[names[0]]), P(wt[names[1]]), P(wt[names[2]]), P(wt[names[3]]), dx.data_ptr(),
+                                        dlin.data_ptr(), dgate.data_ptr(), dz1.data_ptr(), B, C_, T, 20, 9, dil, _st())
+    assert rc == 0, lib.nsc_last_error()
+    torch.cuda.synchronize()
+    g = lambda v: v.cpu().numpy().transpose(0, 2, 1)
+    assert_close(g(dlin), left.grad.numpy(), tol=2e-4, what=f"cin1 dlin {case}")
+    assert_close(g(dgate), rpre.grad.numpy(), tol=2e-4, what=f"cin1 dgate {case}")
+    assert_close(g(dz1), hpre.grad.numpy(), tol=2e-4, what=f"cin1 dz1 {case}")
+    assert_close(g(dx), xin.grad.numpy(), tol=2e-4, what=f"cin1 dx {case}")
+
+
 def test_block_wgrad_batch_equals_per_block_launches(lib):
     """nsc_gated_block_wgrad_batch (deferred, one launch for many blocks of mixed shapes) == per-block nsc_gated_block_wgrad."""
     from nsc_amd._lib import BlockWgradJob
