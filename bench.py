@@ -127,7 +127,7 @@ def main():
     ap.add_argument("--wgrad-waves", type=int, default=8)
     ap.add_argument("--no-split-wgrad", action="store_true")
     ap.add_argument("--no-batch-wgrad", action="store_true", help="debug: per-block weight-gradient launches instead of one deferred batch")
-    ap.add_argument("--batch-conv-wgrad", action="store_true", help="debug: per-conv weight gradients deferred into one batched launch per kernel class")
+    ap.add_argument("--no-batch-conv-wgrad", action="store_true", help="debug: one weight-gradient launch per conv on the side stream instead of one deferred batched launch per kernel class")
     ap.add_argument("--unfused-wgrad", action="store_true", help="debug: per-conv weight gradients")
     ap.add_argument("--unfused-dgrad", action="store_true", help="debug: per-conv data-gradient launches instead of one fused kernel per gated block")
     ap.add_argument("--unfused-fwd", action="store_true", help="debug: per-conv forward/backward (no block fusion)")
@@ -150,7 +150,7 @@ def main():
     eng.fused_wgrad = not args.unfused_wgrad
     eng.fused_dgrad = not args.unfused_dgrad
     eng.batch_wgrad = not args.no_batch_wgrad
-    eng.batch_conv_wgrad = args.batch_conv_wgrad
+    eng.batch_conv_wgrad = not args.no_batch_conv_wgrad
     eng.fused_fwd = not args.unfused_fwd
     xd, lpcd, x_np, lpc_np = synth_batch(B, comm.rank, dev)
     cfg = step_cfg()

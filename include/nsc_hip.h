@@ -112,7 +112,8 @@ int nsc_gated_block_dgrad(const float* x, const float* h, const float* lin, cons
                           float* dz1, int B, int C, int T, int narrow, int k9, int dil, int in_act, void* stream);
 /* The same for the block with ONE input channel (see nsc_gated_block_fwd_cin1): dx [B,1,T] = sum_c w1[c] dz1[c] + sum_o dy[o]
  * (the forward broadcast x over the C output channels; the producer of x is the quantizer, so no activation gradient);
- * wt1 [20]; dlin / dgate as two [B,20,T] tensors.  C in {100, 50}, dil in {1, 2}. */
+ * wt1 [20]; dlin / dgate are two [B,20,T] tensors, or - when dgate == dlin + 20 T and B > 1 - the two halves of one
+ * [B,40,T] tensor (the form nsc_gated_block_wgrad_batch reads).  C in {100, 50}, dil in {1, 2}. */
 int nsc_gated_block_dgrad_cin1(const float* h, const float* lin, const float* th, const float* dy,
                                const float* wt1, const float* wtl, const float* wtr, const float* wt9, float* dx,
                                float* dlin, float* dgate, float* dz1, int B, int C, int T, int narrow, int k9,
@@ -142,6 +143,8 @@ typedef struct nsc_block_wgrad_job {
   const float *x, *h, *g, *dy, *da, *dz1;
   float* grads;
   int C, T, dil;
+  int Cin;   /* channels of x: 0 or C for a C -> C block, 1 for the one-input-channel decoder block (grads then starts
+              * with dW1 [1,20]) */
 } nsc_block_wgrad_job;
 long nsc_gated_block_wgrad_batch_workspace(int Cmax);
 int nsc_gated_block_wgrad_batch(const nsc_block_wgrad_job* jobs, int njobs, int B, int narrow, int k9,

@@ -72,7 +72,7 @@ PROTOTYPES = {
 }
 class BlockWgradJob(C.Structure):
     """include/nsc_hip.h: struct nsc_block_wgrad_job"""
-    _fields_ = [(n, C.c_void_p) for n in ("x", "h", "g", "dy", "da", "dz1", "grads")] + [(n, C.c_int) for n in ("C", "T", "dil")]
+    _fields_ = [(n, C.c_void_p) for n in ("x", "h", "g", "dy", "da", "dz1", "grads")] + [(n, C.c_int) for n in ("C", "T", "dil", "Cin")]
 
 
 class ConvWgradJob(C.Structure):

@@ -652,6 +652,7 @@ struct BlockWgradArgs {
   int ntiles, tiles_per_frame;                             // this workgroup's private partial slab (same relative layout)
   long slab_stride;                                        // floats between consecutive workgroups' slabs (0 = atomics)
   int skip;   // timing-only probe (NSC_WG_SKIP): 1 D1, 2 wgrad MFMA loop, 4 flush, 8 staging loads, 16 staging stores
+  int Cin;    // channels of x (= C, or 1 for the first block of a decoder stage: dW1 is then [1,20] and x one row)
 };
 
 __device__ __forceinline__ void wg_flush(float* p, float v, bool plain) {
@@ -673,10 +674,11 @@ __device__ __forceinline__ void block_wgrad_body(const BlockWgradArgs& a, int ld
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int TT = 64;
   const int C = a.C, T = a.T, d = a.dil;
+  const int Cx = a.Cin;                        // rows of x (the fused D1 below is for Cx == C only)
   const int Hh = 7 * d;
-  // rows C / C+1 of xn are the zero / ones rows used by every part (part 1 keeps only those two rows of xn)
-  float* xn = sm;                              // [C + 2][ldn]      rows C = zeros, C+1 = ones
-  float* dys = xn + (C + 2) * ldn;             // [C][ldn]                              (parts 0, 1)
+  // rows Cx / Cx+1 of xn are the zero / ones rows used by every part (part 1 keeps only those two rows of xn)
+  float* xn = sm;                              // [Cx + 2][ldn]     rows Cx = zeros, Cx+1 = ones
+  float* dys = xn + (Cx + 2) * ldn;            // [C][ldn]                              (parts 0, 1)
   float* gs = dys + (P9 ? C * ldn : 0);        // [NARROW + 2][ldg] g on [t0-4, t0+68)  (parts 0, 1)
   float* hs = gs + (P9 ? (NARROW + 2) * ldg : 0);   // [NARROW + 2][ldh] h on [t0-Hh, t0+64+Hh)   (parts 0, 2)
   float* dl = hs + (PLR ? (NARROW + 2) * ldh : 0);  // [NARROW][ldn] dlin  (dgate follows: dg_ = dl + NARROW*ldn)
@@ -688,7 +690,7 @@ __device__ __forceinline__ void block_wgrad_body(const BlockWgradArgs& a, int ld
 
   // 8 waves (two per SIMD): each owns fewer accumulator tiles (100 registers) and the partner wave hides LDS /
   // global latency that a single wave per SIMD exposed.
-  for (int j = tid; j < ldn; j += 64 * NW) { xn[C * ldn + j] = 0.f; xn[(C + 1) * ldn + j] = 1.f; }
+  for (int j = tid; j < ldn; j += 64 * NW) { xn[Cx * ldn + j] = 0.f; xn[(Cx + 1) * ldn + j] = 1.f; }
   if (PLR) for (int j = tid; j < ldh; j += 64 * NW) { hs[NARROW * ldh + j] = 0.f; hs[(NARROW + 1) * ldh + j] = 1.f; }
   if (P9) for (int j = tid; j < ldg; j += 64 * NW) { gs[NARROW * ldg + j] = 0.f; gs[(NARROW + 1) * ldg + j] = 1.f; }
 
@@ -723,10 +725,10 @@ __device__ __forceinline__ void block_wgrad_body(const BlockWgradArgs& a, int ld
 #pragma unroll
   for (int r = 0; r < R1; ++r) {
     const int ci = (wave + NW * r) * 16 + l15;
-    off1[r] = (ci < C ? ci : (ci == C ? C + 1 : C)) * ldn;
+    off1[r] = (ci < Cx ? ci : (ci == Cx ? Cx + 1 : Cx)) * ldn;
   }
   // B-operand offsets are relative to `sm`; columns that do not exist point at the zero row of xn (no masks needed)
-  const int zrow = (int)(xn - sm) + C * ldn;
+  const int zrow = (int)(xn - sm) + Cx * ldn;
   int offb_lr[3], offb9[RT9];
 #pragma unroll
   for (int ct = 0; ct < 3; ++ct) {
@@ -750,7 +752,8 @@ __device__ __forceinline__ void block_wgrad_body(const BlockWgradArgs& a, int ld
   // just the time index, so the ~50 prefetch loads need no per-load address registers; out-of-frame time indices are
   // sent out of the descriptor's range and come back as 0 from the hardware bounds check (no value selects either).
   const unsigned nbC = (unsigned)((long)a.B * C * T * 4), nbN = (unsigned)((long)a.B * NARROW * T * 4);
-  const __amdgpu_buffer_rsrc_t sx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, nbC, 0x00020000);
+  const __amdgpu_buffer_rsrc_t sx =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (unsigned)((long)a.B * Cx * T * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t sy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, nbC, 0x00020000);
   const __amdgpu_buffer_rsrc_t sa = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.da), 0, 2 * nbN, 0x00020000);
   const __amdgpu_buffer_rsrc_t sz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dz1), 0, nbN, 0x00020000);
@@ -778,7 +781,7 @@ __device__ __forceinline__ void block_wgrad_body(const BlockWgradArgs& a, int ld
     for (int q = 0; q < QX; ++q) {
       const int r = wave + NW * q;                    // rows >= C read the next frame's data: never stored
       const int so = sbC + r * T * 4;
-      if (PLR) rx[q] = bl(sx, vt, so);
+      if (PLR) rx[q] = bl(sx, vt, (b * Cx + r) * T * 4);
       if (P9) ry[q] = bl(sy, vt, so);
     }
     if (PLR) {
@@ -800,10 +803,8 @@ __device__ __forceinline__ void block_wgrad_body(const BlockWgradArgs& a, int ld
 #pragma unroll
     for (int q = 0; q < QX; ++q) {
       const int r = wave + NW * q;
-      if (r < C) {
-        if (PLR) xn[r * ldn + lane] = rx[q];
-        if (P9) dys[r * ldn + lane] = ry[q];
-      }
+      if (PLR && r < Cx) xn[r * ldn + lane] = rx[q];
+      if (P9 && r < C) dys[r * ldn + lane] = ry[q];
     }
     if (PLR) {
 #pragma unroll
@@ -955,12 +956,12 @@ __device__ __forceinline__ void block_wgrad_body(const BlockWgradArgs& a, int ld
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
       const int ci = (wave + NW * r) * 16 + kq * 4 + reg;
-      if (ci > C) continue;
+      if (ci > Cx) continue;
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         const int o = c * 16 + l15;
         if (o >= NARROW) continue;
-        if (ci < C) wg_flush(a.dw1 + so + ci * NARROW + o, g1[r][c][reg], plain);
+        if (ci < Cx) wg_flush(a.dw1 + so + ci * NARROW + o, g1[r][c][reg], plain);
         else wg_flush(a.db1 + so + o, g1[r][c][reg], plain);
       }
     }
@@ -1067,7 +1068,7 @@ extern "C" int nsc_gated_block_wgrad(const float* x, const float* h, const float
                     (part != 1 ? (size_t)(NARROW + 2) * ldh : 0) + (size_t)3 * NARROW * ldn;
   const size_t smem = fl * sizeof(float);
   NSC_REQUIRE(smem <= 160 * 1024, NSC_ERR_UNSUPPORTED, "nsc_gated_block_wgrad: %zu B LDS", smem);
-  BlockWgradArgs a{B, C, T, dil, x, h, g, dy, da, dz1, wt1, dx, in_act, dw1, db1, dwl, dbl, dwr, dbr, dw9, db9, 0, 0, 0, 0};
+  BlockWgradArgs a{B, C, T, dil, x, h, g, dy, da, dz1, wt1, dx, in_act, dw1, db1, dwl, dbl, dwr, dbr, dw9, db9, 0, 0, 0, 0, C};
   { static int skip_env = -1; if (skip_env < 0) { skip_env = NSC_PROBE_INT("NSC_WG_SKIP", 0); } a.skip = skip_env; }
   a.tiles_per_frame = nsc_cdiv(T, 64);
   a.ntiles = B * a.tiles_per_frame;
@@ -1123,16 +1124,16 @@ static int launch_wgrad_batch(const nsc_block_wgrad_job* jobs, const int* idx, i
   size_t smem = 0;
   for (int q = 0; q < n; ++q) {
     const nsc_block_wgrad_job& jb = jobs[idx[q]];
-    const int C = jb.C;
-    const long range = (long)C * NARROW + NARROW + 2L * (K15 * NARROW * NARROW + NARROW) + (long)K9 * NARROW * C + C;
+    const int C = jb.C, Cx = jb.Cin > 0 ? jb.Cin : jb.C;
+    const long range = (long)Cx * NARROW + NARROW + 2L * (K15 * NARROW * NARROW + NARROW) + (long)K9 * NARROW * C + C;
     stride = std::max(stride, (range + 63) & ~63L);
     BlockWgradArgs& a = t.a[q];
-    a.B = B; a.C = C; a.T = jb.T; a.dil = jb.dil;
+    a.B = B; a.C = C; a.Cin = Cx; a.T = jb.T; a.dil = jb.dil;
     a.x = jb.x; a.h = jb.h; a.g = jb.g; a.dy = jb.dy; a.da = jb.da; a.dz1 = jb.dz1;
     a.wt1 = nullptr; a.dx = nullptr; a.in_act = 0;
     // gradient pointers redirected into slab 0 of the workspace, keeping the block's relative layout
     float* p = workspace;
-    a.dw1 = p; p += (long)C * NARROW; a.db1 = p; p += NARROW;
+    a.dw1 = p; p += (long)Cx * NARROW; a.db1 = p; p += NARROW;
     a.dwl = p; p += K15 * NARROW * NARROW; a.dbl = p; p += NARROW;
     a.dwr = p; p += K15 * NARROW * NARROW; a.dbr = p; p += NARROW;
     a.dw9 = p; p += (long)K9 * NARROW * C; a.db9 = p;
@@ -1141,7 +1142,7 @@ static int launch_wgrad_batch(const nsc_block_wgrad_job* jobs, const int* idx, i
     a.skip = skip_env;
     total_tiles += a.ntiles;
     r.grads[q] = jb.grads;
-    r.off9[q] = (int)((long)C * NARROW + NARROW + 2L * (K15 * NARROW * NARROW + NARROW));
+    r.off9[q] = (int)((long)Cx * NARROW + NARROW + 2L * (K15 * NARROW * NARROW + NARROW));
     r.range[q] = (int)range;
     const int ldh = ld2(64 + 14 * jb.dil);
     const size_t f1 = (size_t)(C + 2) * ldn + (size_t)C * ldn + (size_t)(NARROW + 2) * ldg + (size_t)3 * NARROW * ldn;
@@ -1216,8 +1217,9 @@ extern "C" int nsc_gated_block_wgrad_batch(const nsc_block_wgrad_job* jobs, int 
     const nsc_block_wgrad_job& jb = jobs[j];
     NSC_REQUIRE(jb.x && jb.h && jb.g && jb.dy && jb.da && jb.dz1 && jb.grads, NSC_ERR_BAD_ARG,
                 "nsc_gated_block_wgrad_batch: job %d has a null pointer", j);
-    NSC_REQUIRE(jb.C > 1 && jb.C <= 112 && jb.T > 0 && jb.dil > 0 && jb.dil <= 4, NSC_ERR_UNSUPPORTED,
-                "nsc_gated_block_wgrad_batch: job %d: C %d, T %d, dil %d unsupported", j, jb.C, jb.T, jb.dil);
+    NSC_REQUIRE(jb.C > 1 && jb.C <= 112 && jb.T > 0 && jb.dil > 0 && jb.dil <= 4 && (jb.Cin == 0 || jb.Cin == 1 || jb.Cin == jb.C),
+                NSC_ERR_UNSUPPORTED, "nsc_gated_block_wgrad_batch: job %d: C %d, Cin %d, T %d, dil %d unsupported", j, jb.C, jb.Cin,
+                jb.T, jb.dil);
     if (nsc_cdiv(jb.C, 16) <= 4) small[ns++] = j; else big[nb++] = j;
     int rc = flush(false);
     if (rc) return rc;
@@ -2125,7 +2127,8 @@ extern "C" int nsc_gated_block_dgrad_cin1(const float* h, const float* lin, cons
   NSC_REQUIRE(B > 0 && T > 0, NSC_ERR_BAD_ARG, "nsc_gated_block_dgrad_cin1: bad sizes");
   NSC_REQUIRE(narrow == NARROW && k9 == K9 && (dil == 1 || dil == 2) && (C == 100 || C == 50), NSC_ERR_UNSUPPORTED,
               "nsc_gated_block_dgrad_cin1: built for narrow=20, k9=9, dil in {1,2}, C in {100, 50} (got %d, %d, %d, %d)", narrow, k9, dil, C);
-  BlockDgradArgs a{B, C, T, dil, NSC_ACT_NONE, dy /* x: unused */, h, lin, th, dy, wt1, wtl, wtr, wt9, dx, dlin, dz1, dgate, NARROW};
+  BlockDgradArgs a{B, C, T, dil, NSC_ACT_NONE, dy /* x: unused */, h, lin, th, dy, wt1, wtl, wtr, wt9, dx, dlin, dz1, dgate,
+                   (B > 1 && dgate == dlin + (long)NARROW * T) ? 2 * NARROW : NARROW};   // halves of one [B,40,T] tensor, or two [B,20,T]
   hipStream_t st = (hipStream_t)stream;
   if (C == 100) return dil == 1 ? launch_block_dgrad2<7, 25, 1, true>(a, st) : launch_block_dgrad2<7, 25, 2, true>(a, st);
   return dil == 1 ? launch_block_dgrad2<4, 13, 1, true>(a, st) : launch_block_dgrad2<4, 13, 2, true>(a, st);

@@ -310,10 +310,14 @@ class _Block:
         if (self.Cin == 1 and e.fused_fwd and e.fused_dgrad and n == 20 and self.c9.K == 9 and self.wide in (100, 50)
                 and self.cl.dil in (1, 2)):
             # first block of a decoder stage: the whole data path in one persistent kernel (one input channel: the 1x1
-            # gradient is a dot product, the residual branch sums dy over its channels); its four weight gradients stay
-            # per-conv launches on the side stream (the batched block kernel assumes Cin == Cout)
+            # gradient is a dot product, the residual branch sums dy over its channels); its weight gradients join the
+            # step's batched block launch (job.Cin = 1), which reads dlin | dgate as one [B,40,T] tensor
             assert in_kind == "none"
             dx = e.buf(u + ".dx", (B, 1, T))
+            batched = e.batch_wgrad and e.batch_cin1_wgrad and B > 1
+            if batched:
+                da = e.buf(u + ".da", (B, 2 * n, T))
+                dlin, dgate = da[:, :n], da[:, n:]      # data_ptr of the halves: dgate = dlin + 20 T floats
             WT = lambda c: e.wt_ptr + 4 * c.w_off
             tok = e.prof_begin("block_dgrad", self.c1.flops() + self.cl.flops() + self.cr.flops() + self.c9.flops())
             check(e.lib.nsc_gated_block_dgrad_cin1(self.h.data_ptr(), self.lin.data_ptr(), self.th.data_ptr(), dz.data_ptr(),
@@ -321,6 +325,10 @@ class _Block:
                                                    dlin.data_ptr(), dgate.data_ptr(), dh.data_ptr(), B, self.wide, T, n, 9,
                                                    self.cl.dil, e.stream()), "gated_block_dgrad_cin1")
             e.prof_end(tok)
+            if batched:
+                e.defer_block_wgrad(self, dz, da, dh, e.g_ptr + 4 * self.c1.w_off,
+                                    self.c1.flops() + self.cl.flops() + self.cr.flops() + self.c9.flops())
+                return dx if need_dx else None
             self.c9.wgrad(self.g, dz)
             self.cl.wgrad(self.h, dlin)
             self.cr.wgrad(self.h, dgate)
@@ -628,13 +636,16 @@ class CascadeEngine:
     # their prologue, accumulator flush and slab reduction cost more than the MFMA work itself.
     poly_dgrad = True    # stride-2 data gradients in polyphase form (half the MFMAs of the zero-upsampled form)
     batch_wgrad = True
-    batch_conv_wgrad = False  # the same for the convs outside gated blocks (nsc_conv1d_wgrad_batch; measured 4.20 vs 4.15 ms/step:
-                              # the per-conv launches hide in the gaps of the data-gradient chain); False = one launch per
-                              # conv on the side stream
+    batch_cin1_wgrad = True   # the one-input-channel decoder blocks join the batched launch too (False: per-conv launches)
+    batch_conv_wgrad = True   # the same for the convs outside gated blocks (nsc_conv1d_wgrad_batch).  With the block kernels
+                              # persistent at one workgroup per CU and a static split of the tiles, a weight-gradient workgroup
+                              # that holds a CU's LDS when such a kernel starts delays that CU's whole share: per-conv launches
+                              # on the side stream measured 3.57 ms/step when their timing happened to fall well and 3.82 when
+                              # it did not; everything deferred to the tail of the step: 3.55, independent of timing
 
     def defer_block_wgrad(self, blk, dz, da, dz1, dw1_ptr, flops):
         self._wg_jobs.append(_lib.BlockWgradJob(blk.x.data_ptr(), blk.h.data_ptr(), blk.g.data_ptr(), dz.data_ptr(),
-                                                da.data_ptr(), dz1.data_ptr(), dw1_ptr, blk.Cin, blk.T, blk.cl.dil))
+                                                da.data_ptr(), dz1.data_ptr(), dw1_ptr, blk.wide, blk.T, blk.cl.dil, blk.Cin))
         self._wg_keep += [blk.x, blk.h, blk.g, dz, da, dz1]
         self._wg_flops += flops
 

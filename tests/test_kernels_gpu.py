@@ -668,6 +668,41 @@ def test_block_wgrad_batch_equals_per_block_launches(lib):
         assert_close(o_.cpu().numpy(), r.cpu().numpy(), tol=2e-4, what=f"batched block wgrad job {i} {shapes[i]}")
 
 
+def test_block_wgrad_batch_one_input_channel_jobs(lib):
+    """Jobs with Cin = 1 (first block of a decoder stage; dW1 is [1,20], x one row) in the same batched launch as C -> C
+    jobs, against float64 autograd of the four convolutions."""
+    import torch.nn.functional as F
+    from nsc_amd._lib import BlockWgradJob
+    rng = np.random.default_rng(78)
+    B = 5
+    shapes = [(100, 1, 512, 1), (50, 50, 256, 2), (50, 1, 256, 2), (100, 1, 128, 2)]      # (C, Cin, T, dil)
+    lib.nsc_gated_block_wgrad_batch_workspace.restype = C.c_long
+    nws = lib.nsc_gated_block_wgrad_batch_workspace(100)
+    ws = torch.full((nws,), float("nan"), device="cuda")
+    keep, jobs, outs, wants = [], [], [], []
+    for (C_, Ci, T, dil) in shapes:
+        t = {k: dev(rng.standard_normal(s_).astype(np.float32)) for k, s_ in
+             dict(x=(B, Ci, T), h=(B, 20, T), g=(B, 20, T), dy=(B, C_, T), da=(B, 40, T), dz1=(B, 20, T)).items()}
+        d = {k: v.double() for k, v in t.items()}
+        def wgrad(inp, dout, K, dl):
+            w = torch.zeros(dout.shape[1], inp.shape[1], K, dtype=torch.float64, device="cuda", requires_grad=True)
+            b = torch.zeros(dout.shape[1], dtype=torch.float64, device="cuda", requires_grad=True)
+            (F.conv1d(inp, w, b, dilation=dl, padding=(K - 1) // 2 * dl) * dout).sum().backward()
+            return [w.grad.permute(2, 1, 0).reshape(-1), b.grad]          # kernel layout [K, Cin, Cout]
+        want = torch.cat(wgrad(d["x"], d["dz1"], 1, 1) + wgrad(d["h"], d["da"][:, :20], 15, dil) +
+                         wgrad(d["h"], d["da"][:, 20:], 15, dil) + wgrad(d["g"], d["dy"], 9, 1))
+        out = torch.full((want.numel(),), 0.5, device="cuda")
+        jobs.append(BlockWgradJob(t["x"].data_ptr(), t["h"].data_ptr(), t["g"].data_ptr(), t["dy"].data_ptr(), t["da"].data_ptr(),
+                                  t["dz1"].data_ptr(), out.data_ptr(), C_, T, dil, Ci))
+        keep.append(t); outs.append(out); wants.append(want + 0.5)
+    arr = (BlockWgradJob * len(jobs))(*jobs)
+    rc = lib.nsc_gated_block_wgrad_batch(arr, len(jobs), B, 20, 9, ws.data_ptr(), nws, _st())
+    assert rc == 0, lib.nsc_last_error()
+    torch.cuda.synchronize()
+    for i, (w_, o_) in enumerate(zip(wants, outs)):
+        assert_close(o_.cpu().numpy(), w_.cpu().numpy(), tol=2e-4, what=f"batched block wgrad job {i} {shapes[i]}")
+
+
 def test_conv_wgrad_batch_equals_per_conv_launches(lib):
     """nsc_conv1d_wgrad_batch (deferred; mixed shapes and kernel classes, incl. the role-swapped Cout == 1 form, stride 2 and a
     bias-less job) == one nsc_conv1d_wgrad per conv."""
