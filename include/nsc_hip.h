@@ -214,6 +214,13 @@ int nsc_quantize_bwd(const float* code, const float* alpha, const float* bins, f
 int nsc_recon_loss(const float* decoded, const float* target, int B, float ct, float cf,
                    const float* gt, const float* gf, const float* mel, const float* melT,
                    float* time_out, float* freq_out, float* grad, void* stream);
+/* The same with the band structure of the mel matrix handed in (the four banks are triangular filters: a column is
+ * non-zero on one run of bins, a bin belongs to at most a few neighbouring filters of each bank), so only those terms
+ * are visited - identical results, the matrix products shrink ~20x.  ranges: int32 [184][2] = [k_lo, k_hi) of every
+ * mel column, followed by [257][4][2] = [j_lo, j_hi) of every bin within each bank (columns 0:8, 8:24, 24:56, 56:184). */
+int nsc_recon_loss_banded(const float* decoded, const float* target, int B, float ct, float cf,
+                          const float* gt, const float* gf, const float* mel, const float* melT, const int* ranges,
+                          float* time_out, float* freq_out, float* grad, void* stream);
 /* bare rFFT-512 magnitude (tf_stft): re/im/mag [B,257] (any nullable). */
 int nsc_rfft512(const float* sig, int B, float* re, float* im, float* mag, void* stream);
 

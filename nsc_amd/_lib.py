@@ -60,6 +60,7 @@ PROTOTYPES = {
     "nsc_entropy_from_hist": [_P, _I, _P, _P, _P],
     "nsc_quantize_bwd": [_P, _P, _P, _F, _I, _I, _I, _I, _P, _P, _F, _P, _F, _I, _P, _P, _P, _P],
     "nsc_recon_loss": [_P, _P, _I, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P],
+    "nsc_recon_loss_banded": [_P, _P, _I, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "nsc_rfft512": [_P, _I, _P, _P, _P, _P],
     "nsc_adam_tf1_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _P, _P],
     "nsc_increment": [_P, _P],

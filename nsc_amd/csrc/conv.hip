@@ -813,34 +813,51 @@ struct ConvReduceJob {
 struct ConvReduceBatch {
   ConvReduceJob j[NSC_CW_MAXJ];
 };
-__global__ void conv_slab_reduce_batch_kernel(ConvReduceBatch t) {
+// 1024 threads = 64 consecutive elements x 16 slab groups (one wave each; its loads are whole 256-B lines): the slabs of an
+// element are summed by 16 waves in parallel (a single thread walking all of them is a ~100-load dependent chain),
+// the 16 partial sums meet in LDS in a fixed order: results do not depend on timing.
+__global__ __launch_bounds__(1024) void conv_slab_reduce_batch_kernel(ConvReduceBatch t) {
+  __shared__ float part[16][64];
   ConvReduceJob jb = t.j[0];
 #pragma unroll
   for (int q = 1; q < NSC_CW_MAXJ; ++q)
     if (q == (int)blockIdx.y) jb = t.j[q];
   const int nW = jb.K * jb.Cin * jb.Cout;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < jb.n; i += gridDim.x * blockDim.x) {
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int per = (jb.nslabs + 15) >> 4;
+  const int w0 = grp * per, w1 = min(jb.nslabs, w0 + per);
+  for (int i0 = blockIdx.x * 64; i0 < jb.n; i0 += gridDim.x * 64) {     // block-uniform trip count
+    const int i = i0 + lane;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int w = 0;
-    for (; w + 3 < jb.nslabs; w += 4) {
-      s0 += jb.slab[(long)w * jb.stride + i];
-      s1 += jb.slab[(long)(w + 1) * jb.stride + i];
-      s2 += jb.slab[(long)(w + 2) * jb.stride + i];
-      s3 += jb.slab[(long)(w + 3) * jb.stride + i];
-    }
-    for (; w < jb.nslabs; ++w) s0 += jb.slab[(long)w * jb.stride + i];
-    const float v = (s0 + s1) + (s2 + s3);
-    if (i < nW) {
-      int io = i;
-      if (jb.flip) {
-        const int kk = i / jb.Cout, o = i - kk * jb.Cout;
-        const int tap = kk / jb.Cin, ci = kk - tap * jb.Cin;
-        io = ((jb.K - 1 - tap) * jb.Cin + ci) * jb.Cout + o;
+    if (i < jb.n) {
+      int w = w0;
+      for (; w + 3 < w1; w += 4) {
+        s0 += jb.slab[(long)w * jb.stride + i];
+        s1 += jb.slab[(long)(w + 1) * jb.stride + i];
+        s2 += jb.slab[(long)(w + 2) * jb.stride + i];
+        s3 += jb.slab[(long)(w + 3) * jb.stride + i];
       }
-      jb.dw[io] += v;          // one adder per element
-    } else {
-      jb.db[i - nW] += v;
+      for (; w < w1; ++w) s0 += jb.slab[(long)w * jb.stride + i];
     }
+    part[grp][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (grp == 0 && i < jb.n) {
+      float v = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) v += part[g][lane];
+      if (i < nW) {
+        int io = i;
+        if (jb.flip) {
+          const int kk = i / jb.Cout, o = i - kk * jb.Cout;
+          const int tap = kk / jb.Cin, ci = kk - tap * jb.Cin;
+          io = ((jb.K - 1 - tap) * jb.Cin + ci) * jb.Cout + o;
+        }
+        jb.dw[io] += v;          // one adder per element
+      } else {
+        jb.db[i - nW] += v;
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -1038,7 +1055,7 @@ static int launch_cw_class(const nsc_conv_wgrad_job* jobs, const int* idx, const
   }
   hipLaunchKernelGGL(kern, dim3(wg), dim3(512), smem, st, t);
   NSC_CHECK_LAUNCH("conv1d_wgrad_batch");
-  hipLaunchKernelGGL(conv_slab_reduce_batch_kernel, dim3(std::min(64, nsc_cdiv(nmax, 256)), n), dim3(256), 0, st, r);
+  hipLaunchKernelGGL(conv_slab_reduce_batch_kernel, dim3(std::min(512, nsc_cdiv(nmax, 64)), n), dim3(1024), 0, st, r);
   NSC_CHECK_LAUNCH("conv_slab_reduce_batch");
   return NSC_OK;
 }

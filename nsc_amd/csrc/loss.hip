@@ -41,12 +41,16 @@ __device__ __forceinline__ void fft512(float* zr, float* zi, const float* twr, c
   }
 }
 
+// ranges (nullable): the mel matrix is banded (triangular filters), so only the non-zero band of each column / row is
+// visited - same terms in the same order as the dense loops (the skipped ones are exact zeros).  Layout: [184][2]
+// = [k_lo, k_hi) of each mel column, then [257][4][2] = [j_lo, j_hi) of each bin inside each of the four banks.
 __global__ __launch_bounds__(256) void recon_loss_kernel(const float* __restrict__ decoded,
                                                          const float* __restrict__ target, float ct, float cf,
                                                          const float* __restrict__ gt, const float* __restrict__ gf,
                                                          const float* __restrict__ mel,
                                                          const float* __restrict__ melT, float* __restrict__ time_out,
-                                                         float* __restrict__ freq_out, float* __restrict__ grad) {
+                                                         float* __restrict__ freq_out, float* __restrict__ grad,
+                                                         const int* __restrict__ ranges) {
   __shared__ float zr[NFFT], zi[NFFT], twr[256], twi[256];
   __shared__ float psd_d[NBIN], psd_o[NBIN], dre[NBIN], dim_[NBIN];
   __shared__ float sq[NMEL], gm[NMEL];
@@ -86,21 +90,31 @@ __global__ __launch_bounds__(256) void recon_loss_kernel(const float* __restrict
   float diff = 0.f, md = 0.f;
   if (tid < NMEL) {
     float mo = 0.f;
-    for (int k = 0; k < NBIN; ++k) {
+    const int klo = ranges ? ranges[2 * tid] : 0, khi = ranges ? ranges[2 * tid + 1] : NBIN;
+#pragma unroll 8
+    for (int k = klo; k < khi; ++k) {       // the mel loads do not depend on the sums: unrolled, eight are in flight
       const float m = mel[k * NMEL + tid];
       md = fmaf(psd_d[k], m, md);
       mo = fmaf(psd_o[k], m, mo);
     }
     diff = logf(md + 1e-7f) - logf(mo + 1e-7f);
-    sq[tid] = diff * diff;
+  }
+  {
+    // per-bank sums of diff^2: every wave reduces its lanes bank by bank (columns 0:8 | 8:24 | 24:56 | 56:184), the (at
+    // most three) waves that hold columns of a bank meet in LDS
+    const float d2 = tid < NMEL ? diff * diff : 0.f;
+    const int bank = tid < 8 ? 0 : (tid < 24 ? 1 : (tid < 56 ? 2 : 3));
+#pragma unroll
+    for (int bk = 0; bk < 4; ++bk) {
+      const float sb = wave_sum(bank == bk ? d2 : 0.f);
+      if ((tid & 63) == 0) sq[(tid >> 6) * 4 + bk] = sb;
+    }
   }
   __syncthreads();
   if (tid < 4) {
-    const int off = tid == 0 ? 0 : (tid == 1 ? 8 : (tid == 2 ? 24 : 56));
-    const int n = tid == 0 ? 8 : (tid == 1 ? 16 : (tid == 2 ? 32 : 128));
-    float s = 0.f;
-    for (int j = 0; j < n; ++j) s += sq[off + j];
-    bank_rms[tid] = sqrtf(s / (float)n + 1e-7f);
+    const float n = tid == 0 ? 8.f : (tid == 1 ? 16.f : (tid == 2 ? 32.f : 128.f));
+    const float s = (sq[tid] + sq[4 + tid]) + (sq[8 + tid] + sq[12 + tid]);
+    bank_rms[tid] = sqrtf(s / n + 1e-7f);
   }
   __syncthreads();
   if (tid == 0 && freq_out) freq_out[b] = 0.25f * (bank_rms[0] + bank_rms[1] + bank_rms[2] + bank_rms[3]);
@@ -118,7 +132,15 @@ __global__ __launch_bounds__(256) void recon_loss_kernel(const float* __restrict
   __syncthreads();
   for (int k = tid; k < NBIN; k += 256) {
     float g = 0.f;
-    for (int j = 0; j < NMEL; ++j) g = fmaf(gm[j], melT[j * NBIN + k], g);
+    if (ranges) {
+#pragma unroll
+      for (int bk = 0; bk < 4; ++bk) {
+        const int jlo = ranges[2 * NMEL + 8 * k + 2 * bk], jhi = ranges[2 * NMEL + 8 * k + 2 * bk + 1];
+        for (int j = jlo; j < jhi; ++j) g = fmaf(gm[j], melT[j * NBIN + k], g);
+      }
+    } else {
+      for (int j = 0; j < NMEL; ++j) g = fmaf(gm[j], melT[j * NBIN + k], g);
+    }
     g *= 2.f / NFFT;  // d psd / d re = 2 re / 512
     const int r = bitrev9(k & (NFFT - 1));
     // dx[n] = Re sum_k G_k e^{+i theta} = Re FFT(conj(G))[n]
@@ -136,8 +158,17 @@ extern "C" int nsc_recon_loss(const float* decoded, const float* target, int B, 
                               float* grad, void* stream) {
   NSC_REQUIRE(decoded && target && mel && melT && B > 0, NSC_ERR_BAD_ARG, "nsc_recon_loss: bad args");
   hipLaunchKernelGGL(recon_loss_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, decoded, target, ct, cf, gt, gf,
-                     mel, melT, time_out, freq_out, grad);
+                     mel, melT, time_out, freq_out, grad, (const int*)nullptr);
   NSC_CHECK_LAUNCH("recon_loss");
+  return NSC_OK;
+}
+extern "C" int nsc_recon_loss_banded(const float* decoded, const float* target, int B, float ct, float cf, const float* gt,
+                                     const float* gf, const float* mel, const float* melT, const int* ranges,
+                                     float* time_out, float* freq_out, float* grad, void* stream) {
+  NSC_REQUIRE(decoded && target && mel && melT && ranges && B > 0, NSC_ERR_BAD_ARG, "nsc_recon_loss_banded: bad args");
+  hipLaunchKernelGGL(recon_loss_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, decoded, target, ct, cf, gt, gf,
+                     mel, melT, time_out, freq_out, grad, ranges);
+  NSC_CHECK_LAUNCH("recon_loss_banded");
   return NSC_OK;
 }
 

@@ -118,6 +118,68 @@ __global__ __launch_bounds__(256) void depthwise_bwd_dw_kernel(const float* __re
     atomicAdd(dwd + k * C + c, red[0][k] + red[1][k] + red[2][k] + red[3][k]);
   }
 }
+// The same with four frames in flight: all their rows are fetched before the first one is used (the kernel above pays a
+// global-load round trip per frame, ~2.5 us each, with a barrier in between).  T + 16 <= 768.
+#define DWB_NF 4
+__global__ __launch_bounds__(256) void depthwise_bwd_dw4_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                float* __restrict__ dwd, int B, int C, int T, int K) {
+  extern __shared__ float xrow[];            // [DWB_NF][T + 16]
+  __shared__ float red[4][16];
+  const int c = blockIdx.x, padL = (K - 1) / 2, ld = T + 16;
+  const int per = (B + gridDim.y - 1) / gridDim.y;
+  const int b_lo = blockIdx.y * per, b_hi = min(B, b_lo + per);
+  float acc[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+  for (int b0 = b_lo; b0 < b_hi; b0 += DWB_NF) {
+    float xv[DWB_NF][3], gv[DWB_NF][3];
+#pragma unroll
+    for (int f = 0; f < DWB_NF; ++f) {
+      const int b = min(b0 + f, b_hi - 1);                    // duplicate frames past the end are loaded, never used
+      const float* xr = x + ((long)b * C + c) * T;
+      const float* dr = dy + ((long)b * C + c) * T;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int j = threadIdx.x + 256 * q, u = j - padL;
+        xv[f][q] = (j < ld && u >= 0 && u < T) ? xr[u] : 0.f;
+        gv[f][q] = j < T ? dr[j] : 0.f;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int f = 0; f < DWB_NF; ++f)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int j = threadIdx.x + 256 * q;
+        if (j < ld) xrow[f * ld + j] = xv[f][q];
+      }
+    __syncthreads();
+#pragma unroll
+    for (int f = 0; f < DWB_NF; ++f) {
+      const bool live = b0 + f < b_hi;                        // block-uniform
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int t = threadIdx.x + 256 * q;
+        if (live && t < T) {
+#pragma unroll
+          for (int k = 0; k < 16; ++k)
+            if (k < K) acc[k] = fmaf(xrow[f * ld + t + k], gv[f][q], acc[k]);
+        }
+      }
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const float s = wave_sum(acc[k]);
+    if (lane == 0) red[wave][k] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < K) {
+    const int k = threadIdx.x;
+    atomicAdd(dwd + k * C + c, red[0][k] + red[1][k] + red[2][k] + red[3][k]);
+  }
+}
 extern "C" int nsc_depthwise_bwd(const float* x, const float* wd, const float* dy, float* dx, float* dwd, int B, int C,
                                  int T, int K, void* stream) {
   NSC_REQUIRE(x && wd && dy && B > 0 && C > 0 && T > 0 && K > 0, NSC_ERR_BAD_ARG, "nsc_depthwise_bwd: bad args");
@@ -133,8 +195,12 @@ extern "C" int nsc_depthwise_bwd(const float* x, const float* wd, const float* d
     NSC_CHECK_LAUNCH("depthwise_bwd_dx");
   }
   if (dwd) {
-    hipLaunchKernelGGL(depthwise_bwd_dw_kernel, dim3(C, std::min(B, 16)), dim3(256), (T + 16) * sizeof(float),
-                       (hipStream_t)stream, x, dy, dwd, B, C, T, K);
+    if (T + 16 <= 768)
+      hipLaunchKernelGGL(depthwise_bwd_dw4_kernel, dim3(C, nsc_cdiv(B, DWB_NF)), dim3(256),
+                         DWB_NF * (T + 16) * sizeof(float), (hipStream_t)stream, x, dy, dwd, B, C, T, K);
+    else
+      hipLaunchKernelGGL(depthwise_bwd_dw_kernel, dim3(C, std::min(B, 16)), dim3(256), (T + 16) * sizeof(float),
+                         (hipStream_t)stream, x, dy, dwd, B, C, T, K);
     NSC_CHECK_LAUNCH("depthwise_bwd_dw");
   }
   return NSC_OK;

@@ -59,10 +59,22 @@ __device__ __forceinline__ float nsc_act_grad_from_out(float out, int mode) {
   if (mode == 2) return 1.f - out * out;                    // tanh'
   return 1.f;
 }
+// Sum over the 64 lanes, returned to every lane.  DPP moves inside the VALU (quad permutes, row rotates, then the two
+// row broadcasts of gfx9) instead of six ds_bpermute round trips through the LDS pipe: kernels that end in a dozen of
+// these per wave (depthwise / quantizer gradients) were bound by exactly that.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float nsc_dpp_add(float v) {
+  const int m = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false);
+  return v + __builtin_bit_cast(float, m);      // rows outside ROW_MASK receive 0
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v = nsc_dpp_add<0xb1>(v);          // quad_perm [1,0,3,2]
+  v = nsc_dpp_add<0x4e>(v);          // quad_perm [2,3,0,1]   -> quad sums
+  v = nsc_dpp_add<0x124>(v);         // row_ror 4
+  v = nsc_dpp_add<0x128>(v);         // row_ror 8             -> row (16-lane) sums in every lane
+  v = nsc_dpp_add<0x142, 0xa>(v);    // row_bcast 15 into rows 1, 3
+  v = nsc_dpp_add<0x143, 0xc>(v);    // row_bcast 31 into rows 2, 3 -> lane 63 holds the total
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

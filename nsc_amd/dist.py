@@ -1,7 +1,9 @@
 """Data-parallel plumbing: one process per GPU, torch.distributed (backend "nccl" == RCCL over xGMI on ROCm).
 
 The path shards over frames (independent units).  Collectives per step:
-  * gradient all-reduce, SUM, over ONE flat fp32 buffer (1.4 - 8.65 MB: latency-bound, one ring pass);
+  * gradient all-reduce, SUM, one message per trainable scope (a contiguous range of the flat fp32 gradient buffer,
+    0.7 - 2.2 MB): a codec's message is issued as soon as its backward pass and weight gradients are done and runs
+    under the earlier codecs' backward pass; frozen scopes are not sent;
   * optional all-reduce (SUM) of the tiny soft-assignment histograms so entropy_coding_loss sees the global batch.
 On CPU (tests) the same code runs over the gloo backend.
 """
@@ -30,6 +32,13 @@ class Comm:
         if self.world > 1:
             dist.all_reduce(t, op=op)
         return t
+
+    def allreduce_async(self, t, op=dist.ReduceOp.SUM):
+        """Starts the all-reduce and returns a handle whose .wait() orders the caller's stream after it (nccl/RCCL: the
+        collective runs on the process group's own stream, so kernels launched meanwhile overlap with it)."""
+        if self.world > 1:
+            return dist.all_reduce(t, op=op, async_op=True)
+        return None
 
     def allreduce_list(self, tensors):
         for t in tensors:

@@ -24,7 +24,7 @@ import torch
 from . import _lib
 from ._lib import ACT_LRELU, ACT_NONE, ACT_TANH, ConvDesc, check
 from .constants import (beta_boundary, frame_length, init_alpha, lpc_coeff_lsf_bins)
-from .loss_terms_and_measures import mel_matrix_cat
+from .loss_terms_and_measures import mel_band_ranges, mel_matrix_cat
 
 KIND_MUL = {"none": 0, "lrelu": 1, "tanh": 2}
 KIND_ACT = {"none": ACT_NONE, "lrelu": ACT_LRELU, "tanh": ACT_TANH}
@@ -598,6 +598,7 @@ class CascadeEngine:
         mel = mel_matrix_cat().astype(np.float32)
         self.mel = torch.from_numpy(mel).to(self.device).contiguous()
         self.melT = torch.from_numpy(np.ascontiguousarray(mel.T)).to(self.device)
+        self.mel_ranges = torch.from_numpy(mel_band_ranges(mel)).to(self.device)
         self.init_params(seed)
 
     # ---- plumbing ----
@@ -890,9 +891,11 @@ class CascadeEngine:
 
     # ---- losses + backward ----
     def loss_backward(self, target, c_time, c_freq, c_quan, c_ent, trainable, c_quan_lpc=0.0, c_ent_lpc=0.0,
-                      global_batch=None, hist_allreduce=None, train_lpc=None):
+                      global_batch=None, hist_allreduce=None, train_lpc=None, grad_allreduce=None):
         """loss = sum_b [c_time*time + c_freq*freq + sum_i c_quan[i]*quan_i[b]] + Bglobal * sum_i c_ent[i]*ent_i
         (vector loss => implicit sum over the batch).  trainable: list of bool per codec.
+        grad_allreduce (data parallel): t -> handle with .wait(); called once per trainable scope with that scope's
+        range of the flat gradient buffer as soon as it is complete (SUM over ranks), all handles waited on before returning.
         Returns dict of loss terms (device tensors)."""
         B, rs = self.B, self.res_scalar
         Bg = float(global_batch or B)
@@ -900,14 +903,16 @@ class CascadeEngine:
         self.time = self.buf("loss.time", (B,))
         self.freq = self.buf("loss.freq", (B,))
         G = self.buf("loss.G", (B, 1, frame_length))
-        check(self.lib.nsc_recon_loss(self.decoded.data_ptr(), target.data_ptr(), B, float(c_time), float(c_freq), None,
-                                      None, self.mel.data_ptr(), self.melT.data_ptr(), self.time.data_ptr(),
-                                      self.freq.data_ptr(), G.data_ptr(), self.stream()), "recon_loss")
+        check(self.lib.nsc_recon_loss_banded(self.decoded.data_ptr(), target.data_ptr(), B, float(c_time), float(c_freq),
+                                             None, None, self.mel.data_ptr(), self.melT.data_ptr(),
+                                             self.mel_ranges.data_ptr(), self.time.data_ptr(), self.freq.data_ptr(),
+                                             G.data_ptr(), self.stream()), "recon_loss")
         if hist_allreduce is not None:
             hist_allreduce([self._hist_flat[:self._hist_used]])   # every quantizer's soft histogram in one message
         ents = [c.entropy() for c in self.codecs]
         n = B * frame_length
         dsum = None  # running sum over later codecs of dL/dxin_j
+        pending = []
         first_needed = min([i for i, t in enumerate(trainable) if t], default=self.N)
         for i in range(self.N - 1, -1, -1):
             c = self.codecs[i]
@@ -926,6 +931,13 @@ class CascadeEngine:
                 dx = c.backward(ddec, c_quan[i], c_ent[i] * Bg, need_dx=need_dx)
             else:
                 raise NotImplementedError("a frozen codec between trainable ones is not a reference configuration")
+            if grad_allreduce is not None:
+                # data parallel: this codec's gradients are complete once its deferred weight gradients have run; send them
+                # now, under the backward pass of the earlier codecs (scope = one contiguous range of the flat buffer)
+                self.flush_block_wgrads()
+                self.side_join()
+                a, b = self.layout.scope_range(f"scope_{i + 1}")
+                pending.append(grad_allreduce(self.grads[a:b]))
             if need_dx:
                 if dsum is None:
                     dsum = dx
@@ -947,8 +959,14 @@ class CascadeEngine:
                                             gh.data_ptr() if c_ent_lpc != 0.0 else None, float(c_ent_lpc) * Bg, 0, None,
                                             self.g_ptr + 4 * self.lpc_alpha_off, self.g_ptr + 4 * self.lpc_bins_off,
                                             self.stream()), "lpc quantize_bwd")
+            if grad_allreduce is not None:
+                a, b = self.layout.scope_range("lpc_quan")
+                pending.append(grad_allreduce(self.grads[a:b]))
         self.flush_block_wgrads()
         self.side_join()
+        for w in pending:
+            if w is not None:
+                w.wait()
         return dict(time=self.time, freq=self.freq, quan=[c.quan for c in self.codecs], ent=ents, ent_lpc=ent_lpc,
                     quan_lpc=getattr(self, "lpc_quan", None))
 
@@ -1016,9 +1034,9 @@ class CascadeEngine:
                                    # the decision must not depend on a host value that can differ between ranks (tau):
                                    # every quan-op step exchanges the (tiny) histograms, no-quan steps never do
                                    hist_allreduce=(comm.allreduce_list if comm and cfg.get("global_entropy", True) and
-                                                   cfg.get("quan_op", cfg.get("slot", 1) == 1) else None))
-        if comm:
-            comm.allreduce(self.grads)   # SUM, not mean: the reference's vector loss sums over the batch (a18)
+                                                   cfg.get("quan_op", cfg.get("slot", 1) == 1) else None),
+                                   # SUM, not mean: the reference's vector loss sums over the batch (a18)
+                                   grad_allreduce=comm.allreduce_async if comm else None)
         scopes = [f"scope_{i + 1}" for i, t in enumerate(cfg["trainable"]) if t]
         train_lpc = cfg.get("train_lpc")
         if train_lpc is None:

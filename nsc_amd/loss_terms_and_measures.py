@@ -45,6 +45,27 @@ def mel_matrix_cat():
     return _MEL
 
 
+def mel_band_ranges(mel=None):
+    """int32 ranges for nsc_recon_loss_banded (include/nsc_hip.h): [184][2] = [k_lo, k_hi) of every column of the [257,184]
+    mel matrix, then [257][4][2] = [j_lo, j_hi) of every bin inside each bank.  Every non-zero lies inside its range;
+    zeros inside a range are simply multiplied like in the dense form."""
+    m = mel_matrix_cat() if mel is None else np.asarray(mel)
+    nz = m != 0
+    cols = np.zeros((m.shape[1], 2), np.int32)
+    for j in range(m.shape[1]):
+        k = np.flatnonzero(nz[:, j])
+        if k.size:
+            cols[j] = (k[0], k[-1] + 1)
+    edges = np.concatenate([[0], np.cumsum(MEL_BANKS)])
+    rows = np.zeros((m.shape[0], len(MEL_BANKS), 2), np.int32)
+    for k in range(m.shape[0]):
+        for b in range(len(MEL_BANKS)):
+            j = np.flatnonzero(nz[k, edges[b]:edges[b + 1]])
+            if j.size:
+                rows[k, b] = (edges[b] + j[0], edges[b] + j[-1] + 1)
+    return np.concatenate([cols.reshape(-1), rows.reshape(-1)]).astype(np.int32)
+
+
 # ------------------------------------------------------------------------------------------------
 # scalar helpers (pure host arithmetic, as in the reference)
 # ------------------------------------------------------------------------------------------------

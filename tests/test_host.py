@@ -273,3 +273,26 @@ def test_loss_configs_of_the_cli_follow_the_reference():
         ref = bench.step_cfg()
         for k in ("is_quan_on", "c_time", "c_freq", "c_quan", "c_ent", "trainable", "slot", "c_quan_lpc"):
             assert quan[k] == ref[k], k
+
+
+def test_mel_band_ranges_cover_every_nonzero():
+    """nsc_recon_loss_banded visits only [k_lo, k_hi) of a mel column and [j_lo, j_hi) of a bin within each bank: every
+    non-zero of the matrix must lie inside, and the ranges must stay inside their bank."""
+    import numpy as np
+    from nsc_amd.loss_terms_and_measures import MEL_BANKS, mel_band_ranges, mel_matrix_cat
+    m = mel_matrix_cat()
+    r = mel_band_ranges(m)
+    cols, rows = r[:2 * m.shape[1]].reshape(-1, 2), r[2 * m.shape[1]:].reshape(m.shape[0], len(MEL_BANKS), 2)
+    inside_c = np.zeros_like(m, dtype=bool)
+    inside_r = np.zeros_like(m, dtype=bool)
+    edges = np.concatenate([[0], np.cumsum(MEL_BANKS)])
+    for j, (lo, hi) in enumerate(cols):
+        inside_c[lo:hi, j] = True
+    for k in range(m.shape[0]):
+        for b in range(len(MEL_BANKS)):
+            lo, hi = rows[k, b]
+            assert lo == hi or (edges[b] <= lo and hi <= edges[b + 1])
+            inside_r[k, lo:hi] = True
+    nz = m != 0
+    assert not (nz & ~inside_c).any() and not (nz & ~inside_r).any()
+    assert inside_c.sum() < 0.06 * m.size and inside_r.sum() < 0.06 * m.size      # ~1.9 k of 47 k terms

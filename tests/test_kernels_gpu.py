@@ -196,9 +196,11 @@ def test_conv1d_dgrad_wgrad(lib, case):
     assert_close(dx.cpu().numpy().transpose(0, 2, 1), xt.grad.numpy(), what=f"dgrad {case}")
 
 
-def test_depthwise_fwd_bwd(lib):
+@pytest.mark.parametrize("shape", [(3, 100, 256, 9), (9, 50, 128, 9), (6, 20, 520, 5), (2, 12, 1024, 9)])
+def test_depthwise_fwd_bwd(lib, shape):
+    """(the weight gradient takes the four-frames-in-flight kernel up to T = 752, the frame-at-a-time one above that)"""
     rng = np.random.default_rng(11)
-    B, C_, T, K = 3, 100, 256, 9
+    B, C_, T, K = shape
     x = rng.standard_normal((B, T, C_)).astype(np.float32)
     Wd = rng.standard_normal((K, C_, 1)).astype(np.float32)
     dy = rng.standard_normal((B, T, C_)).astype(np.float32)
@@ -349,6 +351,16 @@ def test_recon_loss_and_rfft(lib):
     assert_close(to.cpu().numpy(), tl.detach().numpy(), what="time loss")
     assert_close(fo.cpu().numpy(), fl.detach().numpy(), tol=3e-4, what="freq loss")
     assert_close(g.cpu().numpy()[1:], dt.grad.numpy()[1:], tol=5e-4, what="recon grad")
+    # banded form (the engine's): only the non-zero band of the mel matrix is visited -> the very same floats
+    from nsc_amd.loss_terms_and_measures import mel_band_ranges
+    rg = torch.from_numpy(mel_band_ranges()).cuda()
+    to2, fo2, g2 = torch.empty(B, device="cuda"), torch.empty(B, device="cuda"), torch.empty((B, 512), device="cuda")
+    rc = lib.nsc_recon_loss_banded(P(dec), P(tgt), B, 60.0, 10.0, None, None, md.data_ptr(), mtd.data_ptr(), rg.data_ptr(),
+                                   to2.data_ptr(), fo2.data_ptr(), g2.data_ptr(), _st())
+    assert rc == 0, lib.nsc_last_error()
+    assert torch.equal(to2, to) and torch.equal(fo2, fo) and torch.equal(g2[1:], g[1:])
+    # frame 0 (decoded == target): its gradient is rounding noise of the two spectra divided by ~sqrt(1e-7); last-bit level
+    assert float((g2[0] - g[0]).abs().max()) <= 1e-6 * float(g[0].abs().max())
     # bare rFFT + cosine KAT
     sig = np.stack([np.cos(2 * np.pi * 5 * np.arange(512) / 512), rng.standard_normal(512)]).astype(np.float32)
     re, im, mag = (torch.empty((2, 257), device="cuda") for _ in range(3))
