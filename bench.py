@@ -182,8 +182,8 @@ def main():
             graph.replay() if graph is not None else step()
     run = (graph.replay if graph is not None else step)
     if graph is not None:
-        # the weight-gradient kernels overlap with the data-gradient chain on a side stream; hipGraph replay serialises
-        # part of that concurrency on this stack, so time both launch modes briefly and keep the faster one
+        # time both launch modes briefly (with --no-batch-conv-wgrad the per-conv weight gradients run on a side stream,
+        # which graph replay serialises on this stack)
         def trial(fn, n=4):
             fn(); torch.cuda.synchronize()
             t = time.perf_counter()
@@ -192,7 +192,7 @@ def main():
             torch.cuda.synchronize()
             return (time.perf_counter() - t) / n
         tg, te = trial(graph.replay), trial(step)
-        if te < tg:
+        if te < 0.98 * tg:      # the step is single-stream now: replay wins or ties; keep eager only if clearly faster
             run, graph = step, None
 
     comm.barrier()
