@@ -181,6 +181,14 @@ int nsc_channel_sum(const float* x, float* out, int B, int C, int T, int accumul
 int nsc_unshuffle2(const float* ys /*[B,C/2,2T]*/, float* y /*[B,C,T]*/, int B, int C, int T, void* stream);
 int nsc_transpose_last2(const float* x /*[B,R,Cc]*/, float* y /*[B,Cc,R]*/, int B, int R, int Cc, void* stream);
 int nsc_sum_all(const float* x, float* out /*accumulate [1]*/, long n, void* stream);
+/* up to NSC_SUM_MAXJ such sums in one launch (the bias gradients of the Cout = 1 convs of a step) */
+#define NSC_SUM_MAXJ 8
+typedef struct nsc_sum_job {
+  const float* x;
+  float* out;
+  long n;
+} nsc_sum_job;
+int nsc_sum_all_batch(const nsc_sum_job* jobs, int njobs, void* stream);
 
 /* ---- soft-to-hard scalar quantizer (replaces nn_core_operator.py:140-164 `scalar_softmax_quantization`,
  *      fused with loss_terms_and_measures.py:257-259 `quan_loss` and :262-267 `entropy_coding_loss` partials) ----
@@ -193,6 +201,14 @@ int nsc_quantize_fwd(const float* code, const float* alpha, const float* bins, f
 /* entropy from a (possibly all-reduced) histogram: ent[0] = -sum h log2(h+1e-7), h = hist/sum(hist);
  * ghist[k] = d ent / d hist[k]. */
 int nsc_entropy_from_hist(const float* hist, int nb, float* ent, float* ghist, void* stream);
+/* the same for up to NSC_ENT_MAXJ histograms in one launch (one per codec + the LSF quantizer's) */
+#define NSC_ENT_MAXJ 8
+typedef struct nsc_entropy_job {
+  const float* hist;
+  float *ent, *ghist;   /* both nullable */
+  int nb;
+} nsc_entropy_job;
+int nsc_entropy_from_hist_batch(const nsc_entropy_job* jobs, int njobs, void* stream);
 /* entropy_coding_loss evaluated one frame at a time (the reference's validation loop feeds batches of 1,
  * neural_speech_coding_module.py:685-722): ent[b] = entropy in bits of frame b's own soft histogram, p [B, L, nb]. */
 int nsc_frame_entropy(const float* p, int B, int L, int nb, float* ent, void* stream);

@@ -82,6 +82,18 @@ class ConvWgradJob(C.Structure):
                 ("flip_taps", C.c_int)]
 
 
+class SumJob(C.Structure):
+    """include/nsc_hip.h: struct nsc_sum_job"""
+    _fields_ = [("x", C.c_void_p), ("out", C.c_void_p), ("n", C.c_long)]
+
+
+class EntropyJob(C.Structure):
+    """include/nsc_hip.h: struct nsc_entropy_job"""
+    _fields_ = [("hist", C.c_void_p), ("ent", C.c_void_p), ("ghist", C.c_void_p), ("nb", C.c_int)]
+
+
+PROTOTYPES["nsc_sum_all_batch"] = [C.POINTER(SumJob), _I, _P]
+PROTOTYPES["nsc_entropy_from_hist_batch"] = [C.POINTER(EntropyJob), _I, _P]
 PROTOTYPES["nsc_gated_block_wgrad_batch"] = [C.POINTER(BlockWgradJob), _I, _I, _I, _I, _P, _L, _P]
 PROTOTYPES["nsc_conv1d_wgrad_batch"] = [C.POINTER(ConvWgradJob), _I, _P, _L, _P]
 EXPORTS = sorted(list(PROTOTYPES) + ["nsc_version", "nsc_last_error", "nsc_gated_block_wgrad_workspace",

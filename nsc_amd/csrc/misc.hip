@@ -347,6 +347,37 @@ __global__ __launch_bounds__(256) void sum_all_kernel(const float* __restrict__ 
   __syncthreads();
   if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
 }
+// several sums in one launch: blockIdx.y = job (the bias gradients of a step's Cout = 1 convs)
+struct SumBatch {
+  nsc_sum_job j[NSC_SUM_MAXJ];
+};
+__global__ __launch_bounds__(256) void sum_all_batch_kernel(SumBatch t) {
+  __shared__ float red[4];
+  nsc_sum_job jb = t.j[0];
+#pragma unroll
+  for (int q = 1; q < NSC_SUM_MAXJ; ++q)
+    if (q == (int)blockIdx.y) jb = t.j[q];
+  float s = 0.f;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < jb.n; e += (long)gridDim.x * blockDim.x) s += jb.x[e];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0 && (long)blockIdx.x * blockDim.x < jb.n) atomicAdd(jb.out, red[0] + red[1] + red[2] + red[3]);
+}
+extern "C" int nsc_sum_all_batch(const nsc_sum_job* jobs, int njobs, void* stream) {
+  NSC_REQUIRE(jobs && njobs > 0 && njobs <= NSC_SUM_MAXJ, NSC_ERR_BAD_ARG, "nsc_sum_all_batch: 1..%d jobs", NSC_SUM_MAXJ);
+  SumBatch t;
+  long nmax = 0;
+  for (int q = 0; q < NSC_SUM_MAXJ; ++q) {
+    t.j[q] = jobs[q < njobs ? q : 0];
+    NSC_REQUIRE(t.j[q].x && t.j[q].out && t.j[q].n > 0, NSC_ERR_BAD_ARG, "nsc_sum_all_batch: job %d: bad args", q);
+    nmax = std::max(nmax, t.j[q].n);
+  }
+  hipLaunchKernelGGL(sum_all_batch_kernel, dim3(std::min<long>(256, nsc_cdiv(nmax, 1024)), njobs), dim3(256), 0,
+                     (hipStream_t)stream, t);
+  NSC_CHECK_LAUNCH("sum_all_batch");
+  return NSC_OK;
+}
 extern "C" int nsc_sum_all(const float* x, float* out, long n, void* stream) {
   NSC_REQUIRE(x && out && n > 0, NSC_ERR_BAD_ARG, "nsc_sum_all: bad args");
   hipLaunchKernelGGL(sum_all_kernel, dim3(std::min<long>(256, nsc_cdiv(n, 1024))), dim3(256), 0, (hipStream_t)stream,

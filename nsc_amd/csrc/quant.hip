@@ -399,8 +399,25 @@ extern "C" int nsc_quantize_bwd(const float* code, const float* alpha, const flo
 }
 
 // entropy_coding_loss from the batch histogram (loss_terms_and_measures.py:262-267) + its gradient wrt hist
+__device__ __forceinline__ void entropy_from_hist_body(const float* __restrict__ hist, int nb, float* __restrict__ ent,
+                                                       float* __restrict__ ghist);
 __global__ __launch_bounds__(256) void entropy_from_hist_kernel(const float* __restrict__ hist, int nb,
                                                                 float* __restrict__ ent, float* __restrict__ ghist) {
+  entropy_from_hist_body(hist, nb, ent, ghist);
+}
+// several quantizers' histograms in one launch (one workgroup each): a step has one per codec + the LSF quantizer's
+struct EntropyBatch {
+  nsc_entropy_job j[NSC_ENT_MAXJ];
+};
+__global__ __launch_bounds__(256) void entropy_from_hist_batch_kernel(EntropyBatch t) {
+  nsc_entropy_job jb = t.j[0];
+#pragma unroll
+  for (int q = 1; q < NSC_ENT_MAXJ; ++q)
+    if (q == (int)blockIdx.x) jb = t.j[q];
+  entropy_from_hist_body(jb.hist, jb.nb, jb.ent, jb.ghist);
+}
+__device__ __forceinline__ void entropy_from_hist_body(const float* __restrict__ hist, int nb, float* __restrict__ ent,
+                                                       float* __restrict__ ghist) {
   __shared__ float red[4];
   __shared__ float bc[2];
   const int tid = threadIdx.x;
@@ -490,6 +507,18 @@ extern "C" int nsc_frame_entropy(const float* p, int B, int L, int nb, float* en
   NSC_REQUIRE(p && ent && B > 0 && L > 0 && nb > 0, NSC_ERR_BAD_ARG, "nsc_frame_entropy: bad args");
   hipLaunchKernelGGL(frame_entropy_kernel, dim3(B), dim3(256), (nb + 256) * sizeof(float), (hipStream_t)stream, p, L, nb, ent);
   NSC_CHECK_LAUNCH("frame_entropy");
+  return NSC_OK;
+}
+
+extern "C" int nsc_entropy_from_hist_batch(const nsc_entropy_job* jobs, int njobs, void* stream) {
+  NSC_REQUIRE(jobs && njobs > 0 && njobs <= NSC_ENT_MAXJ, NSC_ERR_BAD_ARG, "nsc_entropy_from_hist_batch: 1..%d jobs", NSC_ENT_MAXJ);
+  EntropyBatch t;
+  for (int q = 0; q < NSC_ENT_MAXJ; ++q) {
+    t.j[q] = jobs[q < njobs ? q : 0];
+    NSC_REQUIRE(t.j[q].hist && t.j[q].nb > 0, NSC_ERR_BAD_ARG, "nsc_entropy_from_hist_batch: job %d: bad args", q);
+  }
+  hipLaunchKernelGGL(entropy_from_hist_batch_kernel, dim3(njobs), dim3(256), 0, (hipStream_t)stream, t);
+  NSC_CHECK_LAUNCH("entropy_from_hist_batch");
   return NSC_OK;
 }
 

@@ -174,7 +174,7 @@ class _Conv:
             d = self.wgrad_desc()
             if self.Cout == 1:
                 e.defer_conv_wgrad(d, dz, x, dw, None, 1)
-                check(e.lib.nsc_sum_all(dz.data_ptr(), db, dz.numel(), e.stream()), "bias grad")
+                e._sum_jobs.append(_lib.SumJob(dz.data_ptr(), db, dz.numel()))     # bias gradient: one launch for all of them
             else:
                 e.defer_conv_wgrad(d, x, dz, dw, db, 0)
             return
@@ -556,6 +556,7 @@ class CascadeEngine:
         self._bufs = {}
         self._wg_jobs, self._wg_keep, self._wg_flops = [], [], 0.0
         self._cw_jobs, self._cw_flops = [], 0.0
+        self._sum_jobs = []
         if self.lpc:  # 'lpc_quan' scope is created before scope_1 (nsc_module:993-996)
             self.lpc_alpha_off = self.layout.add("lpc_quan/alpha", ())
             self.lpc_bins_off = self.layout.add("lpc_quan/bins", (len(lpc_coeff_lsf_bins),))
@@ -655,6 +656,10 @@ class CascadeEngine:
         self._wg_keep += [x, dz]
 
     def flush_conv_wgrads(self):
+        for lo in range(0, len(self._sum_jobs), 8):
+            chunk = self._sum_jobs[lo:lo + 8]
+            check(self.lib.nsc_sum_all_batch((_lib.SumJob * len(chunk))(*chunk), len(chunk), self.stream()), "sum_all_batch")
+        self._sum_jobs = []
         if not self._cw_jobs:
             return
         n = len(self._cw_jobs)
@@ -909,7 +914,7 @@ class CascadeEngine:
                                              G.data_ptr(), self.stream()), "recon_loss")
         if hist_allreduce is not None:
             hist_allreduce([self._hist_flat[:self._hist_used]])   # every quantizer's soft histogram in one message
-        ents = [c.entropy() for c in self.codecs]
+        ents = self.entropies()
         n = B * frame_length
         dsum = None  # running sum over later codecs of dL/dxin_j
         pending = []
@@ -950,9 +955,7 @@ class CascadeEngine:
             train_lpc = c_quan_lpc != 0.0 or c_ent_lpc != 0.0
         if self.lpc and train_lpc and hasattr(self, "lpc_x"):
             L, nb = self.lpc_x.shape[1], len(lpc_coeff_lsf_bins)
-            ent = ent_lpc = self.buf("lpc.ent", (1,))
-            gh = self.buf("lpc.ghist", (nb,))
-            check(self.lib.nsc_entropy_from_hist(self.lpc_hist.data_ptr(), nb, ent.data_ptr(), gh.data_ptr(), self.stream()), "lpc ent")
+            ent_lpc, gh = self.buf("lpc.ent", (1,)), self.buf("lpc.ghist", (nb,))      # filled by entropies() above
             check(self.lib.nsc_quantize_bwd(self.lpc_x.data_ptr(), self.p_ptr + 4 * self.lpc_alpha_off,
                                             self.p_ptr + 4 * self.lpc_bins_off, self.codecs[0].is_quan_on,
                                             self.codecs[0].soft, B, L, nb, None, None, float(c_quan_lpc),
@@ -969,6 +972,24 @@ class CascadeEngine:
                 w.wait()
         return dict(time=self.time, freq=self.freq, quan=[c.quan for c in self.codecs], ent=ents, ent_lpc=ent_lpc,
                     quan_lpc=getattr(self, "lpc_quan", None))
+
+    def entropies(self):
+        """entropy_coding_loss of every quantizer from its (possibly all-reduced) batch histogram, and d ent / d hist, in ONE
+        launch: the codecs' (-> c.ent, c.ghist; returned) and, on the LPC path, the LSF quantizer's (-> lpc.ent, lpc.ghist)."""
+        jobs = []
+        for c in self.codecs:
+            c.ent = self.buf(c.scope + ".ent", (1,))
+            c.ghist = self.buf(c.scope + ".ghist", (c.nb,))
+            jobs.append(_lib.EntropyJob(c.hist.data_ptr(), c.ent.data_ptr(), c.ghist.data_ptr(), c.nb))
+        if self.lpc and hasattr(self, "lpc_x"):
+            nb = len(lpc_coeff_lsf_bins)
+            jobs.append(_lib.EntropyJob(self.lpc_hist.data_ptr(), self.buf("lpc.ent", (1,)).data_ptr(),
+                                        self.buf("lpc.ghist", (nb,)).data_ptr(), nb))
+        for lo in range(0, len(jobs), 8):
+            chunk = jobs[lo:lo + 8]
+            check(self.lib.nsc_entropy_from_hist_batch((_lib.EntropyJob * len(chunk))(*chunk), len(chunk), self.stream()),
+                  "entropy_from_hist_batch")
+        return [c.ent for c in self.codecs]
 
     def frame_entropies(self, x, lpc_x=None):
         """Per-frame entropy (bits) of every codec's soft assignment, as the reference's validation loop measures it:

@@ -796,3 +796,37 @@ def test_stride2_dgrad_polyphase_equals_autograd(lib):
     assert rc == 0, lib.nsc_last_error()
     ref = xt.grad.numpy() * np.where(aux > 0, 1.0, 0.2)
     assert_close(dx.cpu().numpy().transpose(0, 2, 1), ref, tol=2e-4, what="polyphase stride-2 dgrad")
+
+
+def test_sum_all_batch_and_entropy_batch_equal_single_launches(lib):
+    """nsc_sum_all_batch / nsc_entropy_from_hist_batch (one launch for a step's bias sums / quantizer entropies) give what
+    the per-tensor entries give; the entropy values are checked against the oracle."""
+    from nsc_amd._lib import EntropyJob, SumJob
+    rng = np.random.default_rng(91)
+    xs = [dev(rng.standard_normal(n).astype(np.float32)) for n in (65536, 300, 1, 32768, 70000)]
+    one = [torch.full((1,), 0.25, device="cuda") for _ in xs]
+    bat = [torch.full((1,), 0.25, device="cuda") for _ in xs]
+    for x, o in zip(xs, one):
+        assert lib.nsc_sum_all(x.data_ptr(), o.data_ptr(), x.numel(), _st()) == 0
+    jobs = (SumJob * len(xs))(*[SumJob(x.data_ptr(), o.data_ptr(), x.numel()) for x, o in zip(xs, bat)])
+    assert lib.nsc_sum_all_batch(jobs, len(xs), _st()) == 0, lib.nsc_last_error()
+    torch.cuda.synchronize()
+    for x, a, b in zip(xs, one, bat):
+        want = float(x.double().sum()) + 0.25
+        assert abs(float(b) - want) <= 2e-5 * float(x.abs().sum()) + 1e-6 and abs(float(a) - float(b)) <= 2e-5 * float(x.abs().sum())
+    hists = [dev((rng.random(nb) * 50 + 0.01).astype(np.float32)) for nb in (32, 256, 32, 7)]
+    ent1, gh1, ent2, gh2 = [], [], [], []
+    for h in hists:
+        e, g = torch.empty(1, device="cuda"), torch.empty(h.numel(), device="cuda")
+        assert lib.nsc_entropy_from_hist(h.data_ptr(), h.numel(), e.data_ptr(), g.data_ptr(), _st()) == 0
+        ent1.append(e); gh1.append(g)
+        ent2.append(torch.empty(1, device="cuda")); gh2.append(torch.empty(h.numel(), device="cuda"))
+    ej = (EntropyJob * len(hists))(*[EntropyJob(h.data_ptr(), e.data_ptr(), g.data_ptr(), h.numel())
+                                     for h, e, g in zip(hists, ent2, gh2)])
+    assert lib.nsc_entropy_from_hist_batch(ej, len(hists), _st()) == 0, lib.nsc_last_error()
+    torch.cuda.synchronize()
+    for h, e1, g1, e2, g2 in zip(hists, ent1, gh1, ent2, gh2):
+        assert torch.equal(e1, e2) and torch.equal(g1, g2)
+        hn = h.cpu().numpy().astype(np.float64)
+        pr = hn / hn.sum()
+        assert abs(float(e2) - float(-(pr * np.log2(pr + 1e-7)).sum())) < 1e-4
