@@ -155,6 +155,18 @@ int nsc_depthwise_fwd(const float* x, const float* wd /*[K,C]*/, float* y, int B
 int nsc_depthwise_bwd(const float* x, const float* wd, const float* dy, float* dx, float* dwd /*accumulate*/,
                       int B, int C, int T, int K, void* stream);
 
+/* ---- the decoder's whole up-sampling stage in one kernel per direction (replaces conv1d_depth = SeparableConv1D,
+ *      nn_core_operator.py:17-21, + activation + sub-pixel shuffle, neural_speech_coding_module.py:168-181) ----
+ * fwd: y [B,C/2,2T] = shuffle(act(wp . depthwise9(x) + bias)); x [B,C,T], wd [9,C] depthwise taps, wp [C,C] pointwise
+ *      kernel ([1,Cin,Cout] as stored), dwo (nullable) [B,C,T] receives the depthwise output the backward pass needs.
+ * bwd: from dz [B,C/2,2T] = dL/d(pre-activation of y): dzp [B,C,T] (dz un-shuffled: input of the pointwise weight
+ *      gradient), ddw [B,C,T] (gradient at the depthwise output: input of the depthwise weight gradient) and
+ *      dx [B,C,T].  K = 9, C in {100, 50}; other shapes: compose nsc_depthwise_* / nsc_conv1d_* / nsc_unshuffle2. */
+int nsc_upsample_fwd(const float* x, const float* wd, const float* wp, const float* bias, float* dwo, float* y,
+                     int B, int C, int T, int K, int act, void* stream);
+int nsc_upsample_bwd(const float* dz, const float* wd, const float* wp, float* dzp, float* ddw, float* dx,
+                     int B, int C, int T, int K, void* stream);
+
 /* ---- gate (tf.multiply(left, tanh-right), nn_core_operator.py:100) on a fused [B,2n,T] pre-activation ----
  * fwd: a[:, n:] <- tanh(a[:, n:]) in place; g = a[:, :n] * a[:, n:].   bwd: da from dg and the saved a. */
 int nsc_gate_fwd(float* a, float* g, int B, int n, int T, void* stream);

@@ -56,6 +56,8 @@ PROTOTYPES = {
     "nsc_unshuffle2": [_P, _P, _I, _I, _I, _P],
     "nsc_transpose_last2": [_P, _P, _I, _I, _I, _P],
     "nsc_sum_all": [_P, _P, _L, _P],
+    "nsc_upsample_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "nsc_upsample_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "nsc_quantize_fwd": [_P, _P, _P, _F, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "nsc_entropy_from_hist": [_P, _I, _P, _P, _P],
     "nsc_quantize_bwd": [_P, _P, _P, _F, _I, _I, _I, _I, _P, _P, _F, _P, _F, _I, _P, _P, _P, _P],

@@ -454,10 +454,18 @@ class _Codec:
             for blk in blocks:
                 h = blk.fwd(h)
             dwo = e.buf(f"{s}.dw{i}", (B, C_, T))
-            check(e.lib.nsc_depthwise_fwd(h.data_ptr(), e.p_ptr + 4 * dw_off, dwo.data_ptr(), B, C_, T, 9, e.stream()),
-                  "depthwise_fwd")
             up = e.buf(f"{s}.up{i}", (B, C_ // 2, T * 2))
-            pw.fwd(dwo, up, "lrelu", out_mode=1)
+            if e.fused_up and C_ in (100, 50):
+                # depthwise -> pointwise -> leaky-relu -> shuffle in one kernel (dwo kept only when a backward pass follows)
+                tok = e.prof_begin("upsample", pw.flops())
+                check(e.lib.nsc_upsample_fwd(h.data_ptr(), e.p_ptr + 4 * dw_off, e.p_ptr + 4 * pw.w_off, e.p_ptr + 4 * pw.b_off,
+                                             dwo.data_ptr() if e.keep_activations else None, up.data_ptr(), B, C_, T, 9,
+                                             KIND_ACT["lrelu"], e.stream()), "upsample_fwd")
+                e.prof_end(tok)
+            else:
+                check(e.lib.nsc_depthwise_fwd(h.data_ptr(), e.p_ptr + 4 * dw_off, dwo.data_ptr(), B, C_, T, 9, e.stream()),
+                      "depthwise_fwd")
+                pw.fwd(dwo, up, "lrelu", out_mode=1)
             self.up_saved.append((h, dwo, up))
             h = up
         for blk in self.dec_tail:
@@ -492,13 +500,24 @@ class _Codec:
             blocks, dw_off, pw, T, C_ = self.dec_stages[i]
             xin, dwo, up = self.up_saved[i]
             dzp = e.buf(f"{s}.dzp{i}", (B, C_, T))
-            check(e.lib.nsc_unshuffle2(dz.data_ptr(), dzp.data_ptr(), B, C_, T, e.stream()), "unshuffle2")
-            pw.wgrad(dwo, dzp)
             ddw = e.buf(f"{s}.ddw{i}", (B, C_, T))
-            pw.dgrad(dzp, ddw)
-            dz = e.buf(f"{s}.dxup{i}", (B, C_, T))
-            check(e.lib.nsc_depthwise_bwd(xin.data_ptr(), e.p_ptr + 4 * dw_off, ddw.data_ptr(), dz.data_ptr(),
-                                          e.g_ptr + 4 * dw_off, B, C_, T, 9, e.stream()), "depthwise_bwd")
+            dxu = e.buf(f"{s}.dxup{i}", (B, C_, T))
+            if e.fused_up and C_ in (100, 50):
+                # un-shuffle -> pointwise^T -> depthwise^T in one kernel; the two weight gradients read dzp / ddw afterwards
+                tok = e.prof_begin("upsample", pw.flops())
+                check(e.lib.nsc_upsample_bwd(dz.data_ptr(), e.p_ptr + 4 * dw_off, e.p_ptr + 4 * pw.w_off, dzp.data_ptr(),
+                                             ddw.data_ptr(), dxu.data_ptr(), B, C_, T, 9, e.stream()), "upsample_bwd")
+                e.prof_end(tok)
+                pw.wgrad(dwo, dzp)
+                check(e.lib.nsc_depthwise_bwd(xin.data_ptr(), e.p_ptr + 4 * dw_off, ddw.data_ptr(), None,
+                                              e.g_ptr + 4 * dw_off, B, C_, T, 9, e.stream()), "depthwise wgrad")
+            else:
+                check(e.lib.nsc_unshuffle2(dz.data_ptr(), dzp.data_ptr(), B, C_, T, e.stream()), "unshuffle2")
+                pw.wgrad(dwo, dzp)
+                pw.dgrad(dzp, ddw)
+                check(e.lib.nsc_depthwise_bwd(xin.data_ptr(), e.p_ptr + 4 * dw_off, ddw.data_ptr(), dxu.data_ptr(),
+                                              e.g_ptr + 4 * dw_off, B, C_, T, 9, e.stream()), "depthwise_bwd")
+            dz = dxu
             for j in range(len(blocks) - 1, -1, -1):
                 if j > 0:
                     in_kind = "lrelu"
@@ -637,6 +656,7 @@ class CascadeEngine:
     # block width (nsc_gated_block_wgrad_batch): per-block launches walk only 2-4 tiles per workgroup at batch 128, so
     # their prologue, accumulator flush and slab reduction cost more than the MFMA work itself.
     poly_dgrad = True    # stride-2 data gradients in polyphase form (half the MFMAs of the zero-upsampled form)
+    fused_up = True      # decoder up-sampling stage as one kernel per direction (nsc_upsample_fwd / _bwd)
     batch_wgrad = True
     batch_cin1_wgrad = True   # the one-input-channel decoder blocks join the batched launch too (False: per-conv launches)
     batch_conv_wgrad = True   # the same for the convs outside gated blocks (nsc_conv1d_wgrad_batch).  With the block kernels

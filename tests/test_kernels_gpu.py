@@ -830,3 +830,45 @@ def test_sum_all_batch_and_entropy_batch_equal_single_launches(lib):
         hn = h.cpu().numpy().astype(np.float64)
         pr = hn / hn.sum()
         assert abs(float(e2) - float(-(pr * np.log2(pr + 1e-7)).sum())) < 1e-4
+
+
+@pytest.mark.parametrize("shape", [(3, 100, 256), (2, 50, 128), (2, 100, 96), (1, 50, 520)])
+def test_upsample_stage_fwd_bwd(lib, shape):
+    """nsc_upsample_fwd / nsc_upsample_bwd (depthwise k9 -> pointwise -> leaky-relu -> sub-pixel shuffle in one kernel, and
+    its data-path backward) vs float64 autograd of the same three ops; incl. a ragged last tile (T = 96, 520)."""
+    import torch.nn.functional as F
+    B, C_, T = shape
+    rng = np.random.default_rng(500 + C_ + T)
+    x = rng.standard_normal((B, C_, T)).astype(np.float32)
+    wd = (0.3 * rng.standard_normal((9, C_))).astype(np.float32)            # depthwise_kernel [9, C, 1]
+    wp = (0.1 * rng.standard_normal((C_, C_))).astype(np.float32)           # pointwise_kernel [1, Cin, Cout]
+    bias = (0.1 * rng.standard_normal(C_)).astype(np.float32)
+    dz = rng.standard_normal((B, C_ // 2, 2 * T)).astype(np.float32)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    dwo = F.conv1d(xt, torch.tensor(wd.T.copy(), dtype=torch.float64).reshape(C_, 1, 9), padding=4, groups=C_)
+    dwo.retain_grad()
+    pre = torch.einsum("bit,io->bot", dwo, torch.tensor(wp, dtype=torch.float64)) + torch.tensor(bias, dtype=torch.float64)[None, :, None]
+    shuf = lambda z: z.reshape(B, C_ // 2, 2, T).permute(0, 1, 3, 2).reshape(B, C_ // 2, 2 * T)   # [b, oc, 2t + par] = z[b, 2oc + par, t]
+    ypre = shuf(pre)
+    (ypre * torch.tensor(dz, dtype=torch.float64)).sum().backward()
+    want_y = F.leaky_relu(ypre, 0.2).detach().numpy()
+    xd, wdd, wpd, bd, dzd = dev(x), dev(wd), dev(wp), dev(bias), dev(dz)
+    y = torch.full((B, C_ // 2, 2 * T), float("nan"), device="cuda")
+    dw_out = torch.full((B, C_, T), float("nan"), device="cuda")
+    rc = lib.nsc_upsample_fwd(xd.data_ptr(), wdd.data_ptr(), wpd.data_ptr(), bd.data_ptr(), dw_out.data_ptr(), y.data_ptr(),
+                              B, C_, T, 9, 2, _st())
+    assert rc == 0, lib.nsc_last_error()
+    assert_close(dw_out.cpu().numpy(), dwo.detach().numpy(), what=f"upsample depthwise out {shape}")
+    assert_close(y.cpu().numpy(), want_y, what=f"upsample y {shape}")
+    y2 = torch.full_like(y, float("nan"))
+    assert lib.nsc_upsample_fwd(xd.data_ptr(), wdd.data_ptr(), wpd.data_ptr(), bd.data_ptr(), None, y2.data_ptr(), B, C_, T, 9, 2,
+                                _st()) == 0
+    assert torch.equal(y2, y)                                                  # inference form: no saved depthwise output
+    dzp, ddw, dx = (torch.full((B, C_, T), float("nan"), device="cuda") for _ in range(3))
+    rc = lib.nsc_upsample_bwd(dzd.data_ptr(), wdd.data_ptr(), wpd.data_ptr(), dzp.data_ptr(), ddw.data_ptr(), dx.data_ptr(),
+                              B, C_, T, 9, _st())
+    assert rc == 0, lib.nsc_last_error()
+    want_dzp = dz.reshape(B, C_ // 2, T, 2).transpose(0, 1, 3, 2).reshape(B, C_, T)
+    assert np.array_equal(dzp.cpu().numpy(), want_dzp)
+    assert_close(ddw.cpu().numpy(), dwo.grad.numpy(), what=f"upsample ddw {shape}")
+    assert_close(dx.cpu().numpy(), xt.grad.numpy(), what=f"upsample dx {shape}")
