@@ -41,12 +41,11 @@ struct UpBwdArgs {
 // RT row tiles of 16 output channels, NK k-steps of 4 input channels (C = 100: 7, 25;  C = 50: 4, 13).
 // RT == 7: wave w < 7 owns row tile w and every column tile; RT == 4: wave = (row tile w & 3, column half w >> 2).
 template <int RT, int NK>
-__global__ __launch_bounds__(512, 4) void upsample_fwd_kernel(UpFwdArgs a, int tpf) {
+__global__ __launch_bounds__(512, 4) void upsample_fwd_kernel(UpFwdArgs a, int tpf, int skip) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int C4 = 4 * NK, NQ = (C4 + 7) / 8;
   float* xs = sm;                // [C4][ULD]  x on [t0 - 4, t0 + 68); later the output tile os [C][ULO]
   float* dws = xs + C4 * ULD;    // [C4][ULD]  depthwise output on [t0, t0 + 64): B operand of the pointwise MFMAs
-  float* wds = dws + C4 * ULD;   // [9][C4]    depthwise taps
   const int C = a.C, T = a.T;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -64,8 +63,8 @@ __global__ __launch_bounds__(512, 4) void upsample_fwd_kernel(UpFwdArgs a, int t
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int so = (b * C + min(wave + 8 * q, C - 1)) * T * 4;
-      px[q][0] = up_bld(sx, va, so);
-      px[q][1] = up_bld(sx, vb, so);
+      px[q][0] = (skip & 1) ? 1.f : up_bld(sx, va, so);
+      px[q][1] = (skip & 1) ? 1.f : up_bld(sx, vb, so);
     }
   }
   // ---- this wave's fragments of the pointwise kernel wp [ci][co] (A: row = co, k = ci) and its bias ----
@@ -74,13 +73,9 @@ __global__ __launch_bounds__(512, 4) void upsample_fwd_kernel(UpFwdArgs a, int t
   constexpr int NC = RT == 7 ? 4 : 2;
   float ar[NK], br[4];
 #pragma unroll
-  for (int u = 0; u < NK; ++u) ar[u] = a.wp[min(4 * u + kq, C - 1) * C + min(16 * rt + l15, C - 1)];   // ci >= C: zero B rows
+  for (int u = 0; u < NK; ++u) ar[u] = (skip & 16) ? 0.5f : a.wp[min(4 * u + kq, C - 1) * C + min(16 * rt + l15, C - 1)];   // ci >= C: zero B rows
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) br[reg] = a.bias ? a.bias[min(16 * rt + 4 * kq + reg, C - 1)] : 0.f;
-  for (int e = tid; e < UK * C4; e += 512) {
-    const int k = e / C4, c = e - k * C4;
-    wds[e] = c < C ? a.wd[k * C + c] : 0.f;
-  }
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     const int r = wave + 8 * q;
@@ -89,20 +84,22 @@ __global__ __launch_bounds__(512, 4) void upsample_fwd_kernel(UpFwdArgs a, int t
       if (lane < 8) xs[r * ULD + 64 + lane] = r < C ? px[q][1] : 0.f;
     }
   }
-  __syncthreads();
+  nsc_lds_barrier();
   // ---- depthwise stage, LDS -> LDS (+ the copy the backward pass needs) ----
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     const int r = wave + 8 * q;
-    if (r < C4) {
+    if (r < C4 && !(skip & 2)) {
+      // the row's nine taps are wave-uniform: scalar loads (s_load through the constant cache), no LDS table
+      const float* wr = a.wd + min(r, C - 1);
       float v = 0.f;
 #pragma unroll
-      for (int k = 0; k < UK; ++k) v = fmaf(xs[r * ULD + lane + k], wds[k * C4 + r], v);
-      dws[r * ULD + lane] = v;                        // rows >= C: taps and x are zero
+      for (int k = 0; k < UK; ++k) v = fmaf(xs[r * ULD + lane + k], wr[k * C], v);
+      dws[r * ULD + lane] = v;                        // rows >= C: x is zero
       if (a.dwo && r < C && t0 + lane < T) a.dwo[((long)b * C + r) * T + t0 + lane] = v;
     }
   }
-  __syncthreads();
+  nsc_lds_barrier();
   // ---- pointwise conv on the matrix pipe ----
   float* os = xs;                                      // the x tile is dead
   if (RT != 7 || wave < 7) {
@@ -110,6 +107,7 @@ __global__ __launch_bounds__(512, 4) void upsample_fwd_kernel(UpFwdArgs a, int t
 #pragma unroll
     for (int c = 0; c < NC; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float* bb = dws + kq * ULD + cb + l15;
+    if (!(skip & 4))
 #pragma unroll
     for (int u = 0; u < NK; ++u)
 #pragma unroll
@@ -126,7 +124,7 @@ __global__ __launch_bounds__(512, 4) void upsample_fwd_kernel(UpFwdArgs a, int t
         }
       }
   }
-  __syncthreads();
+  nsc_lds_barrier();
   // ---- sub-pixel shuffle on the way out: output row oc interleaves channels 2 oc, 2 oc + 1 in time (256-B lines) ----
   const int Ch = C >> 1;
   for (int oc = wave; oc < Ch; oc += 8) {
@@ -134,7 +132,7 @@ __global__ __launch_bounds__(512, 4) void upsample_fwd_kernel(UpFwdArgs a, int t
     for (int hb = 0; hb < 2; ++hb) {
       const int tl2 = hb * 64 + lane, par = tl2 & 1, tl = tl2 >> 1;
       const int t2 = 2 * t0 + tl2;
-      if (t2 < 2 * T) a.y[((long)b * Ch + oc) * (2L * T) + t2] = os[(2 * oc + par) * ULO + tl];
+      if (t2 < 2 * T && !(skip & 8)) a.y[((long)b * Ch + oc) * (2L * T) + t2] = os[(2 * oc + par) * ULO + tl];
     }
   }
 }
@@ -150,7 +148,6 @@ __global__ __launch_bounds__(512, 4) void upsample_bwd_kernel(UpBwdArgs a, int t
   constexpr int C4 = 4 * NK, NQ = (C4 + 7) / 8, NQH = (C4 / 2 + 7) / 8;
   float* dzs = sm;               // [C4][ULD]  dzp on [t0 - 4, t0 + 76): rows = co (B operand)
   float* dds = dzs + C4 * ULD;   // [C4][ULD]  ddw on the same columns: rows = ci
-  float* wds = dds + C4 * ULD;   // [9][C4]
   const int C = a.C, T = a.T, Ch = C >> 1;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -175,10 +172,6 @@ __global__ __launch_bounds__(512, 4) void upsample_bwd_kernel(UpBwdArgs a, int t
   float ar[NK];
 #pragma unroll
   for (int u = 0; u < NK; ++u) ar[u] = a.wp[min(16 * rt + l15, C - 1) * C + min(4 * u + kq, C - 1)];   // A: row = ci, k = co
-  for (int e = tid; e < UK * C4; e += 512) {
-    const int k = e / C4, c = e - k * C4;
-    wds[e] = c < C ? a.wd[k * C + c] : 0.f;
-  }
   for (int e = tid; e < (C4 - C) * ULD; e += 512) dzs[C * ULD + e] = 0.f;      // k rows >= C multiply zeros
 #pragma unroll
   for (int q = 0; q < NQH; ++q) {
@@ -191,7 +184,7 @@ __global__ __launch_bounds__(512, 4) void upsample_bwd_kernel(UpBwdArgs a, int t
       }
     }
   }
-  __syncthreads();
+  nsc_lds_barrier();
   // ---- un-shuffled copy out (this tile's own 64 columns) ----
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
@@ -224,16 +217,17 @@ __global__ __launch_bounds__(512, 4) void upsample_bwd_kernel(UpBwdArgs a, int t
   } else {
     mma(std::integral_constant<int, 2>{}, 3);      // column tiles 3, 4
   }
-  __syncthreads();
+  nsc_lds_barrier();
   // ---- ddw copy out + depthwise^T ----
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     const int r = wave + 8 * q;
     if (r < C && t0 + lane < T) {
       const float* dr = dds + r * ULD + lane;
+      const float* wr = a.wd + r;                      // wave-uniform taps: scalar loads
       float v = 0.f;
 #pragma unroll
-      for (int k = 0; k < UK; ++k) v = fmaf(dr[8 - k], wds[k * C4 + r], v);
+      for (int k = 0; k < UK; ++k) v = fmaf(dr[8 - k], wr[k * C], v);
       const long o = ((long)b * C + r) * T + t0 + lane;
       a.ddw[o] = dr[4];
       a.dx[o] = v;
@@ -243,18 +237,19 @@ __global__ __launch_bounds__(512, 4) void upsample_bwd_kernel(UpBwdArgs a, int t
 
 template <int RT, int NK>
 int launch_up_fwd(const UpFwdArgs& a, hipStream_t st) {
-  const size_t smem = ((size_t)2 * 4 * NK * ULD + (size_t)UK * 4 * NK) * sizeof(float);
+  const size_t smem = (size_t)2 * 4 * NK * ULD * sizeof(float);
   auto kern = upsample_fwd_kernel<RT, NK>;
   static const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "upsample_fwd: smem attr: %s", hipGetErrorString(e));
   const int tpf = nsc_cdiv(a.T, UTT);
-  hipLaunchKernelGGL(kern, dim3(a.B * tpf), dim3(512), smem, st, a, tpf);
+  static const int skip = NSC_PROBE_INT("NSC_UP_SKIP", 0);   // timing probe (PROBES build only)
+  hipLaunchKernelGGL(kern, dim3(a.B * tpf), dim3(512), smem, st, a, tpf, skip);
   NSC_CHECK_LAUNCH("upsample_fwd");
   return NSC_OK;
 }
 template <int RT, int NK>
 int launch_up_bwd(const UpBwdArgs& a, hipStream_t st) {
-  const size_t smem = ((size_t)2 * 4 * NK * ULD + (size_t)UK * 4 * NK) * sizeof(float);
+  const size_t smem = (size_t)2 * 4 * NK * ULD * sizeof(float);
   auto kern = upsample_bwd_kernel<RT, NK>;
   static const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "upsample_bwd: smem attr: %s", hipGetErrorString(e));
