@@ -264,12 +264,36 @@ __global__ __launch_bounds__(256) void quantize_bwd_kernel(
 #pragma unroll
     for (int j = 0; j < 4; ++j) dbacc[i][j] = 0.f;
   float daacc = 0.f;
-  for (int l0 = wave * CPW; l0 < L; l0 += 4 * CPW) {
+  // the codes / upstream gradients of the first NPF passes are fetched up front (NPF x 2 loads in flight per lane): with the
+  // loads inside the pass loop every pass waited a memory round trip of its own (8 passes per frame at L = 256: the
+  // kernel was ~14 us of latency at B = 128)
+  constexpr int NPF = LPC >= 64 ? 4 : 8;     // passes per frame in the shapes used: L / (4 * 64 / LPC) = 8 (32 bins, L 256) | 4 (LSF)
+  float cpre[NPF], gpre[NPF];
+#pragma unroll
+  for (int it = 0; it < NPF; ++it) {
+    const int l = (wave + 4 * it) * CPW + gc;
+    const long ci = (long)b * L + (l < L ? l : 0);
+    cpre[it] = code[ci];
+    gpre[it] = dout ? dout[ci] : 0.f;
+  }
+  int it = 0;
+  for (int l0 = wave * CPW; l0 < L; l0 += 4 * CPW, ++it) {
     const int l = l0 + gc;
     const bool live = l < L;
     const long ci = (long)b * L + (live ? l : 0);
-    const float c = code[ci];
-    const float go = (dout && live) ? dout[ci] : 0.f;
+    float c, go;
+    if (it < NPF) {
+      c = cpre[0]; go = gpre[0];
+#pragma unroll
+      for (int q = 1; q < NPF; ++q) {                     // wave-uniform select (it is uniform)
+        c = (it == q) ? cpre[q] : c;
+        go = (it == q) ? gpre[q] : go;
+      }
+    } else {
+      c = code[ci];
+      go = dout ? dout[ci] : 0.f;
+    }
+    go = live ? go : 0.f;
     float dist[ITER][4], p[ITER][4], gp[ITER][4];
     softmax_bins<LPC, ITER>(c, alpha, bv, ok, dist, p);
     int hidx = -1;
