@@ -192,6 +192,10 @@ int nsc_axpby(const float* x, const float* y, float* out, float a, float b, long
 int nsc_channel_sum(const float* x, float* out, int B, int C, int T, int accumulate, void* stream); /* out[b,0,t] (+)= sum_c x[b,c,t] */
 int nsc_unshuffle2(const float* ys /*[B,C/2,2T]*/, float* y /*[B,C,T]*/, int B, int C, int T, void* stream);
 int nsc_transpose_last2(const float* x /*[B,R,Cc]*/, float* y /*[B,Cc,R]*/, int B, int R, int Cc, void* stream);
+/* cascade step between two codecs (cmrl.py:49-94): decoded = sc*dec (+ decoded if accumulate); xin (nullable: last codec)
+ * = rs*x - rs*decoded, i.e. the next codec's input res_scalar * (x - sum of the outputs so far) */
+int nsc_cascade_step(const float* dec, float* decoded, int accumulate, const float* x, float* xin, float sc, float rs,
+                     long n, void* stream);
 int nsc_sum_all(const float* x, float* out /*accumulate [1]*/, long n, void* stream);
 /* up to NSC_SUM_MAXJ such sums in one launch (the bias gradients of the Cout = 1 convs of a step) */
 #define NSC_SUM_MAXJ 8

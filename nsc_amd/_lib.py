@@ -56,6 +56,7 @@ PROTOTYPES = {
     "nsc_unshuffle2": [_P, _P, _I, _I, _I, _P],
     "nsc_transpose_last2": [_P, _P, _I, _I, _I, _P],
     "nsc_sum_all": [_P, _P, _L, _P],
+    "nsc_cascade_step": [_P, _P, _I, _P, _P, _F, _F, _L, _P],
     "nsc_upsample_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "nsc_upsample_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "nsc_quantize_fwd": [_P, _P, _P, _F, _I, _I, _I, _I, _P, _P, _P, _P, _P],

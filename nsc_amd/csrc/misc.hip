@@ -260,6 +260,25 @@ extern "C" int nsc_axpby(const float* x, const float* y, float* out, float a, fl
   return NSC_OK;
 }
 
+// One step of the cascade between two codecs (cmrl.py:49-94): decoded (+)= sc * dec and, when another codec follows, its
+// input xin = rs * (x - decoded) - the same two fused multiply-adds nsc_axpby would make in two launches.
+__global__ void cascade_step_kernel(const float* __restrict__ dec, float* __restrict__ decoded, int accumulate,
+                                    const float* __restrict__ x, float* __restrict__ xin, float sc, float rs, long n) {
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    const float d = accumulate ? fmaf(sc, dec[e], 1.f * decoded[e]) : sc * dec[e];
+    decoded[e] = d;
+    if (xin) xin[e] = fmaf(rs, x[e], -rs * d);
+  }
+}
+extern "C" int nsc_cascade_step(const float* dec, float* decoded, int accumulate, const float* x, float* xin, float sc,
+                                float rs, long n, void* stream) {
+  NSC_REQUIRE(dec && decoded && n > 0 && (!xin || x), NSC_ERR_BAD_ARG, "nsc_cascade_step: bad args");
+  hipLaunchKernelGGL(cascade_step_kernel, dim3(std::min<long>(4096, nsc_cdiv(n, 256))), dim3(256), 0, (hipStream_t)stream,
+                     dec, decoded, accumulate, x, xin, sc, rs, n);
+  NSC_CHECK_LAUNCH("cascade_step");
+  return NSC_OK;
+}
+
 // 64 time steps per workgroup; the 4 waves split the channels (independent partial sums, then an LDS reduction): one thread
 // per (b,t) walking all C channels was a 100-deep dependent chain on 128 workgroups (25 us for 13 MB)
 __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ x, float* __restrict__ out, int C, int T,

@@ -585,7 +585,14 @@ class CascadeEngine:
             return
         f32 = dict(dtype=torch.float32, device=self.device)
         self.params = torch.zeros(n, **f32)
-        self.grads = torch.zeros(n, **f32)
+        # gradients and, right behind them, every quantizer's soft histogram live in ONE allocation padded to 64 KB: a
+        # training step clears both with a single aligned memset (an unaligned size costs a second fill dispatch for the tail)
+        nh = sum(nb_ for nb_ in num_bins) + 4 * len(lpc_coeff_lsf_bins)
+        self._gh_floats = (n + nh + 16383) // 16384 * 16384
+        self._gh = torch.zeros(self._gh_floats, **f32)
+        self.grads = self._gh[:n]
+        self._hist_flat = self._gh[n:n + nh]
+        self._hist_slots, self._hist_used = {}, 0
         # wt = flipped/transposed kernels of every conv at the same offsets as the parameters, followed by one extra
         # region per gated block holding the two k15 gate kernels concatenated along their OUTPUT channels
         # (wt_lr[tap', c' in 0..39, ci]) so that both gate data-gradients run as a single 40-channel conv.
@@ -787,10 +794,6 @@ class CascadeEngine:
 
     def hist_view(self, key, nb):
         """[nb] slice of the flat histogram buffer (codecs' 32-bin and the LSF quantizer's 256-bin histograms side by side)."""
-        if self._hist_flat is None:
-            self._hist_flat = torch.zeros(sum(c.nb for c in self.codecs) + 4 * len(lpc_coeff_lsf_bins), dtype=torch.float32,
-                                          device=self.device)
-            self._hist_slots, self._hist_used = {}, 0
         if key not in self._hist_slots:
             assert self._hist_used + nb <= self._hist_flat.numel()
             self._hist_slots[key] = (self._hist_used, nb)
@@ -869,12 +872,13 @@ class CascadeEngine:
               "gather wt")
 
     # ---- forward ----
-    def forward(self, x, is_quan_on=1.0, soft=True, lpc_x=None, want_p=False):
-        """x [B,1,512] (time-domain frame, or the fed LPC residual).  Returns decoded [B,1,512] (sum of codecs)."""
+    def forward(self, x, is_quan_on=1.0, soft=True, lpc_x=None, want_p=False, hists_clean=False):
+        """x [B,1,512] (time-domain frame, or the fed LPC residual).  Returns decoded [B,1,512] (sum of codecs).
+        hists_clean: the caller has just zeroed the histogram buffer (train_step's memset covers it)."""
         e = self
         B, rs = self.B, self.res_scalar
         assert tuple(x.shape) == (B, 1, frame_length) and x.dtype == torch.float32 and x.is_contiguous()
-        self._hist_clean = False
+        self._hist_clean = bool(hists_clean)
         self.x = x
         n = B * frame_length
         self.decoded = self.buf("decoded", (B, 1, frame_length))
@@ -888,17 +892,14 @@ class CascadeEngine:
                 else:
                     xin = x
             else:
-                xin = self.buf(f"xin{i}", (B, 1, frame_length))
-                check(self.lib.nsc_axpby(x.data_ptr(), self.decoded.data_ptr(), xin.data_ptr(), rs, -rs, n,
-                                         self.stream()), "axpby")
+                xin = xin_next        # written by the cascade step that closed the previous codec
             self.xin.append(xin)
             dec = c.forward(xin, is_quan_on, soft, want_p)
             sc = (1.0 / rs) if scaled else 1.0
-            if i == 0:
-                check(self.lib.nsc_axpby(dec.data_ptr(), None, self.decoded.data_ptr(), sc, 0.0, n, self.stream()), "axpby")
-            else:
-                check(self.lib.nsc_axpby(dec.data_ptr(), self.decoded.data_ptr(), self.decoded.data_ptr(), sc, 1.0, n,
-                                         self.stream()), "axpby")
+            # decoded (+)= sc * dec, and the next codec's input rs * (x - decoded), in one launch
+            xin_next = self.buf(f"xin{i + 1}", (B, 1, frame_length)) if i + 1 < self.N else None
+            check(self.lib.nsc_cascade_step(dec.data_ptr(), self.decoded.data_ptr(), int(i > 0), x.data_ptr(), _lib.ptr(xin_next),
+                                            sc, rs, n, self.stream()), "cascade_step")
         if self.lpc and lpc_x is not None:
             # LSF quantizer (nsc_module:993-1005): only its soft assignment enters the loss (py_func has no grad)
             L, nb = lpc_x.shape[1], len(lpc_coeff_lsf_bins)
@@ -928,7 +929,12 @@ class CascadeEngine:
         self.time = self.buf("loss.time", (B,))
         self.freq = self.buf("loss.freq", (B,))
         G = self.buf("loss.G", (B, 1, frame_length))
-        check(self.lib.nsc_recon_loss_banded(self.decoded.data_ptr(), target.data_ptr(), B, float(c_time), float(c_freq),
+        first_needed = min([i for i, t in enumerate(trainable) if t], default=self.N)
+        # d dec_i = sc_i * (G - rs * sum_{j>i} dxin_j): when every codec that takes part has the same sc (the usual case), the
+        # loss kernel writes sc * G directly and the last codec's d dec is that buffer - one launch less
+        scs = {(1.0 / rs) if (i > 0 or self.scale_first) else 1.0 for i in range(first_needed, self.N)}
+        gsc = scs.pop() if len(scs) == 1 else 1.0
+        check(self.lib.nsc_recon_loss_banded(self.decoded.data_ptr(), target.data_ptr(), B, float(c_time) * gsc, float(c_freq) * gsc,
                                              None, None, self.mel.data_ptr(), self.melT.data_ptr(),
                                              self.mel_ranges.data_ptr(), self.time.data_ptr(), self.freq.data_ptr(),
                                              G.data_ptr(), self.stream()), "recon_loss")
@@ -938,7 +944,6 @@ class CascadeEngine:
         n = B * frame_length
         dsum = None  # running sum over later codecs of dL/dxin_j
         pending = []
-        first_needed = min([i for i, t in enumerate(trainable) if t], default=self.N)
         for i in range(self.N - 1, -1, -1):
             c = self.codecs[i]
             if i < first_needed:
@@ -946,11 +951,15 @@ class CascadeEngine:
             scaled = (i > 0) or self.scale_first
             sc = (1.0 / rs) if scaled else 1.0
             ddec = self.buf(f"ddec{i}", (B, 1, frame_length))
-            # d yhat_i = G - rs * sum_{j>i} dxin_j ; d dec_i = d yhat_i * sc
+            # d yhat_i = G - rs * sum_{j>i} dxin_j ; d dec_i = d yhat_i * sc   (G already carries gsc)
             if dsum is None:
-                check(self.lib.nsc_axpby(G.data_ptr(), None, ddec.data_ptr(), sc, 0.0, n, self.stream()), "axpby")
+                if sc == gsc:
+                    ddec = G
+                else:
+                    check(self.lib.nsc_axpby(G.data_ptr(), None, ddec.data_ptr(), sc / gsc, 0.0, n, self.stream()), "axpby")
             else:
-                check(self.lib.nsc_axpby(G.data_ptr(), dsum.data_ptr(), ddec.data_ptr(), sc, -rs * sc, n, self.stream()), "axpby")
+                check(self.lib.nsc_axpby(G.data_ptr(), dsum.data_ptr(), ddec.data_ptr(), sc / gsc, -rs * sc, n, self.stream()),
+                      "axpby")
             need_dx = i > first_needed
             if trainable[i]:
                 dx = c.backward(ddec, c_quan[i], c_ent[i] * Bg, need_dx=need_dx)
@@ -1065,9 +1074,9 @@ class CascadeEngine:
             self._leave()
 
     def _train_step(self, x, target, cfg, lpc_x, comm):
-        check(self.lib.nsc_zero(self.g_ptr, self.grads.numel(), self.stream()), "zero grads")   # a memset node, no torch kernel
+        check(self.lib.nsc_zero(self.g_ptr, self._gh_floats, self.stream()), "zero grads + hists")   # ONE memset node
         self.refresh_wt()
-        self.forward(x, cfg["is_quan_on"], True, lpc_x=lpc_x)
+        self.forward(x, cfg["is_quan_on"], True, lpc_x=lpc_x, hists_clean=True)
         gb = self.B * (comm.world if comm else 1)
         terms = self.loss_backward(target, cfg["c_time"], cfg["c_freq"], cfg["c_quan"], cfg["c_ent"], cfg["trainable"],
                                    c_quan_lpc=cfg.get("c_quan_lpc", 0.0), c_ent_lpc=cfg.get("c_ent_lpc", 0.0),
