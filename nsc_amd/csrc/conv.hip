@@ -41,6 +41,60 @@ extern "C" int nsc_version(void) { return 100; }
 // NPRE > 0: the k-loop has exactly NPRE k-steps (known shapes: 1x1 100->100, k55 1->C) and ALL of a wave's weight
 // fragments are fetched into registers up front, in flight together with the x-tile staging; the streamed form pays
 // an L2 round trip per group of k-steps, which at one wave per SIMD is most of the kernel for these short reductions.
+// Row-wise copy-out of an output tile os [rows][LDO] (row = output channel rt0*16 + r, column = time t0 + j) that the
+// kernels below have transposed into LDS: a wave handles whole 256-B rows, so y, the residual and aux move as full cache
+// lines and the per-channel bias is a scalar.  NWV waves; TTc columns.
+template <int TTc, int NWV>
+__device__ __forceinline__ void conv_store_rows(const nsc_conv_desc& d, const float* __restrict__ os, int LDO, int rows_here,
+                                                int rt0, int b, int t0, int wave8, int lane, const float* __restrict__ bias,
+                                                const float* __restrict__ res, const float* __restrict__ aux,
+                                                float* __restrict__ y) {
+  const int Cout = d.Cout;
+  const int nrow = min(rows_here, Cout - rt0 * 16);
+  if (d.out_mode == 1) {
+    // sub-pixel shuffle: output row (ch >> 1) interleaves LDS rows 2c, 2c+1 in time, so a wave still writes whole lines;
+    // residual / aux (if any) are laid out like the OUTPUT [B, Cout/2, 2 Tout]
+    for (int orow = wave8; 2 * orow < nrow; orow += NWV) {
+      const int och = (rt0 * 16 >> 1) + orow;
+      const float b0 = bias ? bias[rt0 * 16 + 2 * orow] : 0.f;
+      const float b1 = (bias && 2 * orow + 1 < nrow) ? bias[rt0 * 16 + 2 * orow + 1] : 0.f;
+#pragma unroll
+      for (int hb = 0; hb < 2 * TTc / 64; ++hb) {
+        const int tl2 = hb * 64 + lane, par = tl2 & 1, tl = tl2 >> 1;
+        const int t2 = 2 * t0 + tl2;
+        if (t2 >= 2 * d.Tout || 2 * orow + par >= nrow) continue;
+        float v = os[(2 * orow + par) * LDO + tl] + (par ? b1 : b0);
+        const long oidx = ((long)b * (Cout >> 1) + och) * (2L * d.Tout) + t2;
+        if (d.res_mode == 1) v += res[oidx];
+        else if (d.res_mode == 2) v += res[(long)b * 2 * d.Tout + t2];
+        v = nsc_apply_act(v, d.act);
+        if (d.mul_mode) v *= nsc_act_grad_from_out(aux[oidx], d.mul_mode);
+        if (d.accumulate) y[oidx] += v;
+        else y[oidx] = v;
+      }
+    }
+    return;
+  }
+  for (int row = wave8; row < nrow; row += NWV) {
+    const int ch = rt0 * 16 + row;
+    const float bv = bias ? bias[ch] : 0.f;
+#pragma unroll
+    for (int hb = 0; hb < TTc / 64; ++hb) {
+      const int tl = hb * 64 + lane, t = t0 + tl;
+      if (t >= d.Tout) continue;
+      float v = os[row * LDO + tl] + bv;
+      const long idx = ((long)b * Cout + ch) * d.Tout + t;
+      if (d.res_mode == 1) v += res[idx];
+      else if (d.res_mode == 2) v += res[(long)b * d.Tout + t];
+      v = nsc_apply_act(v, d.act);
+      if (d.mul_mode) v *= nsc_act_grad_from_out(aux[idx], d.mul_mode);
+      const long oidx = d.out_mode == 1 ? ((long)b * (Cout >> 1) + (ch >> 1)) * (2L * d.Tout) + 2 * t + (ch & 1) : idx;
+      if (d.accumulate) y[oidx] += v;
+      else y[oidx] = v;
+    }
+  }
+}
+
 template <int RT, int NC, bool CIN1, int KS, int NPRE = 0>
 __global__ __launch_bounds__(256 * KS) void conv1d_fwd_kernel(nsc_conv_desc d, const float* __restrict__ x,
                                                          const float* __restrict__ w,
@@ -251,49 +305,175 @@ __global__ __launch_bounds__(256 * KS) void conv1d_fwd_kernel(nsc_conv_desc d, c
         for (int c = 0; c < NC; ++c) os[(r * 16 + kq * 4 + reg) * LDO + tcol0 + c * 16] = acc[r][c][reg];
   }
   __syncthreads();
-  const int nrow = min(RT * 16, Cout - rt0 * 16);
-  if (d.out_mode == 1) {
-    // sub-pixel shuffle: output row (ch >> 1) interleaves LDS rows 2c, 2c+1 in time, so a wave still writes whole lines;
-    // residual / aux (if any) are laid out like the OUTPUT [B, Cout/2, 2 Tout]
-    for (int orow = wave8; 2 * orow < nrow; orow += 4 * KS) {
-      const int och = (rt0 * 16 >> 1) + orow;
-      const float b0 = bias ? bias[rt0 * 16 + 2 * orow] : 0.f;
-      const float b1 = (bias && 2 * orow + 1 < nrow) ? bias[rt0 * 16 + 2 * orow + 1] : 0.f;
+  conv_store_rows<TTc, 4 * KS>(d, os, LDO, RT * 16, rt0, b, t0, wave8, lane, bias, res, aux, y);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same implicit GEMM on v_mfma_f32_32x32x2_f32 for the convs with >= 96 output channels (the k9 stride-2 down-sampling
+// conv and its polyphase data gradient: 12 GFLOP per step between them).  On this part the 32x32x2 shape sustains
+// 147-150 TFLOP/s against 115-127 for 16x16x4 (tools/mfma_peak2.hip: it reads half the operands per flop), so the
+// workgroup's ROWS = 32 NP + 16 output rows run as NP 32-row tiles plus one 16-row tile on the small shape (100 = 96 + 4
+// channels: a fourth 32-row tile would be 7/8 padding).  Four waves x 32 time steps; KS = 2 splits the taps over eight
+// waves as above; weights stream through raw buffer loads two k-steps (of 4 input channels) ahead.
+// Fragment layouts (lane l): A32 row l % 32, k l / 32; B32 column l % 32, k l / 32; D32 register j <-> row
+// 8 (j / 4) + 4 (l / 32) + j % 4, column l % 32.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <int NP, int KS>
+__global__ __launch_bounds__(256 * KS) void conv1d_fwd_m32_kernel(nsc_conv_desc d, const float* __restrict__ x,
+                                                                  const float* __restrict__ w,
+                                                                  const float* __restrict__ bias,
+                                                                  const float* __restrict__ res,
+                                                                  const float* __restrict__ aux, float* __restrict__ y,
+                                                                  int ldx, int win) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];
+  constexpr int TT = 128, ROWS = 32 * NP + 16, NA = 2 * NP + 1, G = 2;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = wave8 & 3, khalf = wave8 >> 2;
+  const int l31 = lane & 31, kh = lane >> 5, l15 = lane & 15, kq = lane >> 4;
+  const int b = blockIdx.y, t0 = blockIdx.x * TT, row0 = blockIdx.z * ROWS;
+  const int Cin4 = (d.Cin + 3) & ~3, Cout = d.Cout;
+  const int Tin_virt = d.in_up ? 2 * d.Tin : d.Tin;
+  nsc_stage_rows<4 * KS, NSC_CONV_U>(xs, ldx, Cin4, d.Cin, win, x + (long)b * d.Cin * d.Tin, d.Tin, t0 * d.stride - d.padL,
+                                     Tin_virt, d.in_up, wave8, lane);
+  __syncthreads();
+
+  f32x16 acc[NP];
+  f32x4 acc16[2];
 #pragma unroll
-      for (int hb = 0; hb < 2 * TTc / 64; ++hb) {
-        const int tl2 = hb * 64 + lane, par = tl2 & 1, tl = tl2 >> 1;
-        const int t2 = 2 * t0 + tl2;
-        if (t2 >= 2 * d.Tout || 2 * orow + par >= nrow) continue;
-        float v = os[(2 * orow + par) * LDO + tl] + (par ? b1 : b0);
-        const long oidx = ((long)b * (Cout >> 1) + och) * (2L * d.Tout) + t2;
-        if (d.res_mode == 1) v += res[oidx];
-        else if (d.res_mode == 2) v += res[(long)b * 2 * d.Tout + t2];
-        v = nsc_apply_act(v, d.act);
-        if (d.mul_mode) v *= nsc_act_grad_from_out(aux[oidx], d.mul_mode);
-        if (d.accumulate) y[oidx] += v;
-        else y[oidx] = v;
+  for (int p = 0; p < NP; ++p)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[p][j] = 0.f;
+  acc16[0] = acc16[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // weights: k-step = (tap, 4 input channels) = two K2 steps of the 32-row tiles + one K4 step of the 16-row tile.  Rows
+  // >= Cout are clamped (never stored); k rows >= Cin meet zero rows of the x tile; anything past the array reads 0.
+  const int ncq = Cin4 >> 2;
+  const int ntaps = (d.K - khalf + KS - 1) / KS;
+  const int nsteps = ntaps * ncq;
+  const __amdgpu_buffer_rsrc_t wsrd =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w), 0, d.K * d.Cin * Cout * 4, 0x00020000);
+  int voff[NA];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int o = min(row0 + 32 * p + l31, Cout - 1);
+    voff[2 * p] = (kh * Cout + o) * 4;                 // K2 half 0: input channels ci0 + {0, 1}
+    voff[2 * p + 1] = ((2 + kh) * Cout + o) * 4;       // K2 half 1: ci0 + {2, 3}
+  }
+  voff[NA - 1] = (kq * Cout + min(row0 + 32 * NP + l15, Cout - 1)) * 4;
+  const int step_bytes = 4 * Cout * 4, tap_bytes = d.Cin * Cout * 4;
+  float an[G][NA];
+  int tapp = khalf, cqp = 0;
+  auto fetch = [&](float (&dst)[G][NA]) {
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      const int soff = __builtin_amdgcn_readfirstlane(tapp * tap_bytes + cqp * step_bytes);
+#pragma unroll
+      for (int q = 0; q < NA; ++q)
+        dst[u][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wsrd, voff[q], soff, 0));
+      const bool wrapp = (cqp + 1 == ncq);
+      cqp = wrapp ? 0 : cqp + 1;
+      tapp += wrapp ? KS : 0;
+    }
+  };
+  fetch(an);
+  const int ngroups = (nsteps + G - 1) / G;            // padded steps multiply zero weights (out-of-range buffer reads)
+  const int bb32 = kh * ldx + (wave * 32 + l31) * d.stride;
+  const int bb16 = kq * ldx + (wave * 32 + l15) * d.stride;
+  int tap = khalf, cq = 0;
+  for (int g = 0; g < ngroups; ++g) {
+    float ac[G][NA];
+#pragma unroll
+    for (int u = 0; u < G; ++u)
+#pragma unroll
+      for (int q = 0; q < NA; ++q) ac[u][q] = an[u][q];
+    fetch(an);
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      const int tapc = tap < d.K ? tap : d.K - 1;
+      const float* xr = xs + __builtin_amdgcn_readfirstlane(cq * 4 * ldx + tapc * d.dil);
+      const float b0 = xr[bb32], b1 = xr[bb32 + 2 * ldx];
+      const float c0 = xr[bb16], c1 = xr[bb16 + 16 * d.stride];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u][2 * p], b0, acc[p], 0, 0, 0);
+        acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u][2 * p + 1], b1, acc[p], 0, 0, 0);
       }
+      acc16[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[u][NA - 1], c0, acc16[0], 0, 0, 0);
+      acc16[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[u][NA - 1], c1, acc16[1], 0, 0, 0);
+      const bool wrap = (cq + 1 == ncq);
+      cq = wrap ? 0 : cq + 1;
+      tap += wrap ? KS : 0;
     }
-    return;
   }
-  for (int row = wave8; row < nrow; row += 4 * KS) {
-    const int ch = rt0 * 16 + row;
-    const float bv = bias ? bias[ch] : 0.f;
+
+  constexpr int NREG = 16 * NP + 8;
+  if constexpr (KS == 2) {
+    // partial sums of the odd-tap waves -> LDS (the x tile is dead by now) -> even-tap waves
+    __syncthreads();
+    float* red = xs + wave * (NREG * 64);
+    if (khalf == 1) {
 #pragma unroll
-    for (int hb = 0; hb < TTc / 64; ++hb) {
-      const int tl = hb * 64 + lane, t = t0 + tl;
-      if (t >= d.Tout) continue;
-      float v = os[row * LDO + tl] + bv;
-      const long idx = ((long)b * Cout + ch) * d.Tout + t;
-      if (d.res_mode == 1) v += res[idx];
-      else if (d.res_mode == 2) v += res[(long)b * d.Tout + t];
-      v = nsc_apply_act(v, d.act);
-      if (d.mul_mode) v *= nsc_act_grad_from_out(aux[idx], d.mul_mode);
-      const long oidx = d.out_mode == 1 ? ((long)b * (Cout >> 1) + (ch >> 1)) * (2L * d.Tout) + 2 * t + (ch & 1) : idx;
-      if (d.accumulate) y[oidx] += v;
-      else y[oidx] = v;
+      for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) red[(16 * p + j) * 64 + lane] = acc[p][j];
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) red[(16 * NP + 4 * c + reg) * 64 + lane] = acc16[c][reg];
+    }
+    __syncthreads();
+    if (khalf == 0) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[p][j] += red[(16 * p + j) * 64 + lane];
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) acc16[c][reg] += red[(16 * NP + 4 * c + reg) * 64 + lane];
     }
   }
+  // output tile [ROWS][TT] through LDS, then whole rows out
+  constexpr int LDO = TT + 4;
+  __syncthreads();
+  float* os = xs;
+  if (KS == 1 || khalf == 0) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) os[(32 * p + (j >> 2) * 8 + kh * 4 + (j & 3)) * LDO + wave * 32 + l31] = acc[p][j];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) os[(32 * NP + kq * 4 + reg) * LDO + wave * 32 + 16 * c + l15] = acc16[c][reg];
+  }
+  __syncthreads();
+  conv_store_rows<TT, 4 * KS>(d, os, LDO, ROWS, row0 / 16, b, t0, wave8, lane, bias, res, aux, y);
+}
+
+template <int NP, int KS>
+static int launch_fwd_m32(const nsc_conv_desc* d, const float* x, const float* w, const float* bias, const float* res,
+                          const float* aux, float* y, hipStream_t st, bool* taken) {
+  constexpr int TT = 128, ROWS = 32 * NP + 16, NREG = 16 * NP + 8;
+  const int win = (TT - 1) * d->stride + (d->K - 1) * d->dil + 1;
+  int ldx;
+  if (d->stride == 1) { ldx = win; while ((ldx & 31) != 16) ++ldx; }
+  else ldx = win | 1;
+  const int Cin4 = (d->Cin + 3) & ~3;
+  size_t smem = (size_t)Cin4 * ldx * sizeof(float);
+  if (KS == 2) smem = std::max(smem, (size_t)4 * NREG * 64 * sizeof(float));
+  smem = std::max(smem, (size_t)ROWS * (TT + 4) * sizeof(float));
+  *taken = smem <= 160 * 1024;
+  if (!*taken) return NSC_OK;
+  auto kern = conv1d_fwd_m32_kernel<NP, KS>;
+  static const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "conv1d_fwd_m32: set smem attr: %s", hipGetErrorString(e));
+  dim3 grid(nsc_cdiv(d->Tout, TT), d->B, nsc_cdiv(d->Cout, ROWS));
+  hipLaunchKernelGGL(kern, grid, dim3(256 * KS), smem, st, *d, x, w, bias, res, aux, y, ldx, win);
+  NSC_CHECK_LAUNCH("conv1d_fwd_m32");
+  return NSC_OK;
 }
 
 static int round_ldx_fwd(int win, int stride) {
@@ -390,6 +570,12 @@ extern "C" int nsc_conv1d_fwd(const nsc_conv_desc* d, const float* x, const floa
   static const int force_nc = NSC_PROBE_INT("NSC_CONV_NC", 0);   // profiling switch
   bool nc2 = smem2 <= 72 * 1024 && d->Tout >= 128;
   if (force_nc) nc2 = force_nc == 2;
+  static const bool no_m32 = NSC_PROBE_SET("NSC_CONV_NO_M32");   // A/B switch for profiling
+  if (!cin1 && !no_m32 && d->K >= 2 && d->Cout >= 96 && d->Tout >= 128) {
+    bool taken = false;
+    rc = launch_fwd_m32<3, 2>(d, x, w, bias, res, aux, y, st, &taken);
+    if (rc || taken) return rc;
+  }
   if (cin1) return nc2 ? dispatch_rt<2, true>(d, x, w, bias, res, aux, y, st)
                        : dispatch_rt<1, true>(d, x, w, bias, res, aux, y, st);
   return nc2 ? dispatch_rt<2, false>(d, x, w, bias, res, aux, y, st)

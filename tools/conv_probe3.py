@@ -1,5 +1,6 @@
-"""PROBES build: stride-2 down-sampling conv and its polyphase data gradient with phases off (NSC_CONV_SKIP: 1 staging, 2 MFMA loop)."""
+"""PROBES build: stride-2 down-sampling conv and its polyphase data gradient, 32x32x2 kernel vs the 16x16x4 one (NSC_CONV_NO_M32)."""
 import os, subprocess, sys
 here = os.path.dirname(os.path.abspath(__file__))
-for skip in ("0", "1", "2", "3"):
-    subprocess.run([sys.executable, os.path.join(here, "conv_probe2.py"), "run"], env=dict(os.environ, NSC_CONV_SKIP=skip, NSC_CONV_NC="0"))
+for env in ({}, {"NSC_CONV_NO_M32": "1"}):
+    print(env, flush=True)
+    subprocess.run([sys.executable, os.path.join(here, "conv_probe2.py"), "run"], env=dict(os.environ, NSC_CONV_NC="0", **env))
