@@ -318,7 +318,6 @@ __global__ __launch_bounds__(256 * KS) void conv1d_fwd_kernel(nsc_conv_desc d, c
 // Fragment layouts (lane l): A32 row l % 32, k l / 32; B32 column l % 32, k l / 32; D32 register j <-> row
 // 8 (j / 4) + 4 (l / 32) + j % 4, column l % 32.
 // ------------------------------------------------------------------------------------------------
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 template <int NP, int KS>
 __global__ __launch_bounds__(256 * KS) void conv1d_fwd_m32_kernel(nsc_conv_desc d, const float* __restrict__ x,
                                                                   const float* __restrict__ w,
