@@ -944,6 +944,23 @@ class CascadeEngine:
         n = B * frame_length
         dsum = None  # running sum over later codecs of dL/dxin_j
         pending = []
+        # LSF quantizer first: its loss terms do not depend on the codecs' backward pass, and its two gradients then travel in
+        # the same all-reduce message as scope_1 (adjacent in the flat buffer) instead of a third one
+        lpc_rng = None
+        ent_lpc = None
+        if train_lpc is None:
+            train_lpc = c_quan_lpc != 0.0 or c_ent_lpc != 0.0
+        if self.lpc and train_lpc and hasattr(self, "lpc_x"):
+            L, nb = self.lpc_x.shape[1], len(lpc_coeff_lsf_bins)
+            ent_lpc, gh = self.buf("lpc.ent", (1,)), self.buf("lpc.ghist", (nb,))      # filled by entropies() above
+            check(self.lib.nsc_quantize_bwd(self.lpc_x.data_ptr(), self.p_ptr + 4 * self.lpc_alpha_off,
+                                            self.p_ptr + 4 * self.lpc_bins_off, self.codecs[0].is_quan_on,
+                                            self.codecs[0].soft, B, L, nb, None, None, float(c_quan_lpc),
+                                            gh.data_ptr() if c_ent_lpc != 0.0 else None, float(c_ent_lpc) * Bg, 0, None,
+                                            self.g_ptr + 4 * self.lpc_alpha_off, self.g_ptr + 4 * self.lpc_bins_off,
+                                            self.stream()), "lpc quantize_bwd")
+            if grad_allreduce is not None:
+                lpc_rng = self.layout.scope_range("lpc_quan")    # sent together with the adjacent scope_1 range below
         for i in range(self.N - 1, -1, -1):
             c = self.codecs[i]
             if i < first_needed:
@@ -971,6 +988,8 @@ class CascadeEngine:
                 self.flush_block_wgrads()
                 self.side_join()
                 a, b = self.layout.scope_range(f"scope_{i + 1}")
+                if lpc_rng is not None and lpc_rng[1] == a:
+                    a, lpc_rng = lpc_rng[0], None
                 pending.append(grad_allreduce(self.grads[a:b]))
             if need_dx:
                 if dsum is None:
@@ -979,21 +998,8 @@ class CascadeEngine:
                     acc = self.buf("dsum", (B, 1, frame_length))
                     check(self.lib.nsc_axpby(dx.data_ptr(), dsum.data_ptr(), acc.data_ptr(), 1.0, 1.0, n, self.stream()), "axpby")
                     dsum = acc
-        ent_lpc = None
-        if train_lpc is None:
-            train_lpc = c_quan_lpc != 0.0 or c_ent_lpc != 0.0
-        if self.lpc and train_lpc and hasattr(self, "lpc_x"):
-            L, nb = self.lpc_x.shape[1], len(lpc_coeff_lsf_bins)
-            ent_lpc, gh = self.buf("lpc.ent", (1,)), self.buf("lpc.ghist", (nb,))      # filled by entropies() above
-            check(self.lib.nsc_quantize_bwd(self.lpc_x.data_ptr(), self.p_ptr + 4 * self.lpc_alpha_off,
-                                            self.p_ptr + 4 * self.lpc_bins_off, self.codecs[0].is_quan_on,
-                                            self.codecs[0].soft, B, L, nb, None, None, float(c_quan_lpc),
-                                            gh.data_ptr() if c_ent_lpc != 0.0 else None, float(c_ent_lpc) * Bg, 0, None,
-                                            self.g_ptr + 4 * self.lpc_alpha_off, self.g_ptr + 4 * self.lpc_bins_off,
-                                            self.stream()), "lpc quantize_bwd")
-            if grad_allreduce is not None:
-                a, b = self.layout.scope_range("lpc_quan")
-                pending.append(grad_allreduce(self.grads[a:b]))
+        if lpc_rng is not None:
+            pending.append(grad_allreduce(self.grads[lpc_rng[0]:lpc_rng[1]]))
         self.flush_block_wgrads()
         self.side_join()
         for w in pending:

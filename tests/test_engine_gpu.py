@@ -251,20 +251,28 @@ from nsc_amd.engine import CascadeEngine
 from tests._util import BKD, make_store, synth_frames, dev
 comm = Comm(backend="gloo")                    # two ranks share the one GPU of the test box; the driver's runs use nccl
 B, Bl = 4, 2
-ps = make_store(2, [[2], [2]], [32, 32])
+LPC = %(lpc)r
+ps = make_store(2, [[2], [2]], [32, 32], lpc=LPC)
 x = synth_frames(B)
 cfg = dict(is_quan_on=1.0, c_time=60.0, c_freq=10.0, c_quan=[10.0, 10.0], c_ent=[0.3, 0.5], trainable=[True, True], lr=2e-4, slot=1)
+kw = {}
+lpc_all = None
+if LPC:     # the north-star step: fed LPC residual, every codec scaled, LSF quantizer trained through its quan term
+    ps.params["lpc_quan/alpha"] = np.array(-40.0)
+    cfg.update(c_quan_lpc=10.0, train_lpc=True, quan_op=True)
+    kw = dict(res_scalar=2.0, scale_first=True, lpc=True)
+    lpc_all = np.sort(np.random.default_rng(3).uniform(0.03, 3.1, (B, 16, 1)), axis=1).astype(np.float32)
 lo, hi = comm.shard(B)
-eng = CascadeEngine(Bl, 2, BKD, [[2], [2]], [32, 32])
+eng = CascadeEngine(Bl, 2, BKD, [[2], [2]], [32, 32], **kw)
 eng.load_named(ps.params)
 xd = dev(x[lo:hi].transpose(0, 2, 1))
-eng.train_step(xd, xd, cfg, comm=comm)         # sum all-reduce of grads + all-reduce of the soft histograms
+eng.train_step(xd, xd, cfg, lpc_x=dev(lpc_all[lo:hi]) if LPC else None, comm=comm)   # per-scope grad all-reduces + histograms
 torch.cuda.synchronize()
 if comm.rank == 0:
-    ref = CascadeEngine(B, 2, BKD, [[2], [2]], [32, 32])
+    ref = CascadeEngine(B, 2, BKD, [[2], [2]], [32, 32], **kw)
     ref.load_named(ps.params)
     xf = dev(x.transpose(0, 2, 1))
-    ref.train_step(xf, xf, cfg)
+    ref.train_step(xf, xf, cfg, lpc_x=dev(lpc_all) if LPC else None)
     torch.cuda.synchronize()
     g1, g2 = eng.grads.cpu().numpy(), ref.grads.cpu().numpy()
     p1, p2 = eng.params.cpu().numpy(), ref.params.cpu().numpy()
@@ -276,12 +284,14 @@ comm.close()
 '''
 
 
-def test_data_parallel_engine_two_ranks_equals_one_process(tmp_path):
-    """2 ranks x 2 frames (gradient SUM all-reduce + global-batch entropy histogram) == 1 process x 4 frames, on the HIP path."""
+@pytest.mark.parametrize("lpc", [False, True])
+def test_data_parallel_engine_two_ranks_equals_one_process(tmp_path, lpc):
+    """2 ranks x 2 frames (per-scope gradient SUM all-reduces issued during the backward pass + global-batch entropy histogram)
+    == 1 process x 4 frames, on the HIP path; lpc: the config-3 step, whose LSF-quantizer gradients ride in scope_1's message."""
     import json, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "ddp_worker.py"
-    script.write_text(_DDP_WORKER % {"root": root})
+    script.write_text(_DDP_WORKER % {"root": root, "lpc": bool(lpc)})
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29633")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
                           "127.0.0.1", "--master-port", "29633", str(script)], capture_output=True, text=True, env=env,
