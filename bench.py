@@ -48,7 +48,7 @@ def synth_batch(B, rank, device):
 
 def step_cfg():
     return dict(is_quan_on=1.0, c_time=COEFF[0], c_freq=COEFF[1], c_quan=[COEFF[2], COEFF[2]], c_ent=[0.0, 0.0],
-                trainable=[True, True], lr=LR, slot=1, c_quan_lpc=COEFF[2], c_ent_lpc=0.0, train_lpc=True, quan_op=True)
+                trainable=[True, True], lr=LR, slot=1, c_quan_lpc=COEFF[2], c_ent_lpc=0.0, train_lpc=True, quan_op=True, global_entropy=False)
 
 
 def cpu_baseline(B, x_np, lpc_np, budget_s=24.0):

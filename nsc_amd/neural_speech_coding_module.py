@@ -522,7 +522,9 @@ class neuralSpeechCodingModule(object):
             # cmrl.py:463-485: quan_loss(LSF) + sum_i quan_loss(codec i), every one times coeff[2]; NO entropy term;
             # lpc_quan/alpha, bins are created without `trainable=` (:398-401) -> always trained here
             cq = [c[2]] * num_codecs
-            extra = dict(c_quan_lpc=c[2], train_lpc=True)
+            # no entropy term in this phase by construction (not a tau value): data-parallel runs skip the histogram all-reduce
+            # in the middle of the step (the entropies this phase journals are then those of the local batch)
+            extra = dict(c_quan_lpc=c[2], train_lpc=True, global_entropy=False)
         else:
             # cmrl.py:355: quantization_loss = tf.reduce_sum([quan_0, quan_1]) is a SCALAR (summed over the batch too)
             # that :361-365 broadcasts back into the [B] loss vector => its weight is coeff[2] * (global batch)

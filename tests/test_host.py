@@ -271,7 +271,8 @@ def test_loss_configs_of_the_cli_follow_the_reference():
         _, quan, tau_map = mod(True, is_cq)._loss_cfgs(2, "finetune")
         assert quan["c_quan"] == [10.0, 10.0] and quan["c_quan_lpc"] == 10.0 and quan["train_lpc"] and tau_map == []
         ref = bench.step_cfg()
-        for k in ("is_quan_on", "c_time", "c_freq", "c_quan", "c_ent", "trainable", "slot", "c_quan_lpc"):
+        for k in ("is_quan_on", "c_time", "c_freq", "c_quan", "c_ent", "trainable", "slot", "c_quan_lpc", "train_lpc", "quan_op",
+                  "global_entropy"):
             assert quan[k] == ref[k], k
 
 
