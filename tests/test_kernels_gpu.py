@@ -64,6 +64,8 @@ CONV_CASES = [
     (2, 7, 13, 300, 5, 3, 1, "tanh", 0),      # ragged: odd channels, T not a tile multiple
     (2, 6, 130, 77, 3, 1, 2, "none", 0),      # Cout > 112 (grid.z), odd T with stride 2
     (1, 100, 100, 128, 1, 1, 1, "lrelu", 0),  # pointwise
+    (2, 100, 200, 200, 5, 1, 1, "none", 1),   # 32x32x2 kernel (Cout >= 96): two 112-row groups, ragged second time tile
+    (2, 6, 130, 300, 3, 2, 2, "tanh", 2),     # 32x32x2 kernel: 112 + 18 rows, stride 2 with dilation, T_out = 150
 ]
 
 
