@@ -12,9 +12,8 @@
 #include <algorithm>
 #include <cstdlib>
 
-#define NARROW 20
-#define K15 15
-#define K9 9
+#include "block_args.h"
+
 
 #ifdef NSC_PROBES
 // phase stamps of workgroup 0 / wave 0 (s_memtime), read back with nsc_probe_read: profiling builds only
@@ -27,16 +26,7 @@ extern "C" int nsc_probe_read(unsigned long long* out) {
 #define NSC_STAMP(i) do { } while (0)
 #endif
 
-struct BlockArgs {
-  int B, C, T, dil, flat;
-  const float *x, *w1, *b1, *wl, *bl, *wr, *br, *w9, *b9;
-  float *out, *h_out, *lin_out, *th_out, *g_out;  // *_out optional: saved for the unfused backward
-  int Cin;   // input channels: C (residual block) or 1 (the first decoder block: x [B,1,T] is broadcast into the residual add)
-};
 
-__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
 
 // TT = 64 output steps per workgroup, 8 waves (two per SIMD at one workgroup, four at the usual two workgroups per CU):
 // every phase is split into (row tile, column tile) jobs dealt over the 8 waves, so each wave's MFMA chain is short
@@ -1237,14 +1227,6 @@ extern "C" int nsc_gated_block_wgrad_batch(const nsc_block_wgrad_job* jobs, int 
 // persistent weight-gradient kernel consumes.  Replaces four launches per block on the critical stream.
 // Columns: dys j <-> t0-Hh-4+j ; lin/th/dg j <-> t0-Hh+j ; dhs j <-> t0+j   (Hh = 7*dil).
 // =====================================================================================================
-struct BlockDgradArgs {
-  int B, C, T, dil, in_act;
-  const float *x, *h, *lin, *th, *dy;
-  const float *wt1, *wtl, *wtr, *wt9;
-  float *dx, *da, *dz1;
-  float* dgate;   // where the second half of da goes and the rows per frame of both halves: da + 20 T / 40 for the joint
-  int da_rows;    // [B,40,T] tensor the block weight-gradient kernel reads; a separate [B,20,T] tensor / 20 for per-conv wgrads
-};
 
 template <int RT9>
 __global__ __launch_bounds__(512) void gated_block_dgrad_kernel(BlockDgradArgs a, int ldy, int lda, int ldn) {
