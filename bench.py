@@ -113,6 +113,17 @@ def cpu_baseline(B, x_np, lpc_np, budget_s=24.0):
                        f"of a 1/8/32/{cores}-thread probe); {time.perf_counter() - t_start:.1f} s in all; 1-thread figure: batch 8")
 
 
+class _NullComm:
+    """--dp-selftest: the data-parallel control flow of one rank with every collective a no-op (prices the segmentation)."""
+    world, rank = 1, 0
+
+    def allreduce_async(self, t, op=None):
+        return None
+
+    def allreduce_list(self, tensors):
+        pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -121,6 +132,12 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="frames per GPU (BASELINE: 128)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--passes", type=int, default=3, help="timed passes of --steps steps each (value = the median pass)")
+    ap.add_argument("--dp-selftest", action="store_true",
+                    help="N=1 only: run the data-parallel control flow (segmented hipGraph, collectives as no-ops) to price it")
+    ap.add_argument("--dp-overlap", action="store_true",
+                    help="data parallel: one gradient message per scope under the backward pass (splits the batched weight-gradient "
+                         "launches: measured slower) instead of one message at the tail of the step")
     ap.add_argument("--prof-steps", type=int, default=3)
     ap.add_argument("--no-infer", action="store_true", help="skip the codec-forward us/frame measurement")
     ap.add_argument("--no-overlap", action="store_true", help="weight-gradient kernels on the main stream (profiling)")
@@ -154,55 +171,67 @@ def main():
     eng.fused_fwd = not args.unfused_fwd
     xd, lpcd, x_np, lpc_np = synth_batch(B, comm.rank, dev)
     cfg = step_cfg()
-    dcomm = comm if comm.world > 1 else None
+    dcomm = comm if comm.world > 1 else (_NullComm() if args.dp_selftest else None)
+    eng.dp_overlap = bool(args.dp_overlap)
 
     def step():
         eng.train_step(xd, xd, cfg, lpc_x=lpcd, comm=dcomm)
 
-    use_graph = (not args.no_graph) and comm.world == 1
-    graph = None
-    n_warm_eager = max(1, min(args.warmup, 2)) if use_graph else args.warmup
-    for _ in range(n_warm_eager):
-        step()
-    torch.cuda.synchronize()
-    if use_graph:
-        try:
-            s = torch.cuda.Stream()
-            s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):
-                step()
-            torch.cuda.current_stream().wait_stream(s)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=s):
-                step()
-        except Exception as ex:  # fall back to eager launches, say so in the JSON
-            print(f"[bench] hipGraph capture failed ({type(ex).__name__}: {ex}); running eagerly", file=sys.stderr)
-            graph = None
-        for _ in range(max(0, args.warmup - n_warm_eager)):
-            graph.replay() if graph is not None else step()
-    run = (graph.replay if graph is not None else step)
-    if graph is not None:
-        # time both launch modes briefly (with --no-batch-conv-wgrad the per-conv weight gradients run on a side stream,
-        # which graph replay serialises on this stack)
-        def trial(fn, n=4):
-            fn(); torch.cuda.synchronize()
-            t = time.perf_counter()
-            for _ in range(n):
-                fn()
-            torch.cuda.synchronize()
-            return (time.perf_counter() - t) / n
-        tg, te = trial(graph.replay), trial(step)
-        if te < 0.98 * tg:      # the step is single-stream now: replay wins or ties; keep eager only if clearly faster
-            run, graph = step, None
+    # C-ABI calls of one eager step (kernel dispatches per step come from the rocprof trace: profiles/*_step_timeline.txt)
+    from nsc_amd import _lib as _nl, engine as _ne
+    ncalls = [0]
+    _chk = _nl.check
+    def _counting(rc, what=""):
+        ncalls[0] += 1
+        return _chk(rc, what)
+    step()                                   # allocates every buffer
+    _ne.check = _counting
+    step()
+    _ne.check = _chk
+    calls_per_step = ncalls[0]
 
-    comm.barrier()
+    # launch mode.  N = 1: the whole step is ONE hipGraph.  N > 1: the step is captured as hipGraph SEGMENTS cut at the
+    # collectives (RCCL calls stay eager between two graph launches), so every rank replays the same kernels as the N = 1 run.
+    graph, seg, launch = None, None, "eager"
+    n_warm_eager = 0                         # (the two eager steps above; the W warm-up steps run in the timed launch mode)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
+    if not args.no_graph:
+        try:
+            if dcomm is None:
+                s = torch.cuda.Stream()
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    step()
+                torch.cuda.current_stream().wait_stream(s)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=s):
+                    step()
+                launch = "hipGraph"
+            else:
+                seg = eng.capture_train_step(xd, xd, cfg, lpc_x=lpcd, comm=dcomm)
+                launch = f"hipGraph segments ({seg.nseg}) + {seg.ncoll} eager collective(s)"
+        except Exception as ex:  # fall back to eager launches in this process, say so in the JSON
+            print(f"[bench] hipGraph capture failed ({type(ex).__name__}: {ex}); running eagerly", file=sys.stderr)
+            graph, seg, launch = None, None, f"eager (capture failed: {type(ex).__name__})"
+    run = graph.replay if graph is not None else (seg.replay if seg is not None else step)
+    # every rank must take the same path (a rank that fell back to eager launches would still be correct, but say so)
+    all_same = comm.max_float(0.0 if (graph is not None or seg is not None or args.no_graph) else 1.0, dev) == 0.0
+    for _ in range(max(0, args.warmup - n_warm_eager)):
         run()
     torch.cuda.synchronize()
-    comm.barrier()
-    dt = comm.max_float(time.perf_counter() - t0, dev)
+
+    pass_ms = []
+    for _ in range(max(1, args.passes)):
+        comm.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run()
+        torch.cuda.synchronize()
+        comm.barrier()
+        pass_ms.append(1e3 * comm.max_float(time.perf_counter() - t0, dev) / args.steps)
+    ms_step = float(np.median(pass_ms))
+    dt = ms_step * 1e-3 * args.steps
     fps = comm.world * B * args.steps / dt
 
     # ---- roofline of the dominant kernel: per-launch HIP events on extra (eager) steps of the same workload ----
@@ -220,12 +249,11 @@ def main():
     eng.prof = None
     eng.overlap_wgrad = ov
     # dominant kernel = the instrumented kernel class with the largest share of the step
-    KERNELS = {"conv_mfma": "conv1d_fwd_kernel (per-conv forward + data-gradient launches)",
+    KERNELS = {"conv_mfma": "conv1d_fwd_kernel / conv1d_fwd_m32_kernel (convs outside gated blocks: forward + data gradients)",
                "block_fwd": "gated_block_fwd2_kernel (persistent weight-stationary gated block forward)",
-               "block_wgrad": "gated_block_wgrad_batch_kernel (all blocks' weight gradients, one persistent launch per width)",
-               "block_bwd": "gated_block_bwd_kernel (fused gated block backward)",
+               "block_wgrad": "gated_block_wgrad_batch_kernel + slab_reduce_batch_kernel (all blocks' weight gradients, one launch per width)",
                "block_dgrad": "gated_block_dgrad2_kernel (persistent weight-stationary gated block data-path backward)",
-               "wgrad_mfma": "conv1d_wgrad_kernel (per-conv weight gradients)"}
+               "wgrad_mfma": "conv1d_wgrad_batch_kernel + conv_slab_reduce_batch_kernel (weight gradients of the convs outside gated blocks)"}
     roof, by_kernel = None, {}
     traffic = {}
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # bytes per launch from rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE
@@ -339,15 +367,20 @@ def main():
         out = {
             "metric": "512-sample frames/s train step (2-codec CMRL)", "value": round(fps, 1), "unit": "frames/s",
             "n_gpus": comm.world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(ms_step, 3), "ms_per_step_passes": [round(v, 3) for v in pass_ms],
+            "ms_per_step_min": round(min(pass_ms), 3), "timing": f"median of {len(pass_ms)} passes of {args.steps} steps, each bracketed by barrier + synchronize, max over ranks",
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE config 3: 2-codec CMRL (strides [2], 32 bins) on fed LPC residual + 16x256 "
                                    "LSF quantizer, joint finetune step, fwd+loss+bwd+TF1-Adam" +
                                    ("+RCCL grad all-reduce(sum)" if comm.world > 1 else ""),
                        "batch_per_gpu": B, "global_batch": B * comm.world, "frame": 512,
-                       "parallelism": f"dp{comm.world}", "launch": "hipGraph" if graph is not None else "eager",
-                       "wgrad_overlap": "side stream" if eng.overlap_wgrad else "off",
-                       "roofline_note": "per-kernel numbers are measured with the overlap off (kernel in isolation)"},
+                       "parallelism": f"dp{comm.world}", "launch": launch, "all_ranks_same_launch": all_same,
+                       "c_abi_calls_per_step": calls_per_step,
+                       "grad_message": (("one per trainable scope, under the backward pass" if eng.dp_overlap else
+                                         "one at the tail of the step") if dcomm is not None else None),
+                       "streams": "one (weight gradients batched at the tail of the step)",
+                       "roofline_note": "per-kernel numbers: HIP events around each launch on extra eager steps of the same workload"},
             "model_tflops": round(fps * MFLOP_PER_FRAME_JOINT * 1e6 / 1e12, 2),
             "roofline": roof, "roofline_quantizer": qroof, "cpu_baseline": cpu, "codec_forward": infer, "kernels": kern_ms,
         }

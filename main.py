@@ -3,7 +3,7 @@
 
 Dropped: the three blocking input() calls at exit (main.py:49-51).  Added (all optional, defaults reproduce the
 reference's edit-the-source globals): --lpc_domain (constants.is_pure_time_domain=False), --data_root,
---max_batches_per_epoch, --out_root, --model_id, --seed.  Multi-GPU: launch with torch.distributed.run; frames are
+--max_batches_per_epoch, --out_root, --model_id, --seed, --local_entropy.  Multi-GPU: launch with torch.distributed.run; frames are
 sharded over ranks and gradients all-reduced (sum) over RCCL.
 """
 import argparse
@@ -44,7 +44,10 @@ def build_parser():
                         help='1: tau follows the per-frame entropy of validation frames like the reference; 0: the last training batch')
     parser.add_argument('--out_root', type=str, default='.', help="where ./check and ./doc live")
     parser.add_argument('--model_id', type=str, default=None, help='fix the random model id')
-    parser.add_argument('--seed', type=int, default=20200504)
+    parser.add_argument('--seed', type=int, default=20200504, help='weights, and the per-epoch row order (identical on every rank)')
+    parser.add_argument('--local_entropy', type=int, default=0,
+                        help='data parallel: 1 = entropy term from each rank\'s own batch histogram (no histogram all-reduce)')
+    parser.add_argument('--dump_rows', type=int, default=0, help='debug: write the training rows each rank fed to <out_root>/rows_rank<r>.npy')
     return parser
 
 
@@ -55,9 +58,10 @@ def main(argv=None):
     from nsc_amd.dist import Comm
     comm = Comm()
     args.comm = comm if comm.world > 1 else None
-    args.device = "cuda:%d" % comm.local_rank
     import torch
-    torch.cuda.set_device(comm.local_rank)
+    ldev = comm.local_rank % max(torch.cuda.device_count(), 1)      # one GPU per rank; wraps only in single-GPU tests
+    args.device = "cuda:%d" % ldev
+    torch.cuda.set_device(ldev)
     audio_coding_ae = CMRL(args)
     modes = {'1': 'one_ae', '2': 'retrain_from_somewhere', '3': 'cascaded', '4': 'cascaded', '5': 'finetune',
              '0': 'feedforward'}

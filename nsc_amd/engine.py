@@ -555,6 +555,58 @@ class _Codec:
         return None
 
 
+class _SegmentRecorder:
+    """Captures consecutive hipGraph segments on the current (side) stream; cut() ends one and starts the next.  A cut with
+    no launch since the previous one adds its action to the previous segment instead of capturing an empty graph."""
+
+    def __init__(self, eng):
+        self.eng, self.segs, self.cur, self.mark = eng, [], None, 0
+        self.pool = torch.cuda.graph_pool_handle()
+
+    def begin(self):
+        self.cur = torch.cuda.CUDAGraph()
+        self.cur.capture_begin(pool=self.pool)
+        self.mark = self.eng._nlaunch
+
+    def cut(self, action):
+        if self.eng._nlaunch == self.mark and self.segs:
+            self.segs[-1][1].append(action)
+            return
+        self.cur.capture_end()
+        self.segs.append((self.cur, [action]))
+        self.begin()
+
+    def finish(self):
+        self.cur.capture_end()
+        self.segs.append((self.cur, []))
+
+
+class SegmentedStep:
+    """A train step as [graph, eager collective, graph, ...]: replay() launches the segments in order on the current stream;
+    "sync" collectives block the stream behind them, "async" ones (gradient all-reduces on RCCL's own stream) overlap with
+    the next segment and are waited for at the "wait" cut (just before the optimizer segment)."""
+
+    def __init__(self, segs):
+        self.segs = segs
+        self.nseg = len(segs)
+        self.ncoll = sum(1 for _, acts in segs for a in acts if a[1] is not None)
+
+    def replay(self):
+        handles = []
+        for g, acts in self.segs:
+            g.replay()
+            for kind, fn in acts:
+                if kind == "sync":
+                    fn()
+                elif kind == "async":
+                    handles.append(fn())
+                elif kind == "wait":
+                    for h in handles:
+                        if h is not None:
+                            h.wait()
+                    handles = []
+
+
 class CascadeEngine:
     """N-codec CMRL cascade + losses + TF1 Adam on flat buffers (cmrl.py:22-135, 295-511)."""
 
@@ -631,10 +683,12 @@ class CascadeEngine:
     # ---- plumbing ----
     def stream(self):
         """Raw handle of the current stream, cached for the duration of a public call (the lookup costs ~8 us of host
-        time and an engine step makes ~700 of them)."""
+        time and an engine step makes ~700 of them).  Every launch asks for it: _nlaunch counts them."""
+        self._nlaunch += 1
         return self._st if self._st is not None else torch.cuda.current_stream().cuda_stream
 
     _st = None
+    _nlaunch = 0
 
     def _enter(self):
         self._st = torch.cuda.current_stream().cuda_stream
@@ -671,6 +725,44 @@ class CascadeEngine:
                               # that holds a CU's LDS when such a kernel starts delays that CU's whole share: per-conv launches
                               # on the side stream measured 3.57 ms/step when their timing happened to fall well and 3.82 when
                               # it did not; everything deferred to the tail of the step: 3.55, independent of timing
+
+    # ---- data parallel: how the step meets its collectives ----
+    dp_overlap = False   # True: one gradient all-reduce per trainable scope, started as soon as that codec's backward pass and
+                         # weight gradients are done (runs under the earlier codecs' backward pass); False: one message for
+                         # all scopes at the tail of the step (the batched weight-gradient launches stay whole).  Measured on
+                         # one MI355X with the collectives as no-ops (bench.py --dp-selftest): 3.496 ms/step with per-scope
+                         # flushes, 3.360 at the tail, 3.352 for the single-GPU graph - splitting the batched launches costs
+                         # 0.14 ms, more than the ~0.05 ms an exposed 2.8 MB all-reduce takes
+    _rec = None          # segment recorder while a step is being captured (capture_train_step)
+
+    def _collective(self, kind, fn):
+        """Every collective of a step goes through here.  Eager: run it.  While a step is being captured as hipGraph
+        segments: close the current segment, remember the collective as the eager action that follows it, open the next."""
+        if self._rec is None:
+            assert self._st is None or self._st == torch.cuda.current_stream().cuda_stream, \
+                "collective issued from a different stream than the engine's launches"
+            return fn() if fn is not None else None
+        self._rec.cut((kind, fn))
+        return None
+
+    def capture_train_step(self, x, target, cfg, lpc_x=None, comm=None):
+        """Capture one train step as hipGraph SEGMENTS cut at the collectives (forward + loss | per-scope backward + weight
+        gradients | Adam), so that the data-parallel step replays like the single-GPU one: RCCL calls stay eager between
+        two graph launches (no collective is captured).  The caller has run the step eagerly at least once (buffers allocated).
+        Returns a SegmentedStep; .replay() runs one step on the current stream."""
+        rec = _SegmentRecorder(self)
+        s = torch.cuda.Stream(device=self.device)
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self._rec = rec
+            try:
+                rec.begin()
+                self.train_step(x, target, cfg, lpc_x=lpc_x, comm=comm)
+                rec.finish()
+            finally:
+                self._rec = None
+        torch.cuda.current_stream().wait_stream(s)
+        return SegmentedStep(rec.segs)
 
     def defer_block_wgrad(self, blk, dz, da, dz1, dw1_ptr, flops):
         self._wg_jobs.append(_lib.BlockWgradJob(blk.x.data_ptr(), blk.h.data_ptr(), blk.g.data_ptr(), dz.data_ptr(),
@@ -939,7 +1031,8 @@ class CascadeEngine:
                                              self.mel_ranges.data_ptr(), self.time.data_ptr(), self.freq.data_ptr(),
                                              G.data_ptr(), self.stream()), "recon_loss")
         if hist_allreduce is not None:
-            hist_allreduce([self._hist_flat[:self._hist_used]])   # every quantizer's soft histogram in one message
+            # every quantizer's soft histogram in one message
+            self._collective("sync", lambda: hist_allreduce([self._hist_flat[:self._hist_used]]))
         ents = self.entropies()
         n = B * frame_length
         dsum = None  # running sum over later codecs of dL/dxin_j
@@ -982,7 +1075,7 @@ class CascadeEngine:
                 dx = c.backward(ddec, c_quan[i], c_ent[i] * Bg, need_dx=need_dx)
             else:
                 raise NotImplementedError("a frozen codec between trainable ones is not a reference configuration")
-            if grad_allreduce is not None:
+            if grad_allreduce is not None and self.dp_overlap:
                 # data parallel: this codec's gradients are complete once its deferred weight gradients have run; send them
                 # now, under the backward pass of the earlier codecs (scope = one contiguous range of the flat buffer)
                 self.flush_block_wgrads()
@@ -990,7 +1083,7 @@ class CascadeEngine:
                 a, b = self.layout.scope_range(f"scope_{i + 1}")
                 if lpc_rng is not None and lpc_rng[1] == a:
                     a, lpc_rng = lpc_rng[0], None
-                pending.append(grad_allreduce(self.grads[a:b]))
+                pending.append(self._collective("async", lambda a=a, b=b: grad_allreduce(self.grads[a:b])))
             if need_dx:
                 if dsum is None:
                     dsum = dx
@@ -998,10 +1091,19 @@ class CascadeEngine:
                     acc = self.buf("dsum", (B, 1, frame_length))
                     check(self.lib.nsc_axpby(dx.data_ptr(), dsum.data_ptr(), acc.data_ptr(), 1.0, 1.0, n, self.stream()), "axpby")
                     dsum = acc
-        if lpc_rng is not None:
-            pending.append(grad_allreduce(self.grads[lpc_rng[0]:lpc_rng[1]]))
+        if lpc_rng is not None and self.dp_overlap:
+            pending.append(self._collective("async", lambda r=lpc_rng: grad_allreduce(self.grads[r[0]:r[1]])))
         self.flush_block_wgrads()
         self.side_join()
+        if grad_allreduce is not None and not self.dp_overlap:
+            # one message for everything trainable, after the batched weight-gradient launches at the tail of the step (the
+            # launches stay whole: per-codec flushes split them); frozen scopes in front of the first trainable one are not sent
+            lo = min([self.layout.scope_range(f"scope_{i + 1}")[0] for i in range(first_needed, self.N)] +
+                     ([self.layout.scope_range("lpc_quan")[0]] if lpc_rng is not None else []))
+            hi = self.layout.scope_range(f"scope_{self.N}")[1]
+            pending.append(self._collective("async", lambda lo=lo, hi=hi: grad_allreduce(self.grads[lo:hi])))
+        if grad_allreduce is not None:
+            self._collective("wait", None)
         for w in pending:
             if w is not None:
                 w.wait()

@@ -88,6 +88,65 @@ def journal_line_lpc(i, ave_snr, ave_stoi, ave_pesq, _quan_loss, fully_snr, full
             'fully_entropy: %6.5f \n' % (i, ave_snr, ave_stoi, ave_pesq, _quan_loss, fully_snr, fully_pesq, fully_entropy))
 
 
+def epoch_permutation(n, seed, epoch, perm=None):
+    """Row order of one epoch.  The reference shuffles the training matrix in place after every epoch (nsc_module:460) with
+    NumPy's unseeded global generator; here the same operation is a seeded permutation of row INDICES, identical on every
+    rank: epoch e's order is epoch e-1's order composed with a shuffle drawn from (seed, e)."""
+    perm = np.arange(n, dtype=np.int64) if perm is None else perm
+    if epoch > 0:
+        np.random.default_rng([int(seed), int(epoch)]).shuffle(perm)
+    return perm
+
+
+def epoch_batches(perm, batch, world, rank, seed, epoch, max_batches):
+    """Rows of every step of one epoch for ONE rank.  nsc_module:115-121: batch starts range(0, N - batch, batch), shuffled,
+    contiguous rows i:i+batch of the (shuffled) matrix, first max_batches starts.  Data parallel: the GLOBAL batch is
+    batch * world rows from one start, rank r owns rows [start + r batch, start + (r + 1) batch) - so an N-rank run sees
+    exactly the steps of a 1-process run at batch N * batch, and no two ranks ever see the same row in a step."""
+    gb = batch * world
+    starts = list(range(0, perm.shape[0] - gb, gb))
+    random.Random(f"{int(seed)}/{int(epoch)}").shuffle(starts)
+    return [perm[i + rank * batch:i + (rank + 1) * batch] for i in starts[:max_batches]]
+
+
+class _Feeder:
+    """Host -> HBM feed of the training loop: rows are gathered into one of two PINNED host buffers and copied on a side
+    stream into one of two device buffers while the previous step computes (the reference hands sess.run a pageable
+    NumPy slice per step, nsc_module:455-458).  next() returns device tensors valid until the call after next."""
+
+    def __init__(self, batch, width, device):
+        self.dev = torch.device(device)
+        self.pin = [torch.empty((batch, width), dtype=torch.float32).pin_memory() for _ in range(2)]
+        self.buf = [torch.empty((batch, width), dtype=torch.float32, device=self.dev) for _ in range(2)]
+        self.copy_stream = torch.cuda.Stream(device=self.dev)
+        self.copied = [torch.cuda.Event() for _ in range(2)]      # H2D of slot k finished (pinned buffer reusable)
+        self.used = [None, None]                                   # main-stream event: the step that read slot k has run
+        self.k = 0
+
+    def put(self, rows_np):
+        """Start moving one batch (a [batch, width] float32 array view / gather) to the device; returns the slot."""
+        k = self.k
+        self.k ^= 1
+        self.copied[k].synchronize()                               # the copy that last used this pinned buffer is done
+        np.copyto(self.pin[k].numpy(), rows_np)
+        if self.used[k] is not None:
+            self.copy_stream.wait_event(self.used[k])              # the step two back no longer reads this device buffer
+        with torch.cuda.stream(self.copy_stream):
+            self.buf[k].copy_(self.pin[k], non_blocking=True)
+            self.copied[k].record(self.copy_stream)
+        return k
+
+    def get(self, k):
+        """Device batch of slot k, ordered after its copy on the current stream."""
+        torch.cuda.current_stream().wait_event(self.copied[k])
+        return self.buf[k]
+
+    def done(self, k):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.used[k] = ev
+
+
 class neuralSpeechCodingModule(object):
     def __init__(self, arg):
         """nsc_module:26-71.  Space-separated list flags are parsed exactly like the reference."""
@@ -118,6 +177,9 @@ class neuralSpeechCodingModule(object):
         self._val_data = None
         self._out_root = getattr(arg, "out_root", ".") or "."
         self._seed = int(getattr(arg, "seed", 20200504) or 20200504)
+        self._local_entropy = bool(getattr(arg, "local_entropy", 0))   # skip the histogram all-reduce
+        self._dump_rows = bool(getattr(arg, "dump_rows", 0))
+        self._rows_seen = []
         self._comm = getattr(arg, "comm", None)
         self._device = getattr(arg, "device", "cuda")
         seed_id = getattr(arg, "model_id", None)
@@ -125,6 +187,7 @@ class neuralSpeechCodingModule(object):
         if self._comm is not None and self._comm.world > 1:
             # one id for the whole job: checkpoints / journal are written by rank 0 and read back by every rank
             self._rand_model_id = self._comm.broadcast_object(self._rand_model_id)
+        self._epochs_done = 0           # epochs over all phases: seeds the row order (identical on every rank)
         self._load_training_data()
         for d in ("check", "doc"):
             os.makedirs(os.path.join(self._out_root, d), exist_ok=True)
@@ -133,14 +196,21 @@ class neuralSpeechCodingModule(object):
         self._engine = None
 
     # ------------------------------------------------------------------ data
+    def _world_rank(self):
+        return (self._comm.world, self._comm.rank) if self._comm is not None else (1, 0)
+
     def _load_training_data(self):
-        """nsc_module:40-55: [N,512] frames (time domain) or [N, 512+16+512] (frame | LSF | residual)."""
+        """nsc_module:40-55: [N,512] frames (time domain) or [N, 512+16+512] (frame | LSF | residual).  A --data_root file is
+        memory-mapped: a rank only ever touches the rows of its own share of each global batch (epoch_batches), so N ranks
+        read disjoint rows and no rank holds the matrix.  Row order lives in self._perm (epoch_permutation)."""
         n = int(getattr(self, "_tr_data_size", K.training_data_size))
+        world, _ = self._world_rank()
         if self._data_root and os.path.exists(self._data_root):
-            self._tr_data = np.load(self._data_root)[:n].astype(np.float32)
+            self._tr_data = np.load(self._data_root, mmap_mode="r")[:n]
         else:
-            nb = max(self._batch_size * (min(self._max_batches, 16) + 1), 2 * self._batch_size)
-            rng = np.random.default_rng(1234 + (self._comm.rank if self._comm else 0))
+            # synthetic frames (SURVEY 8d): the SAME matrix on every rank, sized for the global batch, sharded like a file
+            nb = max(self._batch_size * world * (min(self._max_batches, 16) + 1), 2 * self._batch_size * world)
+            rng = np.random.default_rng(1234)
             frames = (np.clip(0.03 * rng.standard_normal((nb, K.frame_length)), -1, 1) * training_window()).astype(np.float32)
             if self._is_pure_time_domain:
                 self._tr_data = frames
@@ -148,12 +218,14 @@ class neuralSpeechCodingModule(object):
                 lsf = np.sort(rng.uniform(0.03, 3.1, (nb, self._lpc_order)), axis=1).astype(np.float32)
                 res = (np.clip(0.03 * rng.standard_normal((nb, K.frame_length)), -1, 1) * training_window()).astype(np.float32)
                 self._tr_data = np.concatenate([frames, lsf, res], 1)
+        self._perm = epoch_permutation(self._tr_data.shape[0], self._seed, 0)
+        self._res_override = None       # residual columns recomputed by _update_lpc_residual (the file itself is read-only)
 
     def _load_validation_data(self):
         """Frames the tau controller's entropy is measured on (the reference reads it off its validation utterances,
         nsc_module:462-470 -> end2end_eval :656-740).  A file next to the training data, or synthetic frames from another seed."""
         root = self._val_data_root
-        n = 4 * self._batch_size
+        n = 4 * self._batch_size * self._world_rank()[0]     # the same frames whatever the number of ranks
         if root and os.path.exists(root):
             self._val_data = np.load(root)[:n].astype(np.float32)
             return
@@ -213,23 +285,26 @@ class neuralSpeechCodingModule(object):
         with open(path, 'a') as f:
             f.write(the_string)
 
-    def _generate_one_epoch_end2end(self, x, y, batchsize):
-        """nsc_module:115-121: shuffled batch starts, contiguous rows, first 2500 batches."""
-        the_list = list(range(0, x.shape[0] - self._batch_size, self._batch_size))
-        random.shuffle(the_list)
-        for i in the_list[:self._max_batches]:
-            ret = np.reshape(self._tr_data[i:(i + batchsize), :K.frame_length], (batchsize, K.frame_length, 1))
+    def _epoch_rows(self, epoch):
+        """This rank's row indices for every step of the epoch (see epoch_batches)."""
+        world, rank = self._world_rank()
+        return epoch_batches(self._perm, self._batch_size, world, rank, self._seed, epoch, self._max_batches)
+
+    def _generate_one_epoch_end2end(self, x, y, batchsize, epoch=0):
+        """nsc_module:115-121: shuffled batch starts, contiguous rows of the shuffled matrix, first 2500 batches."""
+        for rows in self._epoch_rows(epoch):
+            blk = np.asarray(self._tr_data[rows])
+            ret = blk[:, :K.frame_length].reshape(batchsize, K.frame_length, 1)
             yield ret, ret
 
-    def _generate_one_epoch_end2end_lpc_fast(self, x, y, batchsize):
+    def _generate_one_epoch_end2end_lpc_fast(self, x, y, batchsize, epoch=0):
         """nsc_module:132-142: (frame, frame, LSF, precomputed residual)."""
         fl, lo = K.frame_length, self._lpc_order
-        the_list = list(range(0, self._tr_data.shape[0] - self._batch_size, self._batch_size))
-        random.shuffle(the_list)
-        for i in the_list[:self._max_batches]:
-            blk = self._tr_data[i:i + batchsize]
+        for rows in self._epoch_rows(epoch):
+            blk = np.asarray(self._tr_data[rows])
+            res = blk[:, fl + lo:] if self._res_override is None else self._res_override[rows]
             ret = blk[:, :fl].reshape(batchsize, fl, 1)
-            yield ret, ret, blk[:, fl:fl + lo].reshape(batchsize, lo, 1), blk[:, fl + lo:].reshape(batchsize, fl, 1)
+            yield ret, ret, blk[:, fl:fl + lo].reshape(batchsize, lo, 1), res.reshape(batchsize, fl, 1)
 
     # ------------------------------------------------------------------ op-surface graph builders
     # (these run on the autograd op surface; the trainers below use the explicit engine for speed)
@@ -356,11 +431,12 @@ class neuralSpeechCodingModule(object):
         py_func bodies run as HIP kernels (nsc_amd/lpc_utilities.py)."""
         from .lpc_utilities import residual_from_lsf
         fl, lo = K.frame_length, self._lpc_order
-        frames = torch.from_numpy(np.ascontiguousarray(self._tr_data[:, :fl]))
-        lsf = torch.from_numpy(np.ascontiguousarray(self._tr_data[:, fl:fl + lo]))
+        frames = torch.from_numpy(np.ascontiguousarray(self._tr_data[:, :fl], dtype=np.float32))
+        lsf = torch.from_numpy(np.ascontiguousarray(self._tr_data[:, fl:fl + lo], dtype=np.float32))
         alpha = torch.full((1,), float(K.init_alpha), dtype=torch.float32, device=eng.device)   # a fresh alpha, :1084
         res = residual_from_lsf(frames, lsf, alpha, eng.view("lpc_quan/bins"))
-        self._tr_data = np.concatenate([self._tr_data[:, :fl + lo], res.cpu().numpy()], 1).astype(np.float32)
+        # every rank recomputes the whole column block (device kernels, once per 30 epochs); the file stays read-only
+        self._res_override = res.cpu().numpy().astype(np.float32)
 
     def _barrier(self):
         if self._comm is not None:
@@ -412,21 +488,42 @@ class neuralSpeechCodingModule(object):
                     self.save(eng, save_id)
                 self._barrier()
             gen = () if refresh else (self._generate_one_epoch_end2end_lpc_fast if lpc else self._generate_one_epoch_end2end)(
-                self._tr_data, self._tr_data, self._batch_size)
+                self._tr_data, self._tr_data, self._batch_size, epoch=self._epochs_done)
             terms, nsteps = None, 0
-            for batch in gen:
+            fl, lo, Bsz = K.frame_length, self._lpc_order, self._batch_size
+            if getattr(self, "_feeder", None) is None:
+                self._feeder = _Feeder(Bsz, fl + (lo if lpc else 0), dev)
+            feeder = self._feeder
+
+            def put(batch):
+                # one [B, 512 (+16)] host row block per step: residual | LSF on the LPC path (the feed dict of :586-595)
                 if lpc:
-                    _, _, b_lpc, b_res = batch
-                    x = torch.from_numpy(np.ascontiguousarray(b_res.reshape(self._batch_size, 1, -1))).to(dev)
-                    lpc_x = torch.from_numpy(np.ascontiguousarray(b_lpc)).to(dev)
+                    return feeder.put(np.concatenate([batch[3].reshape(Bsz, fl), batch[2].reshape(Bsz, lo)], 1))
+                return feeder.put(batch[0].reshape(Bsz, fl))
+            if self._dump_rows and not refresh:
+                self._rows_seen += [r.copy() for r in self._epoch_rows(self._epochs_done)]
+            it = iter(gen)
+            nxt = next(it, None)
+            slot = put(nxt) if nxt is not None else None
+            while nxt is not None:
+                cur_slot = slot
+                nxt = next(it, None)
+                d = feeder.get(cur_slot)
+                x = d[:, :fl].reshape(Bsz, 1, fl)
+                if lpc:
+                    x = x.contiguous()
+                    lpc_x = d[:, fl:].reshape(Bsz, lo, 1).contiguous()
                 else:
-                    x = torch.from_numpy(np.ascontiguousarray(batch[0].reshape(self._batch_size, 1, -1))).to(dev)
                     lpc_x = None
                 terms = eng.train_step(x, x, cfg, lpc_x=lpc_x, comm=self._comm)
+                feeder.done(cur_slot)
+                if nxt is not None:
+                    slot = put(nxt)              # gathered and copied while the step above runs
                 nsteps += 1
             torch.cuda.synchronize()
             elapsed = time.perf_counter() - start
-            np.random.shuffle(self._tr_data)                                       # nsc_module:460
+            self._epochs_done += 1
+            self._perm = epoch_permutation(self._tr_data.shape[0], self._seed, self._epochs_done, self._perm)   # nsc_module:460
             # ---- validation signal (nsc_module:462-470; the loops themselves are out of scope) ----
             ents = [float(e.item()) for e in terms["ent"]] if terms else [0.0] * len(eng.codecs)
             ent_lpc = float(terms["ent_lpc"].item()) if (terms and terms.get("ent_lpc") is not None) else 0.0
@@ -481,6 +578,9 @@ class neuralSpeechCodingModule(object):
                 break
         if self._is_writer():
             self.save(eng, save_id)
+        if self._dump_rows:
+            _, rank = self._world_rank()
+            np.save(os.path.join(self._out_root, f"rows_rank{rank}.npy"), np.array(self._rows_seen, dtype=np.int64))
         self._barrier()       # no rank restores the checkpoint before rank 0 has finished writing it
         self._last_taus = (init_tau, init_tau_1, init_tau_2)
         return init_tau
@@ -533,6 +633,11 @@ class neuralSpeechCodingModule(object):
             tau_map = [("c_ent", i, 1.0, min(i + 1, 2)) for i in range(num_codecs)]
         quan = dict(is_quan_on=1.0, c_time=c[0], c_freq=c[1], c_quan=cq, c_ent=list(zeros), trainable=train, slot=1,
                     quan_op=True, **extra)
+        if self._local_entropy:
+            # --local_entropy: entropy_coding_loss sees each rank's own batch histogram - the standard
+            # data-parallel behaviour, one all-reduce less per step; an N-rank run then no longer equals a 1-process run at
+            # batch N B, and the entropies rank 0 journals are those of ITS frames
+            quan["global_entropy"] = False
         return no_quan, quan, tau_map
 
     def one_ae(self):

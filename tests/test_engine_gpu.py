@@ -266,19 +266,39 @@ lo, hi = comm.shard(B)
 eng = CascadeEngine(Bl, 2, BKD, [[2], [2]], [32, 32], **kw)
 eng.load_named(ps.params)
 xd = dev(x[lo:hi].transpose(0, 2, 1))
-eng.train_step(xd, xd, cfg, lpc_x=dev(lpc_all[lo:hi]) if LPC else None, comm=comm)   # per-scope grad all-reduces + histograms
+lx = dev(lpc_all[lo:hi]) if LPC else None
+eng.train_step(xd, xd, cfg, lpc_x=lx, comm=comm)   # per-scope grad all-reduces + histograms (eager launches)
 torch.cuda.synchronize()
+g_eager, p_eager = eng.grads.cpu().numpy(), eng.params.cpu().numpy()
+ent_eager = [float(c.ent.item()) for c in eng.codecs]
+# the same step replayed as hipGraph SEGMENTS cut at the collectives (what bench.py does at N > 1), in both message layouts
+seg = {}
+for overlap in (True, False):
+    eng.dp_overlap = overlap
+    eng.load_named(ps.params); eng.reset_adam()
+    eng.train_step(xd, xd, cfg, lpc_x=lx, comm=comm)          # eager warm-up of this layout
+    eng.load_named(ps.params); eng.reset_adam()
+    st = eng.capture_train_step(xd, xd, cfg, lpc_x=lx, comm=comm)
+    eng.load_named(ps.params); eng.reset_adam()
+    st.replay()
+    torch.cuda.synchronize()
+    seg[overlap] = (eng.grads.cpu().numpy(), eng.params.cpu().numpy(), st.nseg, st.ncoll)
+    st.replay(); st.replay()                                  # replays keep working (Adam's device step counter advances)
+    torch.cuda.synchronize()
 if comm.rank == 0:
     ref = CascadeEngine(B, 2, BKD, [[2], [2]], [32, 32], **kw)
     ref.load_named(ps.params)
     xf = dev(x.transpose(0, 2, 1))
     ref.train_step(xf, xf, cfg, lpc_x=dev(lpc_all) if LPC else None)
     torch.cuda.synchronize()
-    g1, g2 = eng.grads.cpu().numpy(), ref.grads.cpu().numpy()
-    p1, p2 = eng.params.cpu().numpy(), ref.params.cpu().numpy()
-    print(json.dumps({"gerr": float(np.abs(g1 - g2).max() / np.abs(g2).max()), "perr": float(np.mean(np.abs(p1 - p2) > 1e-6)),
-                      "ent": [float(e.item()) for e in (c.ent for c in eng.codecs)],
-                      "ent_ref": [float(e.item()) for e in (c.ent for c in ref.codecs)]}))
+    g2, p2 = ref.grads.cpu().numpy(), ref.params.cpu().numpy()
+    ge = lambda g: float(np.abs(g - g2).max() / np.abs(g2).max())
+    pe = lambda p_: float(np.mean(np.abs(p_ - p2) > 1e-6))
+    print(json.dumps({"gerr": ge(g_eager), "perr": pe(p_eager), "ent": ent_eager,
+                      "ent_ref": [float(e.item()) for e in (c.ent for c in ref.codecs)],
+                      "seg_overlap": [ge(seg[True][0]), pe(seg[True][1]), seg[True][2], seg[True][3],
+                                      float(np.abs(seg[True][0] - g_eager).max() / np.abs(g_eager).max())],
+                      "seg_tail": [ge(seg[False][0]), pe(seg[False][1]), seg[False][2], seg[False][3]]}))
 comm.barrier()
 comm.close()
 '''
@@ -303,6 +323,13 @@ def test_data_parallel_engine_two_ranks_equals_one_process(tmp_path, lpc):
     # reduction-order noise floor may differ (a vanishing fraction)
     assert res["perr"] < 2e-3, res
     assert np.allclose(res["ent"], res["ent_ref"], rtol=1e-5), res   # entropy is that of the GLOBAL batch on every rank
+    # segmented hipGraph replay == the eager data-parallel step (same kernels, same messages; a few gradients are float
+    # atomics, so not bit for bit) == one process
+    assert res["seg_overlap"][0] < 2e-4 and res["seg_overlap"][1] < 2e-3 and res["seg_overlap"][4] < 1e-5, res
+    assert res["seg_tail"][0] < 2e-4 and res["seg_tail"][1] < 2e-3, res
+    # forward + loss | histograms | codec 2 | codec 1 (+ LSF quantizer) | wait | Adam   vs  one gradient message at the tail
+    assert res["seg_overlap"][3] == 3 and res["seg_tail"][3] == 2, res        # histograms + two scopes | histograms + one
+    assert res["seg_overlap"][2] == 4 and res["seg_tail"][2] == 3, res        # no empty segment between message and wait
 
 
 def test_validation_frame_entropies_match_batch_of_one_oracle():

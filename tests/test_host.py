@@ -297,3 +297,31 @@ def test_mel_band_ranges_cover_every_nonzero():
     nz = m != 0
     assert not (nz & ~inside_c).any() and not (nz & ~inside_r).any()
     assert inside_c.sum() < 0.06 * m.size and inside_r.sum() < 0.06 * m.size      # ~1.9 k of 47 k terms
+
+
+def test_epoch_rows_shard_like_a_single_process_at_the_global_batch():
+    """Data parallel feed of the trainer (nsc_amd/neural_speech_coding_module.py: epoch_permutation / epoch_batches): in
+    every step the ranks' rows are disjoint and their concatenation (rank order) is exactly the step of a 1-process run at
+    batch world * B; the order is a function of (seed, epoch) only, and one epoch's shuffle acts on the previous order like
+    the reference's in-place np.random.shuffle of the matrix (nsc_module:115-121, 460)."""
+    from nsc_amd.neural_speech_coding_module import epoch_batches, epoch_permutation
+    n, B, world, seed = 203, 4, 2, 7
+    perm = None
+    for epoch in range(3):
+        perm = epoch_permutation(n, seed, epoch, perm)
+        assert sorted(perm.tolist()) == list(range(n))
+        one = epoch_batches(perm, B * world, 1, 0, seed, epoch, 2500)
+        r0 = epoch_batches(perm, B, world, 0, seed, epoch, 2500)
+        r1 = epoch_batches(perm, B, world, 1, seed, epoch, 2500)
+        assert len(one) == len(r0) == len(r1) == len(range(0, n - B * world, B * world))
+        for a, b, c in zip(one, r0, r1):
+            assert np.array_equal(a, np.concatenate([b, c])) and not set(b.tolist()) & set(c.tolist())
+        # contiguous rows of the (shuffled) matrix, shuffled batch starts: every step is perm[i : i + 2B] for a distinct i
+        starts = sorted(int(np.where(perm == a[0])[0][0]) for a in one)
+        assert starts == list(range(0, n - B * world, B * world))
+        again = epoch_batches(epoch_permutation(n, seed, 0), B, world, 1, seed, 0, 3)
+        assert len(again) == 3
+    p0 = epoch_permutation(n, seed, 0)
+    assert np.array_equal(p0, np.arange(n))                       # epoch 0 reads the matrix in file order like the reference
+    assert not np.array_equal(epoch_permutation(n, seed, 1, p0.copy()), np.arange(n))
+    assert np.array_equal(epoch_permutation(n, seed, 1, np.arange(n)), epoch_permutation(n, seed, 1, np.arange(n)))

@@ -160,3 +160,53 @@ def test_framing_on_gpu_roundtrip():
     n = ola.numel()
     inner = slice(600, n - 600)
     assert np.max(np.abs(ola.cpu().numpy()[inner] - utt[:n][inner])) < 1e-5
+
+
+def _cli(tmp, out, batch, nproc, data, extra=()):
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    flags = ["--learning_rate_tanh", "2e-4", "--learning_rate_greedy_followers", "2e-5 2e-6", "--epoch_tanh", "3",
+             "--epoch_greedy_followers", "1 1", "--from_where_step", "2", "--batch_size", str(batch), "--num_resnets", "1",
+             "--training_mode", "1", "--base_model_id", "", "--suffix", "dp", "--window_size", "512",
+             "--bottleneck_kernel_and_dilation", "9 9 100 20 1 2", "--is_cq", "0", "--the_strides", "2", "--save_unique_mark", "",
+             "--coeff_term", "60 10 10 0.3", "--res_scalar", "1.0", "--pretrain_step", "1", "--target_entropy", "2.2",
+             "--num_bins_for_follower", "32", "--data_root", str(data), "--max_batches_per_epoch", "3", "--out_root", str(out),
+             "--model_id", "7654321", "--seed", "3", "--dump_rows", "1", *extra]
+    env = dict(os.environ, NSC_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")     # the ranks share the test box's one GPU
+    if nproc == 1:
+        cmd = [sys.executable, os.path.join(root, "main.py"), *flags]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr",
+               "127.0.0.1", "--master-port", "29641", os.path.join(root, "main.py"), *flags]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=str(tmp))
+    assert r.returncode == 0, r.stderr[-3000:]
+    return open(glob.glob(os.path.join(str(out), "doc", "*_journal.txt"))[0]).read()
+
+
+def test_cli_two_ranks_shard_the_data_file_and_match_one_process(tmp_path):
+    """main.py mode 1 over a --data_root file: 2 ranks x batch 2 == 1 process x batch 4.  The ranks feed DISJOINT rows (each
+    step's global batch is split between them, identical seeded row order on both), gradients are summed and the entropy
+    histogram is that of the global batch - so the journal (SNR / quan loss / tau / entropy per epoch) is the single-process
+    one up to fp32 reduction order.  Reference loop: neural_speech_coding_module.py:115-121, 424-549."""
+    rng = np.random.default_rng(11)
+    win = np.concatenate([np.hanning(63)[:32], np.ones(448), np.hanning(63)[31:]])
+    data = (np.clip(0.03 * rng.standard_normal((30, 512)), -1, 1) * win).astype(np.float32)
+    np.save(tmp_path / "frames.npy", data)
+    (tmp_path / "one").mkdir(); (tmp_path / "two").mkdir()
+    j1 = _cli(tmp_path, tmp_path / "one", 4, 1, tmp_path / "frames.npy")
+    j2 = _cli(tmp_path, tmp_path / "two", 2, 2, tmp_path / "frames.npy")
+    rows1 = np.load(tmp_path / "one" / "rows_rank0.npy")
+    ra, rb = np.load(tmp_path / "two" / "rows_rank0.npy"), np.load(tmp_path / "two" / "rows_rank1.npy")
+    assert rows1.shape == (9, 4) and ra.shape == rb.shape == (9, 2)            # 3 epochs x 3 steps
+    assert np.array_equal(rows1, np.concatenate([ra, rb], axis=1))            # same global batches, split in rank order
+    assert all(not set(a.tolist()) & set(b.tolist()) for a, b in zip(ra, rb))  # disjoint rows in every step
+    import re
+    num = lambda j: [float(v) for v in re.findall(r"(?<![\w.])-?\d+\.\d+(?:e-?\d+)?", j.split("\n\n", 1)[1])]
+    a, b = np.array(num(j1)), np.array(num(j2))
+    assert a.shape == b.shape and a.size >= 3 * 5, (j1, j2)          # SNR, Si-SNR, quan loss, tau, entropy per epoch
+    assert np.allclose(a, b, rtol=2e-3, atol=2e-4), (j1, j2)
+    # --local_entropy: the run still trains (finite journal), but the entropy term no longer sees the global histogram
+    (tmp_path / "loc").mkdir()
+    j3 = _cli(tmp_path, tmp_path / "loc", 2, 2, tmp_path / "frames.npy", extra=("--local_entropy", "1"))
+    c = np.array(num(j3))
+    assert c.shape == a.shape and np.all(np.isfinite(c[~np.isnan(a)]))
