@@ -633,7 +633,7 @@ class neuralSpeechCodingModule(object):
             tau_map = [("c_ent", i, 1.0, min(i + 1, 2)) for i in range(num_codecs)]
         quan = dict(is_quan_on=1.0, c_time=c[0], c_freq=c[1], c_quan=cq, c_ent=list(zeros), trainable=train, slot=1,
                     quan_op=True, **extra)
-        if self._local_entropy:
+        if getattr(self, "_local_entropy", False):
             # --local_entropy: entropy_coding_loss sees each rank's own batch histogram - the standard
             # data-parallel behaviour, one all-reduce less per step; an N-rank run then no longer equals a 1-process run at
             # batch N B, and the entropies rank 0 journals are those of ITS frames
