@@ -112,12 +112,13 @@ int nsc_gated_block_dgrad(const float* x, const float* h, const float* lin, cons
                           float* dz1, int B, int C, int T, int narrow, int k9, int dil, int in_act, void* stream);
 /* The same for the block with ONE input channel (see nsc_gated_block_fwd_cin1): dx [B,1,T] = sum_c w1[c] dz1[c] + sum_o dy[o]
  * (the forward broadcast x over the C output channels; the producer of x is the quantizer, so no activation gradient);
- * wt1 [20]; dlin / dgate are two [B,20,T] tensors, or - when dgate == dlin + 20 T and B > 1 - the two halves of one
- * [B,40,T] tensor (the form nsc_gated_block_wgrad_batch reads).  C in {100, 50}, dil in {1, 2}. */
+ * wt1 [20]; da_rows = channel rows per frame of the tensor(s) dlin / dgate point into: 20 = two separate [B,20,T] tensors,
+ * 40 = the two halves of one [B,40,T] tensor (dgate = dlin + 20 T; the form nsc_gated_block_wgrad_batch reads).
+ * C in {100, 50}, dil in {1, 2}. */
 int nsc_gated_block_dgrad_cin1(const float* h, const float* lin, const float* th, const float* dy,
                                const float* wt1, const float* wtl, const float* wtr, const float* wt9, float* dx,
                                float* dlin, float* dgate, float* dz1, int B, int C, int T, int narrow, int k9,
-                               int dil, void* stream);
+                               int dil, int da_rows, void* stream);
 
 /* Persistent weight-gradient kernel of one gated block: all eight parameter gradients (accumulated) from the saved
  * activations x [B,C,T], h, g [B,20,T] and the data-path gradients dy [B,C,T], da [B,40,T] (= dlin | dgate, the

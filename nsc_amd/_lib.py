@@ -39,7 +39,7 @@ PROTOTYPES = {
     "nsc_gated_block_wgrad": [_P] * 16 + [_I] * 9 + [_P, _P],
     "nsc_glu_bwd_cat": [_P, _P, _P, _P, _I, _I, _I, _P],
     "nsc_gated_block_dgrad": [_P] * 12 + [_I] * 7 + [_P],
-    "nsc_gated_block_dgrad_cin1": [_P] * 12 + [_I] * 6 + [_P],
+    "nsc_gated_block_dgrad_cin1": [_P] * 12 + [_I] * 7 + [_P],
     "nsc_depthwise_fwd": [_P, _P, _P, _I, _I, _I, _I, _P],
     "nsc_depthwise_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "nsc_gate_fwd": [_P, _P, _I, _I, _I, _P],

@@ -15,20 +15,46 @@ import torch
 from .neural_speech_coding_module import neuralSpeechCodingModule, _split
 
 
-def encode_decode_utterance(eng, utt, soft=True, lpc_x=None):
+def encode_decode_utterance(eng, utt, soft=True, lpc_x=None, want_entropy=False):
     """Utterance-level inference of cmrl_eval (cmrl.py:566-597) without host round trips: a 1-D float32 CUDA signal is
     cut into hop-480 frames by the framing kernel (`utterance_to_segment(per_sig, True)`, :566), the frames go through
-    the cascade as ONE batch (the reference feeds them one per sess.run, :585-593 - frames are independent, so the
-    batch is the same arithmetic), and the decoded frames are Hann-windowed (first / middle / last variants) and
-    overlap-added by the OLA kernel (:595-597).  `soft=True` is what cmrl_eval actually feeds (`the_share: 1.0`, :592);
-    end2end_eval feeds hard codes (nsc_module:697).  The engine's batch must equal the utterance's frame count."""
+    the cascade in CHUNKS of the engine's batch (the reference feeds them one per sess.run, :585-593 - frames are
+    independent, so a batch is the same arithmetic; the last chunk is zero-padded and the padding discarded), and the
+    decoded frames are Hann-windowed (first / middle / last variants) and overlap-added by the OLA kernel (:595-597).
+    `soft=True` is what cmrl_eval actually feeds (`the_share: 1.0`, :592); end2end_eval feeds hard codes (nsc_module:697).
+    One fixed-batch engine serves every utterance length.
+    want_entropy: also return the per-frame entropy (bits, summed over the codecs) of each frame's OWN soft histogram -
+    cmrl_eval's all_entropy[j] (:593), whose mean it prints as 'Entropy' (:621)."""
+    from . import _lib
     from .utilities import frames_on_gpu, num_frames, overlap_add_on_gpu
     nf = num_frames(int(utt.numel()))
-    if nf != eng.B:
-        raise ValueError(f"utterance has {nf} frames but the engine was built for a batch of {eng.B}")
-    frames = frames_on_gpu(utt, post_window=True)
-    dec = eng.forward(frames.view(nf, 1, -1), 1.0, soft, lpc_x=lpc_x)
-    return overlap_add_on_gpu(dec.view(nf, -1))
+    B = eng.B
+    frames = frames_on_gpu(utt, post_window=True).view(nf, 1, -1)
+    out = torch.empty((nf, frames.shape[-1]), dtype=torch.float32, device=frames.device)
+    ent = torch.zeros((nf,), dtype=torch.float32, device=frames.device) if want_entropy else None
+    for lo in range(0, nf, B):
+        n = min(B, nf - lo)
+        if n == B:
+            xin = frames[lo:lo + B]
+            lx = lpc_x[lo:lo + B] if lpc_x is not None else None
+        else:
+            xin = eng.buf("infer.in", (B, 1, frames.shape[-1]))
+            xin.zero_()
+            xin[:n].copy_(frames[lo:lo + n])
+            lx = None
+            if lpc_x is not None:
+                lx = eng.buf("infer.lpc", (B,) + tuple(lpc_x.shape[1:]))
+                lx.zero_()
+                lx[:n].copy_(lpc_x[lo:lo + n])
+        dec = eng.forward(xin.contiguous(), 1.0, soft, lpc_x=lx, want_p=want_entropy)
+        out[lo:lo + n].copy_(dec.view(B, -1)[:n])
+        if want_entropy:
+            fe = eng.buf("infer.frame_ent", (B,))
+            for c in eng.codecs:
+                _lib.check(eng.lib.nsc_frame_entropy(c.p.data_ptr(), B, c.L, c.nb, fe.data_ptr(), _lib.stream_ptr()), "frame_entropy")
+                ent[lo:lo + n] += fe[:n]          # padded frames never enter a histogram: each frame has its own
+    sig = overlap_add_on_gpu(out)
+    return (sig, ent) if want_entropy else sig
 
 
 class CMRL(neuralSpeechCodingModule):
@@ -97,29 +123,33 @@ class CMRL(neuralSpeechCodingModule):
         if utterances is None:
             rng = np.random.default_rng(99)
             utterances = [(0.03 * rng.standard_normal(n)).astype(np.float32) for n in (16000, 24000)]
-        outs, engines = [], {}
+        outs = []
+        # ONE fixed-batch engine for every utterance (buffers are sized by the batch; real test sets have nearly unique
+        # utterance lengths, so an engine per frame count would grow without bound): frames run in chunks of this batch
+        from .engine import CascadeEngine
+        strides = [list(self._the_strides)] * num_res
+        bins = (self._num_bins_for_follower + [self._num_bins_for_follower[-1]] * num_res)[:num_res]
+        eng = CascadeEngine(int(getattr(self, "_infer_batch", 64)), num_res, self._bottleneck_kernel_and_dilation, strides, bins,
+                            res_scalar=self._res_scalar, device=self._device, seed=self._seed)
+        eng.keep_activations = False     # inference: nothing is kept for a backward pass
+        self._restore_for_inference(eng, num_res)
+        warm = False
         for i, sig in enumerate(utterances):
             sig = np.asarray(sig, np.float32)
             nf = len(range(0, len(sig) - 512, 480))
             if nf == 0:
                 outs.append(np.zeros(0, np.float32))
                 continue
-            if nf not in engines:       # one engine per frame count (buffers are sized by the batch)
-                strides = [list(self._the_strides)] * num_res
-                bins = (self._num_bins_for_follower + [self._num_bins_for_follower[-1]] * num_res)[:num_res]
-                from .engine import CascadeEngine
-                eng = CascadeEngine(nf, num_res, self._bottleneck_kernel_and_dilation, strides, bins,
-                                    res_scalar=self._res_scalar, device=self._device, seed=self._seed)
-                eng.keep_activations = False     # inference: nothing is kept for a backward pass
-                self._restore_for_inference(eng, num_res)
-                engines[nf] = eng
-            eng = engines[nf]
             u = torch.from_numpy(sig).to(eng.device)
-            encode_decode_utterance(eng, u, soft=True)            # warm-up (first-use allocations)
+            if not warm:
+                encode_decode_utterance(eng, u, soft=True, want_entropy=True)      # first-use allocations
+                warm = True
             torch.cuda.synchronize()
             t0 = time.time()
-            dec = encode_decode_utterance(eng, u, soft=True)
-            ent = sum(float(c.entropy().item()) for c in eng.codecs)    # interested_var = [reduce_sum(ent_loss_arr)], :882
+            dec, frame_ent = encode_decode_utterance(eng, u, soft=True, want_entropy=True)
+            # interested_var = [reduce_sum(ent_loss_arr)] (:882) evaluated on ONE frame per sess.run (:585-593); the printed
+            # value is the mean over the utterance's frames (:621) - not the entropy of the pooled histogram (>= the mean)
+            ent = float(frame_ent.mean().item())
             torch.cuda.synchronize()
             exec_time = time.time() - t0
             sig_duration = len(sig) / 16000.0

@@ -2103,14 +2103,16 @@ extern "C" int nsc_gated_block_dgrad(const float* x, const float* h, const float
 extern "C" int nsc_gated_block_dgrad_cin1(const float* h, const float* lin, const float* th, const float* dy,
                                           const float* wt1, const float* wtl, const float* wtr, const float* wt9, float* dx,
                                           float* dlin, float* dgate, float* dz1, int B, int C, int T, int narrow, int k9,
-                                          int dil, void* stream) {
+                                          int dil, int da_rows, void* stream) {
   NSC_REQUIRE(h && lin && th && dy && wt1 && wtl && wtr && wt9 && dx && dlin && dgate && dz1, NSC_ERR_BAD_ARG,
               "nsc_gated_block_dgrad_cin1: null pointer");
   NSC_REQUIRE(B > 0 && T > 0, NSC_ERR_BAD_ARG, "nsc_gated_block_dgrad_cin1: bad sizes");
+  NSC_REQUIRE(da_rows == NARROW || (da_rows == 2 * NARROW && dgate == dlin + (long)NARROW * T), NSC_ERR_BAD_ARG,
+              "nsc_gated_block_dgrad_cin1: da_rows must be 20 (two [B,20,T] tensors) or 40 with dgate = dlin + 20 T");
   NSC_REQUIRE(narrow == NARROW && k9 == K9 && (dil == 1 || dil == 2) && (C == 100 || C == 50), NSC_ERR_UNSUPPORTED,
               "nsc_gated_block_dgrad_cin1: built for narrow=20, k9=9, dil in {1,2}, C in {100, 50} (got %d, %d, %d, %d)", narrow, k9, dil, C);
   BlockDgradArgs a{B, C, T, dil, NSC_ACT_NONE, dy /* x: unused */, h, lin, th, dy, wt1, wtl, wtr, wt9, dx, dlin, dz1, dgate,
-                   (B > 1 && dgate == dlin + (long)NARROW * T) ? 2 * NARROW : NARROW};   // halves of one [B,40,T] tensor, or two [B,20,T]
+                   da_rows};
   hipStream_t st = (hipStream_t)stream;
   if (C == 100) return dil == 1 ? launch_block_dgrad2<7, 25, 1, true>(a, st) : launch_block_dgrad2<7, 25, 2, true>(a, st);
   return dil == 1 ? launch_block_dgrad2<4, 13, 1, true>(a, st) : launch_block_dgrad2<4, 13, 2, true>(a, st);

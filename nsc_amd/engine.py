@@ -314,7 +314,7 @@ class _Block:
             # step's batched block launch (job.Cin = 1), which reads dlin | dgate as one [B,40,T] tensor
             assert in_kind == "none"
             dx = e.buf(u + ".dx", (B, 1, T))
-            batched = e.batch_wgrad and e.batch_cin1_wgrad and B > 1
+            batched = e.batch_wgrad and e.batch_cin1_wgrad
             if batched:
                 da = e.buf(u + ".da", (B, 2 * n, T))
                 dlin, dgate = da[:, :n], da[:, n:]      # data_ptr of the halves: dgate = dlin + 20 T floats
@@ -323,7 +323,7 @@ class _Block:
             check(e.lib.nsc_gated_block_dgrad_cin1(self.h.data_ptr(), self.lin.data_ptr(), self.th.data_ptr(), dz.data_ptr(),
                                                    WT(self.c1), WT(self.cl), WT(self.cr), WT(self.c9), dx.data_ptr(),
                                                    dlin.data_ptr(), dgate.data_ptr(), dh.data_ptr(), B, self.wide, T, n, 9,
-                                                   self.cl.dil, e.stream()), "gated_block_dgrad_cin1")
+                                                   self.cl.dil, 2 * n if batched else n, e.stream()), "gated_block_dgrad_cin1")
             e.prof_end(tok)
             if batched:
                 e.defer_block_wgrad(self, dz, da, dh, e.g_ptr + 4 * self.c1.w_off,
@@ -455,7 +455,7 @@ class _Codec:
                 h = blk.fwd(h)
             dwo = e.buf(f"{s}.dw{i}", (B, C_, T))
             up = e.buf(f"{s}.up{i}", (B, C_ // 2, T * 2))
-            if e.fused_up and C_ in (100, 50):
+            if e.fused_up and C_ in (100, 50) and B * C_ * T < 2 ** 29:    # (32-bit buffer offsets in the fused kernels)
                 # depthwise -> pointwise -> leaky-relu -> shuffle in one kernel (dwo kept only when a backward pass follows)
                 tok = e.prof_begin("upsample", pw.flops())
                 check(e.lib.nsc_upsample_fwd(h.data_ptr(), e.p_ptr + 4 * dw_off, e.p_ptr + 4 * pw.w_off, e.p_ptr + 4 * pw.b_off,
@@ -502,7 +502,7 @@ class _Codec:
             dzp = e.buf(f"{s}.dzp{i}", (B, C_, T))
             ddw = e.buf(f"{s}.ddw{i}", (B, C_, T))
             dxu = e.buf(f"{s}.dxup{i}", (B, C_, T))
-            if e.fused_up and C_ in (100, 50):
+            if e.fused_up and C_ in (100, 50) and B * C_ * T < 2 ** 29:
                 # un-shuffle -> pointwise^T -> depthwise^T in one kernel; the two weight gradients read dzp / ddw afterwards
                 tok = e.prof_begin("upsample", pw.flops())
                 check(e.lib.nsc_upsample_bwd(dz.data_ptr(), e.p_ptr + 4 * dw_off, e.p_ptr + 4 * pw.w_off, dzp.data_ptr(),

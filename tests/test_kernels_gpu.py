@@ -638,7 +638,7 @@ def test_fused_gated_block_dgrad_one_input_channel(lib, case):
     dlin, dgate, dz1 = (torch.full((B, 20, T), float("nan"), device="cuda") for _ in range(3))
     rc = lib.nsc_gated_block_dgrad_cin1(tr(h.detach().numpy()), tr(left.detach().numpy()), tr(right.detach().numpy()), tr(dy),
                                         P(wt[names[0]]), P(wt[names[1]]), P(wt[names[2]]), P(wt[names[3]]), dx.data_ptr(),
-                                        dlin.data_ptr(), dgate.data_ptr(), dz1.data_ptr(), B, C_, T, 20, 9, dil, _st())
+                                        dlin.data_ptr(), dgate.data_ptr(), dz1.data_ptr(), B, C_, T, 20, 9, dil, 20, _st())
     assert rc == 0, lib.nsc_last_error()
     torch.cuda.synchronize()
     g = lambda v: v.cpu().numpy().transpose(0, 2, 1)

@@ -210,3 +210,38 @@ def test_cli_two_ranks_shard_the_data_file_and_match_one_process(tmp_path):
     j3 = _cli(tmp_path, tmp_path / "loc", 2, 2, tmp_path / "frames.npy", extra=("--local_entropy", "1"))
     c = np.array(num(j3))
     assert c.shape == a.shape and np.all(np.isfinite(c[~np.isnan(a)]))
+
+
+@pytest.mark.parametrize("key,strides", [("s2", [2]), ("s22", [2, 2])])
+def test_product_lpc_graph_builder_matches_reference(key, strides):
+    """The PRODUCT's computational_graph_end2end_quan_on_lpc (nsc_amd/neural_speech_coding_module.py, the op-surface graph
+    of nsc_module:297-335) against what the reference's own builder returned (fixture cg_*_lpc_*): the 7-tuple, soft / hard
+    / unquantised decoded frames, the first frame's code and the soft assignment."""
+    from nsc_amd.scope import VariableStore, set_store
+    from tests._replay import FX, named_store
+    x = FX["cg_x"]
+    ps = named_store(1, [strides], [32])
+    st = VariableStore(device="cuda")
+    set_store(st)
+    try:
+        m = _module()
+        xd = dev(x)
+        r = m.computational_graph_end2end_quan_on_lpc(xd, None, True, 1.0, 32, "scope_1", strides)
+        assert len(r) == 7                                                  # the _lpc variant returns 7 values (:335)
+        assert list(st.vars.keys()) == list(ps.params.keys())
+        with torch.no_grad():
+            for k, v in st.vars.items():
+                v.copy_(torch.tensor(np.asarray(ps.params[k], np.float32).reshape(tuple(v.shape)), device="cuda"))
+        for sh in (True, False):
+            st.begin_pass()
+            p, _, _, code0, dec, alpha, bins = m.computational_graph_end2end_quan_on_lpc(xd, None, sh, 1.0, 32, "scope_1", strides)
+            k = f"cg_{key}_lpc_{'soft' if sh else 'hard'}"
+            assert_close(code0.detach().cpu().numpy(), FX[k + "_code0"], what=k + " code", atol=1e-6)
+            assert_close(dec.detach().cpu().numpy(), FX[k + "_dec"], what=k + " decoded")
+            if sh:
+                assert_close(p.detach().cpu().numpy(), FX[k + "_p"], what=k + " p", atol=1e-6)
+        st.begin_pass()
+        dec0 = m.computational_graph_end2end_quan_on_lpc(xd, None, True, 0.0, 32, "scope_1", strides)[4]
+        assert_close(dec0.detach().cpu().numpy(), FX[f"cg_{key}_lpc_noquan_dec"], what="lpc graph, is_quan_on = 0")
+    finally:
+        set_store(None)

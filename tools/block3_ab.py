@@ -100,7 +100,7 @@ if which in ("dgrad", "both"):
         if Cin == 1:
             def run():
                 _lib.check(lib.nsc_gated_block_dgrad_cin1(p(h), p(lin), p(th), p(dy), p(wt1), p(wtl), p(wtr), p(wt9), p(dx),
-                                                          p(da[:, :20]), p(da[:, 20:]), p(dz1), B, C, T, 20, 9, dil, st), "dgrad1")
+                                                          p(da[:, :20]), p(da[:, 20:]), p(dz1), B, C, T, 20, 9, dil, 40, st), "dgrad1")
         else:
             def run():
                 _lib.check(lib.nsc_gated_block_dgrad(p(x), p(h), p(lin), p(th), p(dy), p(wt1), p(wtl), p(wtr), p(wt9), p(dx), p(da),
