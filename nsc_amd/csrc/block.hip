@@ -17,10 +17,10 @@
 
 #ifdef NSC_PROBES
 // phase stamps of workgroup 0 / wave 0 (s_memtime), read back with nsc_probe_read: profiling builds only
-__device__ unsigned long long nsc_dbg_stamps[64];
-#define NSC_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) nsc_dbg_stamps[i] = __builtin_readcyclecounter(); } while (0)
+__device__ unsigned long long nsc_dbg_stamps[128];     // [0, 64): wave 0, [64, 128): wave 4 of workgroup 0
+#define NSC_STAMP(i) do { if (blockIdx.x == 0 && (threadIdx.x & 255) == 0) nsc_dbg_stamps[(threadIdx.x >> 8) * 64 + (i)] = __builtin_readcyclecounter(); } while (0)
 extern "C" int nsc_probe_read(unsigned long long* out) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(nsc_dbg_stamps), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -3;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(nsc_dbg_stamps), sizeof(unsigned long long) * 128) == hipSuccess ? 0 : -3;
 }
 #else
 #define NSC_STAMP(i) do { } while (0)
@@ -1480,27 +1480,46 @@ __device__ __forceinline__ void d9_packed(const float* w9ps, int C, int w9t, con
   // k-steps (independent MFMA chains) and the caller adds them.
   const int sft = l15 >> 2, ich = l15 & 3;
   const float* ypb = dys + (4 * kg + kq) * LDY_ + 4 * l15;
-#pragma unroll
-  for (int m = 0; m < K9 + 3; ++m) {
+  // The wave that runs this shares its SIMD with a wave streaming the dense k9 gradient from registers: whenever this stream
+  // waits for an LDS operand the dense one takes the matrix pipe, and what is left over runs alone - latency-bound - at the
+  // end of the phase (per-wave stamps: dense wave done after 9.8 k cycles, this one after 13.4 k).  So the operands are
+  // requested TWO steps ahead (steps = half a tap's k-steps, three register slots).
+  constexpr int NH = (NJ + 1) / 2, NSTEP = 2 * (K9 + 3), NS = 3;
+  float av[NS][NH], b0[NS][NH], b1[NT == 2 ? NS : 1][NH];
+  bool okv[NS];
+  auto fetch = [&](int stn, int slot) {
+    const int m = stn >> 1, j0 = (stn & 1) * NH;
     const int tap = m - sft;
     const bool ok = (unsigned)tap < (unsigned)K9;
+    okv[slot] = ok;
     const float* ap = w9ps + (ok ? tap : 0) * w9t + (4 * kg + kq) * 4 + ich;
-    float av[NJ], b0[NJ], b1[NT == 2 ? NJ : 1];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      av[j] = ap[16 * j * 4];
-      b0[j] = ypb[16 * j * LDY_ + m];
-      if (NT == 2) b1[j] = ypb[16 * j * LDY_ + m + 64];
+    for (int j = 0; j < NH; ++j) {
+      if (j0 + j < NJ) {
+        av[slot][j] = ap[16 * (j0 + j) * 4];
+        b0[slot][j] = ypb[16 * (j0 + j) * LDY_ + m];
+        if (NT == 2) b1[NT == 2 ? slot : 0][j] = ypb[16 * (j0 + j) * LDY_ + m + 64];
+      }
     }
-    __builtin_amdgcn_sched_barrier(0);
+  };
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const float a = ok ? av[j] : 0.f;
-      if (NT == 2) {
-        acc[0] = mfma4(a, b0[j], acc[0]);
-        acc[1] = mfma4(a, b1[j], acc[1]);
-      } else {
-        acc[(j + m) & 1] = mfma4(a, b0[j], acc[(j + m) & 1]);
+  for (int i = 0; i < NS - 1; ++i) fetch(i, i);
+#pragma unroll
+  for (int st = 0; st < NSTEP; ++st) {
+    if (st + NS - 1 < NSTEP) fetch(st + NS - 1, (st + NS - 1) % NS);
+    __builtin_amdgcn_sched_barrier(0);
+    const bool ok = okv[st % NS];
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {
+      const int jj = (st & 1) * NH + j, m = st >> 1;
+      if (jj < NJ) {
+        const float a = ok ? av[st % NS][j] : 0.f;
+        if (NT == 2) {
+          acc[0] = mfma4(a, b0[st % NS][j], acc[0]);
+          acc[1] = mfma4(a, b1[NT == 2 ? st % NS : 0][j], acc[1]);
+        } else {
+          acc[(jj + m) & 1] = mfma4(a, b0[st % NS][j], acc[(jj + m) & 1]);
+        }
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -1568,8 +1587,9 @@ __device__ __forceinline__ void d15_packed(const float* w15s, const float* da, i
   constexpr int NM = 4 + 14 * DIL_, NQM = (NM + 3) / 4, NH = 2 * NQM;
   const int sft = l15 >> 2, ich = l15 & 3;
   const float* bb = da + kq * LDA_ + 4 * l15 + kg;
-  float av[2][5], bv[2][5];
-  bool okv[2];
+  constexpr int NS = 3;                                  // operands two half-groups ahead (see d9_packed)
+  float av[NS][5], bv[NS][5];
+  bool okv[NS];
   auto fetch = [&](int hgrp, int slot) {
     const int q = hgrp >> 1, u0 = 5 * (hgrp & 1);
     const int dm = kg + 4 * q - sft;
@@ -1586,19 +1606,21 @@ __device__ __forceinline__ void d15_packed(const float* w15s, const float* da, i
   f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
   // only the LAST q can fall off the end (NM is not a multiple of 4 at DIL 1): live(q) is true for q < NQM - 1
   const bool last_live = kg + 4 * (NQM - 1) < NM;        // wave-uniform
-  fetch(0, 0);
+  auto live_ = [&](int hgrp) { return hgrp < NH && ((hgrp >> 1) < NQM - 1 || last_live); };
+#pragma unroll
+  for (int i = 0; i < NS - 1; ++i)
+    if (live_(i)) fetch(i, i);
 #pragma unroll
   for (int hgrp = 0; hgrp < NH; ++hgrp) {
-    const bool live = (hgrp >> 1) < NQM - 1 || last_live;
-    if (live) {
-      if (hgrp + 1 < NH && (((hgrp + 1) >> 1) < NQM - 1 || last_live)) fetch(hgrp + 1, (hgrp + 1) & 1);
+    if (live_(hgrp)) {
+      if (live_(hgrp + NS - 1)) fetch(hgrp + NS - 1, (hgrp + NS - 1) % NS);
       __builtin_amdgcn_sched_barrier(0);
-      const bool ok = okv[hgrp & 1];
+      const bool ok = okv[hgrp % NS];
 #pragma unroll
       for (int u = 0; u < 5; ++u) {
-        const float a = ok ? av[hgrp & 1][u] : 0.f;
-        if ((u + hgrp) & 1) acc2 = mfma4(a, bv[hgrp & 1][u], acc2);
-        else acc = mfma4(a, bv[hgrp & 1][u], acc);
+        const float a = ok ? av[hgrp % NS][u] : 0.f;
+        if ((u + hgrp) & 1) acc2 = mfma4(a, bv[hgrp % NS][u], acc2);
+        else acc = mfma4(a, bv[hgrp % NS][u], acc);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -1622,8 +1644,14 @@ __device__ __forceinline__ void d15_packed(const float* w15s, const float* da, i
 // CIN1: the block's INPUT has one channel (first block of a decoder stage): dy / dg / dh are as usual, but the 1x1 data
 // gradient is a 20-term dot product per step and the residual branch sums dy over its C channels (the forward broadcast
 // x over them); dx is one row and its producer is the quantizer (no activation gradient).
-template <int RT9, int NK9, int DIL, bool CIN1 = false>
-__global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs a, int ntiles, int tpf, int skip) {
+// ROLE: the kernel body is instantiated twice and dispatched on the (wave-uniform) wave index - ROLE 0 = waves 0-3 (row tile
+// 0 of the k9 / k15 gradients: the dense channel-0..15 tiles, register-resident k9 fragments), ROLE 1 = waves 4-7 (the
+// packed channel-16..19 tiles, operands from LDS).  Two straight-line programs with the same barrier sequence: the register
+// allocator sees each role on its own, so the packed role does not carry the dense role's 57 weight fragments and has room
+// to keep its LDS operands two steps ahead (with both roles in one body the kernel sat at 256 VGPRs and any deeper
+// pipelining of the packed loops spilled).
+template <int RT9, int NK9, int DIL, bool CIN1, int ROLE>
+__device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a, int ntiles, int tpf, int skip) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int TT = 64, Hh = 7 * DIL, W_a = TT + 2 * Hh, W_dy = W_a + 8, NCTA = (W_a + 15) / 16, CR = 4 * NK9;
   // LDY / LDA == 14 (mod 32): the two channel rows a 32-lane group reads sit 14 banks apart.  The packed tiles walk time
@@ -1651,8 +1679,9 @@ __global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, kq = lane >> 4;
-  const int rt = wave >> 2, kg = (wave + rt) & 3;  // this wave's output row tile and K-quarter (the longer quarter 0
-                                                   // lands on different SIMDs for the two row tiles)
+  constexpr int rt = ROLE;                         // this wave's output row tile ...
+  const int kg = (wave + rt) & 3;                  // ... and K-quarter (the longer quarter 0 lands on different SIMDs for the
+                                                   // two row tiles)
 
   // the first tile's x goes out before the weights: its HBM round trip is the longest latency of the prologue
   // ---- prefetch of the next tile: dy (wave w rows w, w+8, ...), lin / tanh (rows w, w+8, w+16), h (elementwise map) ----
@@ -1753,15 +1782,17 @@ __global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs 
   // NK9 = 4 (NJ9-1) + 1 for both shapes: the one left-over channel group (cq = NK9-1) is shared out by TAP (quarter kg takes
   // taps kg, kg+4, kg+8 < 9), so the quarters carry 57 | 56 | 56 | 56 k-steps instead of 63 | 54 | 54 | 54.
   static_assert(NK9 == 4 * (NJ9 - 1) + 1, "left-over channel group is shared out by tap");
-  float w9r[K9][NJ9 - 1], w9x[3];
+  float w9r[ROLE == 0 ? K9 : 1][NJ9 - 1], w9x[3];
+  if (ROLE == 0) {
 #pragma unroll
-  for (int tp = 0; tp < K9; ++tp)
+    for (int tp = 0; tp < K9; ++tp)
 #pragma unroll
-    for (int j = 0; j < NJ9 - 1; ++j)
-      w9r[tp][j] = a.wt9[((long)tp * C + min(4 * (kg + 4 * j) + kq, C - 1)) * NARROW + l15];   // rows = channels 0..15
+      for (int j = 0; j < NJ9 - 1; ++j)
+        w9r[ROLE == 0 ? tp : 0][j] = a.wt9[((long)tp * C + min(4 * (kg + 4 * j) + kq, C - 1)) * NARROW + l15];   // rows = channels 0..15
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
-    w9x[i] = a.wt9[((long)min(kg + 4 * i, K9 - 1) * C + min(4 * (NK9 - 1) + kq, C - 1)) * NARROW + l15];
+    for (int i = 0; i < 3; ++i)
+      w9x[i] = a.wt9[((long)min(kg + 4 * i, K9 - 1) * C + min(4 * (NK9 - 1) + kq, C - 1)) * NARROW + l15];
+  }
   const int rt1 = RT9 == 7 ? (wave < 7 ? wave : 6) : (wave & 3);
   const int cb1 = RT9 == 7 ? 0 : (wave >> 2) * 32;
   constexpr int NC1 = RT9 == 7 ? 4 : 2;
@@ -1818,17 +1849,13 @@ __global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs 
     // Software-pipelined loops with scheduling fences: left alone the scheduler hoists ~30 ds_read2 (60 registers) ahead
     // of the MFMAs, which spills - and a scratch reload waits on vmcnt IN ORDER, i.e. on the next tile's whole prefetch.
     if (!(skip & 1)) {
-      constexpr int NCB = NCTA - 4;                        // column tiles of channels 0..15 left to waves 4-7
-      const float* yb = dys + (4 * kg + kq) * LDY + l15;
-      const float* yx = dys + (4 * (NK9 - 1) + kq) * LDY + l15 + kg;
-      float* pp0 = part + (kg * 16 + kq * 4) * PSW + l15;
-      if (!fresh) {
-        // steady tile: the TT new columns [J0, J0 + TT) only.  Channels 0..15: waves 0-3 column tiles 0..2, waves 4-7 tile 3;
-        // channels 16..19: waves 4-7, ONE packed tile (it spans 64 time steps).
-        constexpr int J0 = 2 * Hh;
-        // Measured with per-wave s_memtime stamps (tools/dgrad_stamps.py): the packed tile is operand-bound (~150 cycles per
-        // MFMA whoever shares the SIMD), so waves 4-7 run ONLY it and waves 0-3 take all four column tiles.
-        if (rt == 0) {
+      if constexpr (ROLE == 0) {
+        // dense rows 0..15: the TT new columns of a steady tile (4 column tiles), all NCTA column tiles of a fresh one
+        const float* yb = dys + (4 * kg + kq) * LDY + l15;
+        const float* yx = dys + (4 * (NK9 - 1) + kq) * LDY + l15 + kg;
+        float* pp0 = part + (kg * 16 + kq * 4) * PSW + l15;
+        if (!fresh) {
+          constexpr int J0 = 2 * Hh;
           f32x4 acc[4];
 #pragma unroll
           for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1838,41 +1865,49 @@ __global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs 
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) pp0[reg * PSW + J0 + ct * 16] = acc[ct][reg];
         } else {
-          f32x4 pk[2];
-          pk[0] = pk[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          // (two passes so that the accumulators stay at 16 registers: column tiles 0..3, then the rest)
+          {
+            f32x4 acc[4];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            d9_rows0<4, NJ9 - 1, LDY>(w9r, w9x, yb, yx, kg, acc);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+              for (int reg = 0; reg < 4; ++reg) pp0[reg * PSW + ct * 16] = acc[ct][reg];
+          }
+          {
+            constexpr int NCB = NCTA - 4;
+            f32x4 acc[NCB];
+#pragma unroll
+            for (int ct = 0; ct < NCB; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            d9_rows0<NCB, NJ9 - 1, LDY>(w9r, w9x, yb + 64, yx + 64, kg, acc);
+#pragma unroll
+            for (int ct = 0; ct < NCB; ++ct)
+#pragma unroll
+              for (int reg = 0; reg < 4; ++reg) pp0[reg * PSW + (4 + ct) * 16] = acc[ct][reg];
+          }
+        }
+      } else {
+        // channels 16..19, packed: ONE tile (64 time steps) on a steady tile, two on a fresh one
+        f32x4 pk[2];
+        pk[0] = pk[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (!fresh) {
+          constexpr int J0 = 2 * Hh;
           d9_packed<NJ9 - 1, NK9, LDY, 1>(w9ps, C, w9t, dys + J0, kg, kq, l15, pk);
           const int col = J0 + 4 * l15 + kq;
 #pragma unroll
           for (int reg = 0; reg < 4; ++reg) part[PART1 + (kg * 4 + reg) * PSW + col] = pk[0][reg] + pk[1][reg];
-        }
-      } else if (rt == 0) {
-        f32x4 acc[4];
+        } else {
+          d9_packed<NJ9 - 1, NK9, LDY>(w9ps, C, w9t, dys, kg, kq, l15, pk);
+          // row (s = kq, i = reg), column n = l15  ->  dg[16 + reg][64 ctp + 4 l15 + kq]
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        d9_rows0<4, NJ9 - 1, LDY>(w9r, w9x, yb, yx, kg, acc);
+          for (int ctp = 0; ctp < 2; ++ctp) {
+            const int col = 64 * ctp + 4 * l15 + kq;
+            if (col < WA16) {
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-          for (int reg = 0; reg < 4; ++reg) pp0[reg * PSW + ct * 16] = acc[ct][reg];
-      } else {
-        f32x4 acc[NCB];
-#pragma unroll
-        for (int ct = 0; ct < NCB; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        d9_rows0<NCB, NJ9 - 1, LDY>(w9r, w9x, yb + 64, yx + 64, kg, acc);
-#pragma unroll
-        for (int ct = 0; ct < NCB; ++ct)
-#pragma unroll
-          for (int reg = 0; reg < 4; ++reg) pp0[reg * PSW + (4 + ct) * 16] = acc[ct][reg];
-        f32x4 pk[2];
-        pk[0] = pk[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        d9_packed<NJ9 - 1, NK9, LDY>(w9ps, C, w9t, dys, kg, kq, l15, pk);
-        // row (s = kq, i = reg), column n = l15  ->  dg[16 + reg][64 ctp + 4 l15 + kq]
-#pragma unroll
-        for (int ctp = 0; ctp < 2; ++ctp) {
-          const int col = 64 * ctp + 4 * l15 + kq;
-          if (col < WA16) {
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) part[PART1 + (kg * 4 + reg) * PSW + col] = pk[ctp][reg];
+              for (int reg = 0; reg < 4; ++reg) part[PART1 + (kg * 4 + reg) * PSW + col] = pk[ctp][reg];
+            }
           }
         }
       }
@@ -1914,7 +1949,7 @@ __global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs 
       const float* ab = lin + kq * LDA + l15 + kg * DIL;
       const float* wb = w15s + kg * W15T + kq * NARROW + l15;
       float* pp0 = part + (kg * 16 + kq * 4) * PST + l15;
-      if (rt == 0) {
+      if constexpr (ROLE == 0) {
         f32x4 acc[4];
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -2038,6 +2073,12 @@ __global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs 
     NSC_STAMP(16);
   }
   NSC_STAMP(17);
+}
+
+template <int RT9, int NK9, int DIL, bool CIN1 = false>
+__global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs a, int ntiles, int tpf, int skip) {
+  if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 8) == 0) gated_block_dgrad2_role<RT9, NK9, DIL, CIN1, 0>(a, ntiles, tpf, skip);
+  else gated_block_dgrad2_role<RT9, NK9, DIL, CIN1, 1>(a, ntiles, tpf, skip);
 }
 
 template <int RT9, int NK9, int DIL, bool CIN1 = false>

@@ -1,7 +1,8 @@
-"""PROBES build only: per-phase s_memtime stamps of workgroup 0 / wave 0 of gated_block_dgrad2 (last tile)."""
+"""Probes library (`make -C nsc_amd/csrc probes`): per-phase s_memtime stamps of workgroup 0, waves 0 and 4, of gated_block_dgrad2 (last tile)."""
 import ctypes as C, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nsc_amd import _lib
+_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "nsc_amd", "libnsc_hip_probes.so")
 lib = _lib.load()
 lib.nsc_probe_read.argtypes = [C.c_void_p]
 dev = "cuda"
@@ -20,9 +21,9 @@ for (B, C_, T, dil) in [(128, 100, 512, 1), (128, 100, 256, 2)]:
         _lib.check(lib.nsc_gated_block_dgrad(p(x), p(h), p(lin), p(th), p(dy), p(wt1), p(wtl), p(wtr), p(wt9), p(dx), p(da), p(dz1),
                                              B, C_, T, 20, 9, dil, 2, st), "dgrad")
     torch.cuda.synchronize()
-    buf = (C.c_ulonglong * 64)()
+    buf = (C.c_ulonglong * 128)()
     assert lib.nsc_probe_read(buf) == 0
-    v = list(buf)[:18]
-    print(f"B={B} C={C_} T={T} dil={dil}: total {v[17]-v[0]} ticks")
+    v, w = list(buf)[:18], list(buf)[64:82]
+    print(f"B={B} C={C_} T={T} dil={dil}: total {v[17]-v[0]} ticks   (wave 0 | wave 4)")
     for i in range(1, 18):
-        print(f"  {names[i]:>14}: +{v[i]-v[i-1]}")
+        print(f"  {names[i]:>14}: +{v[i]-v[i-1]:6d} | +{w[i]-w[i-1]:6d}")

@@ -2,6 +2,7 @@
 import ctypes as C, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nsc_amd import _lib
+_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "nsc_amd", "libnsc_hip_probes.so")
 lib = _lib.load()
 lib.nsc_probe_read.argtypes = [C.c_void_p]
 dev = "cuda"
@@ -20,7 +21,7 @@ for (B, C_, T, dil) in [(128, 100, 512, 1), (128, 100, 256, 2), (128, 50, 512, 2
         _lib.check(lib.nsc_gated_block_fwd(p(x), p(w1), p(b1), p(wl), p(bl), p(wr), p(br), p(w9), p(b9), p(out), p(h), p(lin), p(th), p(g),
                                            B, C_, T, 20, 9, dil, 0, st), "fwd")
     torch.cuda.synchronize()
-    buf = (C.c_ulonglong * 64)()
+    buf = (C.c_ulonglong * 128)()
     assert lib.nsc_probe_read(buf) == 0
     v = list(buf)[32:44]
     print(f"B={B} C={C_} T={T} dil={dil}: total {v[11]-v[0]} cycles")
