@@ -10,6 +10,9 @@
 #include <algorithm>
 
 #define QEPS 1e-20f
+#ifndef NSC_QWGRID
+#define NSC_QWGRID NSC_PROBE_INT("NSC_QWGRID", 1024)   // workgroups (4 frames in flight each) of the wave-per-frame forward kernel
+#endif
 #ifndef NSC_QGRID
 #define NSC_QGRID 1024   // workgroups of the forward kernel (measured at B = 4096: 512 -> 3.7, 768 -> 4.05, 1024 -> 4.08, 1280 -> 3.75, 2048 -> 3.3 TB/s)
 #endif
@@ -364,6 +367,88 @@ __global__ __launch_bounds__(256) void quantize_bwd_kernel(
   if (dalpha && tid == 0) atomicAdd(dalpha, sh[nbpad] + sh[nbpad + 1] + sh[nbpad + 2] + sh[nbpad + 3]);
 }
 
+// ---- the 32-bin forward with p materialised at LARGE batch (the op-surface form; config 5: 4096 frames): one WAVE per frame.
+// The workgroup-per-frame kernel above writes 32 KB of p per frame and then meets at two workgroup barriers (the per-frame
+// quan_loss), loads its codes as eight 32-byte pieces per lane and stores the quantised codes as eight 32-byte pieces per
+// wave: 24 memory instructions per wave for 8 KB of p.  Here a wave owns a frame: it loads 64 codes with ONE coalesced
+// instruction, hands them to the 8-lane groups through the cross-lane network (ds_bpermute), collects the 64 quantised
+// codes the same way and stores them with ONE instruction, reduces quan_loss inside the wave - no barrier in the frame
+// loop - and the 1-KiB float4 stores of p are all that is left per pass.
+template <bool SOFT>
+__global__ __launch_bounds__(256) void quantize_fwd32_wave_kernel(const float* __restrict__ code, const float* __restrict__ alpha_p,
+                                                                  const float* __restrict__ bins, float on, int L,
+                                                                  float* __restrict__ p_out, float* __restrict__ out,
+                                                                  float* __restrict__ quan_out, float* __restrict__ hist, int B) {
+  constexpr int LPC = 8, NB = 32;
+  __shared__ float sh[NB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int gl = lane & 7, gc = lane >> 3;
+  const float alpha = alpha_p[0];
+  float bv[1][4];
+  bool ok[1][4] = {{true, true, true, true}};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bv[0][j] = bins[gl * 4 + j];
+  if (tid < NB) sh[tid] = 0.f;
+  __syncthreads();
+  float hacc[4] = {0.f, 0.f, 0.f, 0.f};
+  const int nwaves = gridDim.x * 4, w0 = blockIdx.x * 4 + wave;
+  const int nch = L >> 6;                                   // chunks of 64 codes per frame (L is a multiple of 64 here)
+  const int tr_idx = (gl * 8 + gc) * 4;                     // ds_bpermute byte index of the transposed lane (gc <-> gl)
+  float vn = w0 < B ? code[(long)w0 * L + lane] : 0.f;      // first chunk of the first frame
+  for (int f = w0; f < B; f += nwaves) {
+    float qacc = 0.f;
+    for (int ch = 0; ch < nch; ++ch) {
+      const float v = vn;
+      {   // next chunk (of this frame or of the wave's next frame): in flight during the eight passes below
+        const int chn = ch + 1 < nch ? ch + 1 : 0;
+        const long fn = ch + 1 < nch ? f : (f + nwaves < B ? f + nwaves : f);
+        vn = code[fn * L + chn * 64 + lane];
+      }
+      float outv = 0.f;
+      const long cbase = (long)f * L + ch * 64;
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        // code of this pass's group gc: element it * 8 + gc of the chunk
+        const float c = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((it * 8 + gc) * 4, __builtin_bit_cast(int, v)));
+        float dist[1][4], p[1][4];
+        softmax_bins<LPC, 1>(c, alpha, bv, ok, dist, p);
+        float q;
+        if (SOFT) {
+          float s_ = 0.f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) s_ = fmaf(p[0][j], bv[0][j], s_);
+          q = grp_sum<LPC>(s_);
+        } else {
+          float best = -1.f;
+          int idx = 0x7fffffff;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (p[0][j] > best) { best = p[0][j]; idx = gl * 4 + j; }
+          idx = grp_argmax<LPC>(best, idx);
+          q = bins[idx];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          hacc[j] += p[0][j];
+          qacc += __builtin_amdgcn_sqrtf(p[0][j] + QEPS);
+        }
+        *reinterpret_cast<float4*>(p_out + (cbase + it * 8 + gc) * NB + gl * 4) = make_float4(p[0][0], p[0][1], p[0][2], p[0][3]);
+        // the group's quantised code travels to lane it * 8 + gc (transposed pick: lanes of group `it` take group gl's value)
+        const float o = (1.f - on) * c + on * q;
+        const float t = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(tr_idx, __builtin_bit_cast(int, o)));
+        outv = gc == it ? t : outv;
+      }
+      out[cbase + lane] = outv;
+    }
+    qacc = wave_sum(qacc);
+    if (quan_out && lane == 0) quan_out[f] = qacc / (float)L;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) atomicAdd(&sh[gl * 4 + j], hacc[j]);
+  __syncthreads();
+  if (hist && tid < NB) atomicAdd(hist + tid, sh[tid]);
+}
+
 // pick (LPC, ITER) for nb bins
 #define QDISPATCH(NB, CALL)                                    \
   do {                                                         \
@@ -386,6 +471,16 @@ extern "C" int nsc_quantize_fwd(const float* code, const float* alpha, const flo
   NSC_REQUIRE(B > 0 && L > 0 && nb > 0, NSC_ERR_BAD_ARG, "nsc_quantize_fwd: non-positive B/L/nb");
   NSC_REQUIRE(nb <= 1024, NSC_ERR_UNSUPPORTED, "nsc_quantize_fwd: nb %d > 1024", nb);
   hipStream_t st = (hipStream_t)stream;
+  if (nb == 32 && p_out && (L & 63) == 0 && B >= 1024 && !NSC_PROBE_SET("NSC_QUANT_WG")) {
+    // op-surface form at inference batch sizes: one wave per frame (see quantize_fwd32_wave_kernel)
+    const int grid = std::min((B + 3) / 4, NSC_QWGRID);
+    if (soft) hipLaunchKernelGGL(quantize_fwd32_wave_kernel<true>, dim3(grid), dim3(256), 0, st, code, alpha, bins, is_quan_on, L,
+                                 p_out, out, quan_out, hist, B);
+    else hipLaunchKernelGGL(quantize_fwd32_wave_kernel<false>, dim3(grid), dim3(256), 0, st, code, alpha, bins, is_quan_on, L,
+                            p_out, out, quan_out, hist, B);
+    NSC_CHECK_LAUNCH("quantize_fwd (wave per frame)");
+    return NSC_OK;
+  }
 #define CALLF(LPC_, IT_)                                                                                          \
   do {                                                                                                            \
     if (nb == 4 * LPC_ * IT_)                                                                                     \

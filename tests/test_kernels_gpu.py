@@ -314,6 +314,47 @@ def test_quantizer_fwd_bwd(lib, case):
     assert abs(float(da) - float(at.grad)) <= 2e-4 * max(abs(float(at.grad)), 1e-3), ("dalpha", float(da), float(at.grad))
 
 
+@pytest.mark.parametrize("L,soft", [(256, True), (128, True), (256, False)])
+def test_quantizer_large_batch_wave_per_frame_kernel(lib, L, soft):
+    """At B >= 1024 with p materialised and 32 bins nsc_quantize_fwd runs the wave-per-frame kernel (csrc/quant.hip):
+    p and the quantised codes must equal the workgroup-per-frame kernel's (same frames in two launches of 512) bit for bit,
+    quan_loss / histogram up to the summation order, a slice of frames is held to the float64 oracle, and frames whose code
+    sits exactly between two bins pick the lower index (tf.nn.top_k) in hard mode."""
+    B, nb = 1030, 32
+    rng = np.random.default_rng(L + int(soft))
+    code = np.tanh(rng.standard_normal((B, L, 1))).astype(np.float32)
+    bins = ((np.arange(nb) - 15.5) / 16.0).astype(np.float32)          # dyadic bins: midpoints and distances are exact in fp32
+    code[7, :nb - 1, 0] = 0.5 * (bins[:-1] + bins[1:])                 # codes exactly between two bins
+    alpha = -20.0
+    cd, ad, bd = dev(code), dev(np.array([alpha])), dev(bins)
+
+    def run(lo, hi):
+        n = hi - lo
+        pd = torch.full((n, L, nb), float("nan"), device="cuda")
+        od = torch.full((n, L, 1), float("nan"), device="cuda")
+        qd = torch.full((n,), float("nan"), device="cuda")
+        hist = torch.zeros((nb,), device="cuda")
+        assert lib.nsc_quantize_fwd(cd[lo:hi].contiguous().data_ptr(), ad.data_ptr(), bd.data_ptr(), 1.0, int(soft), n, L, nb,
+                                    pd.data_ptr(), od.data_ptr(), qd.data_ptr(), hist.data_ptr(), _st()) == 0, lib.nsc_last_error()
+        torch.cuda.synchronize()
+        return pd.cpu().numpy(), od.cpu().numpy(), qd.cpu().numpy(), hist.cpu().numpy()
+
+    big = run(0, B)                                                     # one launch: wave per frame
+    parts = [run(0, 512), run(512, 1024), run(1024, B)]                 # B < 1024 each: workgroup per frame
+    for k in range(2):
+        assert np.array_equal(big[k], np.concatenate([p_[k] for p_ in parts], 0)), ("p", "out")[k]
+    assert_close(big[2], np.concatenate([p_[2] for p_ in parts], 0), tol=1e-6, what="quan partial")
+    assert_close(big[3], sum(p_[3] for p_ in parts), tol=1e-5, what="histogram")
+    sl = slice(0, 16)
+    pt, ot = OT.scalar_softmax_quantization(torch.tensor(code[sl], dtype=torch.float64), torch.tensor(alpha, dtype=torch.float64),
+                                            torch.tensor(bins, dtype=torch.float64), 1.0, soft)
+    assert_close(big[0][sl], pt.numpy(), what="p vs oracle", atol=1e-7)
+    if soft:
+        assert_close(big[1][sl], ot.numpy(), what="codes vs oracle", atol=1e-6)
+    else:
+        assert np.array_equal(big[1][7, :nb - 1, 0], bins[:-1])          # ties -> lowest index, exact bin values
+
+
 def test_quantizer_identity_and_nearest_bin(lib):
     rng = np.random.default_rng(2)
     B, L, nb = 2, 256, 32
