@@ -11,7 +11,7 @@
 
 #define QEPS 1e-20f
 #ifndef NSC_QWGRID
-#define NSC_QWGRID NSC_PROBE_INT("NSC_QWGRID", 1024)   // workgroups (4 frames in flight each) of the wave-per-frame forward kernel
+#define NSC_QWGRID NSC_PROBE_INT("NSC_QWGRID", 512)   // workgroups (4 waves = 4 frames in flight each) of the wave-per-frame forward kernel: 512 -> 5.06, 1024 -> 4.8, 256 -> 4.2 TB/s at B = 4096
 #endif
 #ifndef NSC_QGRID
 #define NSC_QGRID 1024   // workgroups of the forward kernel (measured at B = 4096: 512 -> 3.7, 768 -> 4.05, 1024 -> 4.08, 1280 -> 3.75, 2048 -> 3.3 TB/s)
@@ -374,32 +374,49 @@ __global__ __launch_bounds__(256) void quantize_bwd_kernel(
 // instruction, hands them to the 8-lane groups through the cross-lane network (ds_bpermute), collects the 64 quantised
 // codes the same way and stores them with ONE instruction, reduces quan_loss inside the wave - no barrier in the frame
 // loop - and the 1-KiB float4 stores of p are all that is left per pass.
-template <bool SOFT>
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+// LPC lanes share a code (ITER = 8 / LPC float4 groups of bins per lane).  LPC = 8 ships (p bit-equal to the workgroup kernel).
+// LPC = 4 (probes library, NSC_QLPC=4: 16 codes per pass, two DPP steps per reduction, ~320 instead of ~560 lane-instructions
+// per code) measured NO faster (4.6-5.1 vs 4.8-5.1 TB/s), as did single 16-byte stores instead of the 12 + 4-byte splits the
+// allocator produced in half of the passes: the kernel is bound neither by its VALU count nor by the store shape; a
+// write-only probe in the same grid and geometry reaches 6.8 TB/s on this (Infinity-Cache-sized) buffer.
+template <bool SOFT, int LPC>
 __global__ __launch_bounds__(256) void quantize_fwd32_wave_kernel(const float* __restrict__ code, const float* __restrict__ alpha_p,
                                                                   const float* __restrict__ bins, float on, int L,
                                                                   float* __restrict__ p_out, float* __restrict__ out,
                                                                   float* __restrict__ quan_out, float* __restrict__ hist, int B) {
-  constexpr int LPC = 8, NB = 32;
+  constexpr int NB = 32, ITER = NB / (4 * LPC), CPW = 64 / LPC, NPASS = 64 / CPW;
   __shared__ float sh[NB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int gl = lane & 7, gc = lane >> 3;
+  const int gl = lane % LPC, gc = lane / LPC;
   const float alpha = alpha_p[0];
-  float bv[1][4];
-  bool ok[1][4] = {{true, true, true, true}};
+  float bv[ITER][4];
+  bool ok[ITER][4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) bv[0][j] = bins[gl * 4 + j];
+  for (int i = 0; i < ITER; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bv[i][j] = bins[(i * LPC + gl) * 4 + j];
+      ok[i][j] = true;
+    }
   if (tid < NB) sh[tid] = 0.f;
   __syncthreads();
-  float hacc[4] = {0.f, 0.f, 0.f, 0.f};
+  float hacc[ITER][4];
+#pragma unroll
+  for (int i = 0; i < ITER; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) hacc[i][j] = 0.f;
   const int nwaves = gridDim.x * 4, w0 = blockIdx.x * 4 + wave;
   const int nch = L >> 6;                                   // chunks of 64 codes per frame (L is a multiple of 64 here)
-  const int tr_idx = (gl * 8 + gc) * 4;                     // ds_bpermute byte index of the transposed lane (gc <-> gl)
+  // lane X of the wave keeps the quantised code of chunk element X: at pass X / CPW it picks it from a lane of group X % CPW
+  const int pick_idx = ((lane % CPW) * LPC) * 4, pick_pass = lane / CPW;
+  const __amdgpu_buffer_rsrc_t sp = __builtin_amdgcn_make_buffer_rsrc(p_out, 0, (unsigned)((long)B * L * NB * 4), 0x00020000);
   float vn = w0 < B ? code[(long)w0 * L + lane] : 0.f;      // first chunk of the first frame
   for (int f = w0; f < B; f += nwaves) {
     float qacc = 0.f;
     for (int ch = 0; ch < nch; ++ch) {
       const float v = vn;
-      {   // next chunk (of this frame or of the wave's next frame): in flight during the eight passes below
+      {   // next chunk (of this frame or of the wave's next frame): in flight during the passes below
         const int chn = ch + 1 < nch ? ch + 1 : 0;
         const long fn = ch + 1 < nch ? f : (f + nwaves < B ? f + nwaves : f);
         vn = code[fn * L + chn * 64 + lane];
@@ -407,36 +424,48 @@ __global__ __launch_bounds__(256) void quantize_fwd32_wave_kernel(const float* _
       float outv = 0.f;
       const long cbase = (long)f * L + ch * 64;
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        // code of this pass's group gc: element it * 8 + gc of the chunk
-        const float c = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((it * 8 + gc) * 4, __builtin_bit_cast(int, v)));
-        float dist[1][4], p[1][4];
-        softmax_bins<LPC, 1>(c, alpha, bv, ok, dist, p);
+      for (int it = 0; it < NPASS; ++it) {
+        // code of this pass's group gc: element it * CPW + gc of the chunk
+        const float c = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((it * CPW + gc) * 4, __builtin_bit_cast(int, v)));
+        float dist[ITER][4], p[ITER][4];
+        softmax_bins<LPC, ITER>(c, alpha, bv, ok, dist, p);
         float q;
         if (SOFT) {
           float s_ = 0.f;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) s_ = fmaf(p[0][j], bv[0][j], s_);
+          for (int i = 0; i < ITER; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s_ = fmaf(p[i][j], bv[i][j], s_);
           q = grp_sum<LPC>(s_);
         } else {
           float best = -1.f;
           int idx = 0x7fffffff;
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (p[0][j] > best) { best = p[0][j]; idx = gl * 4 + j; }
+          for (int i = 0; i < ITER; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int k = (i * LPC + gl) * 4 + j;
+              if (p[i][j] > best) { best = p[i][j]; idx = k; }
+            }
           idx = grp_argmax<LPC>(best, idx);
           q = bins[idx];
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          hacc[j] += p[0][j];
-          qacc += __builtin_amdgcn_sqrtf(p[0][j] + QEPS);
+        for (int i = 0; i < ITER; ++i) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            hacc[i][j] += p[i][j];
+            qacc += __builtin_amdgcn_sqrtf(p[i][j] + QEPS);
+          }
+          // ONE 16-byte store per lane and float4 group (a plain float4 assignment was split into a 12-byte and a 4-byte store
+          // in half of the unrolled passes, where the allocator had not kept the four values in consecutive registers)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, (f32x4){p[i][0], p[i][1], p[i][2], p[i][3]}), sp,
+                                                 (int)((cbase + it * CPW + gc) * (NB * 4) + (i * LPC + gl) * 16), 0, 0);
         }
-        *reinterpret_cast<float4*>(p_out + (cbase + it * 8 + gc) * NB + gl * 4) = make_float4(p[0][0], p[0][1], p[0][2], p[0][3]);
-        // the group's quantised code travels to lane it * 8 + gc (transposed pick: lanes of group `it` take group gl's value)
+        // the group's quantised code travels to lane it * CPW + gc
         const float o = (1.f - on) * c + on * q;
-        const float t = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(tr_idx, __builtin_bit_cast(int, o)));
-        outv = gc == it ? t : outv;
+        const float t = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(pick_idx, __builtin_bit_cast(int, o)));
+        outv = pick_pass == it ? t : outv;
       }
       out[cbase + lane] = outv;
     }
@@ -444,10 +473,35 @@ __global__ __launch_bounds__(256) void quantize_fwd32_wave_kernel(const float* _
     if (quan_out && lane == 0) quan_out[f] = qacc / (float)L;
   }
 #pragma unroll
-  for (int j = 0; j < 4; ++j) atomicAdd(&sh[gl * 4 + j], hacc[j]);
+  for (int i = 0; i < ITER; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) atomicAdd(&sh[(i * LPC + gl) * 4 + j], hacc[i][j]);
   __syncthreads();
   if (hist && tid < NB) atomicAdd(hist + tid, sh[tid]);
 }
+
+#ifdef NSC_PROBES
+// write-only probe in the SAME grid / geometry as quantize_fwd32_wave_kernel (probes library, NSC_QUANT_WRITE_ONLY=1): every
+// wave writes its frames' 32 KB of p as 1-KiB float4 wave-stores plus the 256-B rows of out, nothing else.  NT: nontemporal.
+template <bool NT>
+__global__ __launch_bounds__(256) void quantize_write_probe_kernel(int L, float* __restrict__ p_out, float* __restrict__ out, int B) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int gl = lane & 7, gc = lane >> 3;
+  const int nwaves = gridDim.x * 4, w0 = blockIdx.x * 4 + wave;
+  const f32x4 v = {0.03125f, 0.03125f, 0.03125f, 0.03125f};
+  for (int f = w0; f < B; f += nwaves)
+    for (int ch = 0; ch < (L >> 6); ++ch) {
+      const long cbase = (long)f * L + ch * 64;
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        f32x4* dst = reinterpret_cast<f32x4*>(p_out + (cbase + it * 8 + gc) * 32 + gl * 4);
+        if (NT) __builtin_nontemporal_store(v, dst);
+        else *dst = v;
+      }
+      out[cbase + lane] = 0.5f;
+    }
+}
+#endif
 
 // pick (LPC, ITER) for nb bins
 #define QDISPATCH(NB, CALL)                                    \
@@ -471,13 +525,21 @@ extern "C" int nsc_quantize_fwd(const float* code, const float* alpha, const flo
   NSC_REQUIRE(B > 0 && L > 0 && nb > 0, NSC_ERR_BAD_ARG, "nsc_quantize_fwd: non-positive B/L/nb");
   NSC_REQUIRE(nb <= 1024, NSC_ERR_UNSUPPORTED, "nsc_quantize_fwd: nb %d > 1024", nb);
   hipStream_t st = (hipStream_t)stream;
-  if (nb == 32 && p_out && (L & 63) == 0 && B >= 1024 && !NSC_PROBE_SET("NSC_QUANT_WG")) {
+  if (nb == 32 && p_out && (L & 63) == 0 && B >= 1024 && (long)B * L * 128 < (1L << 31) && !NSC_PROBE_SET("NSC_QUANT_WG")) {
     // op-surface form at inference batch sizes: one wave per frame (see quantize_fwd32_wave_kernel)
     const int grid = std::min((B + 3) / 4, NSC_QWGRID);
-    if (soft) hipLaunchKernelGGL(quantize_fwd32_wave_kernel<true>, dim3(grid), dim3(256), 0, st, code, alpha, bins, is_quan_on, L,
-                                 p_out, out, quan_out, hist, B);
-    else hipLaunchKernelGGL(quantize_fwd32_wave_kernel<false>, dim3(grid), dim3(256), 0, st, code, alpha, bins, is_quan_on, L,
-                            p_out, out, quan_out, hist, B);
+#ifdef NSC_PROBES
+    if (NSC_PROBE_SET("NSC_QUANT_WRITE_ONLY")) {
+      if (NSC_PROBE_INT("NSC_QUANT_WRITE_ONLY", 1) == 2) hipLaunchKernelGGL(quantize_write_probe_kernel<true>, dim3(grid), dim3(256), 0, st, L, p_out, out, B);
+      else hipLaunchKernelGGL(quantize_write_probe_kernel<false>, dim3(grid), dim3(256), 0, st, L, p_out, out, B);
+      return NSC_OK;
+    }
+#endif
+#define QWAVE(SOFT_, LPC_) hipLaunchKernelGGL((quantize_fwd32_wave_kernel<SOFT_, LPC_>), dim3(grid), dim3(256), 0, st, code, alpha, bins, \
+                                              is_quan_on, L, p_out, out, quan_out, hist, B)
+    if (NSC_PROBE_INT("NSC_QLPC", 8) == 8) { if (soft) QWAVE(true, 8); else QWAVE(false, 8); }
+    else { if (soft) QWAVE(true, 4); else QWAVE(false, 4); }
+#undef QWAVE
     NSC_CHECK_LAUNCH("quantize_fwd (wave per frame)");
     return NSC_OK;
   }

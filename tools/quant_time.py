@@ -16,9 +16,10 @@ def run(soft, p, outq, qv, hist):
     _lib.check(lib.nsc_quantize_fwd(code.data_ptr(), alpha.data_ptr(), bins.data_ptr(), 1.0, soft, Bq, L, nb, p.data_ptr(), outq.data_ptr(),
                                     qv.data_ptr(), hist.data_ptr(), st), "q")
 res = {}
-for variant, env in (("workgroup per frame", {"NSC_QUANT_WG": "1"}), ("wave per frame, grid 1024", {}), ("wave per frame, grid 512", {"NSC_QWGRID": "512"}),
-                     ("wave per frame, grid 2048", {"NSC_QWGRID": "2048"}), ("wave per frame, grid 256", {"NSC_QWGRID": "256"})):
-    for k in ("NSC_QUANT_WG", "NSC_QWGRID"):
+for variant, env in (("workgroup per frame", {"NSC_QUANT_WG": "1"}), ("wave per frame, grid 512 (shipped)", {}), ("wave per frame, grid 1024", {"NSC_QWGRID": "1024"}), ("wave per frame, 4 lanes/code, grid 512", {"NSC_QLPC": "4"}),
+                     ("write-only probe, same geometry", {"NSC_QUANT_WRITE_ONLY": "1"}), ("write-only probe, nontemporal", {"NSC_QUANT_WRITE_ONLY": "2"}),
+                     ("wave per frame, grid 512 (again)", {})):
+    for k in ("NSC_QUANT_WG", "NSC_QWGRID", "NSC_QUANT_WRITE_ONLY", "NSC_QLPC"):
         os.environ.pop(k, None)
     os.environ.update(env)
     outs = []
@@ -40,9 +41,11 @@ for variant, env in (("workgroup per frame", {"NSC_QUANT_WG": "1"}), ("wave per 
         ts.append(1e3 * e0.elapsed_time(e1) / 20)
     us = sorted(ts)[len(ts) // 2]
     byts = Bq * L * (4 + 4 * nb + 4)
-    print(f"{variant:30s}: {us:6.2f} us (min {min(ts):6.2f})  {byts / us / 1e6:5.2f} TB/s  = {byts / us / 1e6 / 8:.3f} of 8 TB/s", flush=True)
+    print(f"{variant:44s}: {us:6.2f} us (min {min(ts):6.2f})  {byts / us / 1e6:5.2f} TB/s  = {byts / us / 1e6 / 8:.3f} of 8 TB/s", flush=True)
 base = res["workgroup per frame"]
 for k, v in res.items():
+    if "probe" in k:
+        continue
     d = [max(float((a - b).abs().max()) for a, b in zip(v[s][:3], base[s][:3])) for s in (0, 1)]
     dh = [float(((v[s][3] - base[s][3]).abs() / base[s][3].abs().clamp_min(1)).max()) for s in (0, 1)]
     print(f"  {k:30s} max |diff| vs workgroup kernel: soft {d[0]:.2e}, hard {d[1]:.2e}; histogram rel {dh[0]:.1e} / {dh[1]:.1e}")
