@@ -1442,38 +1442,48 @@ template <int NC, int NJ, int LDY_>
 __device__ __forceinline__ void d9_rows0(const float (&w9r)[K9][NJ], const float (&w9x)[3], const float* yb, const float* yx,
                                          int kg, f32x4 (&acc)[NC]) {
   constexpr int NSTEP = K9 * NJ;
-  float bb[2][NC];                                       // ping-pong (compile-time index: no register copies)
+  // B fragments DEPTH - 1 steps ahead (compile-time slot index: no register copies).  A step of NC MFMAs covers 32 NC
+  // cycles; an LDS round trip in this kernel is ~170 (the 4-tile loop ran at 42 cycles per MFMA with one step in flight),
+  // so short steps keep more in flight: >= 8 MFMAs' worth.
+  constexpr int DEPTH = NC >= 4 ? 3 : (NC == 3 ? 4 : 5);
+  float bb[DEPTH][NC];
+  auto fetch = [&](int stn) {
+    const int tpn = stn / NJ, jn = stn - tpn * NJ;
 #pragma unroll
-  for (int ct = 0; ct < NC; ++ct) bb[0][ct] = yb[ct * 16];
+    for (int ct = 0; ct < NC; ++ct) bb[stn % DEPTH][ct] = yb[16 * jn * LDY_ + tpn + ct * 16];
+  };
+#pragma unroll
+  for (int i = 0; i < DEPTH - 1; ++i) fetch(i);
 #pragma unroll
   for (int st = 0; st < NSTEP; ++st) {
     const int tp = st / NJ, j = st - tp * NJ;
-    if (st + 1 < NSTEP) {
-      const int tpn = (st + 1) / NJ, jn = (st + 1) - tpn * NJ;
-#pragma unroll
-      for (int ct = 0; ct < NC; ++ct) bb[(st + 1) & 1][ct] = yb[16 * jn * LDY_ + tpn + ct * 16];
-    }
+    if (st + DEPTH - 1 < NSTEP) fetch(st + DEPTH - 1);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int ct = 0; ct < NC; ++ct) acc[ct] = mfma4(w9r[tp][j], bb[st & 1][ct], acc[ct]);
+    for (int ct = 0; ct < NC; ++ct) acc[ct] = mfma4(w9r[tp][j], bb[st % DEPTH][ct], acc[ct]);
     __builtin_amdgcn_sched_barrier(0);
   }
+  // the left-over channel group: this quarter's taps kg + 4 i (tap kg + 8 exists for quarter 0 only: wave-uniform)
+  float bx[3][NC];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {                          // the left-over channel group: this quarter's taps kg + 4 i
-    if (i == 2 && kg != 0) break;                        // tap kg + 8 exists for quarter 0 only (wave-uniform)
+  for (int i = 0; i < 3; ++i)
 #pragma unroll
-    for (int ct = 0; ct < NC; ++ct) bb[0][ct] = yx[4 * i + ct * 16];
-    __builtin_amdgcn_sched_barrier(0);
+    for (int ct = 0; ct < NC; ++ct) bx[i][ct] = yx[4 * (i == 2 && kg != 0 ? 1 : i) + ct * 16];
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int ct = 0; ct < NC; ++ct) acc[ct] = mfma4(w9x[i], bb[0][ct], acc[ct]);
-    __builtin_amdgcn_sched_barrier(0);
+  for (int i = 0; i < 3; ++i) {
+    if (i == 2 && kg != 0) break;
+#pragma unroll
+    for (int ct = 0; ct < NC; ++ct) acc[ct] = mfma4(w9x[i], bx[i][ct], acc[ct]);
   }
+  __builtin_amdgcn_sched_barrier(0);
 }
 // channels 16..19, PACKED: a 16-row tile of [4 time shifts s][4 channels i] instead of 4 useful rows + 12 of padding.
 // Row (s,i), column n  ->  dg[16+i][64 ctp + 4n + s] = sum_{m,o} A[(s,i)][(m,o)] dy[o][64 ctp + 4n + m],
 // A = wt9[m-s][o][16+i] for 0 <= m-s < 9 else 0: 12 "taps" m instead of 9, but one MFMA column tile now spans 64 time steps
 // instead of 16 (2 tiles instead of 6).  A from LDS (w9ps [9][C][4]), lane (4s+i, kq); B lanes walk time with stride 4.
-template <int NJ, int NK9_, int LDY_, int NT = 2>
+// HALF: 0 / 1 = the first / second half of the (tap, half-group) steps (the two waves that share a K-quarter split them)
+template <int NJ, int NK9_, int LDY_, int NT, int HALF>
 __device__ __forceinline__ void d9_packed(const float* w9ps, int C, int w9t, const float* dys, int kg, int kq, int l15,
                                           f32x4 (&acc)[2]) {
   // NT = 2: acc[0] / acc[1] are the column tiles at +0 / +64.  NT = 1: one column tile; acc[0] / acc[1] take alternate
@@ -1484,10 +1494,11 @@ __device__ __forceinline__ void d9_packed(const float* w9ps, int C, int w9t, con
   // waits for an LDS operand the dense one takes the matrix pipe, and what is left over runs alone - latency-bound - at the
   // end of the phase (per-wave stamps: dense wave done after 9.8 k cycles, this one after 13.4 k).  So the operands are
   // requested TWO steps ahead (steps = half a tap's k-steps, three register slots).
-  constexpr int NH = (NJ + 1) / 2, NSTEP = 2 * (K9 + 3), NS = 3;
+  constexpr int NH = (NJ + 1) / 2, NSTEP_ALL = 2 * (K9 + 3), S0 = HALF * (NSTEP_ALL / 2), NSTEP = NSTEP_ALL / 2, NS = 3;
   float av[NS][NH], b0[NS][NH], b1[NT == 2 ? NS : 1][NH];
   bool okv[NS];
-  auto fetch = [&](int stn, int slot) {
+  auto fetch = [&](int stl, int slot) {
+    const int stn = S0 + stl;
     const int m = stn >> 1, j0 = (stn & 1) * NH;
     const int tap = m - sft;
     const bool ok = (unsigned)tap < (unsigned)K9;
@@ -1511,7 +1522,7 @@ __device__ __forceinline__ void d9_packed(const float* w9ps, int C, int w9t, con
     const bool ok = okv[st % NS];
 #pragma unroll
     for (int j = 0; j < NH; ++j) {
-      const int jj = (st & 1) * NH + j, m = st >> 1;
+      const int jj = ((S0 + st) & 1) * NH + j, m = (S0 + st) >> 1;
       if (jj < NJ) {
         const float a = ok ? av[st % NS][j] : 0.f;
         if (NT == 2) {
@@ -1527,7 +1538,7 @@ __device__ __forceinline__ void d9_packed(const float* w9ps, int C, int w9t, con
   // the left-over channel group (cq = NK9-1): this quarter's m = kg, kg+4, kg+8
   const float* ypx = dys + (4 * (NK9_ - 1) + kq) * LDY_ + 4 * l15 + kg;
 #pragma unroll
-  for (int e = 0; e < 3; ++e) {
+  for (int e = HALF == 0 ? 0 : 2; e < (HALF == 0 ? 2 : 3); ++e) {      // first half: e = 0, 1; second half: e = 2
     const int tap = kg + 4 * e - sft;
     const bool ok = (unsigned)tap < (unsigned)K9;
     // channel rows >= C (C = 50: rows 50, 51) meet zero rows of the dy tile: clamp the index so the fragment is a finite
@@ -1553,9 +1564,10 @@ __device__ __forceinline__ void d15_rows0(const float* wb, const float* ab, int 
   // groups of two k-steps, software-pipelined like d9_rows0: the operands of group g+1 are requested before the MFMAs of
   // group g issue (unpipelined, every group exposed a full LDS round trip: the phase ran at 2/3 of its MFMA rate)
   constexpr int NG = 4 * 5;                              // (tap quarter e4, channel-group pair u/2)
-  float av[2][2], bv[2][2][NC];
-  auto fetch = [&](int g, int slot) {
-    const int e4 = g / 5, u = 2 * (g - 5 * e4);
+  constexpr int DEPTH = NC >= 4 ? 2 : 3;                 // groups in flight + 1 (a group = 2 NC MFMAs; see d9_rows0)
+  float av[DEPTH][2], bv[DEPTH][2][NC];
+  auto fetch = [&](int g) {
+    const int e4 = g / 5, u = 2 * (g - 5 * e4), slot = g % DEPTH;
 #pragma unroll
     for (int uu = 0; uu < 2; ++uu) {
       av[slot][uu] = wb[e4 * 4 * W15T + 4 * (u + uu) * NARROW];
@@ -1564,16 +1576,18 @@ __device__ __forceinline__ void d15_rows0(const float* wb, const float* ab, int 
     }
   };
   const bool last_q = kg != 3;                           // tap 15 (groups 15..19 of quarter 3) does not exist: wave-uniform
-  fetch(0, 0);
+  auto live_ = [&](int g) { return g < NG && (g < 15 || last_q); };
+#pragma unroll
+  for (int i = 0; i < DEPTH - 1; ++i) fetch(i);
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
-    if (g < 15 || last_q) {
-      if (g + 1 < NG && (g + 1 < 15 || last_q)) fetch(g + 1, (g + 1) & 1);
+    if (live_(g)) {
+      if (live_(g + DEPTH - 1)) fetch(g + DEPTH - 1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int uu = 0; uu < 2; ++uu)
 #pragma unroll
-        for (int ct = 0; ct < NC; ++ct) acc[ct] = mfma4(av[g & 1][uu], bv[g & 1][uu][ct], acc[ct]);
+        for (int ct = 0; ct < NC; ++ct) acc[ct] = mfma4(av[g % DEPTH][uu], bv[g % DEPTH][uu][ct], acc[ct]);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -1582,9 +1596,9 @@ __device__ __forceinline__ void d15_rows0(const float* wb, const float* ab, int 
 // m = s + tap*DIL in [0, 4 + 14 DIL) and A = w15s[tap][c'][16+i] where (m - s) is a valid multiple of DIL, else 0.
 // This wave owns the m = kg (mod 4).  One column tile covers the 64 output steps.  Two accumulators (even / odd
 // k-steps, summed at the end) so that consecutive MFMAs are independent; half-groups of five are pipelined.
-template <int DIL_, int LDA_>
+template <int DIL_, int LDA_, int HALF>
 __device__ __forceinline__ void d15_packed(const float* w15s, const float* da, int kg, int kq, int l15, f32x4& acc) {
-  constexpr int NM = 4 + 14 * DIL_, NQM = (NM + 3) / 4, NH = 2 * NQM;
+  constexpr int NM = 4 + 14 * DIL_, NQM = (NM + 3) / 4, NH = 2 * NQM, H0 = HALF * (NH / 2), H1 = H0 + NH / 2;
   const int sft = l15 >> 2, ich = l15 & 3;
   const float* bb = da + kq * LDA_ + 4 * l15 + kg;
   constexpr int NS = 3;                                  // operands two half-groups ahead (see d9_packed)
@@ -1606,12 +1620,12 @@ __device__ __forceinline__ void d15_packed(const float* w15s, const float* da, i
   f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
   // only the LAST q can fall off the end (NM is not a multiple of 4 at DIL 1): live(q) is true for q < NQM - 1
   const bool last_live = kg + 4 * (NQM - 1) < NM;        // wave-uniform
-  auto live_ = [&](int hgrp) { return hgrp < NH && ((hgrp >> 1) < NQM - 1 || last_live); };
+  auto live_ = [&](int hgrp) { return hgrp < H1 && ((hgrp >> 1) < NQM - 1 || last_live); };
 #pragma unroll
   for (int i = 0; i < NS - 1; ++i)
-    if (live_(i)) fetch(i, i);
+    if (live_(H0 + i)) fetch(H0 + i, (H0 + i) % NS);
 #pragma unroll
-  for (int hgrp = 0; hgrp < NH; ++hgrp) {
+  for (int hgrp = H0; hgrp < H1; ++hgrp) {
     if (live_(hgrp)) {
       if (live_(hgrp + NS - 1)) fetch(hgrp + NS - 1, (hgrp + NS - 1) % NS);
       __builtin_amdgcn_sched_barrier(0);
@@ -1644,12 +1658,14 @@ __device__ __forceinline__ void d15_packed(const float* w15s, const float* da, i
 // CIN1: the block's INPUT has one channel (first block of a decoder stage): dy / dg / dh are as usual, but the 1x1 data
 // gradient is a 20-term dot product per step and the residual branch sums dy over its C channels (the forward broadcast
 // x over them); dx is one row and its producer is the quantizer (no activation gradient).
-// ROLE: the kernel body is instantiated twice and dispatched on the (wave-uniform) wave index - ROLE 0 = waves 0-3 (row tile
-// 0 of the k9 / k15 gradients: the dense channel-0..15 tiles, register-resident k9 fragments), ROLE 1 = waves 4-7 (the
-// packed channel-16..19 tiles, operands from LDS).  Two straight-line programs with the same barrier sequence: the register
-// allocator sees each role on its own, so the packed role does not carry the dense role's 57 weight fragments and has room
-// to keep its LDS operands two steps ahead (with both roles in one body the kernel sat at 256 VGPRs and any deeper
-// pipelining of the packed loops spilled).
+// ROLE: the kernel body is instantiated twice and dispatched on the (wave-uniform) wave index.  Waves w and w + 4 share a
+// SIMD and a K-quarter (kg = w & 3) of both data gradients; ROLE = w >> 2 says which HALF of that quarter's work a wave does:
+// two of the four dense column tiles (channels 0..15, k9 fragments in registers) AND half of the steps of the packed tile
+// (channels 16..19, operands from LDS).  Until round 3 the dense tiles ran on waves 0-3 and the packed ones on waves 4-7: a
+// wave streaming MFMAs from registers is never held up by its SIMD partner (tools/mfma_valu_coexec.hip), so the packed wave
+// got the matrix pipe only when the dense one had finished and then ran alone, latency-bound (per-wave stamps: 9.8 k cycles
+// dense, 13.4 k packed, of which the SIMD idled ~3 k; k15 gradient at dil 2: 7.8 k / 12.0 k).  With identical streams on both
+// waves of a SIMD each fills the other's LDS waits and both end together.
 template <int RT9, int NK9, int DIL, bool CIN1, int ROLE>
 __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a, int ntiles, int tpf, int skip) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -1679,9 +1695,8 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, kq = lane >> 4;
-  constexpr int rt = ROLE;                         // this wave's output row tile ...
-  const int kg = (wave + rt) & 3;                  // ... and K-quarter (the longer quarter 0 lands on different SIMDs for the
-                                                   // two row tiles)
+  constexpr int hf = ROLE;                         // which half of a K-quarter's work this wave does (see the kernel)
+  const int kg = wave & 3;                         // this wave's K-quarter: waves w and w + 4 share it (and a SIMD)
 
   // the first tile's x goes out before the weights: its HBM round trip is the longest latency of the prologue
   // ---- prefetch of the next tile: dy (wave w rows w, w+8, ...), lin / tanh (rows w, w+8, w+16), h (elementwise map) ----
@@ -1782,17 +1797,15 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
   // NK9 = 4 (NJ9-1) + 1 for both shapes: the one left-over channel group (cq = NK9-1) is shared out by TAP (quarter kg takes
   // taps kg, kg+4, kg+8 < 9), so the quarters carry 57 | 56 | 56 | 56 k-steps instead of 63 | 54 | 54 | 54.
   static_assert(NK9 == 4 * (NJ9 - 1) + 1, "left-over channel group is shared out by tap");
-  float w9r[ROLE == 0 ? K9 : 1][NJ9 - 1], w9x[3];
-  if (ROLE == 0) {
+  float w9r[K9][NJ9 - 1], w9x[3];
 #pragma unroll
-    for (int tp = 0; tp < K9; ++tp)
+  for (int tp = 0; tp < K9; ++tp)
 #pragma unroll
-      for (int j = 0; j < NJ9 - 1; ++j)
-        w9r[ROLE == 0 ? tp : 0][j] = a.wt9[((long)tp * C + min(4 * (kg + 4 * j) + kq, C - 1)) * NARROW + l15];   // rows = channels 0..15
+    for (int j = 0; j < NJ9 - 1; ++j)
+      w9r[tp][j] = a.wt9[((long)tp * C + min(4 * (kg + 4 * j) + kq, C - 1)) * NARROW + l15];   // rows = channels 0..15
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
-      w9x[i] = a.wt9[((long)min(kg + 4 * i, K9 - 1) * C + min(4 * (NK9 - 1) + kq, C - 1)) * NARROW + l15];
-  }
+  for (int i = 0; i < 3; ++i)
+    w9x[i] = a.wt9[((long)min(kg + 4 * i, K9 - 1) * C + min(4 * (NK9 - 1) + kq, C - 1)) * NARROW + l15];
   const int rt1 = RT9 == 7 ? (wave < 7 ? wave : 6) : (wave & 3);
   const int cb1 = RT9 == 7 ? 0 : (wave >> 2) * 32;
   constexpr int NC1 = RT9 == 7 ? 4 : 2;
@@ -1849,65 +1862,52 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
     // Software-pipelined loops with scheduling fences: left alone the scheduler hoists ~30 ds_read2 (60 registers) ahead
     // of the MFMAs, which spills - and a scratch reload waits on vmcnt IN ORDER, i.e. on the next tile's whole prefetch.
     if (!(skip & 1)) {
-      if constexpr (ROLE == 0) {
-        // dense rows 0..15: the TT new columns of a steady tile (4 column tiles), all NCTA column tiles of a fresh one
-        const float* yb = dys + (4 * kg + kq) * LDY + l15;
-        const float* yx = dys + (4 * (NK9 - 1) + kq) * LDY + l15 + kg;
-        float* pp0 = part + (kg * 16 + kq * 4) * PSW + l15;
-        if (!fresh) {
-          constexpr int J0 = 2 * Hh;
-          f32x4 acc[4];
+      // dense rows 0..15: this wave's half of the column tiles (steady: 2 of the 4 new tiles; fresh: NA | NCTA - NA of all)
+      const float* yb = dys + (4 * kg + kq) * LDY + l15;
+      const float* yx = dys + (4 * (NK9 - 1) + kq) * LDY + l15 + kg;
+      float* pp0 = part + (kg * 16 + kq * 4) * PSW + l15;
+      // channels 16..19, packed: this wave's half of the steps; the second half's partial sums go to the (idle) dz1 tile
+      float* ppk = (hf == 0 ? part + PART1 : dhs) + kg * 4 * PSW;
+      static_assert(16 * PSW <= NARROW * LDN, "second set of packed partial sums lives in the dz1 tile");
+      if (!fresh) {
+        constexpr int J0 = 2 * Hh, JB = J0 + 32 * hf;
+        {
+          f32x4 acc[2];
+          acc[0] = acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          d9_rows0<2, NJ9 - 1, LDY>(w9r, w9x, yb + JB, yx + JB, kg, acc);
 #pragma unroll
-          for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          d9_rows0<4, NJ9 - 1, LDY>(w9r, w9x, yb + J0, yx + J0, kg, acc);
+          for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-          for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) pp0[reg * PSW + J0 + ct * 16] = acc[ct][reg];
-        } else {
-          // (two passes so that the accumulators stay at 16 registers: column tiles 0..3, then the rest)
-          {
-            f32x4 acc[4];
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            d9_rows0<4, NJ9 - 1, LDY>(w9r, w9x, yb, yx, kg, acc);
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-              for (int reg = 0; reg < 4; ++reg) pp0[reg * PSW + ct * 16] = acc[ct][reg];
-          }
-          {
-            constexpr int NCB = NCTA - 4;
-            f32x4 acc[NCB];
-#pragma unroll
-            for (int ct = 0; ct < NCB; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            d9_rows0<NCB, NJ9 - 1, LDY>(w9r, w9x, yb + 64, yx + 64, kg, acc);
-#pragma unroll
-            for (int ct = 0; ct < NCB; ++ct)
-#pragma unroll
-              for (int reg = 0; reg < 4; ++reg) pp0[reg * PSW + (4 + ct) * 16] = acc[ct][reg];
-          }
+            for (int reg = 0; reg < 4; ++reg) pp0[reg * PSW + JB + ct * 16] = acc[ct][reg];
         }
-      } else {
-        // channels 16..19, packed: ONE tile (64 time steps) on a steady tile, two on a fresh one
         f32x4 pk[2];
         pk[0] = pk[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (!fresh) {
-          constexpr int J0 = 2 * Hh;
-          d9_packed<NJ9 - 1, NK9, LDY, 1>(w9ps, C, w9t, dys + J0, kg, kq, l15, pk);
-          const int col = J0 + 4 * l15 + kq;
+        d9_packed<NJ9 - 1, NK9, LDY, 1, hf>(w9ps, C, w9t, dys + J0, kg, kq, l15, pk);
+        const int col = J0 + 4 * l15 + kq;
 #pragma unroll
-          for (int reg = 0; reg < 4; ++reg) part[PART1 + (kg * 4 + reg) * PSW + col] = pk[0][reg] + pk[1][reg];
-        } else {
-          d9_packed<NJ9 - 1, NK9, LDY>(w9ps, C, w9t, dys, kg, kq, l15, pk);
-          // row (s = kq, i = reg), column n = l15  ->  dg[16 + reg][64 ctp + 4 l15 + kq]
+        for (int reg = 0; reg < 4; ++reg) ppk[reg * PSW + col] = pk[0][reg] + pk[1][reg];
+      } else {
+        constexpr int NA = (NCTA + 1) / 2, NMINE = hf == 0 ? NA : NCTA - NA, CB = hf == 0 ? 0 : NA * 16;
+        {
+          f32x4 acc[NMINE];
 #pragma unroll
-          for (int ctp = 0; ctp < 2; ++ctp) {
-            const int col = 64 * ctp + 4 * l15 + kq;
-            if (col < WA16) {
+          for (int ct = 0; ct < NMINE; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          d9_rows0<NMINE, NJ9 - 1, LDY>(w9r, w9x, yb + CB, yx + CB, kg, acc);
 #pragma unroll
-              for (int reg = 0; reg < 4; ++reg) part[PART1 + (kg * 4 + reg) * PSW + col] = pk[ctp][reg];
-            }
+          for (int ct = 0; ct < NMINE; ++ct)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) pp0[reg * PSW + CB + ct * 16] = acc[ct][reg];
+        }
+        f32x4 pk[2];
+        pk[0] = pk[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        d9_packed<NJ9 - 1, NK9, LDY, 2, hf>(w9ps, C, w9t, dys, kg, kq, l15, pk);
+        // row (s = kq, i = reg), column n = l15  ->  dg[16 + reg][64 ctp + 4 l15 + kq]
+#pragma unroll
+        for (int ctp = 0; ctp < 2; ++ctp) {
+          const int col = 64 * ctp + 4 * l15 + kq;
+          if (col < WA16) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) ppk[reg * PSW + col] = pk[ctp][reg];
           }
         }
       }
@@ -1927,7 +1927,11 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
         const int c = e / ncol, ja = j_lo + (e - c * ncol);
         const float* pp = c < 16 ? part + c * PSW + ja : part + PART1 + (c - 16) * PSW + ja;
         const int ps = c < 16 ? 16 * PSW : 4 * PSW;
-        const float gg = (pp[0] + pp[ps]) + (pp[2 * ps] + pp[3 * ps]);
+        float gg = (pp[0] + pp[ps]) + (pp[2 * ps] + pp[3 * ps]);
+        if (c >= 16) {                                     // the second halves of the packed K-quarters
+          const float* pq = dhs + (c - 16) * PSW + ja;
+          gg += (pq[0] + pq[ps]) + (pq[2 * ps] + pq[3 * ps]);
+        }
         const float l = lin[c * LDA + ja], tg = th[c * LDA + ja];
         const float dl_ = gg * tg, dgt = gg * l * (1.f - tg * tg);
         lin[c * LDA + ja] = dl_;
@@ -1946,25 +1950,24 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
     // ---- D15: dh[ci][tt] = sum wt_lr[tap'][c'][ci] * da[c'][tt + tap' d], taps split in quarters kg.
     // Channels 0..15: waves 0-3 column tiles 0..2, waves 4-7 tile 3; channels 16..19: waves 4-7, packed tile.
     if (!(skip & 2)) {
-      const float* ab = lin + kq * LDA + l15 + kg * DIL;
+      const float* ab = lin + kq * LDA + l15 + kg * DIL + 32 * hf;
       const float* wb = w15s + kg * W15T + kq * NARROW + l15;
-      float* pp0 = part + (kg * 16 + kq * 4) * PST + l15;
-      if constexpr (ROLE == 0) {
-        f32x4 acc[4];
+      float* pp0 = part + (kg * 16 + kq * 4) * PST + l15 + 32 * hf;
+      {
+        f32x4 acc[2];
+        acc[0] = acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        d15_rows0<2, DIL, LDA>(wb, ab, kg, acc);
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        d15_rows0<4, DIL, LDA>(wb, ab, kg, acc);
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
+        for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
           for (int reg = 0; reg < 4; ++reg) pp0[reg * PST + ct * 16] = acc[ct][reg];
-      } else {
-        f32x4 pk = {0.f, 0.f, 0.f, 0.f};
-        d15_packed<DIL, LDA>(w15s, lin, kg, kq, l15, pk);
-        // row (s = kq, i = reg), column n = l15  ->  dh[16 + reg][4 l15 + kq]
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) part[4 * 16 * PST + (kg * 4 + reg) * PST + 4 * l15 + kq] = pk[reg];
       }
+      f32x4 pk = {0.f, 0.f, 0.f, 0.f};
+      d15_packed<DIL, LDA, hf>(w15s, lin, kg, kq, l15, pk);
+      // row (s = kq, i = reg), column n = l15  ->  dh[16 + reg][4 l15 + kq]; eight partial sums per element (K-quarter, half)
+      static_assert((64 + 32) * PST <= PARTSZ, "partial sums of the k15 gradient");
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) part[4 * 16 * PST + ((hf * 4 + kg) * 4 + reg) * PST + 4 * l15 + kq] = pk[reg];
     }
     // x rows of the copy-out phase (for act'(x)): wave w rows w, w+8, ...; issued here, consumed three barriers later
     float xv[NQ];
@@ -2001,7 +2004,8 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
         const int t = t0 + tt;
         const float* pp = c < 16 ? part + c * PST + tt : part + 4 * 16 * PST + (c - 16) * PST + tt;
         const int ps = c < 16 ? 16 * PST : 4 * PST;
-        const float dh = (pp[0] + pp[ps]) + (pp[2 * ps] + pp[3 * ps]);
+        float dh = (pp[0] + pp[ps]) + (pp[2 * ps] + pp[3 * ps]);
+        if (c >= 16) dh += (pp[4 * ps] + pp[5 * ps]) + (pp[6 * ps] + pp[7 * ps]);   // second halves of the packed K-quarters
         const float v = t < T ? dh * (hv[q] > 0.f ? 1.f : NSC_LRELU_ALPHA) : 0.f;
         dhs[c * LDN + tt] = v;
         if (t < T) a.dz1[((long)b * NARROW + c) * T + t] = v;
