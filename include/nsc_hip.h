@@ -120,6 +120,23 @@ int nsc_gated_block_dgrad_cin1(const float* h, const float* lin, const float* th
                                float* dlin, float* dgate, float* dz1, int B, int C, int T, int narrow, int k9,
                                int dil, int da_rows, void* stream);
 
+/* Kernel-ready parameter IMAGES of a gated block: the fast prologue of the two persistent kernels above (no counterpart in
+ * the reference: TensorFlow keeps its own packed filter copies).  A caller that runs the same block many times keeps one
+ * image per block and direction on the device and rebuilds it with ONE nsc_gather launch whenever the parameters change:
+ *   nsc_gated_block_image_floats(which, C, Cin, dil)   size of the image in floats (0: no image kernel for this shape)
+ *   nsc_gated_block_image_index(which, ..., offs, idx) host index map for nsc_gather: image[i] = src[idx[i]] (-1: pad).
+ *       which = 0 (forward):       offs = offsets of w1, b1, wl, bl, wr, br, w9, b9 in the gathered buffer
+ *       which = 1 (data gradient): offs = offsets of wt1, wtl, wtr, wt9 (the flipped / transposed kernels)
+ *   nsc_gated_block_fwd_img / _dgrad_img: nsc_gated_block_fwd[_cin1] / nsc_gated_block_dgrad[_cin1] on an image (16-byte aligned);
+ *       Cin = C or 1; same outputs bit for bit.  C in {100, 50}, dil in {1, 2}. */
+long nsc_gated_block_image_floats(int which, int C, int Cin, int dil);
+int nsc_gated_block_image_index(int which, int C, int Cin, int dil, const long* offs, int* idx);
+int nsc_gated_block_fwd_img(const float* img, const float* x, float* out, float* h_out, float* lin_out, float* th_out,
+                            float* g_out, int B, int C, int Cin, int T, int dil, int flat, void* stream);
+int nsc_gated_block_dgrad_img(const float* img, const float* x, const float* h, const float* lin, const float* th,
+                              const float* dy, float* dx, float* dlin, float* dgate, float* dz1, int B, int C, int Cin,
+                              int T, int dil, int in_act, int da_rows, void* stream);
+
 /* Persistent weight-gradient kernel of one gated block: all eight parameter gradients (accumulated) from the saved
  * activations x [B,C,T], h, g [B,20,T] and the data-path gradients dy [B,C,T], da [B,40,T] (= dlin | dgate, the
  * nsc_glu_bwd_cat output), dz1 [B,20,T] (= dL/d(pre-activation of h)).  Optionally (dx != NULL) it also produces the

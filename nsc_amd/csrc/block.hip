@@ -292,6 +292,64 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
   NSC_STAMP(32);
   prefetch(first);
   // ---- once per workgroup: weights -> LDS / registers ----
+  const int r1 = wave >> 2;
+  float w1r[NK1];
+  const int rt3 = RT9 == 7 ? (wave < 7 ? wave : 6) : (wave & 3);
+  const int cb3 = RT9 == 7 ? 0 : (wave >> 2) * 32;      // first output column of this wave in phase 3
+  constexpr int NC3 = RT9 == 7 ? 4 : 2;                  // column tiles per wave in phase 3
+  float w9r[K9][5];
+  float b1r[4], b9r[4];
+  // phase-2 jobs: q -> (row tile q % 3, column tile q / 3); wave w runs q = w and w + 8 (wave 7: a discarded duplicate)
+  int jrt[2], jct[2];
+  bool jlive[2];
+  float blr[2][2], brr[2][2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int q = wave + 8 * e;
+    jlive[e] = q < 15;
+    const int qq = jlive[e] ? q : wave;
+    jrt[e] = qq % 3;
+    jct[e] = qq / 3;
+  }
+  if (a.img) {
+    // FAST prologue: the engine keeps a kernel-ready IMAGE of the block's parameters (rebuilt once per step by the same
+    // gather launch that flips the data-gradient kernels): the LDS image of the k15 gate kernels as it stands, then every
+    // lane's register fragments laid out [wave][group of 4][lane][4], so that the whole prologue is ~30 coalesced 16-byte
+    // loads per lane instead of ~115 dword loads with index arithmetic (a memory instruction costs the issuing wave 60-100
+    // cycles whatever its width: the prologue was 9-13 k cycles of a 40-70 us launch).
+    const f32x4* img4 = reinterpret_cast<const f32x4*>(a.img);
+    constexpr int NA4 = K15 * NARROW * LDW / 4, NE4 = (NA4 + 511) / 512;
+    constexpr int NFR = NK1 + K9 * 5 + 16, NF4 = (NFR + 3) / 4;
+    f32x4 tA[NE4], fr[NF4];
+#pragma unroll
+    for (int i = 0; i < NE4; ++i) tA[i] = img4[min(tid + 512 * i, NA4 - 1)];
+    const f32x4* fp = img4 + NA4 + wave * NF4 * 64 + lane;
+#pragma unroll
+    for (int g = 0; g < NF4; ++g) fr[g] = fp[g * 64];
+#pragma unroll
+    for (int i = 0; i < NE4; ++i)
+      if (tid + 512 * i < NA4) reinterpret_cast<f32x4*>(w2s)[tid + 512 * i] = tA[i];
+#define NSC_FR(f) fr[(f) / 4][(f) % 4]
+#pragma unroll
+    for (int u = 0; u < NK1; ++u) w1r[u] = NSC_FR(u);
+#pragma unroll
+    for (int tap = 0; tap < K9; ++tap)
+#pragma unroll
+      for (int u = 0; u < 5; ++u) w9r[tap][u] = NSC_FR(NK1 + tap * 5 + u);
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      b1r[reg] = NSC_FR(NK1 + 45 + reg);
+      b9r[reg] = NSC_FR(NK1 + 49 + reg);
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        blr[e][u] = NSC_FR(NK1 + 53 + 2 * e + u);
+        brr[e][u] = NSC_FR(NK1 + 57 + 2 * e + u);
+      }
+#undef NSC_FR
+  } else {
   // Every load below uses a CLAMPED index instead of a mask: pad rows of A (output channels >= 20 / >= C) only feed
   // output rows that are never stored, and pad k-rows (ci >= C) multiply x rows that phase 0 writes as zeros, so any
   // finite stand-in value is harmless - and without selects all ~125 loads per lane are in flight at once.
@@ -315,35 +373,19 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
   }
   // phase 1: a wave owns ONE of the two row tiles of h (waves 0-3: channels 0..15, waves 4-7: 16..19 + padding), so it
   // keeps NK1 fragments of W1, not 2 NK1 (the second set cost 25 registers and pushed the C = 100 kernel into scratch)
-  const int r1 = wave >> 2;
-  float w1r[NK1];
 #pragma unroll
   for (int u = 0; u < NK1; ++u) w1r[u] = a.w1[min(4 * u + kq, Cin - 1) * NARROW + min(r1 * 16 + l15, NARROW - 1)];
-  const int rt3 = RT9 == 7 ? (wave < 7 ? wave : 6) : (wave & 3);
-  const int cb3 = RT9 == 7 ? 0 : (wave >> 2) * 32;      // first output column of this wave in phase 3
-  constexpr int NC3 = RT9 == 7 ? 4 : 2;                  // column tiles per wave in phase 3
-  float w9r[K9][5];
 #pragma unroll
   for (int tap = 0; tap < K9; ++tap)
 #pragma unroll
     for (int u = 0; u < 5; ++u) w9r[tap][u] = a.w9[(tap * NARROW + 4 * u + kq) * C + min(rt3 * 16 + l15, C - 1)];
-  float b1r[4], b9r[4];
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) {
     b1r[reg] = a.b1[min(r1 * 16 + kq * 4 + reg, NARROW - 1)];
     b9r[reg] = a.b9[min(rt3 * 16 + kq * 4 + reg, C - 1)];
   }
-  // phase-2 jobs: q -> (row tile q % 3, column tile q / 3); wave w runs q = w and w + 8 (wave 7: a discarded duplicate)
-  int jrt[2], jct[2];
-  bool jlive[2];
-  float blr[2][2], brr[2][2];
 #pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    const int q = wave + 8 * e;
-    jlive[e] = q < 15;
-    const int qq = jlive[e] ? q : wave;
-    jrt[e] = qq % 3;
-    jct[e] = qq / 3;
+  for (int e = 0; e < 2; ++e)
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int c = jrt[e] * 8 + kq * 2 + u;
@@ -578,7 +620,7 @@ extern "C" int nsc_gated_block_fwd(const float* x, const float* w1, const float*
   const int C4 = (C + 3) & ~3;
   const size_t smem = ((size_t)(C4 + NARROW) * ldx + (size_t)NARROW * ldg) * sizeof(float);
   NSC_REQUIRE(smem <= 160 * 1024, NSC_ERR_UNSUPPORTED, "nsc_gated_block_fwd: %zu B LDS", smem);
-  BlockArgs a{B, C, T, dil, flat, x, w1, b1, wl, bl, wr, br, w9, b9, out, h_out, lin_out, th_out, g_out, C};
+  BlockArgs a{B, C, T, dil, flat, x, w1, b1, wl, bl, wr, br, w9, b9, out, h_out, lin_out, th_out, g_out, C, nullptr};
   dim3 grid(nsc_cdiv(T, 64), B);
   hipStream_t st = (hipStream_t)stream;
   static const bool v1_only = NSC_PROBE_SET("NSC_BLOCK_FWD_V1");   // A/B switch for profiling
@@ -617,7 +659,7 @@ extern "C" int nsc_gated_block_fwd_cin1(const float* x, const float* w1, const f
               "nsc_gated_block_fwd_cin1: built for narrow=20, k9=9, C in {100, 50}, dil in {1, 2} (got %d, %d, %d, %d)", narrow, k9, C, dil);
   NSC_REQUIRE(!(lin_out || th_out || g_out) || (lin_out && th_out && g_out), NSC_ERR_BAD_ARG,
               "nsc_gated_block_fwd_cin1: lin/th/g outputs must be given together");
-  BlockArgs a{B, C, T, dil, flat, x, w1, b1, wl, bl, wr, br, w9, b9, out, h_out, lin_out, th_out, g_out, 1};
+  BlockArgs a{B, C, T, dil, flat, x, w1, b1, wl, bl, wr, br, w9, b9, out, h_out, lin_out, th_out, g_out, 1, nullptr};
   hipStream_t st = (hipStream_t)stream;
   if (C == 100) return dil == 1 ? launch_block_fwd2<7, 1, 1>(a, st) : launch_block_fwd2<7, 1, 2>(a, st);
   return dil == 1 ? launch_block_fwd2<4, 1, 1>(a, st) : launch_block_fwd2<4, 1, 2>(a, st);
@@ -1755,6 +1797,40 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
   NSC_STAMP(0);
   prefetch_dy(first);
   prefetch_a(first);
+  static_assert(NK9 == 4 * (NJ9 - 1) + 1, "left-over channel group is shared out by tap");
+  float w9r[K9][NJ9 - 1], w9x[3];
+  const int rt1 = RT9 == 7 ? (wave < 7 ? wave : 6) : (wave & 3);
+  const int cb1 = RT9 == 7 ? 0 : (wave >> 2) * 32;
+  constexpr int NC1 = RT9 == 7 ? 4 : 2;
+  float w1r[5];
+  if (a.img) {
+    // FAST prologue from the engine's kernel-ready image (see gated_block_fwd2_kernel): the LDS image of w15s | w9ps as it
+    // stands, then every lane's k9 / 1x1 fragments [wave][group of 4][lane][4]: ~24 coalesced 16-byte loads per lane
+    // instead of ~95 dword loads with index arithmetic (the prologue was 12-17 k cycles of a 47-85 us launch).
+    const f32x4* img4 = reinterpret_cast<const f32x4*>(a.img);
+    const int nA4 = (K15 * W15T + K9 * w9t) / 4;
+    constexpr int NE4 = (K15 * W15T + K9 * (4 * 4 * NK9 + 8) + 4 * 512 - 1) / (4 * 512);
+    constexpr int NFR = K9 * (NJ9 - 1) + 3 + 5, NF4 = (NFR + 3) / 4;
+    f32x4 tA[NE4], fr[NF4];
+#pragma unroll
+    for (int i = 0; i < NE4; ++i) tA[i] = img4[min(tid + 512 * i, nA4 - 1)];
+    const f32x4* fp = img4 + nA4 + wave * NF4 * 64 + lane;
+#pragma unroll
+    for (int g = 0; g < NF4; ++g) fr[g] = fp[g * 64];
+#pragma unroll
+    for (int i = 0; i < NE4; ++i)
+      if (tid + 512 * i < nA4) reinterpret_cast<f32x4*>(w15s)[tid + 512 * i] = tA[i];
+#define NSC_FR(f) fr[(f) / 4][(f) % 4]
+#pragma unroll
+    for (int tp = 0; tp < K9; ++tp)
+#pragma unroll
+      for (int j = 0; j < NJ9 - 1; ++j) w9r[tp][j] = NSC_FR(tp * (NJ9 - 1) + j);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) w9x[i] = NSC_FR(K9 * (NJ9 - 1) + i);
+#pragma unroll
+    for (int s5 = 0; s5 < 5; ++s5) w1r[s5] = CIN1 ? 0.f : NSC_FR(K9 * (NJ9 - 1) + 3 + s5);
+#undef NSC_FR
+  } else {
   // ---- once per workgroup: weights -> registers / LDS (clamped indices: pad k-rows meet zero rows of the staged
   // tiles; only k-steps / taps past the end need a real zero) ----
   // (all loads of a table are issued before its first LDS store: a plain load->store loop serialises ~24 L2 round
@@ -1796,8 +1872,6 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
   }
   // NK9 = 4 (NJ9-1) + 1 for both shapes: the one left-over channel group (cq = NK9-1) is shared out by TAP (quarter kg takes
   // taps kg, kg+4, kg+8 < 9), so the quarters carry 57 | 56 | 56 | 56 k-steps instead of 63 | 54 | 54 | 54.
-  static_assert(NK9 == 4 * (NJ9 - 1) + 1, "left-over channel group is shared out by tap");
-  float w9r[K9][NJ9 - 1], w9x[3];
 #pragma unroll
   for (int tp = 0; tp < K9; ++tp)
 #pragma unroll
@@ -1806,17 +1880,17 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
 #pragma unroll
   for (int i = 0; i < 3; ++i)
     w9x[i] = a.wt9[((long)min(kg + 4 * i, K9 - 1) * C + min(4 * (NK9 - 1) + kq, C - 1)) * NARROW + l15];
-  const int rt1 = RT9 == 7 ? (wave < 7 ? wave : 6) : (wave & 3);
-  const int cb1 = RT9 == 7 ? 0 : (wave >> 2) * 32;
-  constexpr int NC1 = RT9 == 7 ? 4 : 2;
-  float w1r[5];
 #pragma unroll
   for (int s5 = 0; s5 < 5; ++s5) w1r[s5] = CIN1 ? 0.f : a.wt1[(s5 * 4 + kq) * C + min(rt1 * 16 + l15, C - 1)];
+  }
+
   // CIN1: wt1 is [20] (the flipped / transposed [1,1,20] kernel); lane tt of wave 0 needs all of it
   float w1c[CIN1 ? NARROW : 1];
   if (CIN1) {
+    // (with an image: the 20 taps follow the fragment region)
+    const float* w1p = a.img ? a.img + (K15 * W15T + K9 * w9t) + 8 * 64 * 4 * ((K9 * (NJ9 - 1) + 3 + 5 + 3) / 4) : a.wt1;
 #pragma unroll
-    for (int c = 0; c < NARROW; ++c) w1c[c] = a.wt1[c];
+    for (int c = 0; c < NARROW; ++c) w1c[c] = w1p[c];
   }
 
 
@@ -2121,7 +2195,7 @@ extern "C" int nsc_gated_block_dgrad(const float* x, const float* h, const float
   const int C4 = (C + 3) & ~3;
   const size_t smem = ((size_t)C4 * ldy + (size_t)3 * NARROW * lda + (size_t)NARROW * ldn) * sizeof(float);
   NSC_REQUIRE(smem <= 160 * 1024, NSC_ERR_UNSUPPORTED, "nsc_gated_block_dgrad: %zu B LDS", smem);
-  BlockDgradArgs a{B, C, T, dil, in_act, x, h, lin, th, dy, wt1, wtl, wtr, wt9, dx, da, dz1, da + (long)NARROW * T, 2 * NARROW};
+  BlockDgradArgs a{B, C, T, dil, in_act, x, h, lin, th, dy, wt1, wtl, wtr, wt9, dx, da, dz1, da + (long)NARROW * T, 2 * NARROW, nullptr};
   dim3 grid(nsc_cdiv(T, 64), B);
   hipStream_t st = (hipStream_t)stream;
   static const bool v1_only = NSC_PROBE_SET("NSC_BLOCK_DGRAD_V1");   // A/B switch for profiling
@@ -2157,8 +2231,149 @@ extern "C" int nsc_gated_block_dgrad_cin1(const float* h, const float* lin, cons
   NSC_REQUIRE(narrow == NARROW && k9 == K9 && (dil == 1 || dil == 2) && (C == 100 || C == 50), NSC_ERR_UNSUPPORTED,
               "nsc_gated_block_dgrad_cin1: built for narrow=20, k9=9, dil in {1,2}, C in {100, 50} (got %d, %d, %d, %d)", narrow, k9, dil, C);
   BlockDgradArgs a{B, C, T, dil, NSC_ACT_NONE, dy /* x: unused */, h, lin, th, dy, wt1, wtl, wtr, wt9, dx, dlin, dz1, dgate,
-                   da_rows};
+                   da_rows, nullptr};
   hipStream_t st = (hipStream_t)stream;
   if (C == 100) return dil == 1 ? launch_block_dgrad2<7, 25, 1, true>(a, st) : launch_block_dgrad2<7, 25, 2, true>(a, st);
   return dil == 1 ? launch_block_dgrad2<4, 13, 1, true>(a, st) : launch_block_dgrad2<4, 13, 2, true>(a, st);
+}
+
+
+// =====================================================================================================
+// Kernel-ready parameter IMAGES of a gated block (fast prologue of the persistent kernels).  The caller keeps one image per
+// block and direction in device memory and rebuilds it whenever the parameters change with ONE gather (nsc_gather) over
+// the index map built here - for the engine that is the launch that flips the data-gradient kernels anyway.
+//   which = 0 (forward):  [300][48] LDS image of the k15 gate kernels | per wave and lane: W1 fragments, k9 fragments, biases
+//   which = 1 (data gradient): [15][808] | [9][w9t] LDS images | per wave and lane: k9^T fragments, 1x1^T fragments | (Cin = 1: 20 taps)
+// Source offsets `offs` (floats, into the buffer the gather reads): which = 0: w1, b1, wl, bl, wr, br, w9, b9;
+// which = 1: wt1, wtl, wtr, wt9 (the flipped / transposed kernels of nsc_weight_flip_transpose).  idx[i] = -1: unused pad.
+// =====================================================================================================
+static bool img_shape(int C, int Cin, int dil, int* rt9, int* nk) {
+  if (!(dil == 1 || dil == 2) || !(C == 100 || C == 50) || !(Cin == C || Cin == 1)) return false;
+  *rt9 = C == 100 ? 7 : 4;
+  *nk = C == 100 ? 25 : 13;
+  return true;
+}
+extern "C" long nsc_gated_block_image_floats(int which, int C, int Cin, int dil) {
+  int rt9, nk;
+  if (!img_shape(C, Cin, dil, &rt9, &nk)) return 0;
+  if (which == 0) {
+    const int nk1 = Cin == 1 ? 1 : nk;
+    return (long)K15 * NARROW * 48 + 8L * 64 * 4 * ((nk1 + K9 * 5 + 16 + 3) / 4);
+  }
+  if (which == 1) {
+    const int w9t = C * 4 + (((C * 4) & 15) == 8 ? 0 : 8), nj = (nk + 3) / 4 - 1;
+    return (long)K15 * W15T + (long)K9 * w9t + 8L * 64 * 4 * ((K9 * nj + 3 + 5 + 3) / 4) + (Cin == 1 ? NARROW : 0);
+  }
+  return 0;
+}
+extern "C" int nsc_gated_block_image_index(int which, int C, int Cin, int dil, const long* offs, int* idx) {
+  NSC_REQUIRE(offs && idx, NSC_ERR_BAD_ARG, "nsc_gated_block_image_index: null pointer");
+  int rt9, nk;
+  NSC_REQUIRE(img_shape(C, Cin, dil, &rt9, &nk) && (which == 0 || which == 1), NSC_ERR_UNSUPPORTED,
+              "nsc_gated_block_image_index: no image for C %d, Cin %d, dil %d, which %d", C, Cin, dil, which);
+  const long n = nsc_gated_block_image_floats(which, C, Cin, dil);
+  for (long i = 0; i < n; ++i) idx[i] = -1;
+  auto mn = [](int a, int b) { return a < b ? a : b; };
+  if (which == 0) {
+    const long w1 = offs[0], b1 = offs[1], wl = offs[2], bl = offs[3], wr = offs[4], br = offs[5], w9 = offs[6], b9 = offs[7];
+    const int nk1 = Cin == 1 ? 1 : nk, LDW = 48;
+    for (int e = 0; e < K15 * NARROW * LDW; ++e) {
+      const int row = e / LDW, r = e - row * LDW, ii = r & 15;
+      const int c = mn((r >> 4) * 8 + (ii >> 2) * 2 + (ii & 1), NARROW - 1);
+      idx[e] = (int)(((ii & 2) ? wr : wl) + row * NARROW + c);
+    }
+    const int nfr = nk1 + K9 * 5 + 16, nf4 = (nfr + 3) / 4;
+    const long baseB = (long)K15 * NARROW * LDW;
+    for (int wave = 0; wave < 8; ++wave) {
+      const int r1 = wave >> 2, rt3 = rt9 == 7 ? mn(wave, 6) : (wave & 3);
+      int jrt[2];
+      for (int e = 0; e < 2; ++e) { const int q = wave + 8 * e; jrt[e] = (q < 15 ? q : wave) % 3; }
+      for (int lane = 0; lane < 64; ++lane) {
+        const int l15 = lane & 15, kq = lane >> 4;
+        for (int f = 0; f < nfr; ++f) {
+          long src;
+          if (f < nk1) src = w1 + (long)mn(4 * f + kq, Cin - 1) * NARROW + mn(r1 * 16 + l15, NARROW - 1);
+          else if (f < nk1 + 45) { const int t = f - nk1, tap = t / 5, u = t % 5; src = w9 + (long)(tap * NARROW + 4 * u + kq) * C + mn(rt3 * 16 + l15, C - 1); }
+          else if (f < nk1 + 49) src = b1 + mn(r1 * 16 + kq * 4 + (f - nk1 - 45), NARROW - 1);
+          else if (f < nk1 + 53) src = b9 + mn(rt3 * 16 + kq * 4 + (f - nk1 - 49), C - 1);
+          else if (f < nk1 + 57) { const int t = f - nk1 - 53; src = bl + mn(jrt[t >> 1] * 8 + kq * 2 + (t & 1), NARROW - 1); }
+          else { const int t = f - nk1 - 57; src = br + mn(jrt[t >> 1] * 8 + kq * 2 + (t & 1), NARROW - 1); }
+          idx[baseB + ((long)(wave * nf4 + f / 4) * 64 + lane) * 4 + (f & 3)] = (int)src;
+        }
+      }
+    }
+    return NSC_OK;
+  }
+  const long wt1 = offs[0], wtl = offs[1], wtr = offs[2], wt9 = offs[3];
+  const int w9t = C * 4 + (((C * 4) & 15) == 8 ? 0 : 8), nj = (nk + 3) / 4 - 1;
+  for (int e = 0; e < K15 * 2 * NARROW * NARROW; ++e) {
+    const int tp = e / (2 * NARROW * NARROW), r = e - tp * 2 * NARROW * NARROW, cp = r / NARROW, ci = r - cp * NARROW;
+    idx[e + 8 * tp] = (int)((cp < NARROW ? wtl : wtr) + (long)(tp * NARROW + (cp < NARROW ? cp : cp - NARROW)) * NARROW + ci);
+  }
+  const long base9 = (long)K15 * W15T;
+  for (int e = 0; e < K9 * C * 4; ++e)
+    idx[base9 + (long)(e / (4 * C)) * w9t + (e % (4 * C))] = (int)(wt9 + (long)(e >> 2) * NARROW + 16 + (e & 3));
+  const long baseB = base9 + (long)K9 * w9t;
+  const int nfr = K9 * nj + 3 + 5, nf4 = (nfr + 3) / 4;
+  for (int wave = 0; wave < 8; ++wave) {
+    const int kg = wave & 3, rt1 = rt9 == 7 ? mn(wave, 6) : (wave & 3);
+    for (int lane = 0; lane < 64; ++lane) {
+      const int l15 = lane & 15, kq = lane >> 4;
+      for (int f = 0; f < nfr; ++f) {
+        long src;
+        if (f < K9 * nj) { const int tp = f / nj, j = f % nj; src = wt9 + ((long)tp * C + mn(4 * (kg + 4 * j) + kq, C - 1)) * NARROW + l15; }
+        else if (f < K9 * nj + 3) { const int i = f - K9 * nj; src = wt9 + ((long)mn(kg + 4 * i, K9 - 1) * C + mn(4 * (nk - 1) + kq, C - 1)) * NARROW + l15; }
+        else if (Cin == 1) continue;                       // (the 1x1 gradient of a one-channel input is a dot product)
+        else { const int s5 = f - K9 * nj - 3; src = wt1 + (long)(s5 * 4 + kq) * C + mn(rt1 * 16 + l15, C - 1); }
+        idx[baseB + ((long)(wave * nf4 + f / 4) * 64 + lane) * 4 + (f & 3)] = (int)src;
+      }
+    }
+  }
+  if (Cin == 1)
+    for (int c = 0; c < NARROW; ++c) idx[baseB + 8L * 64 * 4 * nf4 + c] = (int)(wt1 + c);
+  return NSC_OK;
+}
+
+// The two persistent kernels on an image (shapes of the codec only: C in {100, 50}, Cin in {C, 1}, dil in {1, 2}).
+extern "C" int nsc_gated_block_fwd_img(const float* img, const float* x, float* out, float* h_out, float* lin_out, float* th_out,
+                                       float* g_out, int B, int C, int Cin, int T, int dil, int flat, void* stream) {
+  NSC_REQUIRE(img && x && out, NSC_ERR_BAD_ARG, "nsc_gated_block_fwd_img: null pointer");
+  NSC_REQUIRE(B > 0 && T > 0, NSC_ERR_BAD_ARG, "nsc_gated_block_fwd_img: bad sizes");
+  NSC_REQUIRE(nsc_gated_block_image_floats(0, C, Cin, dil) > 0, NSC_ERR_UNSUPPORTED,
+              "nsc_gated_block_fwd_img: no image kernel for C %d, Cin %d, dil %d", C, Cin, dil);
+  NSC_REQUIRE(((uintptr_t)img & 15) == 0, NSC_ERR_BAD_ARG, "nsc_gated_block_fwd_img: image must be 16-byte aligned");
+  NSC_REQUIRE(!(lin_out || th_out || g_out) || (lin_out && th_out && g_out), NSC_ERR_BAD_ARG,
+              "nsc_gated_block_fwd_img: lin/th/g outputs must be given together");
+  BlockArgs a{B, C, T, dil, flat, x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, out, h_out, lin_out,
+              th_out, g_out, Cin, img};
+  hipStream_t st = (hipStream_t)stream;
+  if (Cin == 1) {
+    if (C == 100) return dil == 1 ? launch_block_fwd2<7, 1, 1>(a, st) : launch_block_fwd2<7, 1, 2>(a, st);
+    return dil == 1 ? launch_block_fwd2<4, 1, 1>(a, st) : launch_block_fwd2<4, 1, 2>(a, st);
+  }
+  if (C == 100) return dil == 1 ? launch_block_fwd2<7, 25, 1>(a, st) : launch_block_fwd2<7, 25, 2>(a, st);
+  return dil == 1 ? launch_block_fwd2<4, 13, 1>(a, st) : launch_block_fwd2<4, 13, 2>(a, st);
+}
+
+extern "C" int nsc_gated_block_dgrad_img(const float* img, const float* x, const float* h, const float* lin, const float* th,
+                                         const float* dy, float* dx, float* dlin, float* dgate, float* dz1, int B, int C, int Cin,
+                                         int T, int dil, int in_act, int da_rows, void* stream) {
+  NSC_REQUIRE(img && h && lin && th && dy && dx && dlin && dgate && dz1 && (x || Cin == 1), NSC_ERR_BAD_ARG,
+              "nsc_gated_block_dgrad_img: null pointer");
+  NSC_REQUIRE(B > 0 && T > 0, NSC_ERR_BAD_ARG, "nsc_gated_block_dgrad_img: bad sizes");
+  NSC_REQUIRE(nsc_gated_block_image_floats(1, C, Cin, dil) > 0, NSC_ERR_UNSUPPORTED,
+              "nsc_gated_block_dgrad_img: no image kernel for C %d, Cin %d, dil %d", C, Cin, dil);
+  NSC_REQUIRE(((uintptr_t)img & 15) == 0, NSC_ERR_BAD_ARG, "nsc_gated_block_dgrad_img: image must be 16-byte aligned");
+  NSC_REQUIRE(in_act == NSC_ACT_NONE || (in_act == NSC_ACT_LRELU && Cin > 1), NSC_ERR_BAD_ARG, "nsc_gated_block_dgrad_img: in_act");
+  NSC_REQUIRE(da_rows == NARROW || (da_rows == 2 * NARROW && dgate == dlin + (long)NARROW * T), NSC_ERR_BAD_ARG,
+              "nsc_gated_block_dgrad_img: da_rows must be 20 (two [B,20,T] tensors) or 40 with dgate = dlin + 20 T");
+  BlockDgradArgs a{B, C, T, dil, in_act, Cin == 1 ? dy : x, h, lin, th, dy, nullptr, nullptr, nullptr, nullptr, dx, dlin, dz1, dgate,
+                   da_rows, img};
+  hipStream_t st = (hipStream_t)stream;
+  if (Cin == 1) {
+    if (C == 100) return dil == 1 ? launch_block_dgrad2<7, 25, 1, true>(a, st) : launch_block_dgrad2<7, 25, 2, true>(a, st);
+    return dil == 1 ? launch_block_dgrad2<4, 13, 1, true>(a, st) : launch_block_dgrad2<4, 13, 2, true>(a, st);
+  }
+  if (C == 100) return dil == 1 ? launch_block_dgrad2<7, 25, 1>(a, st) : launch_block_dgrad2<7, 25, 2>(a, st);
+  return dil == 1 ? launch_block_dgrad2<4, 13, 1>(a, st) : launch_block_dgrad2<4, 13, 2>(a, st);
 }

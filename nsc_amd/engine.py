@@ -224,12 +224,15 @@ class _Block:
             tok = e.prof_begin("block_fwd", self.c1.flops() + self.cl.flops() + self.cr.flops() + self.c9.flops())
             # the fused backward recomputes the intermediates from x; an inference-only engine never reads them
             save = e.keep_activations
-            fn = e.lib.nsc_gated_block_fwd_cin1 if cin1 else e.lib.nsc_gated_block_fwd
-            check(fn(x.data_ptr(), w1, b1, wl, bl, wr, br, w9, b9, self.out.data_ptr(),
-                                            self.h.data_ptr() if save else None, self.lin.data_ptr() if save else None,
-                                            self.th.data_ptr() if save else None, self.g.data_ptr() if save else None,
-                                            B, self.wide, T, n, 9, self.cl.dil, int(self.flat),
-                                            e.stream()), "gated_block_fwd")
+            sv = [t.data_ptr() if save else None for t in (self.h, self.lin, self.th, self.g)]
+            if e.use_images and e.images_valid and self.img_fwd_off is not None:
+                check(e.lib.nsc_gated_block_fwd_img(e.wt_ptr + 4 * self.img_fwd_off, x.data_ptr(), self.out.data_ptr(), *sv, B,
+                                                    self.wide, self.Cin, T, self.cl.dil, int(self.flat), e.stream()),
+                      "gated_block_fwd_img")
+            else:
+                fn = e.lib.nsc_gated_block_fwd_cin1 if cin1 else e.lib.nsc_gated_block_fwd
+                check(fn(x.data_ptr(), w1, b1, wl, bl, wr, br, w9, b9, self.out.data_ptr(), *sv, B, self.wide, T, n, 9, self.cl.dil,
+                         int(self.flat), e.stream()), "gated_block_fwd")
             e.prof_end(tok)
             return self.out
         self.c1.fwd(x, self.h, "lrelu")
@@ -260,10 +263,17 @@ class _Block:
                 dxf = e.buf(u + ".dx", (B, self.Cin, T))
                 WT = lambda c: e.wt_ptr + 4 * c.w_off
                 tok = e.prof_begin("block_dgrad", self.c1.flops() + self.cl.flops() + self.cr.flops() + self.c9.flops())
-                check(e.lib.nsc_gated_block_dgrad(self.x.data_ptr(), self.h.data_ptr(), self.lin.data_ptr(),
-                                                  self.th.data_ptr(), dz.data_ptr(), WT(self.c1), WT(self.cl), WT(self.cr),
-                                                  WT(self.c9), dxf.data_ptr(), da.data_ptr(), dh.data_ptr(), B, self.Cin, T,
-                                                  n, 9, self.cl.dil, KIND_ACT[in_kind], e.stream()), "gated_block_dgrad")
+                if e.use_images and self.img_bwd_off is not None:     # (the data-gradient images are rebuilt with wt every step)
+                    check(e.lib.nsc_gated_block_dgrad_img(e.wt_ptr + 4 * self.img_bwd_off, self.x.data_ptr(), self.h.data_ptr(),
+                                                          self.lin.data_ptr(), self.th.data_ptr(), dz.data_ptr(), dxf.data_ptr(),
+                                                          da.data_ptr(), da.data_ptr() + 4 * n * T, dh.data_ptr(), B, self.wide,
+                                                          self.Cin, T, self.cl.dil, KIND_ACT[in_kind], 2 * n, e.stream()),
+                          "gated_block_dgrad_img")
+                else:
+                    check(e.lib.nsc_gated_block_dgrad(self.x.data_ptr(), self.h.data_ptr(), self.lin.data_ptr(),
+                                                      self.th.data_ptr(), dz.data_ptr(), WT(self.c1), WT(self.cl), WT(self.cr),
+                                                      WT(self.c9), dxf.data_ptr(), da.data_ptr(), dh.data_ptr(), B, self.Cin, T,
+                                                      n, 9, self.cl.dil, KIND_ACT[in_kind], e.stream()), "gated_block_dgrad")
                 e.prof_end(tok)
             else:
                 self.c9.dgrad(dz, dg)
@@ -320,10 +330,16 @@ class _Block:
                 dlin, dgate = da[:, :n], da[:, n:]      # data_ptr of the halves: dgate = dlin + 20 T floats
             WT = lambda c: e.wt_ptr + 4 * c.w_off
             tok = e.prof_begin("block_dgrad", self.c1.flops() + self.cl.flops() + self.cr.flops() + self.c9.flops())
-            check(e.lib.nsc_gated_block_dgrad_cin1(self.h.data_ptr(), self.lin.data_ptr(), self.th.data_ptr(), dz.data_ptr(),
-                                                   WT(self.c1), WT(self.cl), WT(self.cr), WT(self.c9), dx.data_ptr(),
-                                                   dlin.data_ptr(), dgate.data_ptr(), dh.data_ptr(), B, self.wide, T, n, 9,
-                                                   self.cl.dil, 2 * n if batched else n, e.stream()), "gated_block_dgrad_cin1")
+            if e.use_images and self.img_bwd_off is not None:
+                check(e.lib.nsc_gated_block_dgrad_img(e.wt_ptr + 4 * self.img_bwd_off, None, self.h.data_ptr(), self.lin.data_ptr(),
+                                                      self.th.data_ptr(), dz.data_ptr(), dx.data_ptr(), dlin.data_ptr(),
+                                                      dgate.data_ptr(), dh.data_ptr(), B, self.wide, 1, T, self.cl.dil,
+                                                      KIND_ACT["none"], 2 * n if batched else n, e.stream()), "gated_block_dgrad_img")
+            else:
+                check(e.lib.nsc_gated_block_dgrad_cin1(self.h.data_ptr(), self.lin.data_ptr(), self.th.data_ptr(), dz.data_ptr(),
+                                                       WT(self.c1), WT(self.cl), WT(self.cr), WT(self.c9), dx.data_ptr(),
+                                                       dlin.data_ptr(), dgate.data_ptr(), dh.data_ptr(), B, self.wide, T, n, 9,
+                                                       self.cl.dil, 2 * n if batched else n, e.stream()), "gated_block_dgrad_cin1")
             e.prof_end(tok)
             if batched:
                 e.defer_block_wgrad(self, dz, da, dh, e.g_ptr + 4 * self.c1.w_off,
@@ -658,9 +674,23 @@ class CascadeEngine:
         for c in poly:
             c.wtpoly_off = n + extra
             extra += 5 * c.Cout * 2 * c.Cin
+        # kernel-ready parameter images of the gated blocks the persistent kernels serve (fast prologue: include/nsc_hip.h,
+        # nsc_gated_block_image_index): one forward and one data-gradient image per block, 16-byte aligned, rebuilt by the
+        # same gather launch as the flipped kernels
+        for b in blocks:
+            b.img_fwd_off = b.img_bwd_off = None
+            if b.narrow == 20 and b.c9.K == 9:
+                for which, attr in ((0, "img_fwd_off"), (1, "img_bwd_off")):
+                    nf = int(self.lib.nsc_gated_block_image_floats(which, int(b.wide), int(b.Cin), int(b.cl.dil)))
+                    if nf > 0:
+                        extra = (n + extra + 3) // 4 * 4 - n
+                        setattr(b, attr, n + extra)
+                        extra += nf
         self.wt = torch.zeros(n + extra, **f32)
         self.p_ptr, self.g_ptr, self.wt_ptr = self.params.data_ptr(), self.grads.data_ptr(), self.wt.data_ptr()
+        assert self.wt_ptr % 16 == 0
         idx = np.arange(n + extra, dtype=np.int32)
+        idx[n:] = -1                                  # alignment gaps between the extra regions: never read (gather writes 0)
         for c in self.convs:
             idx[c.w_off:c.w_off + c.K * c.Cin * c.Cout] = c.wt_index()
         for b in blocks:
@@ -670,6 +700,21 @@ class CascadeEngine:
             idx[b.wtlr_off:b.wtlr_off + K * 2 * nn * nn] = np.concatenate([il, ir], axis=1).reshape(-1)
         for c in poly:
             idx[c.wtpoly_off:c.wtpoly_off + 5 * c.Cout * 2 * c.Cin] = c.wtpoly_index()
+        for b in blocks:
+            for which, off in ((0, b.img_fwd_off), (1, b.img_bwd_off)):
+                if off is None:
+                    continue
+                nf = int(self.lib.nsc_gated_block_image_floats(which, int(b.wide), int(b.Cin), int(b.cl.dil)))
+                if which == 0:      # straight from the parameters
+                    offs = [b.c1.w_off, b.c1.b_off, b.cl.w_off, b.cl.b_off, b.cr.w_off, b.cr.b_off, b.c9.w_off, b.c9.b_off]
+                else:               # from the flipped / transposed kernels: compose with their own index map
+                    offs = [b.c1.w_off, b.cl.w_off, b.cr.w_off, b.c9.w_off]
+                im = np.empty(nf, dtype=np.int32)
+                check(self.lib.nsc_gated_block_image_index(which, int(b.wide), int(b.Cin), int(b.cl.dil), (C.c_long * len(offs))(*offs),
+                                                           im.ctypes.data_as(C.c_void_p)), "gated_block_image_index")
+                if which == 1:
+                    im = np.where(im >= 0, idx[np.maximum(im, 0)], -1).astype(np.int32)
+                idx[off:off + nf] = im
         self.wt_idx = torch.from_numpy(idx).to(self.device)
         # two Adam slot sets (no-quan op / quan op) with independent state (nsc_module:922-926)
         self.adam = [dict(m=torch.zeros(n, **f32), v=torch.zeros(n, **f32), t=0,
@@ -941,6 +986,7 @@ class CascadeEngine:
                 lim = math.sqrt(6.0 / (fi + fo))
                 host[off:off + n] = rng.uniform(-lim, lim, size=n).astype(np.float32)
         self.params.copy_(torch.from_numpy(host))
+        self.images_valid = False
 
     def load_named(self, named):
         """Copy a name->array dict (oracle ParamStore layout, TF shapes) into the flat buffer."""
@@ -950,6 +996,7 @@ class CascadeEngine:
                 a = np.asarray(named[name], np.float32).reshape(-1)
                 host[off:off + a.size] = a
         self.params.copy_(torch.from_numpy(host))
+        self.images_valid = False
 
     def named(self, which="params"):
         host = getattr(self, which).detach().cpu().numpy()
@@ -959,9 +1006,16 @@ class CascadeEngine:
             out[name] = host[off:off + n].reshape(shape).copy()
         return out
 
+    images_valid = False   # the forward images mirror self.params: set by refresh_wt, cleared by everything that writes params
+    use_images = True      # fast prologue of the persistent block kernels from the images (False: A/B and tests)
+
     def refresh_wt(self):
+        """Rebuild everything derived from the parameters: the flipped / transposed data-gradient kernels and the kernel-ready
+        block images.  train_step does it every step; an inference user calls it once after loading weights (without it the
+        forward simply takes the slower prologue that reads the parameters themselves)."""
         check(self.lib.nsc_gather(self.p_ptr, self.wt_idx.data_ptr(), self.wt_ptr, self.wt.numel(), self.stream()),
               "gather wt")
+        self.images_valid = True
 
     # ---- forward ----
     def forward(self, x, is_quan_on=1.0, soft=True, lpc_x=None, want_p=False, hists_clean=False):
@@ -1162,6 +1216,7 @@ class CascadeEngine:
                 ranges[-1][1] = b
             else:
                 ranges.append([a, b])
+        self.images_valid = False
         for a, b in ranges:
             check(self.lib.nsc_adam_tf1_step(self.p_ptr + 4 * a, self.g_ptr + 4 * a, st["m"].data_ptr() + 4 * a,
                                              st["v"].data_ptr() + 4 * a, b - a, float(lr), beta1, beta2, eps, st["t"],

@@ -915,3 +915,82 @@ def test_upsample_stage_fwd_bwd(lib, shape):
     assert np.array_equal(dzp.cpu().numpy(), want_dzp)
     assert_close(ddw.cpu().numpy(), dwo.grad.numpy(), what=f"upsample ddw {shape}")
     assert_close(dx.cpu().numpy(), xt.grad.numpy(), what=f"upsample dx {shape}")
+
+
+@pytest.mark.parametrize("C_,Cin,dil,T,B", [(100, 100, 1, 256, 3), (100, 100, 2, 512, 2), (50, 50, 1, 512, 2), (50, 50, 2, 200, 3),
+                                           (100, 1, 1, 256, 2), (100, 1, 2, 300, 3), (50, 1, 1, 130, 2), (50, 1, 2, 512, 70)])
+def test_block_kernels_on_parameter_images_equal_the_plain_entry_points(lib, C_, Cin, dil, T, B):
+    """nsc_gated_block_fwd_img / _dgrad_img (fast prologue from a kernel-ready image built by nsc_gated_block_image_index +
+    nsc_gather) produce the same bits as nsc_gated_block_fwd[_cin1] / nsc_gated_block_dgrad[_cin1] on the same parameters."""
+    import ctypes as C
+    rng = np.random.default_rng(C_ + Cin + dil + T)
+    f = lambda *sh: (0.1 * rng.standard_normal(sh)).astype(np.float32)
+    w1, b1, wl, bl, wr, br, w9, b9 = f(1, Cin, 20), f(20), f(15, 20, 20), f(20), f(15, 20, 20), f(20), f(9, 20, C_), f(C_)
+    flat = np.concatenate([a.reshape(-1) for a in (w1, b1, wl, bl, wr, br, w9, b9)])
+    sizes = [a.size for a in (w1, b1, wl, bl, wr, br, w9, b9)]
+    offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+    pd = dev(flat)
+    pw = lambda i: pd.data_ptr() + 4 * int(offs[i])
+
+    def image(which, src, offsets):
+        n = int(lib.nsc_gated_block_image_floats(which, C_, Cin, dil))
+        assert n > 0
+        idx = np.empty(n, np.int32)
+        assert lib.nsc_gated_block_image_index(which, C_, Cin, dil, (C.c_long * len(offsets))(*[int(o) for o in offsets]),
+                                               idx.ctypes.data_as(C.c_void_p)) == 0, lib.nsc_last_error()
+        img = torch.empty(n, device="cuda")
+        idx_d = torch.tensor(idx, device="cuda")
+        assert lib.nsc_gather(src.data_ptr(), idx_d.data_ptr(), img.data_ptr(), n, _st()) == 0
+        return img
+
+    x = dev(rng.standard_normal((B, Cin, T)).astype(np.float32))
+    outs = {}
+    for use_img in (False, True):
+        out = torch.full((B, C_, T), float("nan"), device="cuda")
+        sv = [torch.full((B, 20, T), float("nan"), device="cuda") for _ in range(4)]
+        if use_img:
+            img = image(0, pd, offs)
+            rc = lib.nsc_gated_block_fwd_img(img.data_ptr(), x.data_ptr(), out.data_ptr(), *[t.data_ptr() for t in sv], B, C_, Cin, T, dil,
+                                             0, _st())
+        else:
+            fn = lib.nsc_gated_block_fwd_cin1 if Cin == 1 else lib.nsc_gated_block_fwd
+            rc = fn(x.data_ptr(), pw(0), pw(1), pw(2), pw(3), pw(4), pw(5), pw(6), pw(7), out.data_ptr(), *[t.data_ptr() for t in sv],
+                    B, C_, T, 20, 9, dil, 0, _st())
+        assert rc == 0, lib.nsc_last_error()
+        torch.cuda.synchronize()
+        outs[use_img] = [out] + sv
+    for a, b in zip(outs[False], outs[True]):
+        assert torch.equal(a, b) and bool(torch.isfinite(a).all())
+    # ---- data gradient: flipped / transposed kernels, then the same comparison ----
+    wt = {}
+    for name, w in (("1", w1), ("l", wl), ("r", wr), ("9", w9)):
+        wt[name] = np.ascontiguousarray(w[::-1].transpose(0, 2, 1))
+    tflat = np.concatenate([wt[k].reshape(-1) for k in ("1", "l", "r", "9")])
+    toffs = np.concatenate([[0], np.cumsum([wt[k].size for k in ("1", "l", "r", "9")])[:-1]]).astype(np.int64)
+    td = dev(tflat)
+    tw = lambda i: td.data_ptr() + 4 * int(toffs[i])
+    h, lin = dev(rng.standard_normal((B, 20, T)).astype(np.float32)), dev(rng.standard_normal((B, 20, T)).astype(np.float32))
+    th = torch.tanh(dev(rng.standard_normal((B, 20, T)).astype(np.float32)))
+    dy = dev(rng.standard_normal((B, C_, T)).astype(np.float32))
+    res = {}
+    for use_img in (False, True):
+        dx = torch.full((B, Cin, T), float("nan"), device="cuda")
+        da = torch.full((B, 40, T), float("nan"), device="cuda")
+        dz1 = torch.full((B, 20, T), float("nan"), device="cuda")
+        dl, dg = da.data_ptr(), da.data_ptr() + 4 * 20 * T
+        if use_img:
+            img = image(1, td, toffs)
+            rc = lib.nsc_gated_block_dgrad_img(img.data_ptr(), None if Cin == 1 else x.data_ptr(), h.data_ptr(), lin.data_ptr(),
+                                               th.data_ptr(), dy.data_ptr(), dx.data_ptr(), dl, dg, dz1.data_ptr(), B, C_, Cin, T, dil,
+                                               0 if Cin == 1 else 2, 40, _st())
+        elif Cin == 1:
+            rc = lib.nsc_gated_block_dgrad_cin1(h.data_ptr(), lin.data_ptr(), th.data_ptr(), dy.data_ptr(), tw(0), tw(1), tw(2), tw(3),
+                                                dx.data_ptr(), dl, dg, dz1.data_ptr(), B, C_, T, 20, 9, dil, 40, _st())
+        else:
+            rc = lib.nsc_gated_block_dgrad(x.data_ptr(), h.data_ptr(), lin.data_ptr(), th.data_ptr(), dy.data_ptr(), tw(0), tw(1), tw(2),
+                                           tw(3), dx.data_ptr(), da.data_ptr(), dz1.data_ptr(), B, C_, T, 20, 9, dil, 2, _st())
+        assert rc == 0, lib.nsc_last_error()
+        torch.cuda.synchronize()
+        res[use_img] = (dx, da, dz1)
+    for a, b in zip(res[False], res[True]):
+        assert torch.equal(a, b) and bool(torch.isfinite(a).all())
