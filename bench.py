@@ -46,6 +46,29 @@ def synth_batch(B, rank, device):
     return torch.from_numpy(x).to(device), torch.from_numpy(lpc).to(device), x, lpc
 
 
+# ---- the other BASELINE.json train configurations (parity-test cases; `--config N` times them too, the default and the
+# driver's run is config 3).  name, codecs, strides per codec, LPC path, default batch per GPU, MFLOP per frame
+CONFIGS = {
+    2: ("BASELINE config 2: 1 codec (strides [2], 32-bin quantizer, quan + entropy terms, tau 0.3), time-domain frames, "
+        "fwd+loss+bwd+TF1-Adam - run in fp32 (the reference's precision), not the bf16 the config names", 1, [2], False, 128, 714.1),
+    3: (None, 2, [2], True, 128, MFLOP_PER_FRAME_JOINT),
+    4: ("BASELINE config 4: 4-codec CMRL, every codec with two down-/up-sampling stages ('2 2': 128 codes, blocks at C = 100, 50, "
+        "25), joint finetune step (cmrl.py:295-390 generalised to 4 codecs: quan weight coeff[2] x global batch, tau_i ent_i), "
+        "fwd+loss+bwd+TF1-Adam", 4, [2, 2], False, 256, 3237.3),
+}
+
+
+def step_cfg_for(config, B, world):
+    if config == 3:
+        return step_cfg()
+    n = CONFIGS[config][1]
+    if config == 2:      # one_ae quan op (nsc_module:914-926): coeff[2] quan + tau ent, entropy of the global batch
+        return dict(is_quan_on=1.0, c_time=COEFF[0], c_freq=COEFF[1], c_quan=[COEFF[2]], c_ent=[0.3], trainable=[True], lr=LR, slot=1,
+                    quan_op=True)
+    return dict(is_quan_on=1.0, c_time=COEFF[0], c_freq=COEFF[1], c_quan=[COEFF[2] * B * world] * n, c_ent=[0.3] * n,
+                trainable=[True] * n, lr=LR, slot=1, quan_op=True)
+
+
 def step_cfg():
     return dict(is_quan_on=1.0, c_time=COEFF[0], c_freq=COEFF[1], c_quan=[COEFF[2], COEFF[2]], c_ent=[0.0, 0.0],
                 trainable=[True, True], lr=LR, slot=1, c_quan_lpc=COEFF[2], c_ent_lpc=0.0, train_lpc=True, quan_op=True, global_entropy=False)
@@ -129,7 +152,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=128, help="frames per GPU (BASELINE: 128)")
+    ap.add_argument("--batch", type=int, default=None, help="frames per GPU (BASELINE: 128; config 4: 256)")
+    ap.add_argument("--config", type=int, default=3, choices=(2, 3, 4),
+                    help="BASELINE.json configuration to time (3 = the headline 2-codec joint step; 2 and 4: the other train configs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--passes", type=int, default=3, help="timed passes of --steps steps each (value = the median pass)")
@@ -159,8 +184,12 @@ def main():
     ldev = comm.local_rank % torch.cuda.device_count()   # one GPU per rank on a real node; wraps only in single-GPU smoke tests
     torch.cuda.set_device(ldev)
     dev = torch.device("cuda", ldev)
-    B = args.batch
-    eng = CascadeEngine(B, 2, BKD, [[2], [2]], [32, 32], res_scalar=RES_SCALAR, scale_first=True, lpc=True, device=dev)
+    wl_name, ncodec, strides_c, use_lpc, B_default, mflop_frame = CONFIGS[args.config]
+    B = args.batch or B_default
+    if args.config != 3:
+        args.no_infer = args.no_cpu_baseline = True       # those legs belong to the headline configuration
+    eng = CascadeEngine(B, ncodec, BKD, [list(strides_c)] * ncodec, [32] * ncodec, res_scalar=RES_SCALAR, scale_first=use_lpc,
+                        lpc=use_lpc, device=dev)
     eng.overlap_wgrad = not args.no_overlap
     eng.wgrad_waves = args.wgrad_waves
     eng.split_wgrad = not args.no_split_wgrad
@@ -170,7 +199,9 @@ def main():
     eng.batch_conv_wgrad = not args.no_batch_conv_wgrad
     eng.fused_fwd = not args.unfused_fwd
     xd, lpcd, x_np, lpc_np = synth_batch(B, comm.rank, dev)
-    cfg = step_cfg()
+    cfg = step_cfg_for(args.config, B, comm.world)
+    if not use_lpc:
+        lpcd = None
     dcomm = comm if comm.world > 1 else (_NullComm() if args.dp_selftest else None)
     eng.dp_overlap = bool(args.dp_overlap)
 
@@ -271,12 +302,12 @@ def main():
         roof = dict(bound="mfma", kernel=KERNELS[tag], achieved=round(ach, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
                     frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic.get(tag),
                     launches_per_step=n // args.prof_steps, avg_launch_us=round(1e3 * ms / n, 2),
-                    flop_per_launch_avg=fl / n, peak_measured_on_box=127.4)
+                    flop_per_launch_avg=fl / n, peak_measured_on_box=153.7)
     kern_ms = by_kernel
 
     # HBM-bound quantizer at the op-surface form (p materialised, 34 816 B/frame fwd): measured at the config-5 batch
     qroof = None
-    if comm.rank == 0:
+    if comm.rank == 0 and args.config == 3:
         import ctypes as C
         from nsc_amd import _lib
         lib = _lib.load()
@@ -371,8 +402,8 @@ def main():
             "ms_per_step_min": round(min(pass_ms), 3), "timing": f"median of {len(pass_ms)} passes of {args.steps} steps, each bracketed by barrier + synchronize, max over ranks",
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE config 3: 2-codec CMRL (strides [2], 32 bins) on fed LPC residual + 16x256 "
-                                   "LSF quantizer, joint finetune step, fwd+loss+bwd+TF1-Adam" +
+            "config": {"workload": (wl_name or "BASELINE config 3: 2-codec CMRL (strides [2], 32 bins) on fed LPC residual + 16x256 "
+                                    "LSF quantizer, joint finetune step, fwd+loss+bwd+TF1-Adam") +
                                    ("+RCCL grad all-reduce(sum)" if comm.world > 1 else ""),
                        "batch_per_gpu": B, "global_batch": B * comm.world, "frame": 512,
                        "parallelism": f"dp{comm.world}", "launch": launch, "all_ranks_same_launch": all_same,
@@ -381,7 +412,7 @@ def main():
                                          "one at the tail of the step") if dcomm is not None else None),
                        "streams": "one (weight gradients batched at the tail of the step)",
                        "roofline_note": "per-kernel numbers: HIP events around each launch on extra eager steps of the same workload"},
-            "model_tflops": round(fps * MFLOP_PER_FRAME_JOINT * 1e6 / 1e12, 2),
+            "model_tflops": round(fps * mflop_frame * 1e6 / 1e12, 2), "mflop_per_frame": mflop_frame,
             "roofline": roof, "roofline_quantizer": qroof, "cpu_baseline": cpu, "codec_forward": infer, "kernels": kern_ms,
         }
         print(json.dumps(out), flush=True)

@@ -633,7 +633,7 @@ extern "C" int nsc_gated_block_fwd(const float* x, const float* w1, const float*
   do {                                                                                                              \
     auto kern = gated_block_fwd_kernel<RT>;                                                                         \
     if (smem > 64 * 1024) {                                                                                         \
-      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+      static const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
       NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "gated_block_fwd: smem attr: %s", hipGetErrorString(e));         \
     }                                                                                                               \
     hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, a, ldx, ldg);                                               \
@@ -1122,7 +1122,7 @@ extern "C" int nsc_gated_block_wgrad(const float* x, const float* h, const float
   do {                                                                                                              \
     auto kern = part == 0 ? gated_block_wgrad_kernel<RT, NW_, 0>                                                    \
                           : (part == 1 ? gated_block_wgrad_kernel<RT, NW_, 1> : gated_block_wgrad_kernel<RT, NW_, 2>); \
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);   \
+    static const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   \
     NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "gated_block_wgrad: smem attr: %s", hipGetErrorString(e));         \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW_), smem, st, a, ldn, ldg, ldh);                               \
   } while (0)
@@ -1215,7 +1215,7 @@ static int launch_wgrad_batch(const nsc_block_wgrad_job* jobs, const int* idx, i
   t.njobs = n;
   for (int q = 0; q < n; ++q) t.a[q].slab_stride = stride;
   auto kern = gated_block_wgrad_batch_kernel<RT9>;
-  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  static const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "gated_block_wgrad_batch: smem attr: %s", hipGetErrorString(e));
   hipLaunchKernelGGL(kern, dim3(2 * used), dim3(256), smem, st, t, ldn, ldg);
   NSC_CHECK_LAUNCH("gated_block_wgrad_batch");
@@ -2206,7 +2206,7 @@ extern "C" int nsc_gated_block_dgrad(const float* x, const float* h, const float
 #define LAUNCH_DG(RT)                                                                                               \
   do {                                                                                                              \
     auto kern = gated_block_dgrad_kernel<RT>;                                                                       \
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);   \
+    static const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   \
     NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "gated_block_dgrad: smem attr: %s", hipGetErrorString(e));         \
     hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, a, ldy, lda, ldn);                                          \
   } while (0)

@@ -187,7 +187,7 @@ def test_two_codec_lpc_finetune():
     ps = make_store(2, [[2], [2]], [32, 32], lpc=True)
     # seed 1234 puts one pre-activation of codec 2's up-sampler at |z| ~ 1e-8, i.e. ON the leaky-relu kink: the
     # float64 oracle and any float32 run may then legitimately pick different slopes for that element (measured:
-    # tests/debug_lpc.py).  Use a seed without such an element; kink handling itself is unit-tested per kernel.
+    # a one-off probe in round 2).  Use a seed without such an element; kink handling itself is unit-tested per kernel.
     x = synth_frames(B, seed=4321)
     rng = np.random.default_rng(3)
     lpc_x = np.sort(rng.uniform(0.03, 3.1, (B, 16, 1)), axis=1).astype(np.float32).astype(np.float64)
