@@ -262,8 +262,17 @@ class neuralSpeechCodingModule(object):
             tot = e.sum(dim=1) if tot is None else tot + e.sum(dim=1)
             if lpc_x is not None:
                 tot_lpc += float(eng.lpc_frame_ent.sum().item())
-            ori.append(x.reshape(-1).cpu().numpy())
-            dec.append(eng.decoded.reshape(-1).cpu().numpy())
+                # end2end_eval_lpc scores the SYNTHESISED signal against the (filtered) utterance (nsc_module:826-860), not the
+                # residual against its reconstruction: hard-quantised LSFs -> A(z) -> all-pole synthesis of the decoded residual,
+                # compared with the raw-frame columns of the validation matrix (frame by frame: the matrix holds frames, not utterances)
+                from .lpc_utilities import lpc_synthesizer_tr, lsf2poly_after_quan, quantize_lsf_hard
+                q = quantize_lsf_hard(lpc_x, eng.view("lpc_quan/alpha"), eng.view("lpc_quan/bins"))
+                syn = lpc_synthesizer_tr(lsf2poly_after_quan(q, lo), eng.decoded.reshape(B, fl))
+                ori.append(rows[:, :fl].reshape(-1).astype(np.float32))
+                dec.append(syn.reshape(-1).cpu().numpy())
+            else:
+                ori.append(x.reshape(-1).cpu().numpy())
+                dec.append(eng.decoded.reshape(-1).cpu().numpy())
             cnt += B
         if not cnt:
             return None

@@ -249,7 +249,7 @@ import numpy as np, torch
 from nsc_amd.dist import Comm
 from nsc_amd.engine import CascadeEngine
 from tests._util import BKD, make_store, synth_frames, dev
-comm = Comm(backend="gloo")                    # two ranks share the one GPU of the test box; the driver's runs use nccl
+comm = Comm(backend=%(backend)r)                # gloo: two ranks share the one GPU of the test box; nccl: one GPU per rank
 B, Bl = 4, 2
 LPC = %(lpc)r
 ps = make_store(2, [[2], [2]], [32, 32], lpc=LPC)
@@ -304,17 +304,25 @@ comm.close()
 '''
 
 
+def test_data_parallel_engine_two_ranks_over_rccl(tmp_path):
+    """The same two-rank run over RCCL (backend nccl, one GPU per rank): skipped on a one-GPU box (the builder's test boxes
+    have one; the driver's multi-GPU node is where this runs)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    test_data_parallel_engine_two_ranks_equals_one_process(tmp_path, True, backend="nccl", port="29637")
+
+
 @pytest.mark.parametrize("lpc", [False, True])
-def test_data_parallel_engine_two_ranks_equals_one_process(tmp_path, lpc):
+def test_data_parallel_engine_two_ranks_equals_one_process(tmp_path, lpc, backend="gloo", port="29633"):
     """2 ranks x 2 frames (per-scope gradient SUM all-reduces issued during the backward pass + global-batch entropy histogram)
     == 1 process x 4 frames, on the HIP path; lpc: the config-3 step, whose LSF-quantizer gradients ride in scope_1's message."""
     import json, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "ddp_worker.py"
-    script.write_text(_DDP_WORKER % {"root": root, "lpc": bool(lpc)})
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29633")
+    script.write_text(_DDP_WORKER % {"root": root, "lpc": bool(lpc), "backend": backend})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
-                          "127.0.0.1", "--master-port", "29633", str(script)], capture_output=True, text=True, env=env,
+                          "127.0.0.1", "--master-port", port, str(script)], capture_output=True, text=True, env=env,
                          timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
