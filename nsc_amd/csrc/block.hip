@@ -11,6 +11,7 @@
 #include "nsc_common.h"
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "block_args.h"
 
@@ -1478,6 +1479,12 @@ __global__ __launch_bounds__(512) void gated_block_dgrad_kernel(BlockDgradArgs a
   }
 }
 
+#ifndef NSC_D9_NS
+#define NSC_D9_NS 3
+#endif
+#ifndef NSC_D15_NS
+#define NSC_D15_NS 3
+#endif
 // ---- helpers of gated_block_dgrad2_kernel's k9 data gradient ----
 // rows 0..15 (channels 0..15): NC column tiles starting at yb, this wave's K-quarter (register-resident fragments)
 template <int NC, int NJ, int LDY_>
@@ -1492,7 +1499,11 @@ __device__ __forceinline__ void d9_rows0(const float (&w9r)[K9][NJ], const float
   auto fetch = [&](int stn) {
     const int tpn = stn / NJ, jn = stn - tpn * NJ;
 #pragma unroll
+#if defined(NSC_EXP) && (NSC_EXP & 4)
+    for (int ct = 0; ct < NC; ++ct) bb[stn % DEPTH][ct] = w9x[ct % 3];     // timing experiment: no LDS operand reads
+#else
     for (int ct = 0; ct < NC; ++ct) bb[stn % DEPTH][ct] = yb[16 * jn * LDY_ + tpn + ct * 16];
+#endif
   };
 #pragma unroll
   for (int i = 0; i < DEPTH - 1; ++i) fetch(i);
@@ -1536,21 +1547,30 @@ __device__ __forceinline__ void d9_packed(const float* w9ps, int C, int w9t, con
   // waits for an LDS operand the dense one takes the matrix pipe, and what is left over runs alone - latency-bound - at the
   // end of the phase (per-wave stamps: dense wave done after 9.8 k cycles, this one after 13.4 k).  So the operands are
   // requested TWO steps ahead (steps = half a tap's k-steps, three register slots).
-  constexpr int NH = (NJ + 1) / 2, NSTEP_ALL = 2 * (K9 + 3), S0 = HALF * (NSTEP_ALL / 2), NSTEP = NSTEP_ALL / 2, NS = 3;
+  constexpr int NH = (NJ + 1) / 2, NSTEP_ALL = 2 * (K9 + 3), S0 = HALF * (NSTEP_ALL / 2), NSTEP = NSTEP_ALL / 2, NS = NSC_D9_NS;
   float av[NS][NH], b0[NS][NH], b1[NT == 2 ? NS : 1][NH];
   bool okv[NS];
+#if defined(NSC_EXP) && (NSC_EXP & 8)
+  float expv[2] = {w9ps[l15], ypb[0]};
+#endif
   auto fetch = [&](int stl, int slot) {
     const int stn = S0 + stl;
     const int m = stn >> 1, j0 = (stn & 1) * NH;
     const int tap = m - sft;
-    const bool ok = (unsigned)tap < (unsigned)K9;
+    // 3 <= m <= 8: every shift 0..3 has a real tap (m is a compile-time constant of the unrolled step: the selects fold away)
+    const bool ok = (m >= 3 && m <= K9 - 1) || (unsigned)tap < (unsigned)K9;
     okv[slot] = ok;
     const float* ap = w9ps + (ok ? tap : 0) * w9t + (4 * kg + kq) * 4 + ich;
 #pragma unroll
     for (int j = 0; j < NH; ++j) {
       if (j0 + j < NJ) {
+#if defined(NSC_EXP) && (NSC_EXP & 8)
+        av[slot][j] = expv[0];
+        b0[slot][j] = expv[1];
+#else
         av[slot][j] = ap[16 * (j0 + j) * 4];
         b0[slot][j] = ypb[16 * (j0 + j) * LDY_ + m];
+#endif
         if (NT == 2) b1[NT == 2 ? slot : 0][j] = ypb[16 * (j0 + j) * LDY_ + m + 64];
       }
     }
@@ -1566,7 +1586,7 @@ __device__ __forceinline__ void d9_packed(const float* w9ps, int C, int w9t, con
     for (int j = 0; j < NH; ++j) {
       const int jj = ((S0 + st) & 1) * NH + j, m = (S0 + st) >> 1;
       if (jj < NJ) {
-        const float a = ok ? av[st % NS][j] : 0.f;
+        const float a = (m >= 3 && m <= K9 - 1) || ok ? av[st % NS][j] : 0.f;
         if (NT == 2) {
           acc[0] = mfma4(a, b0[st % NS][j], acc[0]);
           acc[1] = mfma4(a, b1[NT == 2 ? st % NS : 0][j], acc[1]);
@@ -1608,13 +1628,23 @@ __device__ __forceinline__ void d15_rows0(const float* wb, const float* ab, int 
   constexpr int NG = 4 * 5;                              // (tap quarter e4, channel-group pair u/2)
   constexpr int DEPTH = NC >= 4 ? 2 : 3;                 // groups in flight + 1 (a group = 2 NC MFMAs; see d9_rows0)
   float av[DEPTH][2], bv[DEPTH][2][NC];
+#if defined(NSC_EXP) && (NSC_EXP & 4)
+  float expv[2 + NC];
+  for (int i = 0; i < 2 + NC; ++i) expv[i] = wb[i * 16];
+#endif
   auto fetch = [&](int g) {
     const int e4 = g / 5, u = 2 * (g - 5 * e4), slot = g % DEPTH;
 #pragma unroll
     for (int uu = 0; uu < 2; ++uu) {
+#if defined(NSC_EXP) && (NSC_EXP & 4)
+      av[slot][uu] = expv[uu];
+#pragma unroll
+      for (int ct = 0; ct < NC; ++ct) bv[slot][uu][ct] = expv[2 + ct];
+#else
       av[slot][uu] = wb[e4 * 4 * W15T + 4 * (u + uu) * NARROW];
 #pragma unroll
       for (int ct = 0; ct < NC; ++ct) bv[slot][uu][ct] = ab[4 * (u + uu) * LDA_ + e4 * 4 * DIL_ + ct * 16];
+#endif
     }
   };
   const bool last_q = kg != 3;                           // tap 15 (groups 15..19 of quarter 3) does not exist: wave-uniform
@@ -1634,29 +1664,47 @@ __device__ __forceinline__ void d15_rows0(const float* wb, const float* ab, int 
     }
   }
 }
-// channels 16..19 PACKED as in d9_packed: row (s,i), column n -> dh[16+i][4n + s] = sum_{m,c'} A da[c'][4n + m], with
-// m = s + tap*DIL in [0, 4 + 14 DIL) and A = w15s[tap][c'][16+i] where (m - s) is a valid multiple of DIL, else 0.
+// channels 16..19 PACKED as in d9_packed.  Dilation 1: row (s,i), column n -> dh[16+i][4n + s] = sum_{m,c'} A da[c'][4n + m],
+// m = s + tap in [0, 18), A = w15s[m - s][c'][16+i] where 0 <= m - s < 15, else 0.
+// Dilation 2 keeps the two time parities apart (a tap moves time by 2, so even outputs read even inputs only): column
+// n = (parity n >> 3, n' = n & 7), row (s,i) -> dh[16+i][8n' + 2s + parity] = sum_{m,c'} A da[c'][8n' + parity + 2m] with the
+// SAME A as dilation 1.  (Round 2 walked time with stride 4 at both dilations, m = s + 2 tap in [0, 32): for every m half of
+// the shifts s had the wrong parity, so half the rows of every A fragment were zeros - 80 MFMAs per K-quarter instead of 50.)
 // This wave owns the m = kg (mod 4).  One column tile covers the 64 output steps.  Two accumulators (even / odd
 // k-steps, summed at the end) so that consecutive MFMAs are independent; half-groups of five are pipelined.
+// d15_packed_col(kq, l15) = the time step of accumulator row group kq (= s), column l15
+template <int DIL_>
+__device__ __forceinline__ int d15_packed_col(int kq, int l15) {
+  return DIL_ == 1 ? 4 * l15 + kq : 8 * (l15 & 7) + 2 * kq + (l15 >> 3);
+}
 template <int DIL_, int LDA_, int HALF>
 __device__ __forceinline__ void d15_packed(const float* w15s, const float* da, int kg, int kq, int l15, f32x4& acc) {
-  constexpr int NM = 4 + 14 * DIL_, NQM = (NM + 3) / 4, NH = 2 * NQM, H0 = HALF * (NH / 2), H1 = H0 + NH / 2;
+  constexpr int NM = 4 + 14, NQM = (NM + 3) / 4, NH = 2 * NQM, H0 = HALF * (NH / 2), H1 = H0 + NH / 2;
+  constexpr int QS = 4 * DIL_;                           // columns per step of m by 4
   const int sft = l15 >> 2, ich = l15 & 3;
-  const float* bb = da + kq * LDA_ + 4 * l15 + kg;
-  constexpr int NS = 3;                                  // operands two half-groups ahead (see d9_packed)
+  const float* bb = da + kq * LDA_ + (DIL_ == 1 ? 4 * l15 + kg : 8 * (l15 & 7) + (l15 >> 3) + 2 * kg);
+  static_assert(8 * 7 + 1 + 2 * (NM - 1) < 64 + 14 * 2, "dilation 2: the last column read is inside the da window");
+  constexpr int NS = NSC_D15_NS;                         // operands NS - 1 half-groups ahead (see d9_packed)
   float av[NS][5], bv[NS][5];
   bool okv[NS];
+#if defined(NSC_EXP) && (NSC_EXP & 8)
+  float expv[2] = {w15s[l15], bb[0]};
+#endif
   auto fetch = [&](int hgrp, int slot) {
     const int q = hgrp >> 1, u0 = 5 * (hgrp & 1);
-    const int dm = kg + 4 * q - sft;
-    const int tap = DIL_ == 1 ? dm : (dm >> 1);
-    const bool ok = dm >= 0 && (DIL_ == 1 || !(dm & 1)) && tap < K15;
+    const int tap = kg + 4 * q - sft;
+    const bool ok = (unsigned)tap < (unsigned)K15;
     okv[slot] = ok;
     const float* ap = w15s + (ok ? tap : 0) * W15T + kq * NARROW + 16 + ich;
 #pragma unroll
     for (int u = 0; u < 5; ++u) {
+#if defined(NSC_EXP) && (NSC_EXP & 8)
+      av[slot][u] = expv[0];
+      bv[slot][u] = expv[1];
+#else
       av[slot][u] = ap[4 * (u0 + u) * NARROW];
-      bv[slot][u] = bb[4 * (u0 + u) * LDA_ + 4 * q];
+      bv[slot][u] = bb[4 * (u0 + u) * LDA_ + QS * q];
+#endif
     }
   };
   f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
@@ -1724,10 +1772,17 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
   constexpr int LDD = 68;                          // dxs row stride: == 4 (mod 32), D-fragment stores conflict-free
   constexpr int PARTSZ = 4 * NARROW * PSW > CR * LDD ? 4 * NARROW * PSW : CR * LDD;
   static_assert(WA16 + 8 <= LDY && 63 + 15 * DIL < LDA, "tile widths");
-  float* dys = sm;                                 // [CR][LDY]       j  <-> t0 - Hh - 4 + j   (pad rows zero)
-  float* lin = dys + CR * LDY;                     // [20][LDA]       ja <-> t0 - Hh + ja      -> dlin  (rows 0..19 of da)
+  // The staged tiles sit DLT columns to the right of their logical position, so that physical column 0 of a row is a time
+  // that is a multiple of 4: the tiles then arrive as ALIGNED 16-byte loads that lie wholly inside or wholly outside a frame
+  // row (T a multiple of 4; else per-element masks), zeros for the outside come from the buffer bounds check.
+  constexpr int DLT = (4 - (Hh & 3)) & 3;          // Hh + DLT == 0 (mod 4)
+  float* dys = sm + DLT;                           // [CR][LDY]       j  <-> t0 - Hh - 4 + j   (pad rows zero)
+  float* lin = sm + CR * LDY + DLT;                // [20][LDA]       ja <-> t0 - Hh + ja      -> dlin  (rows 0..19 of da)
+  static_assert(WA16 + 8 + DLT <= LDY && 64 + 15 * DIL + DLT <= LDA && (LDY % 2 == 0) && (LDA % 2 == 0) && ((CR * LDY) % 2 == 0),
+                "shifted tiles fit their rows; 8-byte aligned row bases");
   float* th = lin + NARROW * LDA;                  // [20][LDA]                                 -> dgate (rows 20..39 of da)
-  float* dhs = th + NARROW * LDA;                  // [20][LDN]       tt <-> t0 + tt : dz1
+  float* dhs = sm + CR * LDY + 2 * NARROW * LDA;   // [20][LDN]       tt <-> t0 + tt : dz1   (16-byte aligned, like all below)
+  static_assert((CR * LDY + 2 * NARROW * LDA) % 4 == 0 && LDN % 4 == 0 && PST % 4 == 0 && PARTSZ % 4 == 0, "float4 LDS rows");
   float* part = dhs + NARROW * LDN;                // [4][16][WA16] + [4][4][WA16]  partial sums of the K-quarters;
   float* dxs = part;                               //   later [CR][LDD]: dx before act'(x), for the row-wise copy-out
   float* w15s = part + PARTSZ;                     // [15][40][20]   wt_l | wt_r concatenated along the reduced channel
@@ -1750,43 +1805,54 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
   const __amdgpu_buffer_rsrc_t sh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.h), 0, nbN, 0x00020000);
   const __amdgpu_buffer_rsrc_t sxx =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (unsigned)((long)a.B * C * T * 4), 0x00020000);
-  float pfy[NQ][2], pfl[3][2], pft[3][2], pfh[3];
+  // da / dgate: two views of one [B][da_rows][T] tensor (dgate = da + 20 T) or two [B][20][T] tensors: the range check of either
+  // resource covers what is addressable from its base
+  const unsigned nbDA = (unsigned)(((long)a.B * a.da_rows - (a.da_rows == NARROW ? 0 : NARROW)) * T * 4);
+  const __amdgpu_buffer_rsrc_t sdlin = __builtin_amdgcn_make_buffer_rsrc(a.da, 0, nbDA, 0x00020000);
+  const __amdgpu_buffer_rsrc_t sdgate = __builtin_amdgcn_make_buffer_rsrc(a.dgate, 0, nbDA, 0x00020000);
+  // ---- prefetch of the next tile, 16 bytes per lane: lane = (row half lane >> 5, float4 index lane & 31); a wave instruction
+  // covers two rows.  dy: wave w rows 2 w + half + 16 q; lin / tanh: rows 2 w + half (+ 16: waves 0, 1); h: float4 tid of the
+  // [20][64] tile.  (Round 2 moved these as dword loads + ds_write_b32, one float per lane and instruction: with every MFMA
+  // phase skipped the kernel still took 8 of its 19 us per tile - tools/dgrad_skip_probe.py - all of it issue-bound data movement.)
+  constexpr int NQY = (CR + 15) / 16, NY4 = (W_dy + DLT + 3) / 4, NA4 = (W_a + DLT + 3) / 4;
+  static_assert(NY4 <= 32 && NA4 <= 32, "a row's window fits 32 float4 lanes");
+  f32x4 pfy[NQY], pfl[2], pft[2], pfh;
+  const int pi4 = lane & 31, phalf = lane >> 5;
+  const bool tvec = (T & 3) == 0;                  // rows are 16-byte aligned: float4 pieces never straddle a row end
+  auto bld4 = [](const __amdgpu_buffer_rsrc_t& r, int voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+  };
   auto bld = [](const __amdgpu_buffer_rsrc_t& r, int voff, int soff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
   };
   const int OOB = 0x7ffffff0;
-  auto prefetch_dy = [&](int tile) {
+  // per-lane byte offset of (time ty0 + 4 pi4) inside a row, or out of range when the piece lies outside [0, T) (T % 4 == 0)
+  // or at least starts outside it (general T: the pieces that straddle the row end are masked per element when staged)
+  auto prefetch_dy = [&](int tile, bool steady) {
     const int tl = __builtin_amdgcn_readfirstlane(tile < ntiles ? tile : 0);
     const int b = tl / tpf, t0 = (tl - b * tpf) * TT;
+    const int ty = t0 - Hh - 4 - DLT + 4 * pi4;
+    // a steady tile reads its dy window from column Hh + 4 on (the residual path; the k9 gradient from 2 Hh): the rest is not fetched
+    const bool need = pi4 < NY4 && ty >= 0 && ty < T && !(steady && 4 * pi4 + 3 < Hh + 4 + DLT);
+    const int vy = need ? ty * 4 : OOB;
 #pragma unroll
-    for (int hb = 0; hb < 2; ++hb) {
-      const int j = hb * 64 + lane;
-      const int ty = t0 - Hh - 4 + j;
-      const int vy = (j < W_dy && ty >= 0 && ty < T) ? ty * 4 : OOB;
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) pfy[q][hb] = bld(sdy, vy, (b * C + min(wave + 8 * q, C - 1)) * T * 4);
-    }
+    for (int q = 0; q < NQY; ++q) pfy[q] = bld4(sdy, vy, (b * C + min(2 * wave + phalf + 16 * q, C - 1)) * T * 4);
   };
-  auto prefetch_a = [&](int tile) {
+  auto prefetch_a = [&](int tile, bool steady) {
     const int tl = __builtin_amdgcn_readfirstlane(tile < ntiles ? tile : 0);
     const int b = tl / tpf, t0 = (tl - b * tpf) * TT;
+    const int ta = t0 - Hh - DLT + 4 * pi4;
+    const bool need = pi4 < NA4 && ta >= 0 && ta < T && !(steady && 4 * pi4 + 3 < 2 * Hh + DLT);
+    const int va = need ? ta * 4 : OOB;
 #pragma unroll
-    for (int hb = 0; hb < 2; ++hb) {
-      const int j = hb * 64 + lane;
-      const int ta = t0 - Hh + j;
-      const int va = (j < W_a && ta >= 0 && ta < T) ? ta * 4 : OOB;
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        const int so = (b * NARROW + min(wave + 8 * q, NARROW - 1)) * T * 4;
-        pfl[q][hb] = bld(slin, va, so);
-        pft[q][hb] = bld(sth, va, so);
-      }
+    for (int q = 0; q < 2; ++q) {
+      const int so = (b * NARROW + min(2 * wave + phalf + 16 * q, NARROW - 1)) * T * 4;
+      pfl[q] = bld4(slin, va, so);
+      pft[q] = bld4(sth, va, so);
     }
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {    // h at element e = tid + 512 q of the [20][64] dz1 tile (q = 2: only e < 1280)
-      const int e = tid + 512 * q;
-      const int c = e >> 6, t = t0 + (e & 63);
-      pfh[q] = bld(sh, (c < NARROW && t < T) ? t * 4 : OOB, (b * NARROW + min(c, NARROW - 1)) * T * 4);
+    {   // h: float4 tid of the [20][64] dz1 tile (tid < 320)
+      const int c = tid >> 4, t = t0 + 4 * (tid & 15);
+      pfh = bld4(sh, (c < NARROW && t < T) ? t * 4 : OOB, (b * NARROW + min(c, NARROW - 1)) * T * 4);
     }
   };
   // CHAIN: a workgroup walks CONSECUTIVE tiles [first, last).  Consecutive tiles of one frame overlap in the 2*Hh columns of
@@ -1795,8 +1861,8 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
   // 1.44x of the k9 gradient's MFMAs).  A tile is "fresh" (full width) at the start of a chain and at the start of a frame.
   const int first = (int)((long)blockIdx.x * ntiles / gridDim.x), last = (int)((long)(blockIdx.x + 1) * ntiles / gridDim.x);
   NSC_STAMP(0);
-  prefetch_dy(first);
-  prefetch_a(first);
+  prefetch_dy(first, false);
+  prefetch_a(first, false);
   static_assert(NK9 == 4 * (NJ9 - 1) + 1, "left-over channel group is shared out by tap");
   float w9r[K9][NJ9 - 1], w9x[3];
   const int rt1 = RT9 == 7 ? (wave < 7 ? wave : 6) : (wave & 3);
@@ -1901,35 +1967,76 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
     const bool fresh = tile == first || t0 == 0;                                   // workgroup-uniform
     const bool next_steady = tile + 1 < last && (tile + 1) - ((tile + 1) / tpf) * tpf != 0;
     NSC_STAMP(2);
-    // ---- phase 0: prefetched tiles -> LDS ----
+    // ---- phase 0: prefetched tiles -> LDS (8-byte stores: the row strides are even, not multiples of 4) ----
+    {
+      // (indices from an opaque copy of the lane id: left visible, the compiler hoists the ~15 LDS addresses of this phase out
+      // of the tile loop and holds them across the MFMA phases - the registers those need for operand double-buffering)
+      int lane_o = lane;
+      asm volatile("" : "+v"(lane_o));
+      const int pi4 = lane_o & 31, phalf = lane_o >> 5;
+      float* dyp = dys - DLT;                      // physical row bases
+      float* lip = lin - DLT;
+      float* thp = th - DLT;
+      if (pi4 < LDY / 4) {
+        const int ty = t0 - Hh - 4 - DLT + 4 * pi4;
 #pragma unroll
-    for (int hb = 0; hb < 2; ++hb) {
-      const int j = hb * 64 + lane;
-      if (j < LDY) {
+        for (int q = 0; q < NQY; ++q) {
+          const int r = 2 * wave + phalf + 16 * q;
+          if (r < CR) {
+            f32x4 v = pfy[q];
+            if (r >= C) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (!tvec) {                                  // a row ends inside this piece: the rest came from the next row
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          const int r = wave + 8 * q;
-          if (r < CR) dys[r * LDY + j] = r < C ? pfy[q][hb] : 0.f;
+              for (int e = 0; e < 4; ++e) v[e] = (unsigned)(ty + e) < (unsigned)T ? v[e] : 0.f;
+            }
+            float2* dst = reinterpret_cast<float2*>(dyp + r * LDY + 4 * pi4);
+            dst[0] = make_float2(v[0], v[1]);
+            dst[1] = make_float2(v[2], v[3]);
+          }
         }
+      }
+      if (pi4 < NA4 + 1 && 4 * pi4 + 3 < LDA) {
+        const int ta = t0 - Hh - DLT + 4 * pi4;
+        constexpr int BND = 2 * Hh + DLT;                 // first physical column of a steady tile's new dlin / dgate
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-          const int r = wave + 8 * q;
-          if (r < NARROW && (fresh || j >= 2 * Hh)) {       // steady tile: columns [0, 2 Hh) hold the carried dlin / dgate
-            lin[r * LDA + j] = pfl[q][hb];
-            th[r * LDA + j] = pft[q][hb];
+        for (int q = 0; q < 2; ++q) {
+          const int r = 2 * wave + phalf + 16 * q;
+          if (r < NARROW) {
+            f32x4 vl = pfl[q], vt = pft[q];
+            if (!tvec) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const bool in = (unsigned)(ta + e) < (unsigned)T;
+                vl[e] = in ? vl[e] : 0.f;
+                vt[e] = in ? vt[e] : 0.f;
+              }
+            }
+            // steady tile: physical columns [DLT, BND) hold the carried dlin / dgate and must stay
+#pragma unroll
+            for (int hp = 0; hp < 2; ++hp) {
+              const int p0 = 4 * pi4 + 2 * hp;
+              float* dl_ = lip + r * LDA + p0;
+              float* dt_ = thp + r * LDA + p0;
+              if (fresh || p0 >= BND) {
+                *reinterpret_cast<float2*>(dl_) = make_float2(vl[2 * hp], vl[2 * hp + 1]);
+                *reinterpret_cast<float2*>(dt_) = make_float2(vt[2 * hp], vt[2 * hp + 1]);
+              } else if (p0 + 1 >= BND) {                 // (odd boundary: dil 1)
+                dl_[1] = vl[2 * hp + 1];
+                dt_[1] = vt[2 * hp + 1];
+              }
+            }
           }
         }
       }
     }
-    float hv[3];
-#pragma unroll
-    for (int q = 0; q < 3; ++q) hv[q] = pfh[q];
+    // lrelu'(h) of this lane's four dz1 elements, as sign bits (one register across the two long MFMA phases)
+    const unsigned hpos = (pfh[0] > 0.f ? 1u : 0u) | (pfh[1] > 0.f ? 2u : 0u) | (pfh[2] > 0.f ? 4u : 0u) | (pfh[3] > 0.f ? 8u : 0u);
     NSC_STAMP(3);
     nsc_lds_barrier();
     NSC_STAMP(4);
     // the next tile's dy goes out now: all workgroups prefetch at the same moment (a ~17 MB burst), so it needs the two long
     // MFMA phases to arrive; lin / tanh / h (a third of the bytes) go out after the k15 gradient, when their registers are free
-    if (!(skip & 8)) prefetch_dy(tile + 1 < last ? tile + 1 : tile);
+    if (!(skip & 8)) prefetch_dy(tile + 1 < last ? tile + 1 : tile, next_steady);
 
     // ---- D9: dg[ci][ja] = sum_{tap', o} wt9[tap'][o][ci] * dy[o][ja + tap'], K split in quarters kg.
     // Channels 0..15: waves 0-3 take column tiles 0..3, waves 4-7 the rest; channels 16..19: waves 4-7, packed tile.
@@ -1937,6 +2044,9 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
     // of the MFMAs, which spills - and a scratch reload waits on vmcnt IN ORDER, i.e. on the next tile's whole prefetch.
     if (!(skip & 1)) {
       // dense rows 0..15: this wave's half of the column tiles (steady: 2 of the 4 new tiles; fresh: NA | NCTA - NA of all)
+      // (the row stride 110 == 14 (mod 32) makes lanes kq = 0 / 1 of this read overlap in two banks - a 2-way conflict on every
+      // dense operand read, SQ_LDS_BANK_CONFLICT ~ 5 k cycles per tile; a build with conflict-free rows ran no faster: the LDS
+      // array is < 50 % busy and the loops wait on MFMA issue, not on it.  profiles/r03d_dgrad_experiments.txt)
       const float* yb = dys + (4 * kg + kq) * LDY + l15;
       const float* yx = dys + (4 * (NK9 - 1) + kq) * LDY + l15 + kg;
       float* pp0 = part + (kg * 16 + kq * 4) * PSW + l15;
@@ -1995,27 +2105,43 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
     // HBM for this tile's own range [Hh, Hh + TT) - and, when the next tile is steady, for the right halo too: those values
     // are final (the next tile would recompute exactly them) and the next tile then never touches its carried columns.
     {
-      const int j_lo = fresh ? 0 : 2 * Hh, ncol = fresh ? WA16 : TT;
-      const int st_lo = fresh ? Hh : 2 * Hh, st_hi = next_steady ? W_a : Hh + TT;
-      for (int e = tid; e < NARROW * ncol; e += 512) {
-        const int c = e / ncol, ja = j_lo + (e - c * ncol);
-        const float* pp = c < 16 ? part + c * PSW + ja : part + PART1 + (c - 16) * PSW + ja;
-        const int ps = c < 16 ? 16 * PSW : 4 * PSW;
-        float gg = (pp[0] + pp[ps]) + (pp[2 * ps] + pp[3 * ps]);
-        if (c >= 16) {                                     // the second halves of the packed K-quarters
-          const float* pq = dhs + (c - 16) * PSW + ja;
-          gg += (pq[0] + pq[ps]) + (pq[2 * ps] + pq[3 * ps]);
+      // (column count as a compile-time constant - the item -> (channel, column) split is a shift or a multiply, not a
+      // division - and da / dgate leave through buffer stores with a scalar frame offset: this phase is VALU-issue bound)
+      const int st_hi = next_steady ? W_a : Hh + TT;
+      const int sda = b * a.da_rows * T * 4;
+      int tid_g = tid;
+      asm volatile("" : "+v"(tid_g));
+      auto glu = [&](auto fresh_c) {
+        constexpr bool FR = decltype(fresh_c)::value;
+        constexpr int j_lo = FR ? 0 : 2 * Hh, ncol = FR ? WA16 : TT, st_lo = FR ? Hh : 2 * Hh;
+        constexpr int NIT = (NARROW * ncol + 511) / 512;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          const int e = tid_g + 512 * it;
+          if (NARROW * ncol % 512 == 0 || it + 1 < NIT || e < NARROW * ncol) {
+            const int c = e / ncol, ja = j_lo + (e - c * ncol);
+            const float* pp = c < 16 ? part + c * PSW + ja : part + PART1 + (c - 16) * PSW + ja;
+            const int ps = c < 16 ? 16 * PSW : 4 * PSW;
+            float gg = (pp[0] + pp[ps]) + (pp[2 * ps] + pp[3 * ps]);
+            if (c >= 16) {                                     // the second halves of the packed K-quarters
+              const float* pq = dhs + (c - 16) * PSW + ja;
+              gg += (pq[0] + pq[ps]) + (pq[2 * ps] + pq[3 * ps]);
+            }
+            float* pl = lin + c * LDA + ja;
+            float* pt = th + c * LDA + ja;
+            const float l = *pl, tg = *pt;
+            const float dl_ = gg * tg, dgt = gg * l * (1.f - tg * tg);
+            *pl = dl_;
+            *pt = dgt;
+            const int t = t0 - Hh + ja;
+            const int vo = (ja >= st_lo && ja < st_hi && t < T) ? (c * T + t) * 4 : OOB;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, dl_), sdlin, vo, sda, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, dgt), sdgate, vo, sda, 0);
+          }
         }
-        const float l = lin[c * LDA + ja], tg = th[c * LDA + ja];
-        const float dl_ = gg * tg, dgt = gg * l * (1.f - tg * tg);
-        lin[c * LDA + ja] = dl_;
-        th[c * LDA + ja] = dgt;
-        const int t = t0 - Hh + ja;
-        if (ja >= st_lo && ja < st_hi && t < T) {
-          a.da[((long)b * a.da_rows + c) * T + t] = dl_;
-          a.dgate[((long)b * a.da_rows + c) * T + t] = dgt;
-        }
-      }
+      };
+      if (fresh) glu(std::true_type{});
+      else glu(std::false_type{});
     }
     NSC_STAMP(7);
     nsc_lds_barrier();
@@ -2038,17 +2164,22 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
       }
       f32x4 pk = {0.f, 0.f, 0.f, 0.f};
       d15_packed<DIL, LDA, hf>(w15s, lin, kg, kq, l15, pk);
-      // row (s = kq, i = reg), column n = l15  ->  dh[16 + reg][4 l15 + kq]; eight partial sums per element (K-quarter, half)
+      // row (s = kq, i = reg), column n = l15  ->  dh[16 + reg][time step of (kq, l15)]; eight partial sums per element
+      // (K-quarter, half)
       static_assert((64 + 32) * PST <= PARTSZ, "partial sums of the k15 gradient");
+      const int pcol = d15_packed_col<DIL>(kq, l15);
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) part[4 * 16 * PST + ((hf * 4 + kg) * 4 + reg) * PST + 4 * l15 + kq] = pk[reg];
+      for (int reg = 0; reg < 4; ++reg) part[4 * 16 * PST + ((hf * 4 + kg) * 4 + reg) * PST + pcol] = pk[reg];
     }
     // x rows of the copy-out phase (for act'(x)): wave w rows w, w+8, ...; issued here, consumed three barriers later
-    float xv[NQ];
+    // float4 (row, 4 q4) items of the [C][64] dx tile: row = tid / 16 + 32 q, q4 = tid % 16
+    constexpr int NQX = (CR + 31) / 32;
+    f32x4 xv[NQX];
     if (!CIN1 && a.in_act == NSC_ACT_LRELU) {
-      const int vx = (t0 + lane < T) ? (t0 + lane) * 4 : OOB;
+      const int tx = t0 + 4 * (tid & 15);
+      const int vx = tx < T ? tx * 4 : OOB;
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) xv[q] = bld(sxx, vx, (b * C + min(wave + 8 * q, C - 1)) * T * 4);
+      for (int q = 0; q < NQX; ++q) xv[q] = bld4(sxx, vx, (b * C + min((tid >> 4) + 32 * q, C - 1)) * T * 4);
     }
     NSC_STAMP(9);
     nsc_lds_barrier();
@@ -2057,33 +2188,60 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
     // are then free during D9 / D15 (which need them for operand double-buffering), and the three short phases that
     // follow (~6k cycles) still cover the HBM round trip
     if (!(skip & 8)) {
-      prefetch_a(tile + 1 < last ? tile + 1 : tile);
+      prefetch_a(tile + 1 < last ? tile + 1 : tile, next_steady);
     }
+    NSC_STAMP(18);
     if (next_steady) {
       // carry: the last 2 Hh columns of dlin / dgate (columns [TT, TT + 2 Hh) of this tile) are columns [0, 2 Hh) of the next
       // tile.  The k15 gradient is done with them (barrier above) and source / destination ranges are disjoint.
-      for (int e = tid; e < 2 * NARROW * 2 * Hh; e += 512) {
-        const int r = e / (2 * Hh), cidx = e - r * (2 * Hh);
-        float* buf = r < NARROW ? lin + r * LDA : th + (r - NARROW) * LDA;
-        buf[cidx] = buf[cidx + TT];
+      if constexpr (DLT % 2 == 0) {                        // pairs of columns (8-byte aligned: the row bases and the shift are even)
+        for (int e = tid; e < 2 * NARROW * Hh; e += 512) {
+          const int r = e / Hh, cidx = 2 * (e - r * Hh);
+          float* buf = r < NARROW ? lin + r * LDA : th + (r - NARROW) * LDA;
+          *reinterpret_cast<float2*>(buf + cidx) = *reinterpret_cast<const float2*>(buf + cidx + TT);
+        }
+      } else {
+        for (int e = tid; e < 2 * NARROW * 2 * Hh; e += 512) {
+          const int r = e / (2 * Hh), cidx = e - r * (2 * Hh);
+          float* buf = r < NARROW ? lin + r * LDA : th + (r - NARROW) * LDA;
+          buf[cidx] = buf[cidx + TT];
+        }
       }
     }
 
-    // ---- dz1 = (sum of the four partial dh) . lrelu'(h) -> LDS + global ----
+    // ---- dz1 = (sum of the partial dh) . lrelu'(h) -> LDS + global: one float4 (channel c, steps 4 q4 ..) per lane ----
+    NSC_STAMP(19);
+    int tid_o = tid;
+    asm volatile("" : "+v"(tid_o));                // (as in the staging phase: addresses recomputed per tile, not held)
+    if (tid_o < NARROW * 16) {
+      const int c = tid_o >> 4, tt = 4 * (tid_o & 15);
+      const int t = t0 + tt;
+      const float* pp = c < 16 ? part + c * PST + tt : part + 4 * 16 * PST + (c - 16) * PST + tt;
+      const int ps = c < 16 ? 16 * PST : 4 * PST;
+      auto ld4 = [](const float* q_) { return *reinterpret_cast<const f32x4*>(q_); };
+      f32x4 dh = (ld4(pp) + ld4(pp + ps)) + (ld4(pp + 2 * ps) + ld4(pp + 3 * ps));
+      if (c >= 16) dh += (ld4(pp + 4 * ps) + ld4(pp + 5 * ps)) + (ld4(pp + 6 * ps) + ld4(pp + 7 * ps));   // second halves of the packed K-quarters
+      f32x4 v;
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      const int e = tid + 512 * q;
-      if (e < NARROW * TT) {
-        const int c = e >> 6, tt = e & 63;
-        const int t = t0 + tt;
-        const float* pp = c < 16 ? part + c * PST + tt : part + 4 * 16 * PST + (c - 16) * PST + tt;
-        const int ps = c < 16 ? 16 * PST : 4 * PST;
-        float dh = (pp[0] + pp[ps]) + (pp[2 * ps] + pp[3 * ps]);
-        if (c >= 16) dh += (pp[4 * ps] + pp[5 * ps]) + (pp[6 * ps] + pp[7 * ps]);   // second halves of the packed K-quarters
-        const float v = t < T ? dh * (hv[q] > 0.f ? 1.f : NSC_LRELU_ALPHA) : 0.f;
-        dhs[c * LDN + tt] = v;
-        if (t < T) a.dz1[((long)b * NARROW + c) * T + t] = v;
+      for (int e = 0; e < 4; ++e) v[e] = t + e < T ? dh[e] * ((hpos >> e) & 1u ? 1.f : NSC_LRELU_ALPHA) : 0.f;
+      *reinterpret_cast<f32x4*>(dhs + c * LDN + tt) = v;
+      float* gp = a.dz1 + ((long)b * NARROW + c) * T + t;
+      if (tvec) {
+        if (t < T) *reinterpret_cast<f32x4*>(gp) = v;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (t + e < T) gp[e] = v[e];
       }
+    }
+    // act'(x) of this lane's copy-out items as sign bits: the x rows (requested before the last barrier but one) have arrived
+    // by now, and 16 registers become one across the 1x1 gradient
+    unsigned xpos = 0;
+    if (!CIN1 && a.in_act == NSC_ACT_LRELU) {
+#pragma unroll
+      for (int q = 0; q < NQX; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xpos |= xv[q][e] > 0.f ? 1u << (4 * q + e) : 0u;
     }
     NSC_STAMP(11);
     nsc_lds_barrier();
@@ -2126,22 +2284,40 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
   #pragma unroll
           for (int reg = 0; reg < 4; ++reg) {
             const int co = rt1 * 16 + kq * 4 + reg;
-            if (co < C) dxs[co * LDD + tt] = acc[c][reg] + dys[co * LDY + tt + Hh + 4];
+            if (co < C) dxs[co * LDD + tt] = acc[c][reg];        // (+ dy: added row-wise in the copy-out, 8 bytes per read)
           }
         }
       }
       NSC_STAMP(13);
       nsc_lds_barrier();
       NSC_STAMP(14);
-      // ---- copy-out: dx rows as whole 256-B lines (the D-fragment stores were 64-B pieces), . act'(x) ----
-      if (t0 + lane < T) {
+      // ---- copy-out: dx rows as whole 256-B lines, 16 bytes per lane (the D-fragment stores were 64-B pieces), . act'(x) ----
+      {
+        int tid_c = tid;
+        asm volatile("" : "+v"(tid_c));
+        const int tx = t0 + 4 * (tid_c & 15);
   #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          const int r = wave + 8 * q;
-          if (r < C) {
-            float v = dxs[r * LDD + lane];
-            if (a.in_act == NSC_ACT_LRELU) v *= (xv[q] > 0.f ? 1.f : NSC_LRELU_ALPHA);
-            a.dx[((long)b * C + r) * T + t0 + lane] = v;
+        for (int q = 0; q < NQX; ++q) {
+          const int r = (tid_c >> 4) + 32 * q;
+          if (r < C && tx < T) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(dxs + r * LDD + 4 * (tid_c & 15));
+            {   // the residual path: + dy (physical column Hh + 4 + DLT + 4 q4 of the staged row: a multiple of 4, rows 8-byte aligned)
+              const float2* yr = reinterpret_cast<const float2*>(dys + r * LDY + Hh + 4 + 4 * (tid_c & 15));
+              const float2 y0 = yr[0], y1 = yr[1];
+              v[0] += y0.x; v[1] += y0.y; v[2] += y1.x; v[3] += y1.y;
+            }
+            if (a.in_act == NSC_ACT_LRELU) {
+  #pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] *= ((xpos >> (4 * q + e)) & 1u ? 1.f : NSC_LRELU_ALPHA);
+            }
+            float* gp = a.dx + ((long)b * C + r) * T + tx;
+            if (tvec) {
+              *reinterpret_cast<f32x4*>(gp) = v;
+            } else {
+  #pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (tx + e < T) gp[e] = v[e];
+            }
           }
         }
       }

@@ -2,6 +2,8 @@
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nsc_amd import _lib
+if os.environ.get("NSC_LIB"):
+    _lib.LIB_PATH = os.path.abspath(os.environ["NSC_LIB"])      # A/B against another build
 lib = _lib.load()
 dev = "cuda"
 st = torch.cuda.current_stream().cuda_stream

@@ -3,13 +3,15 @@ import ctypes as C, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nsc_amd import _lib
 _lib.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "nsc_amd", "libnsc_hip_probes.so")
+if os.environ.get("NSC_LIB"):
+    _lib.LIB_PATH = os.path.abspath(os.environ["NSC_LIB"])
 lib = _lib.load()
 lib.nsc_probe_read.argtypes = [C.c_void_p]
 dev = "cuda"
 st = torch.cuda.current_stream().cuda_stream
 names = ["start", "prologue done", "tile start", "staged", "bar0", "D9 done", "bar1", "GLU done", "bar2", "D15 done", "bar3",
          "dz1 done", "bar4", "D1 done", "bar5", "copyout done", "bar6", "end"]
-for (B, C_, T, dil) in [(128, 100, 512, 1), (128, 100, 256, 2)]:
+for (B, C_, T, dil) in [(128, 100, 512, 1), (128, 100, 256, 2), (1024, 100, 512, 2)]:
     x = torch.randn(B, C_, T, device=dev); dy = torch.randn(B, C_, T, device=dev)
     h, lin, th = (torch.randn(B, 20, T, device=dev) for _ in range(3)); th = torch.tanh(th)
     wt1 = torch.randn(1, 20, C_, device=dev) * 0.1
@@ -27,3 +29,6 @@ for (B, C_, T, dil) in [(128, 100, 512, 1), (128, 100, 256, 2)]:
     print(f"B={B} C={C_} T={T} dil={dil}: total {v[17]-v[0]} ticks   (wave 0 | wave 4)")
     for i in range(1, 18):
         print(f"  {names[i]:>14}: +{v[i]-v[i-1]:6d} | +{w[i]-w[i-1]:6d}")
+    a, c = list(buf)[:20], list(buf)[64:84]
+    print(f"  inside 'dz1 done': next tile's lin/tanh/h requested +{a[18]-a[10]} | +{c[18]-c[10]}, halo carried +{a[19]-a[18]} | +{c[19]-c[18]}, "
+          f"dz1 +{a[11]-a[19]} | +{c[11]-c[19]}")
