@@ -572,7 +572,11 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
           const int o = rt3 * 16 + kq * 4 + reg;
+#if defined(NSC_EXP) && (NSC_EXP & 16)
+          if (o < C && t < T && a.B < 0) {                 // timing experiment: the output epilogue never stores
+#else
           if (o < C && t < T) {
+#endif
             float v = acc[c][reg] + b9r[reg] + xs[(NK1 == 1 ? 0 : o) * LDX + H + tt];   // Cin = 1: broadcast residual
             if (!a.flat) v = v > 0.f ? v : NSC_LRELU_ALPHA * v;
             a.out[((long)b * C + o) * T + t] = v;
@@ -1479,6 +1483,14 @@ __global__ __launch_bounds__(512) void gated_block_dgrad_kernel(BlockDgradArgs a
   }
 }
 
+// compile-time loop: f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N - 1>)
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void nsc_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    nsc_static_for<N, I + 1>(f);
+  }
+}
 #ifndef NSC_D9_NS
 #define NSC_D9_NS 3
 #endif
@@ -1487,9 +1499,10 @@ __global__ __launch_bounds__(512) void gated_block_dgrad_kernel(BlockDgradArgs a
 #endif
 // ---- helpers of gated_block_dgrad2_kernel's k9 data gradient ----
 // rows 0..15 (channels 0..15): NC column tiles starting at yb, this wave's K-quarter (register-resident fragments)
-template <int NC, int NJ, int LDY_>
+// hook(std::integral_constant<int, st>) runs once per step, before the step's MFMAs (the caller's load-issue slot)
+template <int NC, int NJ, int LDY_, class Hook>
 __device__ __forceinline__ void d9_rows0(const float (&w9r)[K9][NJ], const float (&w9x)[3], const float* yb, const float* yx,
-                                         int kg, f32x4 (&acc)[NC]) {
+                                         int kg, f32x4 (&acc)[NC], Hook&& hook) {
   constexpr int NSTEP = K9 * NJ;
   // B fragments DEPTH - 1 steps ahead (compile-time slot index: no register copies).  A step of NC MFMAs covers 32 NC
   // cycles; an LDS round trip in this kernel is ~170 (the 4-tile loop ran at 42 cycles per MFMA with one step in flight),
@@ -1507,15 +1520,16 @@ __device__ __forceinline__ void d9_rows0(const float (&w9r)[K9][NJ], const float
   };
 #pragma unroll
   for (int i = 0; i < DEPTH - 1; ++i) fetch(i);
-#pragma unroll
-  for (int st = 0; st < NSTEP; ++st) {
+  nsc_static_for<NSTEP>([&](auto st_c) {
+    constexpr int st = decltype(st_c)::value;
     const int tp = st / NJ, j = st - tp * NJ;
     if (st + DEPTH - 1 < NSTEP) fetch(st + DEPTH - 1);
+    hook(st_c);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ct = 0; ct < NC; ++ct) acc[ct] = mfma4(w9r[tp][j], bb[st % DEPTH][ct], acc[ct]);
     __builtin_amdgcn_sched_barrier(0);
-  }
+  });
   // the left-over channel group: this quarter's taps kg + 4 i (tap kg + 8 exists for quarter 0 only: wave-uniform)
   float bx[3][NC];
 #pragma unroll
@@ -1621,8 +1635,8 @@ __device__ __forceinline__ void d9_packed(const float* w9ps, int C, int w9t, con
 // different bank groups (at the natural stride 800 == 0 they were a 4-way conflict).
 constexpr int W15T = 2 * NARROW * NARROW + 8;
 // rows = channels 0..15, NC column tiles starting at ab; this wave's taps kg, kg+4, kg+8, (kg+12)
-template <int NC, int DIL_, int LDA_>
-__device__ __forceinline__ void d15_rows0(const float* wb, const float* ab, int kg, f32x4 (&acc)[NC]) {
+template <int NC, int DIL_, int LDA_, class Hook>
+__device__ __forceinline__ void d15_rows0(const float* wb, const float* ab, int kg, f32x4 (&acc)[NC], Hook&& hook) {
   // groups of two k-steps, software-pipelined like d9_rows0: the operands of group g+1 are requested before the MFMAs of
   // group g issue (unpipelined, every group exposed a full LDS round trip: the phase ran at 2/3 of its MFMA rate)
   constexpr int NG = 4 * 5;                              // (tap quarter e4, channel-group pair u/2)
@@ -1651,10 +1665,11 @@ __device__ __forceinline__ void d15_rows0(const float* wb, const float* ab, int 
   auto live_ = [&](int g) { return g < NG && (g < 15 || last_q); };
 #pragma unroll
   for (int i = 0; i < DEPTH - 1; ++i) fetch(i);
-#pragma unroll
-  for (int g = 0; g < NG; ++g) {
+  nsc_static_for<NG>([&](auto g_c) {
+    constexpr int g = decltype(g_c)::value;
     if (live_(g)) {
       if (live_(g + DEPTH - 1)) fetch(g + DEPTH - 1);
+      hook(g_c);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int uu = 0; uu < 2; ++uu)
@@ -1662,7 +1677,7 @@ __device__ __forceinline__ void d15_rows0(const float* wb, const float* ab, int 
         for (int ct = 0; ct < NC; ++ct) acc[ct] = mfma4(av[g % DEPTH][uu], bv[g % DEPTH][uu][ct], acc[ct]);
       __builtin_amdgcn_sched_barrier(0);
     }
-  }
+  });
 }
 // channels 16..19 PACKED as in d9_packed.  Dilation 1: row (s,i), column n -> dh[16+i][4n + s] = sum_{m,c'} A da[c'][4n + m],
 // m = s + tap in [0, 18), A = w15s[m - s][c'][16+i] where 0 <= m - s < 15, else 0.
@@ -1828,32 +1843,44 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
   const int OOB = 0x7ffffff0;
   // per-lane byte offset of (time ty0 + 4 pi4) inside a row, or out of range when the piece lies outside [0, T) (T % 4 == 0)
   // or at least starts outside it (general T: the pieces that straddle the row end are masked per element when staged)
-  auto prefetch_dy = [&](int tile, bool steady) {
+  // The 12 loads of a prefetch are NOT issued together: with all 8 waves of all 256 workgroups requesting ~40 KB per CU at the
+  // same moment the memory pipeline's queues fill and every further load stalls its wave at issue for about an HBM round trip
+  // (stamps: 5 loads took 1800 cycles to issue).  pf_setup computes the tile's offsets; the loads go out one at a time from
+  // hooks inside the two long MFMA loops (the stalled wave's SIMD partner keeps the matrix pipe busy).
+  int pf_vy = 0, pf_va = 0, pf_vh = 0, pf_b = 0;
+  auto pf_setup = [&](int tile, bool steady) {
     const int tl = __builtin_amdgcn_readfirstlane(tile < ntiles ? tile : 0);
     const int b = tl / tpf, t0 = (tl - b * tpf) * TT;
+    pf_b = b;
     const int ty = t0 - Hh - 4 - DLT + 4 * pi4;
     // a steady tile reads its dy window from column Hh + 4 on (the residual path; the k9 gradient from 2 Hh): the rest is not fetched
     const bool need = pi4 < NY4 && ty >= 0 && ty < T && !(steady && 4 * pi4 + 3 < Hh + 4 + DLT);
-    const int vy = need ? ty * 4 : OOB;
-#pragma unroll
-    for (int q = 0; q < NQY; ++q) pfy[q] = bld4(sdy, vy, (b * C + min(2 * wave + phalf + 16 * q, C - 1)) * T * 4);
-  };
-  auto prefetch_a = [&](int tile, bool steady) {
-    const int tl = __builtin_amdgcn_readfirstlane(tile < ntiles ? tile : 0);
-    const int b = tl / tpf, t0 = (tl - b * tpf) * TT;
+    // (the per-lane part of the row - the half-wave - sits in the VECTOR offset: a non-uniform scalar offset makes the compiler
+    // wrap every load in a readfirstlane "waterfall" loop)
+    pf_vy = need ? (phalf * T + ty) * 4 : OOB;
     const int ta = t0 - Hh - DLT + 4 * pi4;
-    const bool need = pi4 < NA4 && ta >= 0 && ta < T && !(steady && 4 * pi4 + 3 < 2 * Hh + DLT);
-    const int va = need ? ta * 4 : OOB;
+    const bool needa = pi4 < NA4 && ta >= 0 && ta < T && !(steady && 4 * pi4 + 3 < 2 * Hh + DLT);
+    pf_va = needa ? (phalf * T + ta) * 4 : OOB;
+    const int c = tid >> 4, t = t0 + 4 * (tid & 15);          // h: float4 tid of the [20][64] dz1 tile (tid < 320)
+    pf_vh = (c < NARROW && t < T) ? ((lane >> 4) * T + t) * 4 : OOB;
+  };
+  // rows past the last channel read the next frame's rows or fall off the descriptor (zeros): the staging step zeroes them
+  auto pf_dy1 = [&](int q) { pfy[q] = bld4(sdy, pf_vy, (pf_b * C + 2 * wave + 16 * q) * T * 4); };
+  auto pf_a1 = [&](int i) {                                    // i = 0..4: lin rows, tanh rows, lin rows + 16, tanh rows + 16, h
+    const int so = (pf_b * NARROW + 2 * wave + 16 * (i >> 1)) * T * 4;
+    if (i == 0) pfl[0] = bld4(slin, pf_va, so);
+    else if (i == 1) pft[0] = bld4(sth, pf_va, so);
+    else if (i == 2) pfl[1] = bld4(slin, pf_va, so);
+    else if (i == 3) pft[1] = bld4(sth, pf_va, so);
+    else pfh = bld4(sh, pf_vh, (pf_b * NARROW + 4 * wave) * T * 4);
+  };
+  auto prefetch_dy = [&]() {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int so = (b * NARROW + min(2 * wave + phalf + 16 * q, NARROW - 1)) * T * 4;
-      pfl[q] = bld4(slin, va, so);
-      pft[q] = bld4(sth, va, so);
-    }
-    {   // h: float4 tid of the [20][64] dz1 tile (tid < 320)
-      const int c = tid >> 4, t = t0 + 4 * (tid & 15);
-      pfh = bld4(sh, (c < NARROW && t < T) ? t * 4 : OOB, (b * NARROW + min(c, NARROW - 1)) * T * 4);
-    }
+    for (int q = 0; q < NQY; ++q) pf_dy1(q);
+  };
+  auto prefetch_a = [&]() {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) pf_a1(i);
   };
   // CHAIN: a workgroup walks CONSECUTIVE tiles [first, last).  Consecutive tiles of one frame overlap in the 2*Hh columns of
   // da (= dlin | dgate) that the k15 gradient reads on either side: from the second tile of a chain on, those columns are
@@ -1861,8 +1888,9 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
   // 1.44x of the k9 gradient's MFMAs).  A tile is "fresh" (full width) at the start of a chain and at the start of a frame.
   const int first = (int)((long)blockIdx.x * ntiles / gridDim.x), last = (int)((long)(blockIdx.x + 1) * ntiles / gridDim.x);
   NSC_STAMP(0);
-  prefetch_dy(first, false);
-  prefetch_a(first, false);
+  pf_setup(first, false);
+  prefetch_dy();
+  prefetch_a();
   static_assert(NK9 == 4 * (NJ9 - 1) + 1, "left-over channel group is shared out by tap");
   float w9r[K9][NJ9 - 1], w9x[3];
   const int rt1 = RT9 == 7 ? (wave < 7 ? wave : 6) : (wave & 3);
@@ -2034,9 +2062,23 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
     NSC_STAMP(3);
     nsc_lds_barrier();
     NSC_STAMP(4);
-    // the next tile's dy goes out now: all workgroups prefetch at the same moment (a ~17 MB burst), so it needs the two long
-    // MFMA phases to arrive; lin / tanh / h (a third of the bytes) go out after the k15 gradient, when their registers are free
-    if (!(skip & 8)) prefetch_dy(tile + 1 < last ? tile + 1 : tile, next_steady);
+    // the next tile's dy goes out during the k9 gradient, lin / tanh / h during the k15 gradient, one load at a time (see
+    // pf_setup).  Probe runs that skip phases issue them in one piece.
+    pf_setup(tile + 1 < last ? tile + 1 : tile, next_steady);
+    const bool spread = skip == 0;
+    if (!spread && !(skip & 8)) prefetch_dy();
+    auto hook9 = [&](auto st_c) {
+      constexpr int st = decltype(st_c)::value, NST = K9 * (NJ9 - 1), EV = NST / (NQY + 1);
+      if constexpr (st % EV == 0 && st > 0 && st / EV <= NQY) {
+        if (spread) pf_dy1(st / EV - 1);
+      }
+    };
+    auto hook15 = [&](auto g_c) {
+      constexpr int g = decltype(g_c)::value;
+      if constexpr (g % 3 == 1 && g < 15) {
+        if (spread) pf_a1(g / 3);
+      }
+    };
 
     // ---- D9: dg[ci][ja] = sum_{tap', o} wt9[tap'][o][ci] * dy[o][ja + tap'], K split in quarters kg.
     // Channels 0..15: waves 0-3 take column tiles 0..3, waves 4-7 the rest; channels 16..19: waves 4-7, packed tile.
@@ -2058,7 +2100,7 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
         {
           f32x4 acc[2];
           acc[0] = acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          d9_rows0<2, NJ9 - 1, LDY>(w9r, w9x, yb + JB, yx + JB, kg, acc);
+          d9_rows0<2, NJ9 - 1, LDY>(w9r, w9x, yb + JB, yx + JB, kg, acc, hook9);
 #pragma unroll
           for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -2076,7 +2118,7 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
           f32x4 acc[NMINE];
 #pragma unroll
           for (int ct = 0; ct < NMINE; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          d9_rows0<NMINE, NJ9 - 1, LDY>(w9r, w9x, yb + CB, yx + CB, kg, acc);
+          d9_rows0<NMINE, NJ9 - 1, LDY>(w9r, w9x, yb + CB, yx + CB, kg, acc, hook9);
 #pragma unroll
           for (int ct = 0; ct < NMINE; ++ct)
 #pragma unroll
@@ -2156,7 +2198,7 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
       {
         f32x4 acc[2];
         acc[0] = acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        d15_rows0<2, DIL, LDA>(wb, ab, kg, acc);
+        d15_rows0<2, DIL, LDA>(wb, ab, kg, acc, hook15);
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -2171,24 +2213,19 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) part[4 * 16 * PST + ((hf * 4 + kg) * 4 + reg) * PST + pcol] = pk[reg];
     }
-    // x rows of the copy-out phase (for act'(x)): wave w rows w, w+8, ...; issued here, consumed three barriers later
-    // float4 (row, 4 q4) items of the [C][64] dx tile: row = tid / 16 + 32 q, q4 = tid % 16
+    NSC_STAMP(9);
+    nsc_lds_barrier();
+    NSC_STAMP(10);
+    if (!spread && !(skip & 8)) prefetch_a();
+    // x rows of the copy-out phase (for act'(x)): float4 (row, 4 q4) items of the [C][64] dx tile, row = tid / 16 + 32 q,
+    // q4 = tid % 16; consumed two barriers later
     constexpr int NQX = (CR + 31) / 32;
     f32x4 xv[NQX];
     if (!CIN1 && a.in_act == NSC_ACT_LRELU) {
       const int tx = t0 + 4 * (tid & 15);
-      const int vx = tx < T ? tx * 4 : OOB;
+      const int vx = tx < T ? ((lane >> 4) * T + tx) * 4 : OOB;
 #pragma unroll
-      for (int q = 0; q < NQX; ++q) xv[q] = bld4(sxx, vx, (b * C + min((tid >> 4) + 32 * q, C - 1)) * T * 4);
-    }
-    NSC_STAMP(9);
-    nsc_lds_barrier();
-    NSC_STAMP(10);
-    // the next tile's dy / lin / tanh / h go out HERE, not before the two long MFMA phases: their ~40 destination registers
-    // are then free during D9 / D15 (which need them for operand double-buffering), and the three short phases that
-    // follow (~6k cycles) still cover the HBM round trip
-    if (!(skip & 8)) {
-      prefetch_a(tile + 1 < last ? tile + 1 : tile, next_steady);
+      for (int q = 0; q < NQX; ++q) xv[q] = bld4(sxx, vx, (b * C + 4 * wave + 32 * q) * T * 4);
     }
     NSC_STAMP(18);
     if (next_steady) {
@@ -2233,15 +2270,6 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
         for (int e = 0; e < 4; ++e)
           if (t + e < T) gp[e] = v[e];
       }
-    }
-    // act'(x) of this lane's copy-out items as sign bits: the x rows (requested before the last barrier but one) have arrived
-    // by now, and 16 registers become one across the 1x1 gradient
-    unsigned xpos = 0;
-    if (!CIN1 && a.in_act == NSC_ACT_LRELU) {
-#pragma unroll
-      for (int q = 0; q < NQX; ++q)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) xpos |= xv[q][e] > 0.f ? 1u << (4 * q + e) : 0u;
     }
     NSC_STAMP(11);
     nsc_lds_barrier();
@@ -2308,7 +2336,7 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
             }
             if (a.in_act == NSC_ACT_LRELU) {
   #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] *= ((xpos >> (4 * q + e)) & 1u ? 1.f : NSC_LRELU_ALPHA);
+              for (int e = 0; e < 4; ++e) v[e] *= (xv[q][e] > 0.f ? 1.f : NSC_LRELU_ALPHA);
             }
             float* gp = a.dx + ((long)b * C + r) * T + tx;
             if (tvec) {

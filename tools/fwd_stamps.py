@@ -3,12 +3,14 @@ import ctypes as C, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nsc_amd import _lib
 _lib.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "nsc_amd", "libnsc_hip_probes.so")
+if os.environ.get("NSC_LIB"):
+    _lib.LIB_PATH = os.path.abspath(os.environ["NSC_LIB"])
 lib = _lib.load()
 lib.nsc_probe_read.argtypes = [C.c_void_p]
 dev = "cuda"
 st = torch.cuda.current_stream().cuda_stream
 names = ["start", "prologue done", "tile start", "staged", "bar0", "ph1 done", "bar1", "ph2 done", "bar2", "ph3 done", "bar3", "end"]
-for (B, C_, T, dil) in [(128, 100, 512, 1), (128, 100, 256, 2), (128, 50, 512, 2)]:
+for (B, C_, T, dil) in [(128, 100, 512, 1), (128, 50, 512, 2), (1024, 100, 512, 2)]:
     x = torch.randn(B, C_, T, device=dev)
     w1 = torch.randn(1, C_, 20, device=dev) * 0.1; b1 = torch.randn(20, device=dev) * 0.1
     wl = torch.randn(15, 20, 20, device=dev) * 0.05; bl = torch.randn(20, device=dev) * 0.1
@@ -23,7 +25,7 @@ for (B, C_, T, dil) in [(128, 100, 512, 1), (128, 100, 256, 2), (128, 50, 512, 2
     torch.cuda.synchronize()
     buf = (C.c_ulonglong * 128)()
     assert lib.nsc_probe_read(buf) == 0
-    v = list(buf)[32:44]
-    print(f"B={B} C={C_} T={T} dil={dil}: total {v[11]-v[0]} cycles")
+    v, w = list(buf)[32:44], list(buf)[96:108]
+    print(f"B={B} C={C_} T={T} dil={dil}: total {v[11]-v[0]} cycles   (wave 0 | wave 4)")
     for i in range(1, 12):
-        print(f"  {names[i]:>14}: +{v[i]-v[i-1]}")
+        print(f"  {names[i]:>14}: +{v[i]-v[i-1]:6d} | +{w[i]-w[i-1]:6d}")
