@@ -167,7 +167,7 @@ __global__ __launch_bounds__(512) void gated_block_fwd_kernel(BlockArgs a, int l
         const int c = c0 + u;
         if (c < NARROW && jj < ldg) {
           const float lin = acc[e][u] + a.bl[c];
-          const float th = tanhf(acc[e][2 + u] + a.br[c]);
+          const float th = nsc_tanh(acc[e][2 + u] + a.br[c]);
           gs[c * ldg + jj] = live ? lin * th : 0.f;
           if (a.lin_out && live && jj >= 4 && jj < 4 + TT) {
             const long gi = ((long)b * NARROW + c) * T + t;
@@ -250,12 +250,16 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int TT = 64, H = 4 + 7 * DIL, WX = TT + 2 * H, WGW = TT + 8, LDX = 112, LDG = 80, CR = 4 * NK1, LDW = 48;
   constexpr int NCT1 = (WX + 15) / 16;      // column tiles of the h tile (7 at dil 2, 6 at dil 1)
+  constexpr int W9P = 728;                  // floats of the packed-tile weights + biases (724, padded to 16 bytes)
   constexpr int NQ = (CR + 7) / 8;          // staged x rows per wave
   static_assert(NCT1 * 16 <= LDX && 79 + 14 * DIL < NCT1 * 16, "h tile must cover every column the k15 taps read");
   float* xs = sm;                            // [CR][LDX]
   float* hs = xs + CR * LDX;                 // [20][LDX]
   float* gs = hs + NARROW * LDX;             // [20][LDG]
   float* w2s = gs + NARROW * LDG;            // [15*20][48]  k15 gate kernels, rows interleaved lin/tanh (see header)
+  float* ls = w2s + K15 * NARROW * LDW;      // [20][LDG]  lin   } of this tile, for the row-wise save pass (training forward)
+  float* ts = ls + NARROW * LDG;             // [20][LDG]  tanh  }
+  float* w9p = ts + NARROW * LDG;            // RT9 = 7: [9][20][4] k9 weights of channels 96..99, then their 4 biases
   const int C = a.C, T = a.T;
   const int Cin = a.Cin;                      // 1 with NK1 == 1: rows 1..3 of the only k-step are zero rows
   const int tid = threadIdx.x, lane = tid & 63;
@@ -274,16 +278,20 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
   const __amdgpu_buffer_rsrc_t sx =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (unsigned)((long)a.B * Cin * T * 4), 0x00020000);
   const int pi4 = lane & 31, phalf = lane >> 5;
-  auto prefetch = [&](int tile) {
+  int pf_vo = 0;
+  auto pf_setup = [&](int tile) {
     const int tl = __builtin_amdgcn_readfirstlane(tile < ntiles ? tile : 0);   // past the end: a harmless re-read
     const int b = tl / tpf, t0 = (tl - b * tpf) * TT;
     const int OOB = 0x7ffffff0;
     // byte offset of (row 2 wave + half, time t0 - H + 4 i4).  A negative time reads the previous row's tail; the staging
     // step masks per element.  Only row 0 of frame 0 can start before the tensor: clamped to 0, shifted when staged.
-    const int vo = pi4 < LDX / 4 ? max(((b * Cin + 2 * wave + phalf) * T + t0 - H + 4 * pi4) * 4, 0) : OOB;
+    pf_vo = pi4 < LDX / 4 ? max(((b * Cin + 2 * wave + phalf) * T + t0 - H + 4 * pi4) * 4, 0) : OOB;
+  };
+  auto pf1 = [&](int q) { pf4[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(sx, pf_vo, q * 16 * T * 4, 0)); };
+  auto prefetch = [&](int tile) {
+    pf_setup(tile);
 #pragma unroll
-    for (int q = 0; q < NQ4; ++q)
-      pf4[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(sx, vo, q * 16 * T * 4, 0));
+    for (int q = 0; q < NQ4; ++q) pf1(q);
   };
   // CHAIN (same idea as gated_block_dgrad2_kernel): a workgroup walks CONSECUTIVE tiles [first, last).  From the second tile
   // of a chain on ("steady"), the 14*DIL columns of h and the 8 columns of g that the previous tile already computed are
@@ -295,9 +303,11 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
   // ---- once per workgroup: weights -> LDS / registers ----
   const int r1 = wave >> 2;
   float w1r[NK1];
-  const int rt3 = RT9 == 7 ? (wave < 7 ? wave : 6) : (wave & 3);
-  const int cb3 = RT9 == 7 ? 0 : (wave >> 2) * 32;      // first output column of this wave in phase 3
-  constexpr int NC3 = RT9 == 7 ? 4 : 2;                  // column tiles per wave in phase 3
+  // phase-3 jobs.  C = 50 (RT9 = 4): wave w = row tile w & 3, column tiles 2 (w >> 2) + {0, 1}.  C = 100 (RT9 = 7): SIX dense
+  // row tiles - waves 0-3 own row tiles 0-3 (4 column tiles each), waves 4 | 5 share row tile 4 (2 + 2), waves 6 | 7 row tile 5
+  // (3 + 1) - and wave 7 also computes channels 96..99 as ONE packed tile [4 time shifts][4 channels] (60 MFMAs; as a seventh
+  // padded row tile they cost 180).  Per SIMD (waves w, w + 4): 270 | 270 | 315 | 285 MFMAs; round 2 had 360 | 360 | 360 | 180.
+  const int rt3 = RT9 == 7 ? (wave < 4 ? wave : 4 + ((wave - 4) >> 1)) : (wave & 3);
   float w9r[K9][5];
   float b1r[4], b9r[4];
   // phase-2 jobs: q -> (row tile q % 3, column tile q / 3); wave w runs q = w and w + 8 (wave 7: a discarded duplicate)
@@ -327,9 +337,12 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
     const f32x4* fp = img4 + NA4 + wave * NF4 * 64 + lane;
 #pragma unroll
     for (int g = 0; g < NF4; ++g) fr[g] = fp[g * 64];
+    f32x4 tP = {0.f, 0.f, 0.f, 0.f};
+    if (RT9 == 7 && tid < W9P / 4) tP = img4[NA4 + 8 * NF4 * 64 + tid];
 #pragma unroll
     for (int i = 0; i < NE4; ++i)
       if (tid + 512 * i < NA4) reinterpret_cast<f32x4*>(w2s)[tid + 512 * i] = tA[i];
+    if (RT9 == 7 && tid < W9P / 4) reinterpret_cast<f32x4*>(w9p)[tid] = tP;
 #define NSC_FR(f) fr[(f) / 4][(f) % 4]
 #pragma unroll
     for (int u = 0; u < NK1; ++u) w1r[u] = NSC_FR(u);
@@ -393,6 +406,10 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
       blr[e][u] = a.bl[min(c, NARROW - 1)];
       brr[e][u] = a.br[min(c, NARROW - 1)];
     }
+  if (RT9 == 7) {
+    for (int e = tid; e < W9P; e += 512)
+      w9p[e] = e < K9 * NARROW * 4 ? a.w9[(e >> 2) * C + 96 + (e & 3)] : (e < K9 * NARROW * 4 + 4 ? a.b9[96 + e - K9 * NARROW * 4] : 0.f);
+  }
   }
 
 
@@ -403,11 +420,19 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
     const bool fresh = tile == first || t0 == 0;                                   // workgroup-uniform
     const bool next_steady = tile + 1 < last && (tile + 1) - ((tile + 1) / tpf) * tpf != 0;
     NSC_STAMP(34);
-    if (!fresh && tid < NARROW * 8) {
+    if (!fresh) {
       // carried g: columns [64, 72) of the previous tile are columns [0, 8) of this one (phase 3 of the previous tile is
       // behind the loop-end barrier; phase 2 of this tile writes columns >= 8 only)
-      const int r = tid >> 3, cidx = tid & 7;
-      gs[r * LDG + cidx] = gs[r * LDG + cidx + TT];
+      if (tid < NARROW * 8) {
+        const int r = tid >> 3, cidx = tid & 7;
+        gs[r * LDG + cidx] = gs[r * LDG + cidx + TT];
+      }
+      // carried h: the k15 convs of this tile read h from column 8 on; its columns [8, 2H) are the previous tile's
+      // [72, 2H + 64).  (Here, not at the end of the previous tile: its save pass reads those columns during phase 3.)
+      for (int e = tid; e < NARROW * 14 * DIL; e += 512) {
+        const int r = e / (14 * DIL), cidx = 8 + (e - r * (14 * DIL));
+        hs[r * LDX + cidx] = hs[r * LDX + cidx + TT];
+      }
     }
     // ---- phase 0: prefetched x tile -> LDS (out-of-frame elements are the conv's zero padding) ----
     if (pi4 < LDX / 4) {
@@ -441,7 +466,15 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
     NSC_STAMP(35);
     nsc_lds_barrier();
     NSC_STAMP(36);
-    if (!(skip & 8)) prefetch(tile + 1 < last ? tile + 1 : tile);   // in flight during the three MFMA phases
+    // The next tile's x: one load at a time from inside the k15 loop (issued in one piece here, the NQ4 loads of all 8 waves
+    // of every workgroup cost ~1 k cycles of phase 1 with the matrix pipe idle: gated_block_dgrad2_kernel's pf_setup).  Probe runs that skip
+    // phases issue them in one piece.
+    const bool spread = skip == 0;
+    pf_setup(tile + 1 < last ? tile + 1 : tile);
+    if (!spread && !(skip & 8)) {
+#pragma unroll
+      for (int q = 0; q < NQ4; ++q) pf1(q);
+    }
 
     // ---- phase 1: h = lrelu(W1 x + b1); column tile = wave ----
     if (!(skip & 1)) {
@@ -468,8 +501,6 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
         const int j = (e ? jb1 : jb0) + l15;
         const int t = t0 - H + j;
         const bool live = j < WX && t >= 0 && t < T;
-        // (when the next tile is steady it never recomputes this tile's right halo: those columns leave for HBM now)
-        const bool save = a.h_out && live && j >= (fresh ? H : 2 * H) && j < (next_steady ? WX : H + TT);
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
           const int o = r1 * 16 + kq * 4 + reg;
@@ -477,7 +508,6 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
             float v = (e ? acc1[reg] : acc0[reg]) + b1r[reg];
             v = v > 0.f ? v : NSC_LRELU_ALPHA * v;
             hs[o * LDX + j] = live ? v : 0.f;
-            if (save) a.h_out[((long)b * NARROW + o) * T + t] = v;
           }
         }
       }
@@ -486,6 +516,47 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
     nsc_lds_barrier();
     NSC_STAMP(38);
 
+    int tid_s = tid;
+    asm volatile("" : "+v"(tid_s));               // (addresses of the save pass are recomputed per tile, not held in registers)
+    const bool tvec = (T & 3) == 0;
+    auto store4 = [&](float* gp, const f32x4& v, int t) {
+      if (tvec) {
+        if (t < T) *reinterpret_cast<f32x4*>(gp) = v;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (t + e < T) gp[e] = v[e];
+      }
+    };
+    auto save_h = [&](int it0, int step) {
+#pragma unroll 2
+      for (int it = it0; it < NARROW * 16; it += step) {
+        const int c = it >> 4, t = t0 + 4 * (it & 15);
+        const float* hp = hs + c * LDX + H + 4 * (it & 15);
+        f32x4 v;
+        if (H % 2 == 0) {
+          const float2 v0 = *reinterpret_cast<const float2*>(hp), v1 = *reinterpret_cast<const float2*>(hp + 2);
+          v = (f32x4){v0.x, v0.y, v1.x, v1.y};
+        } else {
+          v = (f32x4){hp[0], hp[1], hp[2], hp[3]};
+        }
+        store4(a.h_out + ((long)b * NARROW + c) * T + t, v, t);
+      }
+    };
+    auto save_lg = [&](int it0, int step) {
+      const int klo = fresh ? 1 : 2, khi = next_steady ? WGW / 4 : 1 + TT / 4;      // float4 groups of columns [4 klo, 4 khi)
+#pragma unroll 2
+      for (int it = it0; it < NARROW * 18; it += step) {
+        const int c = it / 18, k = it - 18 * c;
+        const int t = t0 - 4 + 4 * k;
+        if (k >= klo && k < khi) {
+          const long gi = ((long)b * NARROW + c) * T + t;
+          store4(a.lin_out + gi, *reinterpret_cast<const f32x4*>(ls + c * LDG + 4 * k), t);
+          store4(a.th_out + gi, *reinterpret_cast<const f32x4*>(ts + c * LDG + 4 * k), t);
+          store4(a.g_out + gi, *reinterpret_cast<const f32x4*>(gs + c * LDG + 4 * k), t);
+        }
+      }
+    };
     // ---- phase 2: both k15 gate convs, A from LDS (w2s), B from LDS (hs) ----
     if (!(skip & 2)) {
       // fresh: 15 jobs (3 row tiles x 5 column tiles from column 0); steady: 12 jobs (4 column tiles from column 8: the
@@ -498,23 +569,36 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
       const float* ab1 = w2s + kq * LDW + jrt[1] * 16 + l15;
       const float* hb0 = hs + kq * LDX + jct[0] * 16 + l15 + joff;
       const float* hb1 = hs + kq * LDX + jct[1] * 16 + l15 + joff;
+      // load q of the next tile's x goes out before tap 2 q + 1
+      auto hook = [&](int tap) {
+        if ((tap & 1) && tap / 2 < NQ4 && spread) {
+          __builtin_amdgcn_sched_barrier(0);
+          pf1(tap / 2);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      static_assert(2 * NQ4 - 1 < K15, "one x load per odd tap");
       if (two) {
 #pragma unroll
-        for (int tap = 0; tap < K15; ++tap)
+        for (int tap = 0; tap < K15; ++tap) {
+          hook(tap);
 #pragma unroll
           for (int u = 0; u < 5; ++u) {
             const int ao = (tap * NARROW + 4 * u) * LDW, ho = 4 * u * LDX + tap * DIL;
             acc[0] = mfma4(ab0[ao], hb0[ho], acc[0]);
             acc[1] = mfma4(ab1[ao], hb1[ho], acc[1]);
           }
+        }
       } else {
 #pragma unroll
-        for (int tap = 0; tap < K15; ++tap)
+        for (int tap = 0; tap < K15; ++tap) {
+          hook(tap);
 #pragma unroll
           for (int u = 0; u < 5; ++u) {
             const int ao = (tap * NARROW + 4 * u) * LDW, ho = 4 * u * LDX + tap * DIL;
             acc[0] = mfma4(ab0[ao], hb0[ho], acc[0]);
           }
+        }
       }
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
@@ -523,19 +607,16 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
         const int c0 = jrt[e] * 8 + kq * 2;
         const int t = t0 - 4 + jj;
         const bool live = jj < WGW && t >= 0 && t < T;
-        const bool save = a.lin_out && live && jj >= (fresh ? 4 : 8) && jj < (next_steady ? WGW : 4 + TT);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const int c = c0 + u;
           if (c < NARROW) {
             const float lin = acc[e][u] + blr[e][u];
-            const float th = tanhf(acc[e][2 + u] + brr[e][u]);
+            const float th = nsc_tanh(acc[e][2 + u] + brr[e][u]);
             gs[c * LDG + jj] = live ? lin * th : 0.f;
-            if (save) {
-              const long gi = ((long)b * NARROW + c) * T + t;
-              a.lin_out[gi] = lin;
-              a.th_out[gi] = th;
-              a.g_out[gi] = lin * th;
+            if (a.lin_out) {                  // kept for the backward pass: leave row-wise in the save pass below
+              ls[c * LDG + jj] = lin;
+              ts[c * LDG + jj] = th;
             }
           }
         }
@@ -544,34 +625,52 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
     NSC_STAMP(39);
     nsc_lds_barrier();
     NSC_STAMP(40);
-    if (next_steady) {
-      // carried h: the k15 convs of the next tile read h from column 8 on; its columns [8, 2H) are this tile's [72, 2H + 64)
-      // (phase 2 is done with hs; source and destination ranges are disjoint)
-      for (int e = tid; e < NARROW * 14 * DIL; e += 512) {
-        const int r = e / (14 * DIL), cidx = 8 + (e - r * (14 * DIL));
-        hs[r * LDX + cidx] = hs[r * LDX + cidx + TT];
-      }
+    // ---- save pass (training forward): h, lin, tanh, g leave for HBM row-wise, 16 bytes per lane, whole 256-B lines, from
+    // LDS - not from the accumulator layout (4-byte stores in 64-byte pieces, ~12 per lane and phase).  h: this tile's own 64
+    // steps (columns [H, H + 64): the left part was carried from the previous tile); lin / tanh / g: the columns phase 2
+    // produced that the next tile will not produce again.  Store issue is what costs (a wave's VMEM instruction takes 100+
+    // cycles to issue under load), so the pass runs where the matrix pipe does not wait for it, in phase 3: at C = 100 waves
+    // 4 and 5 - who have half a row tile of MFMAs there, their SIMD partners a whole one - do half of it each, before their
+    // MFMAs; at C = 50 every wave does its share, waves 0-3 before their MFMAs and waves 4-7 (their SIMD partners) after.
+    // (h from waves 4-7 at the end of phase 2, where they run one k15 job against the two of waves 0-3, was slower: that
+    // "slack" is their SIMD partners' MFMA time.  One wave doing the whole pass takes ~10 k cycles.)
+    auto save_pass = [&](int it0, int step) {
+      if (a.h_out) save_h(it0, step);
+      if (a.lin_out) save_lg(it0, step);
+    };
+    if (RT9 == 7) {
+      if (wave == 4 || wave == 5) save_pass(tid_s - 256, 128);
+    } else if (wave < 4) {
+      save_pass(tid_s, 512);
     }
 
     // ---- phase 3: y = W9 * g + b9 + x; this wave's row tile (weights in registers), NC3 column tiles ----
-    if ((RT9 != 7 || wave < 7) && !(skip & 4)) {
-      f32x4 acc[NC3];
+    // (lane-derived indices of this phase from an opaque copy: the compiler otherwise hoists each role's addresses out of the
+    // tile loop and holds them in registers across all phases)
+    int lane3 = lane;
+    asm volatile("" : "+v"(lane3));
+    const int l15p = lane3 & 15, kqp = lane3 >> 4;
+    // dense job: this wave's row tile, NC column tiles from ct0 on (weights in registers)
+    auto dense3 = [&](auto nc_c, int ct0) {
+      constexpr int NC = decltype(nc_c)::value;
+      f32x4 acc[NC];
 #pragma unroll
-      for (int c = 0; c < NC3; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      const float* gb = gs + kq * LDG + cb3 + l15;
+      for (int c = 0; c < NC; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const float* gb = gs + kqp * LDG + ct0 * 16 + l15p;
 #pragma unroll
-      for (int tap = 0; tap < K9; ++tap)
+      for (int tap = 0; tap < K9; ++tap) {
 #pragma unroll
         for (int u = 0; u < 5; ++u)
 #pragma unroll
-          for (int c = 0; c < NC3; ++c) acc[c] = mfma4(w9r[tap][u], gb[4 * u * LDG + c * 16 + tap], acc[c]);
+          for (int c = 0; c < NC; ++c) acc[c] = mfma4(w9r[tap][u], gb[4 * u * LDG + c * 16 + tap], acc[c]);
+      }
 #pragma unroll
-      for (int c = 0; c < NC3; ++c) {
-        const int tt = cb3 + c * 16 + l15;
+      for (int c = 0; c < NC; ++c) {
+        const int tt = (ct0 + c) * 16 + l15p;
         const int t = t0 + tt;
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-          const int o = rt3 * 16 + kq * 4 + reg;
+          const int o = rt3 * 16 + kqp * 4 + reg;
 #if defined(NSC_EXP) && (NSC_EXP & 16)
           if (o < C && t < T && a.B < 0) {                 // timing experiment: the output epilogue never stores
 #else
@@ -583,7 +682,51 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
           }
         }
       }
+    };
+    // channels 96..99 of a C = 100 block, PACKED as in gated_block_dgrad2_kernel's d9_packed: row (s, i), column n ->
+    // y[96 + i][4n + s] = sum_{m, c} A[(s,i)][(m,c)] g[c][4n + m], A = w9[m - s][c][96 + i] for 0 <= m - s < 9, else 0
+    auto packed3 = [&]() {
+      const int sft = l15p >> 2, ich = l15p & 3;
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      const float* gp = gs + kqp * LDG + 4 * l15p;
+#pragma unroll
+      for (int m = 0; m < K9 + 3; ++m) {
+        const int tap = m - sft;
+        const bool ok = (m >= 3 && m <= K9 - 1) || (unsigned)tap < (unsigned)K9;
+        const float* ap = w9p + (ok ? tap : 0) * (NARROW * 4) + kqp * 4 + ich;
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+          const float av = ap[16 * u];
+          const float a_ = ok ? av : 0.f;
+          if ((m * 5 + u) & 1) acc1 = mfma4(a_, gp[4 * u * LDG + m], acc1);
+          else acc0 = mfma4(a_, gp[4 * u * LDG + m], acc0);
+        }
+      }
+      const int tt = 4 * l15p + kqp, t = t0 + tt;
+      if (t < T) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int o = 96 + reg;
+          float v = acc0[reg] + acc1[reg] + w9p[K9 * NARROW * 4 + reg] + xs[(NK1 == 1 ? 0 : o) * LDX + H + tt];
+          if (!a.flat) v = v > 0.f ? v : NSC_LRELU_ALPHA * v;
+          a.out[((long)b * C + o) * T + t] = v;
+        }
+      }
+    };
+    if (!(skip & 4)) {
+      if (RT9 == 7) {
+        if (wave < 4) dense3(std::integral_constant<int, 4>{}, 0);
+        else if (wave < 6) dense3(std::integral_constant<int, 2>{}, 2 * (wave - 4));
+        else if (wave == 6) dense3(std::integral_constant<int, 3>{}, 0);
+        else {
+          dense3(std::integral_constant<int, 1>{}, 3);
+          packed3();
+        }
+      } else {
+        dense3(std::integral_constant<int, 2>{}, 2 * (wave >> 2));
+      }
     }
+    if (RT9 != 7 && wave >= 4) save_pass(tid_s, 512);
     NSC_STAMP(41);
     nsc_lds_barrier();   // xs / hs / gs are rewritten by the next tile
     NSC_STAMP(42);
@@ -594,7 +737,7 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
 template <int RT9, int NK1, int DIL>
 static int launch_block_fwd2(const BlockArgs& a, hipStream_t st) {
   constexpr int CR = 4 * NK1;
-  const size_t smem = ((size_t)(CR + NARROW) * 112 + (size_t)NARROW * 80 + (size_t)K15 * NARROW * 48) * sizeof(float);
+  const size_t smem = ((size_t)(CR + NARROW) * 112 + (size_t)3 * NARROW * 80 + (size_t)K15 * NARROW * 48 + (RT9 == 7 ? 728 : 0)) * sizeof(float);
   auto kern = gated_block_fwd2_kernel<RT9, NK1, DIL>;
   static const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);   // once per instantiation
   NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "gated_block_fwd2: smem attr: %s", hipGetErrorString(e));
@@ -1843,10 +1986,11 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
   const int OOB = 0x7ffffff0;
   // per-lane byte offset of (time ty0 + 4 pi4) inside a row, or out of range when the piece lies outside [0, T) (T % 4 == 0)
   // or at least starts outside it (general T: the pieces that straddle the row end are masked per element when staged)
-  // The 12 loads of a prefetch are NOT issued together: with all 8 waves of all 256 workgroups requesting ~40 KB per CU at the
-  // same moment the memory pipeline's queues fill and every further load stalls its wave at issue for about an HBM round trip
-  // (stamps: 5 loads took 1800 cycles to issue).  pf_setup computes the tile's offsets; the loads go out one at a time from
-  // hooks inside the two long MFMA loops (the stalled wave's SIMD partner keeps the matrix pipe busy).
+  // The 12 loads of a prefetch are NOT issued together: a VMEM instruction takes the issuing wave ~100 cycles under load, and
+  // issued in one piece after a barrier all 8 waves pay that at the same time with the matrix pipe idle (4 loads: 500 cycles of
+  // every tile).  pf_setup computes the tile's offsets; the loads go out one at a time from hooks inside the two long MFMA
+  // loops, where the issuing wave's SIMD partner keeps the matrix pipe busy (the k15-gradient phase got 1.2 k cycles shorter).
+  // The row part of an offset must be wave-uniform where it sits in the scalar operand: see pf_vy.
   int pf_vy = 0, pf_va = 0, pf_vh = 0, pf_b = 0;
   auto pf_setup = [&](int tile, bool steady) {
     const int tl = __builtin_amdgcn_readfirstlane(tile < ntiles ? tile : 0);
@@ -2462,7 +2606,7 @@ extern "C" long nsc_gated_block_image_floats(int which, int C, int Cin, int dil)
   if (!img_shape(C, Cin, dil, &rt9, &nk)) return 0;
   if (which == 0) {
     const int nk1 = Cin == 1 ? 1 : nk;
-    return (long)K15 * NARROW * 48 + 8L * 64 * 4 * ((nk1 + K9 * 5 + 16 + 3) / 4);
+    return (long)K15 * NARROW * 48 + 8L * 64 * 4 * ((nk1 + K9 * 5 + 16 + 3) / 4) + (rt9 == 7 ? 728 : 0);
   }
   if (which == 1) {
     const int w9t = C * 4 + (((C * 4) & 15) == 8 ? 0 : 8), nj = (nk + 3) / 4 - 1;
@@ -2489,7 +2633,7 @@ extern "C" int nsc_gated_block_image_index(int which, int C, int Cin, int dil, c
     const int nfr = nk1 + K9 * 5 + 16, nf4 = (nfr + 3) / 4;
     const long baseB = (long)K15 * NARROW * LDW;
     for (int wave = 0; wave < 8; ++wave) {
-      const int r1 = wave >> 2, rt3 = rt9 == 7 ? mn(wave, 6) : (wave & 3);
+      const int r1 = wave >> 2, rt3 = rt9 == 7 ? (wave < 4 ? wave : 4 + ((wave - 4) >> 1)) : (wave & 3);    // gated_block_fwd2_kernel's job table
       int jrt[2];
       for (int e = 0; e < 2; ++e) { const int q = wave + 8 * e; jrt[e] = (q < 15 ? q : wave) % 3; }
       for (int lane = 0; lane < 64; ++lane) {
@@ -2505,6 +2649,11 @@ extern "C" int nsc_gated_block_image_index(int which, int C, int Cin, int dil, c
           idx[baseB + ((long)(wave * nf4 + f / 4) * 64 + lane) * 4 + (f & 3)] = (int)src;
         }
       }
+    }
+    if (rt9 == 7) {          // packed tile of channels 96..99: [9][20][4] weights, 4 biases
+      const long baseP = baseB + 8L * 64 * 4 * nf4;
+      for (int e = 0; e < K9 * NARROW * 4; ++e) idx[baseP + e] = (int)(w9 + (long)(e >> 2) * C + 96 + (e & 3));
+      for (int e = 0; e < 4; ++e) idx[baseP + K9 * NARROW * 4 + e] = (int)(b9 + 96 + e);
     }
     return NSC_OK;
   }

@@ -212,7 +212,7 @@ __global__ void gate_fwd_kernel(float* __restrict__ a, float* __restrict__ g, in
   for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     const long b = e / nT, r = e - b * nT;
     float* ab = a + b * 2 * nT;
-    const float th = tanhf(ab[nT + r]);
+    const float th = nsc_tanh(ab[nT + r]);
     ab[nT + r] = th;
     g[e] = ab[r] * th;
   }

@@ -50,8 +50,31 @@ __device__ __forceinline__ void nsc_lds_barrier() { asm volatile("s_waitcnt lgkm
     }                                                                              \
   } while (0)
 
+// tanh as the reference's own arithmetic computes it: TensorFlow 1.x evaluates tanh through Eigen's float kernel (Eigen 3.3
+// MathFunctionsImpl.h, generic_fast_tanh_float - a dependency absent from /root/reference; restated from its published form):
+// clamp to [-9, 9], then the rational x P(x^2) / Q(x^2) with the 7 + 4 coefficients below.  ~3 ulp over the whole line, and
+// RELATIVE accuracy near 0 (a 1 - 2 / (exp(2x) + 1) form has 2e-7 absolute error there: the followers' residual inputs are
+// small, and the gradients of a follower step came out 1e-2 off).  14 VALU instructions against ~40 of the library tanhf -
+// whose time next to an fp32 MFMA stream is not hidden (fp32 MFMA runs on the vector ALUs).  The division is v_rcp + mul; the
+// result is clamped to [-1, 1] (the quotient can exceed 1 by an ulp; 1 - th^2 must not go negative).
+__device__ __forceinline__ float nsc_tanh(float x) {
+  x = __builtin_amdgcn_fmed3f(x, -9.f, 9.f);
+  const float x2 = x * x;
+  float p = fmaf(x2, -2.76076847742355e-16f, 2.00018790482477e-13f);
+  p = fmaf(x2, p, -8.60467152213735e-11f);
+  p = fmaf(x2, p, 5.12229709037114e-08f);
+  p = fmaf(x2, p, 1.48572235717979e-05f);
+  p = fmaf(x2, p, 6.37261928875436e-04f);
+  p = fmaf(x2, p, 4.89352455891786e-03f);
+  p *= x;
+  float q = fmaf(x2, 1.19825839466702e-06f, 1.18534705686654e-04f);
+  q = fmaf(x2, q, 2.26843463243900e-03f);
+  q = fmaf(x2, q, 4.89352518554385e-03f);
+  return __builtin_amdgcn_fmed3f(p * __builtin_amdgcn_rcpf(q), -1.f, 1.f);
+}
+
 __device__ __forceinline__ float nsc_apply_act(float v, int act) {
-  if (act == NSC_ACT_TANH) return tanhf(v);
+  if (act == NSC_ACT_TANH) return nsc_tanh(v);
   if (act == NSC_ACT_LRELU) return v > 0.f ? v : NSC_LRELU_ALPHA * v;
   return v;
 }

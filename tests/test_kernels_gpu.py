@@ -222,6 +222,33 @@ def test_depthwise_fwd_bwd(lib, shape):
     assert_close(dwd.cpu().numpy(), wt.grad.numpy()[:, :, 0], what="depthwise dw")
 
 
+def test_fast_tanh(lib):
+    """nsc_tanh (csrc/nsc_common.h: Eigen's rational tanh, the arithmetic TensorFlow itself uses) is what every tanh of the
+    library computes - the fused block kernels' gate, nsc_gate_fwd, nsc_apply_act.  nsc_gate_fwd writes tanh(gate) back in
+    place, so it exposes the function itself: RELATIVE error against float64 tanh over the whole range (small arguments
+    included: the followers' inputs are residuals), saturation, and |tanh| <= 1 (the GLU gradient uses 1 - th^2)."""
+    x = np.concatenate([np.linspace(-20, 20, 20 * 8192 - 8192 - 8), np.linspace(-1e-2, 1e-2, 4096),
+                        np.logspace(-30, -2, 2048), -np.logspace(-30, -2, 2048),
+                        [0.0, -0.0, 1e-38, -1e-38, 88.0, -88.0, 1e30, -1e30]]).astype(np.float32)
+    n = x.size // 20
+    a = np.zeros((1, 40, n), np.float32)
+    a[0, :20] = 1.0
+    a[0, 20:] = x.reshape(20, n)
+    ad = dev(a)
+    g = torch.empty((1, 20, n), device="cuda")
+    assert lib.nsc_gate_fwd(ad.data_ptr(), g.data_ptr(), 1, 20, n, _st()) == 0
+    th = ad.cpu().numpy()[0, 20:].reshape(-1).astype(np.float64)
+    ref = np.tanh(x.astype(np.float64))
+    assert np.all(np.isfinite(th)) and np.all(np.abs(th) <= 1.0)
+    err = np.abs(th - ref)
+    bad = err > 6e-7 * np.abs(ref) + 1e-40          # (x p(x^2) passes through the denormals for |x| < 1e-35)
+    assert not bad.any(), (x[bad][:5], th[bad][:5], ref[bad][:5])
+    assert np.array_equal(g.cpu().numpy().reshape(-1), th.astype(np.float32))       # lin = 1: g is the tanh itself
+    big = np.abs(x) > 10
+    assert np.all(np.abs(th[big] - np.sign(x[big].astype(np.float64))) <= 1.2e-7)
+    assert np.array_equal(np.sign(th), np.sign(x.astype(np.float64)))
+
+
 def test_glue_kernels(lib):
     rng = np.random.default_rng(13)
     a = rng.standard_normal((2, 40, 128)).astype(np.float32)
