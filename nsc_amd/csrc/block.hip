@@ -822,6 +822,9 @@ extern "C" int nsc_gated_block_fwd_cin1(const float* x, const float* w1, const f
 //   dW9[tap,ci,o] += g[ci,t+tap-4] dy[o,t]      dWl/dWr[tap,ci,c] += h[ci,t+(tap-7)d] dlin/dgate[c,t]
 //   dW1[ci,o]     += x[ci,t] dz1[o,t]           bias gradients via a row of ones
 // =====================================================================================================
+#ifndef NSC_WG_UNROLL
+#define NSC_WG_UNROLL 4   // k-steps of the MFMA loop unrolled together: at 1 every step exposed an LDS round trip (-8 % launch time at 4; 8, 16: same)
+#endif
 struct BlockWgradArgs {
   int B, C, T, dil;
   const float *x, *h, *g, *dy, *da, *dz1;   // da [B,40,T] = dlin | dgate
@@ -1014,7 +1017,7 @@ __device__ __forceinline__ void block_wgrad_body(const BlockWgradArgs& a, int ld
     __syncthreads();
     if (tile + nwg < a.ntiles && !(a.skip & 8)) load_tile(tile + nwg);   // in flight during the MFMA loop below
     if (!(a.skip & 2))
-#pragma unroll 1
+#pragma unroll NSC_WG_UNROLL
     for (int s = 0; s < TT / 4; ++s) {
       const int tl = 4 * s + kq;
       if constexpr (P9) {
@@ -1991,6 +1994,8 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
   // every tile).  pf_setup computes the tile's offsets; the loads go out one at a time from hooks inside the two long MFMA
   // loops, where the issuing wave's SIMD partner keeps the matrix pipe busy (the k15-gradient phase got 1.2 k cycles shorter).
   // The row part of an offset must be wave-uniform where it sits in the scalar operand: see pf_vy.
+  // (The same interleaving made the weight-gradient kernels - ~50 DWORD loads per tile with scalar address arithmetic each -
+  // 20 % slower: conv wgrad 100->100 k9 s2 went from 110 to 133 us.  It pays for a handful of 16-byte loads, not for those.)
   int pf_vy = 0, pf_va = 0, pf_vh = 0, pf_b = 0;
   auto pf_setup = [&](int tile, bool steady) {
     const int tl = __builtin_amdgcn_readfirstlane(tile < ntiles ? tile : 0);

@@ -784,6 +784,9 @@ extern "C" int nsc_conv1d_cout1_fwd(const nsc_conv_desc* d, const float* x, cons
 // 2/3 of the stride-2 conv's 283 us); without one, float atomics straight into dw/db (few K-splits).
 // ------------------------------------------------------------------------------------------------
 // bx / gx: this workgroup's K-split index and the number of K-splits; by: its row group
+#ifndef NSC_CW_UNROLL
+#define NSC_CW_UNROLL 4   // k-steps unrolled together (2: +3-7 % launch time; 8: same as 4)
+#endif
 template <int RT, int CT>
 __device__ __forceinline__ void conv_wgrad_body(const nsc_conv_desc& d, const float* __restrict__ x,
                                                 const float* __restrict__ dz, float* __restrict__ dw,
@@ -829,7 +832,7 @@ __device__ __forceinline__ void conv_wgrad_body(const nsc_conv_desc& d, const fl
   const bool busy = rt0 * 16 < nrows;   // waves past the last row tile only help staging
   const int nchunks = d.B * nchunk_t;
   auto mfma_chunk = [&]() {
-#pragma unroll 2
+#pragma unroll NSC_CW_UNROLL
     for (int tt = 0; tt < TT / 4; ++tt) {
       const int tloc = 4 * tt + kq;
       float af[RT], bf[CT];

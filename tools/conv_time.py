@@ -3,6 +3,8 @@ import os, sys, ctypes as C, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nsc_amd import _lib
 from nsc_amd._lib import ConvDesc
+if os.environ.get("NSC_LIB"):
+    _lib.LIB_PATH = os.path.abspath(os.environ["NSC_LIB"])      # A/B against another build
 lib = _lib.load()
 st = torch.cuda.current_stream().cuda_stream
 B = int(os.environ.get("B", 128))
