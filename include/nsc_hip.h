@@ -98,7 +98,7 @@ int nsc_gated_block_fwd(const float* x, const float* w1, const float* b1, const 
                         int narrow, int k9, int dil, int flat, void* stream);
 /* The same block with ONE input channel (first block of a decoder stage, `_the_decoder_in_each_module`
  * neural_speech_coding_module.py:246-251 -> gated_bottleneck on the [B,T,1] code): x [B,1,T], w1 [1,1,20]; the residual add
- * broadcasts x over the C output channels.  C in {100, 50}, dil in {1, 2}; other shapes: NSC_ERR_UNSUPPORTED (per-conv path). */
+ * broadcasts x over the C output channels.  C in {100, 50, 25}, dil in {1, 2}; other shapes: NSC_ERR_UNSUPPORTED (per-conv path). */
 int nsc_gated_block_fwd_cin1(const float* x, const float* w1, const float* b1, const float* wl, const float* bl,
                         const float* wr, const float* br, const float* w9, const float* b9, float* out,
                         float* h_out, float* lin_out, float* th_out, float* g_out, int B, int C, int T,
@@ -114,7 +114,7 @@ int nsc_gated_block_dgrad(const float* x, const float* h, const float* lin, cons
  * (the forward broadcast x over the C output channels; the producer of x is the quantizer, so no activation gradient);
  * wt1 [20]; da_rows = channel rows per frame of the tensor(s) dlin / dgate point into: 20 = two separate [B,20,T] tensors,
  * 40 = the two halves of one [B,40,T] tensor (dgate = dlin + 20 T; the form nsc_gated_block_wgrad_batch reads).
- * C in {100, 50}, dil in {1, 2}. */
+ * C in {100, 50, 25}, dil in {1, 2}. */
 int nsc_gated_block_dgrad_cin1(const float* h, const float* lin, const float* th, const float* dy,
                                const float* wt1, const float* wtl, const float* wtr, const float* wt9, float* dx,
                                float* dlin, float* dgate, float* dz1, int B, int C, int T, int narrow, int k9,
@@ -128,7 +128,7 @@ int nsc_gated_block_dgrad_cin1(const float* h, const float* lin, const float* th
  *       which = 0 (forward):       offs = offsets of w1, b1, wl, bl, wr, br, w9, b9 in the gathered buffer
  *       which = 1 (data gradient): offs = offsets of wt1, wtl, wtr, wt9 (the flipped / transposed kernels)
  *   nsc_gated_block_fwd_img / _dgrad_img: nsc_gated_block_fwd[_cin1] / nsc_gated_block_dgrad[_cin1] on an image (16-byte aligned);
- *       Cin = C or 1; same outputs bit for bit.  C in {100, 50}, dil in {1, 2}. */
+ *       Cin = C or 1; same outputs bit for bit.  C in {100, 50, 25}, dil in {1, 2}. */
 long nsc_gated_block_image_floats(int which, int C, int Cin, int dil);
 int nsc_gated_block_image_index(int which, int C, int Cin, int dil, const long* offs, int* idx);
 int nsc_gated_block_fwd_img(const float* img, const float* x, float* out, float* h_out, float* lin_out, float* th_out,

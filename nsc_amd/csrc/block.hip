@@ -775,6 +775,9 @@ extern "C" int nsc_gated_block_fwd(const float* x, const float* w1, const float*
   if (!v1_only && (dil == 1 || dil == 2)) {
     if (C == 100) return dil == 1 ? launch_block_fwd2<7, 25, 1>(a, st) : launch_block_fwd2<7, 25, 2>(a, st);
     if (C == 50) return dil == 1 ? launch_block_fwd2<4, 13, 1>(a, st) : launch_block_fwd2<4, 13, 2>(a, st);
+    // C = 25 (the third resolution of '2 2' codecs) on the C = 50 job table: two of its four phase-3 row tiles are padding,
+    // but the weights are stationary and the tiles chained - the per-tile kernel fetched every A fragment from global memory
+    if (C == 25) return dil == 1 ? launch_block_fwd2<4, 7, 1>(a, st) : launch_block_fwd2<4, 7, 2>(a, st);
   }
   const int nrt = nsc_cdiv(C, 16);
 #define LAUNCH_BLK(RT)                                                                                              \
@@ -803,8 +806,8 @@ extern "C" int nsc_gated_block_fwd_cin1(const float* x, const float* w1, const f
                                         int narrow, int k9, int dil, int flat, void* stream) {
   NSC_REQUIRE(x && w1 && b1 && wl && bl && wr && br && w9 && b9 && out, NSC_ERR_BAD_ARG, "nsc_gated_block_fwd_cin1: null pointer");
   NSC_REQUIRE(B > 0 && T > 0, NSC_ERR_BAD_ARG, "nsc_gated_block_fwd_cin1: bad sizes");
-  NSC_REQUIRE(narrow == NARROW && k9 == K9 && (C == 100 || C == 50) && (dil == 1 || dil == 2), NSC_ERR_UNSUPPORTED,
-              "nsc_gated_block_fwd_cin1: built for narrow=20, k9=9, C in {100, 50}, dil in {1, 2} (got %d, %d, %d, %d)", narrow, k9, C, dil);
+  NSC_REQUIRE(narrow == NARROW && k9 == K9 && (C == 100 || C == 50 || C == 25) && (dil == 1 || dil == 2), NSC_ERR_UNSUPPORTED,
+              "nsc_gated_block_fwd_cin1: built for narrow=20, k9=9, C in {100, 50, 25}, dil in {1, 2} (got %d, %d, %d, %d)", narrow, k9, C, dil);
   NSC_REQUIRE(!(lin_out || th_out || g_out) || (lin_out && th_out && g_out), NSC_ERR_BAD_ARG,
               "nsc_gated_block_fwd_cin1: lin/th/g outputs must be given together");
   BlockArgs a{B, C, T, dil, flat, x, w1, b1, wl, bl, wr, br, w9, b9, out, h_out, lin_out, th_out, g_out, 1, nullptr};
@@ -2555,6 +2558,9 @@ extern "C" int nsc_gated_block_dgrad(const float* x, const float* h, const float
   if (!v1_only) {
     if (C == 100) return dil == 1 ? launch_block_dgrad2<7, 25, 1>(a, st) : launch_block_dgrad2<7, 25, 2>(a, st);
     if (C == 50) return dil == 1 ? launch_block_dgrad2<4, 13, 1>(a, st) : launch_block_dgrad2<4, 13, 2>(a, st);
+    // C = 25: the K-quarter split of the k9 gradient wants 4 j + 1 channel groups, so the dy tile is staged as 36 rows (9 groups,
+    // rows 25..35 zero) on the C = 50 job table
+    if (C == 25) return dil == 1 ? launch_block_dgrad2<4, 9, 1>(a, st) : launch_block_dgrad2<4, 9, 2>(a, st);
   }
 #define LAUNCH_DG(RT)                                                                                               \
   do {                                                                                                              \
@@ -2581,12 +2587,13 @@ extern "C" int nsc_gated_block_dgrad_cin1(const float* h, const float* lin, cons
   NSC_REQUIRE(B > 0 && T > 0, NSC_ERR_BAD_ARG, "nsc_gated_block_dgrad_cin1: bad sizes");
   NSC_REQUIRE(da_rows == NARROW || (da_rows == 2 * NARROW && dgate == dlin + (long)NARROW * T), NSC_ERR_BAD_ARG,
               "nsc_gated_block_dgrad_cin1: da_rows must be 20 (two [B,20,T] tensors) or 40 with dgate = dlin + 20 T");
-  NSC_REQUIRE(narrow == NARROW && k9 == K9 && (dil == 1 || dil == 2) && (C == 100 || C == 50), NSC_ERR_UNSUPPORTED,
-              "nsc_gated_block_dgrad_cin1: built for narrow=20, k9=9, dil in {1,2}, C in {100, 50} (got %d, %d, %d, %d)", narrow, k9, dil, C);
+  NSC_REQUIRE(narrow == NARROW && k9 == K9 && (dil == 1 || dil == 2) && (C == 100 || C == 50 || C == 25), NSC_ERR_UNSUPPORTED,
+              "nsc_gated_block_dgrad_cin1: built for narrow=20, k9=9, dil in {1,2}, C in {100, 50, 25} (got %d, %d, %d, %d)", narrow, k9, dil, C);
   BlockDgradArgs a{B, C, T, dil, NSC_ACT_NONE, dy /* x: unused */, h, lin, th, dy, wt1, wtl, wtr, wt9, dx, dlin, dz1, dgate,
                    da_rows, nullptr};
   hipStream_t st = (hipStream_t)stream;
   if (C == 100) return dil == 1 ? launch_block_dgrad2<7, 25, 1, true>(a, st) : launch_block_dgrad2<7, 25, 2, true>(a, st);
+  if (C == 25) return dil == 1 ? launch_block_dgrad2<4, 9, 1, true>(a, st) : launch_block_dgrad2<4, 9, 2, true>(a, st);
   return dil == 1 ? launch_block_dgrad2<4, 13, 1, true>(a, st) : launch_block_dgrad2<4, 13, 2, true>(a, st);
 }
 
@@ -2600,15 +2607,16 @@ extern "C" int nsc_gated_block_dgrad_cin1(const float* h, const float* lin, cons
 // Source offsets `offs` (floats, into the buffer the gather reads): which = 0: w1, b1, wl, bl, wr, br, w9, b9;
 // which = 1: wt1, wtl, wtr, wt9 (the flipped / transposed kernels of nsc_weight_flip_transpose).  idx[i] = -1: unused pad.
 // =====================================================================================================
-static bool img_shape(int C, int Cin, int dil, int* rt9, int* nk) {
-  if (!(dil == 1 || dil == 2) || !(C == 100 || C == 50) || !(Cin == C || Cin == 1)) return false;
+// rt9 / nk: the template parameters RT9 and NK1 (which = 0) | NK9 (which = 1) of the persistent kernel that serves the shape
+static bool img_shape(int which, int C, int Cin, int dil, int* rt9, int* nk) {
+  if (!(dil == 1 || dil == 2) || !(C == 100 || C == 50 || C == 25) || !(Cin == C || Cin == 1)) return false;
   *rt9 = C == 100 ? 7 : 4;
-  *nk = C == 100 ? 25 : 13;
+  *nk = C == 100 ? 25 : (C == 50 ? 13 : (which == 0 ? 7 : 9));
   return true;
 }
 extern "C" long nsc_gated_block_image_floats(int which, int C, int Cin, int dil) {
   int rt9, nk;
-  if (!img_shape(C, Cin, dil, &rt9, &nk)) return 0;
+  if (!img_shape(which, C, Cin, dil, &rt9, &nk)) return 0;
   if (which == 0) {
     const int nk1 = Cin == 1 ? 1 : nk;
     return (long)K15 * NARROW * 48 + 8L * 64 * 4 * ((nk1 + K9 * 5 + 16 + 3) / 4) + (rt9 == 7 ? 728 : 0);
@@ -2622,7 +2630,7 @@ extern "C" long nsc_gated_block_image_floats(int which, int C, int Cin, int dil)
 extern "C" int nsc_gated_block_image_index(int which, int C, int Cin, int dil, const long* offs, int* idx) {
   NSC_REQUIRE(offs && idx, NSC_ERR_BAD_ARG, "nsc_gated_block_image_index: null pointer");
   int rt9, nk;
-  NSC_REQUIRE(img_shape(C, Cin, dil, &rt9, &nk) && (which == 0 || which == 1), NSC_ERR_UNSUPPORTED,
+  NSC_REQUIRE((which == 0 || which == 1) && img_shape(which, C, Cin, dil, &rt9, &nk), NSC_ERR_UNSUPPORTED,
               "nsc_gated_block_image_index: no image for C %d, Cin %d, dil %d, which %d", C, Cin, dil, which);
   const long n = nsc_gated_block_image_floats(which, C, Cin, dil);
   for (long i = 0; i < n; ++i) idx[i] = -1;
@@ -2692,7 +2700,7 @@ extern "C" int nsc_gated_block_image_index(int which, int C, int Cin, int dil, c
   return NSC_OK;
 }
 
-// The two persistent kernels on an image (shapes of the codec only: C in {100, 50}, Cin in {C, 1}, dil in {1, 2}).
+// The two persistent kernels on an image (shapes of the codec only: C in {100, 50, 25}, Cin in {C, 1}, dil in {1, 2}).
 extern "C" int nsc_gated_block_fwd_img(const float* img, const float* x, float* out, float* h_out, float* lin_out, float* th_out,
                                        float* g_out, int B, int C, int Cin, int T, int dil, int flat, void* stream) {
   NSC_REQUIRE(img && x && out, NSC_ERR_BAD_ARG, "nsc_gated_block_fwd_img: null pointer");
@@ -2710,6 +2718,7 @@ extern "C" int nsc_gated_block_fwd_img(const float* img, const float* x, float* 
     return dil == 1 ? launch_block_fwd2<4, 1, 1>(a, st) : launch_block_fwd2<4, 1, 2>(a, st);
   }
   if (C == 100) return dil == 1 ? launch_block_fwd2<7, 25, 1>(a, st) : launch_block_fwd2<7, 25, 2>(a, st);
+  if (C == 25) return dil == 1 ? launch_block_fwd2<4, 7, 1>(a, st) : launch_block_fwd2<4, 7, 2>(a, st);
   return dil == 1 ? launch_block_fwd2<4, 13, 1>(a, st) : launch_block_fwd2<4, 13, 2>(a, st);
 }
 
@@ -2730,8 +2739,10 @@ extern "C" int nsc_gated_block_dgrad_img(const float* img, const float* x, const
   hipStream_t st = (hipStream_t)stream;
   if (Cin == 1) {
     if (C == 100) return dil == 1 ? launch_block_dgrad2<7, 25, 1, true>(a, st) : launch_block_dgrad2<7, 25, 2, true>(a, st);
+    if (C == 25) return dil == 1 ? launch_block_dgrad2<4, 9, 1, true>(a, st) : launch_block_dgrad2<4, 9, 2, true>(a, st);
     return dil == 1 ? launch_block_dgrad2<4, 13, 1, true>(a, st) : launch_block_dgrad2<4, 13, 2, true>(a, st);
   }
   if (C == 100) return dil == 1 ? launch_block_dgrad2<7, 25, 1>(a, st) : launch_block_dgrad2<7, 25, 2>(a, st);
+  if (C == 25) return dil == 1 ? launch_block_dgrad2<4, 9, 1>(a, st) : launch_block_dgrad2<4, 9, 2>(a, st);
   return dil == 1 ? launch_block_dgrad2<4, 13, 1>(a, st) : launch_block_dgrad2<4, 13, 2>(a, st);
 }

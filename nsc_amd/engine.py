@@ -216,7 +216,7 @@ class _Block:
         self.th = e.buf(u + ".th", (B, n, T))
         self.g = e.buf(u + ".g", (B, n, T))
         self.out = e.buf(u + ".out", (B, self.wide, T))
-        cin1 = self.Cin == 1 and self.wide in (100, 50) and self.cl.dil in (1, 2)   # first block of a decoder stage
+        cin1 = self.Cin == 1 and self.wide in (100, 50, 25) and self.cl.dil in (1, 2)   # first block of a decoder stage
         if e.fused_fwd and (self.Cin > 1 or cin1) and n == 20 and self.c9.K == 9 and self.wide <= 112 and self.cl.dil <= 4:
             # (other reference-legal shapes, e.g. wide 128 or dilation 8, take the per-conv path below)
             P = lambda c, base=e.p_ptr: (base + 4 * c.w_off, base + 4 * c.b_off)
@@ -317,7 +317,7 @@ class _Block:
             if need_dx and not fuse_d1:
                 self.c1.dgrad(dh, dx, res=dz, res_mode=1, mul_kind=in_kind, aux=self.x)
             return dx
-        if (self.Cin == 1 and e.fused_fwd and e.fused_dgrad and n == 20 and self.c9.K == 9 and self.wide in (100, 50)
+        if (self.Cin == 1 and e.fused_fwd and e.fused_dgrad and n == 20 and self.c9.K == 9 and self.wide in (100, 50, 25)
                 and self.cl.dil in (1, 2)):
             # first block of a decoder stage: the whole data path in one persistent kernel (one input channel: the 1x1
             # gradient is a dot product, the residual branch sums dy over its channels); its weight gradients join the

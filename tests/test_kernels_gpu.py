@@ -493,7 +493,9 @@ def test_bad_arguments_return_status(lib):
 @pytest.mark.parametrize("case", [(2, 100, 512, 2, 0), (2, 100, 256, 1, 1), (3, 50, 512, 2, 0), (2, 50, 512, 1, 1),
                                   (1, 100, 200, 2, 0), (2, 36, 70, 1, 0), (70, 100, 300, 2, 0), (40, 50, 512, 1, 1),
                                   # long chains of consecutive tiles (carried h / g columns), crossing frame boundaries
-                                  (150, 100, 512, 1, 0), (150, 50, 512, 2, 1), (72, 100, 256, 2, 0)])
+                                  (150, 100, 512, 1, 0), (150, 50, 512, 2, 1), (72, 100, 256, 2, 0),
+                                  # C = 25 (third resolution of '2 2' codecs): persistent kernel on the C = 50 job table
+                                  (3, 25, 128, 1, 0), (300, 25, 128, 2, 1), (2, 25, 200, 2, 0)])
 def test_fused_gated_block_fwd(lib, case):
     """csrc/block.hip vs the oracle's gated_bottleneck (nn_core_operator.py:82-112), incl. saved intermediates."""
     B, C_, T, dil, flat = case
@@ -597,7 +599,8 @@ def test_block_wgrad_kernel(lib, case):
         off += n_ + s_[2]
 
 
-@pytest.mark.parametrize("case", [(2, 100, 256, 1, 0), (3, 100, 256, 2, 1), (2, 50, 512, 1, 0), (150, 100, 256, 2, 0), (70, 100, 300, 1, 0)])
+@pytest.mark.parametrize("case", [(2, 100, 256, 1, 0), (3, 100, 256, 2, 1), (2, 50, 512, 1, 0), (150, 100, 256, 2, 0), (70, 100, 300, 1, 0),
+                                  (3, 25, 128, 1, 0), (300, 25, 128, 2, 1)])
 def test_fused_gated_block_fwd_one_input_channel(lib, case):
     """nsc_gated_block_fwd_cin1 vs the oracle's gated_bottleneck on a [B,T,1] input (broadcast residual), incl. the saved
     intermediates and chains of tiles."""
@@ -635,7 +638,9 @@ def test_fused_gated_block_fwd_one_input_channel(lib, case):
                                   (1, 100, 200, 2, 0), (5, 36, 70, 1, 2),
                                   # more tiles than workgroups: chains of consecutive tiles with the carried da halo, chains
                                   # that cross frame boundaries, a ragged last tile
-                                  (40, 100, 512, 2, 2), (72, 100, 256, 1, 2), (150, 50, 512, 2, 2), (61, 100, 300, 1, 0)])
+                                  (40, 100, 512, 2, 2), (72, 100, 256, 1, 2), (150, 50, 512, 2, 2), (61, 100, 300, 1, 0),
+                                  # C = 25: dy staged as 36 rows (9 channel groups) on the C = 50 job table
+                                  (3, 25, 128, 1, 2), (300, 25, 128, 2, 2), (2, 25, 200, 2, 0)])
 def test_fused_gated_block_dgrad(lib, case):
     """8-wave data-path backward (dx, dlin|dgate, dz1) vs autograd of the oracle block with its saved intermediates."""
     B, C_, T, dil, in_act = case
@@ -677,7 +682,8 @@ def test_fused_gated_block_dgrad(lib, case):
     assert_close(g(dx), zt.grad.numpy(), tol=2e-4, what=f"dx {case}")
 
 
-@pytest.mark.parametrize("case", [(2, 100, 256, 1), (3, 100, 256, 2), (2, 50, 512, 2), (150, 100, 256, 2), (70, 100, 300, 1)])
+@pytest.mark.parametrize("case", [(2, 100, 256, 1), (3, 100, 256, 2), (2, 50, 512, 2), (150, 100, 256, 2), (70, 100, 300, 1),
+                                  (3, 25, 128, 1), (300, 25, 128, 2)])
 def test_fused_gated_block_dgrad_one_input_channel(lib, case):
     """nsc_gated_block_dgrad_cin1 vs autograd of the oracle block on a [B,T,1] input: dx (incl. the channel-summed residual
     branch), dlin, dgate, dz1 - with chains of tiles."""
@@ -945,7 +951,8 @@ def test_upsample_stage_fwd_bwd(lib, shape):
 
 
 @pytest.mark.parametrize("C_,Cin,dil,T,B", [(100, 100, 1, 256, 3), (100, 100, 2, 512, 2), (50, 50, 1, 512, 2), (50, 50, 2, 200, 3),
-                                           (100, 1, 1, 256, 2), (100, 1, 2, 300, 3), (50, 1, 1, 130, 2), (50, 1, 2, 512, 70)])
+                                           (100, 1, 1, 256, 2), (100, 1, 2, 300, 3), (50, 1, 1, 130, 2), (50, 1, 2, 512, 70),
+                                           (25, 25, 1, 128, 3), (25, 25, 2, 128, 300), (25, 1, 2, 128, 5)])
 def test_block_kernels_on_parameter_images_equal_the_plain_entry_points(lib, C_, Cin, dil, T, B):
     """nsc_gated_block_fwd_img / _dgrad_img (fast prologue from a kernel-ready image built by nsc_gated_block_image_index +
     nsc_gather) produce the same bits as nsc_gated_block_fwd[_cin1] / nsc_gated_block_dgrad[_cin1] on the same parameters."""
