@@ -287,7 +287,12 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
     // step masks per element.  Only row 0 of frame 0 can start before the tensor: clamped to 0, shifted when staged.
     pf_vo = pi4 < LDX / 4 ? max(((b * Cin + 2 * wave + phalf) * T + t0 - H + 4 * pi4) * 4, 0) : OOB;
   };
-  auto pf1 = [&](int q) { pf4[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(sx, pf_vo, q * 16 * T * 4, 0)); };
+  // (rows >= Cin - the last q of a wave at C = 100 / 50 / 25, all but row 0 of a one-channel input - are not fetched: their
+  // lanes' offset goes out of range; the staging step writes zeros there either way)
+  auto pf1 = [&](int q) {
+    const int vo = (q == NQ4 - 1 && 2 * wave + phalf + 16 * q >= Cin) ? 0x7ffffff0 : pf_vo;
+    pf4[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(sx, vo, q * 16 * T * 4, 0));
+  };
   auto prefetch = [&](int tile) {
     pf_setup(tile);
 #pragma unroll
@@ -2016,14 +2021,19 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
     const int c = tid >> 4, t = t0 + 4 * (tid & 15);          // h: float4 tid of the [20][64] dz1 tile (tid < 320)
     pf_vh = (c < NARROW && t < T) ? ((lane >> 4) * T + t) * 4 : OOB;
   };
-  // rows past the last channel read the next frame's rows or fall off the descriptor (zeros): the staging step zeroes them
-  auto pf_dy1 = [&](int q) { pfy[q] = bld4(sdy, pf_vy, (pf_b * C + 2 * wave + 16 * q) * T * 4); };
+  // (rows past the last channel would read the next frame's rows - the staging step zeroes them, but they are HBM traffic:
+  // 112 rows fetched for 100.  Only the last q of a wave can reach them: those lanes' offset goes out of range.)
+  auto pf_dy1 = [&](int q) {
+    const int vo = (q == NQY - 1 && 2 * wave + phalf + 16 * q >= C) ? OOB : pf_vy;
+    pfy[q] = bld4(sdy, vo, (pf_b * C + 2 * wave + 16 * q) * T * 4);
+  };
   auto pf_a1 = [&](int i) {                                    // i = 0..4: lin rows, tanh rows, lin rows + 16, tanh rows + 16, h
     const int so = (pf_b * NARROW + 2 * wave + 16 * (i >> 1)) * T * 4;
+    const int va1 = 2 * wave + phalf + 16 >= NARROW ? OOB : pf_va;       // rows 20..31 of the second pass do not exist
     if (i == 0) pfl[0] = bld4(slin, pf_va, so);
     else if (i == 1) pft[0] = bld4(sth, pf_va, so);
-    else if (i == 2) pfl[1] = bld4(slin, pf_va, so);
-    else if (i == 3) pft[1] = bld4(sth, pf_va, so);
+    else if (i == 2) pfl[1] = bld4(slin, va1, so);
+    else if (i == 3) pft[1] = bld4(sth, va1, so);
     else pfh = bld4(sh, pf_vh, (pf_b * NARROW + 4 * wave) * T * 4);
   };
   auto prefetch_dy = [&]() {
@@ -2377,7 +2387,8 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
       const int tx = t0 + 4 * (tid & 15);
       const int vx = tx < T ? ((lane >> 4) * T + tx) * 4 : OOB;
 #pragma unroll
-      for (int q = 0; q < NQX; ++q) xv[q] = bld4(sxx, vx, (b * C + 4 * wave + 32 * q) * T * 4);
+      for (int q = 0; q < NQX; ++q)
+        xv[q] = bld4(sxx, (q == NQX - 1 && 4 * wave + (lane >> 4) + 32 * q >= C) ? OOB : vx, (b * C + 4 * wave + 32 * q) * T * 4);
     }
     NSC_STAMP(18);
     if (next_steady) {
