@@ -832,7 +832,7 @@ __device__ __forceinline__ void conv_wgrad_body(const nsc_conv_desc& d, const fl
   const bool busy = rt0 * 16 < nrows;   // waves past the last row tile only help staging
   const int nchunks = d.B * nchunk_t;
   auto mfma_chunk = [&]() {
-#pragma unroll NSC_CW_UNROLL
+#pragma unroll (RT >= 4 ? 2 : NSC_CW_UNROLL)
     for (int tt = 0; tt < TT / 4; ++tt) {
       const int tloc = 4 * tt + kq;
       float af[RT], bf[CT];
@@ -1108,6 +1108,16 @@ static WgradPlan wgrad_plan(const nsc_conv_desc* d, int CT, bool bias, bool use_
 }
 
 static bool wgrad_big(const nsc_conv_desc* d, bool bias) { return nsc_cdiv(d->K * d->Cin + (bias ? 1 : 0), 16) > 24; }
+// Row tiles per wave.  Every workgroup stages the whole x and dz tile of its chunk but owns only 8 RT of dW's row tiles, so a
+// tall dW pays the staging once per row group: the stride-2 k9 100 -> 100 conv (57 row tiles) at RT = 2 staged every chunk
+// four times, 24 of its 100 us (probe builds without the loads / the LDS stores / the MFMA loop: profiles/r03d).  RT = 4 (112
+// accumulator registers, 7-column-tile class only) halves that.
+static int wgrad_rt_class(const nsc_conv_desc* d, bool bias, int ct) {
+  static const bool no_rt4 = NSC_PROBE_SET("NSC_WGRAD_NO_RT4");   // A/B switch for profiling
+  const int nrt = nsc_cdiv(d->K * d->Cin + (bias ? 1 : 0), 16);
+  if (nrt > 48 && ct == 7 && !no_rt4) return 4;
+  return nrt > 24 ? 2 : 1;
+}
 
 template <int RT, int CT>
 static int launch_wgrad(const nsc_conv_desc* d, const float* x, const float* dz, float* dw, float* db, int flip,
@@ -1139,14 +1149,20 @@ static int launch_wgrad(const nsc_conv_desc* d, const float* x, const float* dz,
 template <int CT>
 static int dispatch_wgrad_rt(const nsc_conv_desc* d, const float* x, const float* dz, float* dw, float* db, int flip,
                              float* ws, long ws_floats, hipStream_t st) {
-  if (!wgrad_big(d, db != nullptr)) return launch_wgrad<1, CT>(d, x, dz, dw, db, flip, ws, ws_floats, st);
-  return launch_wgrad<2, CT>(d, x, dz, dw, db, flip, ws, ws_floats, st);   // very tall dW (stride-2 k9 100->100)
+  const int rt = wgrad_rt_class(d, db != nullptr, CT);
+  if (rt == 1) return launch_wgrad<1, CT>(d, x, dz, dw, db, flip, ws, ws_floats, st);
+  if constexpr (CT == 7) {
+    if (rt == 4) return launch_wgrad<4, CT>(d, x, dz, dw, db, flip, ws, ws_floats, st);   // very tall dW (stride-2 k9 100->100)
+  }
+  return launch_wgrad<2, CT>(d, x, dz, dw, db, flip, ws, ws_floats, st);
 }
 
 extern "C" long nsc_conv1d_wgrad_workspace(const nsc_conv_desc* d) {
   if (!d || d->K <= 0 || d->Cin <= 0 || d->Cout <= 0) return 0;
-  const WgradPlan p = wgrad_big(d, true) ? wgrad_plan<2>(d, nsc_cdiv(d->Cout, 16), true, true)
-                                         : wgrad_plan<1>(d, nsc_cdiv(d->Cout, 16), true, true);
+  int ct = nsc_cdiv(d->Cout, 16);
+  if (ct > 4) ct = 7;
+  const int rt = wgrad_rt_class(d, true, ct);
+  const WgradPlan p = rt == 4 ? wgrad_plan<4>(d, ct, true, true) : (rt == 2 ? wgrad_plan<2>(d, ct, true, true) : wgrad_plan<1>(d, ct, true, true));
   return (long)p.gx * p.slab_stride;
 }
 
@@ -1181,8 +1197,8 @@ static CwPlan cw_plan(const nsc_conv_wgrad_job& jb) {
   const bool bias = jb.db != nullptr;
   c.ct = nsc_cdiv(d->Cout, 16);
   if (c.ct > 4) c.ct = 7;
-  c.rt = wgrad_big(d, bias) ? 2 : 1;
-  c.p = c.rt == 2 ? wgrad_plan<2>(d, c.ct, bias, true) : wgrad_plan<1>(d, c.ct, bias, true);
+  c.rt = wgrad_rt_class(d, bias, c.ct);
+  c.p = c.rt == 4 ? wgrad_plan<4>(d, c.ct, bias, true) : (c.rt == 2 ? wgrad_plan<2>(d, c.ct, bias, true) : wgrad_plan<1>(d, c.ct, bias, true));
   c.gy = c.p.gy;
   c.nchunks = d->B * c.p.nchunk_t;
   c.stride = c.p.slab_stride;
@@ -1250,7 +1266,7 @@ static int launch_cw_class(const nsc_conv_wgrad_job* jobs, const int* idx, const
 static int cw_dispatch(int rt, int ct, const nsc_conv_wgrad_job* jobs, const int* idx, const CwPlan* cp, int n, float* ws,
                        long wsf, hipStream_t st) {
 #define CW(RT_, CT_) if (rt == RT_ && ct == CT_) return launch_cw_class<RT_, CT_>(jobs, idx, cp, n, ws, wsf, st)
-  CW(1, 1); CW(1, 2); CW(1, 3); CW(1, 4); CW(1, 7); CW(2, 1); CW(2, 2); CW(2, 3); CW(2, 4); CW(2, 7);
+  CW(1, 1); CW(1, 2); CW(1, 3); CW(1, 4); CW(1, 7); CW(2, 1); CW(2, 2); CW(2, 3); CW(2, 4); CW(2, 7); CW(4, 7);
 #undef CW
   nsc_set_error("nsc_conv1d_wgrad_batch: no kernel for class (%d, %d)", rt, ct);
   return NSC_ERR_UNSUPPORTED;
