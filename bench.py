@@ -155,6 +155,9 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="frames per GPU (BASELINE: 128; config 4: 256)")
     ap.add_argument("--config", type=int, default=3, choices=(2, 3, 4),
                     help="BASELINE.json configuration to time (3 = the headline 2-codec joint step; 2 and 4: the other train configs)")
+    ap.add_argument("--follower", action="store_true",
+                    help="config 3 only: time the FOLLOWER step instead of the joint one (SURVEY 8d: codec 1 frozen and forward-only, "
+                         "codec 2 trains on its residual: cmrl.py:137-293; 952.2 MFLOP per frame)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--passes", type=int, default=3, help="timed passes of --steps steps each (value = the median pass)")
@@ -200,6 +203,17 @@ def main():
     eng.fused_fwd = not args.unfused_fwd
     xd, lpcd, x_np, lpc_np = synth_batch(B, comm.rank, dev)
     cfg = step_cfg_for(args.config, B, comm.world)
+    if args.follower:
+        assert args.config == 3, "--follower is the second step of config 3"
+        # neural_speech_coding_module._loss_cfgs(2, "follower"): only the newest scope trains, quan / entropy terms of the newest
+        # codec only (cmrl.py:97-98, 106-113); tau 0.3 as in config 2 so that the entropy term (and, data-parallel, its histogram
+        # all-reduce) is part of the step
+        cfg = dict(is_quan_on=1.0, c_time=COEFF[0], c_freq=COEFF[1], c_quan=[0.0, COEFF[2]], c_ent=[0.0, 0.3], trainable=[False, True],
+                   lr=LR, slot=1, quan_op=True)
+        mflop_frame = 952.2                   # forward of both codecs + backward of the second (4 x 238.04)
+        wl_name = ("BASELINE config 3, FOLLOWER step: 2-codec CMRL (strides [2], 32 bins) on fed LPC residual, codec 1 frozen "
+                   "(forward only), codec 2 trains on its residual (quan + entropy terms of codec 2, tau 0.3), fwd+loss+bwd+TF1-Adam")
+        args.no_infer = args.no_cpu_baseline = True
     if not use_lpc:
         lpcd = None
     dcomm = comm if comm.world > 1 else (_NullComm() if args.dp_selftest else None)

@@ -1018,9 +1018,11 @@ class CascadeEngine:
         self.images_valid = True
 
     # ---- forward ----
-    def forward(self, x, is_quan_on=1.0, soft=True, lpc_x=None, want_p=False, hists_clean=False):
+    def forward(self, x, is_quan_on=1.0, soft=True, lpc_x=None, want_p=False, hists_clean=False, first_needed=0):
         """x [B,1,512] (time-domain frame, or the fed LPC residual).  Returns decoded [B,1,512] (sum of codecs).
-        hists_clean: the caller has just zeroed the histogram buffer (train_step's memset covers it)."""
+        hists_clean: the caller has just zeroed the histogram buffer (train_step's memset covers it).
+        first_needed: index of the first codec a backward pass will go through (train_step: the first trainable scope; the
+        frozen codecs in front of it - a follower step's earlier scopes, cmrl.py:106-113 - run forward-only and keep nothing)."""
         e = self
         B, rs = self.B, self.res_scalar
         assert tuple(x.shape) == (B, 1, frame_length) and x.dtype == torch.float32 and x.is_contiguous()
@@ -1040,7 +1042,12 @@ class CascadeEngine:
             else:
                 xin = xin_next        # written by the cascade step that closed the previous codec
             self.xin.append(xin)
-            dec = c.forward(xin, is_quan_on, soft, want_p)
+            keep = self.keep_activations
+            self.keep_activations = keep and i >= first_needed
+            try:
+                dec = c.forward(xin, is_quan_on, soft, want_p)
+            finally:
+                self.keep_activations = keep
             sc = (1.0 / rs) if scaled else 1.0
             # decoded (+)= sc * dec, and the next codec's input rs * (x - decoded), in one launch
             xin_next = self.buf(f"xin{i + 1}", (B, 1, frame_length)) if i + 1 < self.N else None
@@ -1239,7 +1246,8 @@ class CascadeEngine:
     def _train_step(self, x, target, cfg, lpc_x, comm):
         check(self.lib.nsc_zero(self.g_ptr, self._gh_floats, self.stream()), "zero grads + hists")   # ONE memset node
         self.refresh_wt()
-        self.forward(x, cfg["is_quan_on"], True, lpc_x=lpc_x, hists_clean=True)
+        self.forward(x, cfg["is_quan_on"], True, lpc_x=lpc_x, hists_clean=True,
+                     first_needed=min([i for i, t in enumerate(cfg["trainable"]) if t], default=self.N))
         gb = self.B * (comm.world if comm else 1)
         terms = self.loss_backward(target, cfg["c_time"], cfg["c_freq"], cfg["c_quan"], cfg["c_ent"], cfg["trainable"],
                                    c_quan_lpc=cfg.get("c_quan_lpc", 0.0), c_ent_lpc=cfg.get("c_ent_lpc", 0.0),
