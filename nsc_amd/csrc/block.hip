@@ -2051,8 +2051,10 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
   const int first = (int)((long)blockIdx.x * ntiles / gridDim.x), last = (int)((long)(blockIdx.x + 1) * ntiles / gridDim.x);
   NSC_STAMP(0);
   pf_setup(first, false);
+#if !(defined(NSC_EXP) && (NSC_EXP & 1))
   prefetch_dy();
   prefetch_a();
+#endif
   static_assert(NK9 == 4 * (NJ9 - 1) + 1, "left-over channel group is shared out by tap");
   float w9r[K9][NJ9 - 1], w9x[3];
   const int rt1 = RT9 == 7 ? (wave < 7 ? wave : 6) : (wave & 3);
@@ -2069,10 +2071,17 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
     constexpr int NFR = K9 * (NJ9 - 1) + 3 + 5, NF4 = (NFR + 3) / 4;
     f32x4 tA[NE4], fr[NF4];
 #pragma unroll
+#if defined(NSC_EXP) && (NSC_EXP & 2)
+    for (int i = 0; i < NE4; ++i) tA[i] = (f32x4){0.f, 0.f, 0.f, (float)tid};
+    const f32x4* fp = img4 + nA4 + wave * NF4 * 64 + lane;
+#pragma unroll
+    for (int g = 0; g < NF4; ++g) fr[g] = (f32x4){0.f, 0.f, (float)g, (float)tid};
+#else
     for (int i = 0; i < NE4; ++i) tA[i] = img4[min(tid + 512 * i, nA4 - 1)];
     const f32x4* fp = img4 + nA4 + wave * NF4 * 64 + lane;
 #pragma unroll
     for (int g = 0; g < NF4; ++g) fr[g] = fp[g * 64];
+#endif
 #pragma unroll
     for (int i = 0; i < NE4; ++i)
       if (tid + 512 * i < nA4) reinterpret_cast<f32x4*>(w15s)[tid + 512 * i] = tA[i];
