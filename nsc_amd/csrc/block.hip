@@ -1736,7 +1736,9 @@ __device__ __forceinline__ void d9_packed(const float* w9ps, int C, int w9t, con
         av[slot][j] = expv[0];
         b0[slot][j] = expv[1];
 #else
-        av[slot][j] = ap[16 * (j0 + j) * 4];
+        // (NK9 = 9 is the C = 25 shape staged as 36 rows: channel groups past C - their dy rows are zeros - would index the table
+        // past its C entries per tap, and past its end for the last tap: whatever LDS holds there, NaN included.  Clamped.)
+        av[slot][j] = NK9_ == 9 ? ap[(min(4 * kg + kq + 16 * (j0 + j), C - 1) - (4 * kg + kq)) * 4] : ap[16 * (j0 + j) * 4];
         b0[slot][j] = ypb[16 * (j0 + j) * LDY_ + m];
 #endif
         if (NT == 2) b1[NT == 2 ? slot : 0][j] = ypb[16 * (j0 + j) * LDY_ + m + 64];

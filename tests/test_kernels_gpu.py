@@ -515,6 +515,7 @@ def test_fused_gated_block_fwd(lib, case):
     Bv = [P(ps.params[n + "/bias"]) for n in names]
     out = torch.full((B, C_, T), float("nan"), device="cuda")
     h, lin, th, g = (torch.full((B, 20, T), float("nan"), device="cuda") for _ in range(4))
+    _poison_lds_with_nan(lib)
     rc = lib.nsc_gated_block_fwd(P(x.transpose(0, 2, 1)), W[0], Bv[0], W[1], Bv[1], W[2], Bv[2], W[3], Bv[3],
                                  out.data_ptr(), h.data_ptr(), lin.data_ptr(), th.data_ptr(), g.data_ptr(), B, C_, T,
                                  20, 9, dil, flat, _st())
@@ -620,6 +621,7 @@ def test_fused_gated_block_fwd_one_input_channel(lib, case):
     Bv = [P(ps.params[n + "/bias"]) for n in names]
     out = torch.full((B, C_, T), float("nan"), device="cuda")
     h, lin, th, g = (torch.full((B, 20, T), float("nan"), device="cuda") for _ in range(4))
+    _poison_lds_with_nan(lib)
     rc = lib.nsc_gated_block_fwd_cin1(P(x.transpose(0, 2, 1)), W[0], Bv[0], W[1], Bv[1], W[2], Bv[2], W[3], Bv[3],
                                       out.data_ptr(), h.data_ptr(), lin.data_ptr(), th.data_ptr(), g.data_ptr(), B, C_, T,
                                       20, 9, dil, flat, _st())
@@ -632,6 +634,21 @@ def test_fused_gated_block_fwd_one_input_channel(lib, case):
     assert_close(tr(out), ref, what=f"cin1 block out {case}")
     assert lib.nsc_gated_block_fwd_cin1(P(x.transpose(0, 2, 1)), W[0], Bv[0], W[1], Bv[1], W[2], Bv[2], W[3], Bv[3],
                                         out.data_ptr(), None, None, None, None, B, 36, T, 20, 9, dil, flat, _st()) == -2
+
+
+def _poison_lds_with_nan(lib):
+    """Leaves NaN in the LDS of every CU: one C = 100 data-gradient launch on all-NaN tensors and weights (its tiles and weight
+    tables cover the 160 KB).  A kernel that then reads LDS it never wrote - a table pad, a channel group past C - picks the
+    NaN up (NaN x 0 = NaN), instead of passing by the luck of what the previous kernel left there."""
+    B, C_, T = 256, 100, 64
+    nan = lambda *sh: torch.full(sh, float("nan"), device="cuda")
+    x, dy, h, lin, th = nan(B, C_, T), nan(B, C_, T), nan(B, 20, T), nan(B, 20, T), nan(B, 20, T)
+    w1, wl, wr, w9 = nan(1, 20, C_), nan(15, 20, 20), nan(15, 20, 20), nan(9, C_, 20)
+    dx, da, dz1 = nan(B, C_, T), nan(B, 40, T), nan(B, 20, T)
+    assert lib.nsc_gated_block_dgrad(x.data_ptr(), h.data_ptr(), lin.data_ptr(), th.data_ptr(), dy.data_ptr(), w1.data_ptr(),
+                                     wl.data_ptr(), wr.data_ptr(), w9.data_ptr(), dx.data_ptr(), da.data_ptr(), dz1.data_ptr(),
+                                     B, C_, T, 20, 9, 2, 0, _st()) == 0
+    torch.cuda.synchronize()
 
 
 @pytest.mark.parametrize("case", [(2, 100, 512, 2, 2), (2, 100, 256, 1, 0), (3, 50, 512, 2, 2), (2, 50, 512, 1, 2),
@@ -670,6 +687,7 @@ def test_fused_gated_block_dgrad(lib, case):
     dx = torch.full((B, C_, T), float("nan"), device="cuda")
     da = torch.full((B, 40, T), float("nan"), device="cuda")
     dz1 = torch.full((B, 20, T), float("nan"), device="cuda")
+    _poison_lds_with_nan(lib)
     rc = lib.nsc_gated_block_dgrad(tr(xin_np), tr(h.detach().numpy()), tr(left.detach().numpy()), tr(right.detach().numpy()),
                                    tr(dy), P(wt[names[0]]), P(wt[names[1]]), P(wt[names[2]]), P(wt[names[3]]), dx.data_ptr(),
                                    da.data_ptr(), dz1.data_ptr(), B, C_, T, 20, 9, dil, in_act, _st())
@@ -710,6 +728,7 @@ def test_fused_gated_block_dgrad_one_input_channel(lib, case):
     tr = lambda v: P(np.ascontiguousarray(np.asarray(v, np.float32).transpose(0, 2, 1)))
     dx = torch.full((B, 1, T), float("nan"), device="cuda")
     dlin, dgate, dz1 = (torch.full((B, 20, T), float("nan"), device="cuda") for _ in range(3))
+    _poison_lds_with_nan(lib)
     rc = lib.nsc_gated_block_dgrad_cin1(tr(h.detach().numpy()), tr(left.detach().numpy()), tr(right.detach().numpy()), tr(dy),
                                         P(wt[names[0]]), P(wt[names[1]]), P(wt[names[2]]), P(wt[names[3]]), dx.data_ptr(),
                                         dlin.data_ptr(), dgate.data_ptr(), dz1.data_ptr(), B, C_, T, 20, 9, dil, 20, _st())
