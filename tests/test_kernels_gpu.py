@@ -12,10 +12,36 @@ from tests._util import assert_close, dev, relerr
 pytestmark = pytest.mark.gpu
 
 
+class _PoisonedLib:
+    """The C-ABI library with every launch preceded by _poison_lds_with_nan: each kernel under test starts on LDS full of NaN
+    instead of on whatever the previous kernel left there, so a read of LDS the kernel never wrote (a table pad, a row or
+    channel group past the tensor) shows up as NaN x 0 = NaN in its output - every time, not when the stale bytes fall badly."""
+    _PLAIN = ("nsc_last_error", "nsc_version", "nsc_gated_block_image_floats", "nsc_gated_block_image_index",
+              "nsc_conv1d_wgrad_workspace", "nsc_gated_block_wgrad_batch_workspace", "nsc_conv1d_wgrad_batch_workspace",
+              "nsc_gated_block_wgrad_workspace")
+
+    def __init__(self, real):
+        object.__setattr__(self, "_real", real)
+
+    def __getattr__(self, name):
+        fn = getattr(self._real, name)
+        if name in self._PLAIN or not name.startswith("nsc_"):
+            return fn
+        real = self._real
+
+        def call(*a, **k):
+            _poison_lds_with_nan(real)
+            return fn(*a, **k)
+        return call
+
+    def __setattr__(self, name, value):
+        setattr(self._real, name, value)
+
+
 @pytest.fixture(scope="module")
 def lib():
     from nsc_amd import _lib
-    return _lib.load()
+    return _PoisonedLib(_lib.load())
 
 
 def _desc(**kw):
@@ -515,7 +541,6 @@ def test_fused_gated_block_fwd(lib, case):
     Bv = [P(ps.params[n + "/bias"]) for n in names]
     out = torch.full((B, C_, T), float("nan"), device="cuda")
     h, lin, th, g = (torch.full((B, 20, T), float("nan"), device="cuda") for _ in range(4))
-    _poison_lds_with_nan(lib)
     rc = lib.nsc_gated_block_fwd(P(x.transpose(0, 2, 1)), W[0], Bv[0], W[1], Bv[1], W[2], Bv[2], W[3], Bv[3],
                                  out.data_ptr(), h.data_ptr(), lin.data_ptr(), th.data_ptr(), g.data_ptr(), B, C_, T,
                                  20, 9, dil, flat, _st())
@@ -621,7 +646,6 @@ def test_fused_gated_block_fwd_one_input_channel(lib, case):
     Bv = [P(ps.params[n + "/bias"]) for n in names]
     out = torch.full((B, C_, T), float("nan"), device="cuda")
     h, lin, th, g = (torch.full((B, 20, T), float("nan"), device="cuda") for _ in range(4))
-    _poison_lds_with_nan(lib)
     rc = lib.nsc_gated_block_fwd_cin1(P(x.transpose(0, 2, 1)), W[0], Bv[0], W[1], Bv[1], W[2], Bv[2], W[3], Bv[3],
                                       out.data_ptr(), h.data_ptr(), lin.data_ptr(), th.data_ptr(), g.data_ptr(), B, C_, T,
                                       20, 9, dil, flat, _st())
@@ -636,15 +660,19 @@ def test_fused_gated_block_fwd_one_input_channel(lib, case):
                                         out.data_ptr(), None, None, None, None, B, 36, T, 20, 9, dil, flat, _st()) == -2
 
 
+_POISON = []
+
+
 def _poison_lds_with_nan(lib):
     """Leaves NaN in the LDS of every CU: one C = 100 data-gradient launch on all-NaN tensors and weights (its tiles and weight
     tables cover the 160 KB).  A kernel that then reads LDS it never wrote - a table pad, a channel group past C - picks the
     NaN up (NaN x 0 = NaN), instead of passing by the luck of what the previous kernel left there."""
     B, C_, T = 256, 100, 64
-    nan = lambda *sh: torch.full(sh, float("nan"), device="cuda")
-    x, dy, h, lin, th = nan(B, C_, T), nan(B, C_, T), nan(B, 20, T), nan(B, 20, T), nan(B, 20, T)
-    w1, wl, wr, w9 = nan(1, 20, C_), nan(15, 20, 20), nan(15, 20, 20), nan(9, C_, 20)
-    dx, da, dz1 = nan(B, C_, T), nan(B, 40, T), nan(B, 20, T)
+    if not _POISON:
+        nan = lambda *sh: torch.full(sh, float("nan"), device="cuda")
+        _POISON.extend([nan(B, C_, T), nan(B, C_, T), nan(B, 20, T), nan(B, 20, T), nan(B, 20, T), nan(1, 20, C_), nan(15, 20, 20),
+                        nan(15, 20, 20), nan(9, C_, 20), nan(B, C_, T), nan(B, 40, T), nan(B, 20, T)])
+    x, dy, h, lin, th, w1, wl, wr, w9, dx, da, dz1 = _POISON
     assert lib.nsc_gated_block_dgrad(x.data_ptr(), h.data_ptr(), lin.data_ptr(), th.data_ptr(), dy.data_ptr(), w1.data_ptr(),
                                      wl.data_ptr(), wr.data_ptr(), w9.data_ptr(), dx.data_ptr(), da.data_ptr(), dz1.data_ptr(),
                                      B, C_, T, 20, 9, 2, 0, _st()) == 0
@@ -687,7 +715,6 @@ def test_fused_gated_block_dgrad(lib, case):
     dx = torch.full((B, C_, T), float("nan"), device="cuda")
     da = torch.full((B, 40, T), float("nan"), device="cuda")
     dz1 = torch.full((B, 20, T), float("nan"), device="cuda")
-    _poison_lds_with_nan(lib)
     rc = lib.nsc_gated_block_dgrad(tr(xin_np), tr(h.detach().numpy()), tr(left.detach().numpy()), tr(right.detach().numpy()),
                                    tr(dy), P(wt[names[0]]), P(wt[names[1]]), P(wt[names[2]]), P(wt[names[3]]), dx.data_ptr(),
                                    da.data_ptr(), dz1.data_ptr(), B, C_, T, 20, 9, dil, in_act, _st())
@@ -728,7 +755,6 @@ def test_fused_gated_block_dgrad_one_input_channel(lib, case):
     tr = lambda v: P(np.ascontiguousarray(np.asarray(v, np.float32).transpose(0, 2, 1)))
     dx = torch.full((B, 1, T), float("nan"), device="cuda")
     dlin, dgate, dz1 = (torch.full((B, 20, T), float("nan"), device="cuda") for _ in range(3))
-    _poison_lds_with_nan(lib)
     rc = lib.nsc_gated_block_dgrad_cin1(tr(h.detach().numpy()), tr(left.detach().numpy()), tr(right.detach().numpy()), tr(dy),
                                         P(wt[names[0]]), P(wt[names[1]]), P(wt[names[2]]), P(wt[names[3]]), dx.data_ptr(),
                                         dlin.data_ptr(), dgate.data_ptr(), dz1.data_ptr(), B, C_, T, 20, 9, dil, 20, _st())
