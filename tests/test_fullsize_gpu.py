@@ -158,6 +158,55 @@ def test_headline_step_values_match_the_float64_oracle():
     assert not fails, "gradient mismatches at B = 128:\n" + "\n".join(fails)
 
 
+def test_follower_step_values_match_the_float64_oracle():
+    """The second step of config 3 (bench.py --follower; cmrl.py:137-293): codec 1 frozen - it runs forward-only and keeps
+    no activations -, codec 2 trains on its residual with its own quan + entropy terms (tau 0.3, histogram of the batch).
+    Decoded frames, loss terms and every gradient of scope_2 against the float64 oracle at B = 128; scope_1 and the LSF
+    quantizer get exactly zero."""
+    import bench
+    from oracle import nsc_oracle_torch as OT
+    from tests._util import assert_close, make_store
+    _, eng, x, lpc = _setup()
+    _, _, x_np, lpc_np = bench.synth_batch(B, 0, torch.device("cuda", 0))
+    ps = make_store(2, [[2], [2]], [32, 32], rand_bias=True, alpha=-20.0, lpc=True)
+    eng.load_named(ps.params)
+    c, tau = bench.COEFF, 0.3
+    cfg = dict(is_quan_on=1.0, c_time=c[0], c_freq=c[1], c_quan=[0.0, c[2]], c_ent=[0.0, tau], trainable=[False, True], lr=0.0, slot=1,
+               quan_op=True)
+    eng.refresh_wt()
+    eng.grads.zero_()
+    dec = eng.forward(x, 1.0, True, lpc_x=lpc, first_needed=1)
+    terms = eng.loss_backward(x, c[0], c[1], cfg["c_quan"], cfg["c_ent"], cfg["trainable"])
+    torch.cuda.synchronize()
+
+    def oracle(dtype):
+        tp = OT.TorchParams(ps, dtype=dtype)
+        xt = torch.tensor(np.ascontiguousarray(x_np.transpose(0, 2, 1)), dtype=dtype)
+        outs, d = OT.cascade_forward(xt, tp, bench.BKD, [[2], [2]], 1.0, True, bench.RES_SCALAR, True)
+        tgt = xt[:, :, 0]
+        OT.total_loss_sum(d, tgt, [o["p"] for o in outs], c, tau, "quan_last").backward()
+        g = {k: (t.grad.numpy().astype(np.float64) if t.grad is not None else np.zeros(tuple(t.shape))) for k, t in tp.t.items()}
+        return d.detach().numpy(), outs, g
+    d64, outs64, g64 = oracle(torch.float64)
+    _, _, g32 = oracle(torch.float32)
+    assert_close(dec.cpu().numpy()[:, 0], d64, what="decoded, follower step")
+    assert_close(terms["quan"][1].cpu().numpy(), OT.quan_loss(outs64[1]["p"]).detach().numpy(), what="quan loss of codec 2 per frame")
+    mine = eng.named("grads")
+    fails = []
+    for name, g in g64.items():
+        a, b = mine[name].reshape(-1), g.reshape(-1)
+        if not name.startswith("scope_2/"):
+            if np.any(a != 0.0):
+                fails.append(f"{name}: frozen, but its gradient is not zero")
+            continue
+        scale = max(float(np.max(np.abs(b))), 1e-6)
+        err = float(np.max(np.abs(a - b))) / scale
+        lim = max(5e-4, 4.0 * float(np.max(np.abs(g32[name].reshape(-1) - b))) / scale)
+        if not np.all(np.isfinite(a)) or err > lim:
+            fails.append(f"{name}: rel err {err:.3e} > {lim:.3e}")
+    assert not fails, "follower-step gradient mismatches at B = 128:\n" + "\n".join(fails)
+
+
 def test_config4_forward_values_match_the_float64_oracle():
     """BASELINE config 4 at its full per-GPU batch: 4 codecs, each with two down-/up-sampling stages ('2 2': 128 codes, blocks
     at C = 100, 50 and 25), B = 256, forward with hard codes - decoded frames and every codec's codes vs the float64 oracle
