@@ -15,6 +15,7 @@ Reference structure being replaced (file:line in cocosci/NSC):
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 from collections import OrderedDict
 
@@ -36,6 +37,8 @@ def same_pad(T, k, dil=1, stride=1):
     pad = max((t_out - 1) * stride + (k - 1) * dil + 1 - T, 0)
     return t_out, pad // 2
 
+
+_POISON_BUFS = os.environ.get("NSC_POISON_BUFS", "") not in ("", "0")
 
 class ParamLayout:
     """Flat fp32 parameter buffer layout; creation order == TF trainable_variables order inside a scope."""
@@ -952,6 +955,8 @@ class CascadeEngine:
         t = self._bufs.get(name)
         if t is None or tuple(t.shape) != tuple(shape):
             t = torch.empty(shape, dtype=torch.float32, device=self.device)
+            if _POISON_BUFS:      # debugging aid (NSC_POISON_BUFS=1): a kernel that reads an element nobody wrote meets NaN, not
+                t.fill_(float("nan"))   # the zeros of a fresh allocation or last step's value
             self._bufs[name] = t
         return t
 
