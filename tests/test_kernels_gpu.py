@@ -521,7 +521,9 @@ def test_bad_arguments_return_status(lib):
                                   # long chains of consecutive tiles (carried h / g columns), crossing frame boundaries
                                   (150, 100, 512, 1, 0), (150, 50, 512, 2, 1), (72, 100, 256, 2, 0),
                                   # C = 25 (third resolution of '2 2' codecs): persistent kernel on the C = 50 job table
-                                  (3, 25, 128, 1, 0), (300, 25, 128, 2, 1), (2, 25, 200, 2, 0)])
+                                  (3, 25, 128, 1, 0), (300, 25, 128, 2, 1), (2, 25, 200, 2, 0),
+                                  # T not a multiple of 4: rows are not 16-byte aligned (element-wise masks, scalar stores)
+                                  (3, 100, 130, 2, 0), (40, 100, 203, 1, 1), (5, 50, 70, 2, 0), (3, 25, 67, 1, 0)])
 def test_fused_gated_block_fwd(lib, case):
     """csrc/block.hip vs the oracle's gated_bottleneck (nn_core_operator.py:82-112), incl. saved intermediates."""
     B, C_, T, dil, flat = case
@@ -626,7 +628,7 @@ def test_block_wgrad_kernel(lib, case):
 
 
 @pytest.mark.parametrize("case", [(2, 100, 256, 1, 0), (3, 100, 256, 2, 1), (2, 50, 512, 1, 0), (150, 100, 256, 2, 0), (70, 100, 300, 1, 0),
-                                  (3, 25, 128, 1, 0), (300, 25, 128, 2, 1)])
+                                  (3, 25, 128, 1, 0), (300, 25, 128, 2, 1), (3, 100, 130, 2, 0), (40, 50, 203, 1, 0)])
 def test_fused_gated_block_fwd_one_input_channel(lib, case):
     """nsc_gated_block_fwd_cin1 vs the oracle's gated_bottleneck on a [B,T,1] input (broadcast residual), incl. the saved
     intermediates and chains of tiles."""
@@ -685,7 +687,9 @@ def _poison_lds_with_nan(lib):
                                   # that cross frame boundaries, a ragged last tile
                                   (40, 100, 512, 2, 2), (72, 100, 256, 1, 2), (150, 50, 512, 2, 2), (61, 100, 300, 1, 0),
                                   # C = 25: dy staged as 36 rows (9 channel groups) on the C = 50 job table
-                                  (3, 25, 128, 1, 2), (300, 25, 128, 2, 2), (2, 25, 200, 2, 0)])
+                                  (3, 25, 128, 1, 2), (300, 25, 128, 2, 2), (2, 25, 200, 2, 0),
+                                  # T not a multiple of 4: rows are not 16-byte aligned (element-wise masks, scalar stores)
+                                  (3, 100, 130, 2, 2), (40, 100, 203, 1, 2), (5, 50, 70, 2, 0), (3, 25, 67, 1, 2)])
 def test_fused_gated_block_dgrad(lib, case):
     """8-wave data-path backward (dx, dlin|dgate, dz1) vs autograd of the oracle block with its saved intermediates."""
     B, C_, T, dil, in_act = case
@@ -728,7 +732,7 @@ def test_fused_gated_block_dgrad(lib, case):
 
 
 @pytest.mark.parametrize("case", [(2, 100, 256, 1), (3, 100, 256, 2), (2, 50, 512, 2), (150, 100, 256, 2), (70, 100, 300, 1),
-                                  (3, 25, 128, 1), (300, 25, 128, 2)])
+                                  (3, 25, 128, 1), (300, 25, 128, 2), (3, 100, 130, 2), (40, 50, 203, 1)])
 def test_fused_gated_block_dgrad_one_input_channel(lib, case):
     """nsc_gated_block_dgrad_cin1 vs autograd of the oracle block on a [B,T,1] input: dx (incl. the channel-summed residual
     branch), dlin, dgate, dz1 - with chains of tiles."""
