@@ -1001,7 +1001,8 @@ def test_upsample_stage_fwd_bwd(lib, shape):
 
 @pytest.mark.parametrize("C_,Cin,dil,T,B", [(100, 100, 1, 256, 3), (100, 100, 2, 512, 2), (50, 50, 1, 512, 2), (50, 50, 2, 200, 3),
                                            (100, 1, 1, 256, 2), (100, 1, 2, 300, 3), (50, 1, 1, 130, 2), (50, 1, 2, 512, 70),
-                                           (25, 25, 1, 128, 3), (25, 25, 2, 128, 300), (25, 1, 2, 128, 5)])
+                                           (25, 25, 1, 128, 3), (25, 25, 2, 128, 300), (25, 1, 2, 128, 5),
+                                           (100, 100, 2, 130, 3), (25, 25, 1, 67, 3)])
 def test_block_kernels_on_parameter_images_equal_the_plain_entry_points(lib, C_, Cin, dil, T, B):
     """nsc_gated_block_fwd_img / _dgrad_img (fast prologue from a kernel-ready image built by nsc_gated_block_image_index +
     nsc_gather) produce the same bits as nsc_gated_block_fwd[_cin1] / nsc_gated_block_dgrad[_cin1] on the same parameters."""
