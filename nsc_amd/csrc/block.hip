@@ -1966,8 +1966,7 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
   constexpr int hf = ROLE;                         // which half of a K-quarter's work this wave does (see the kernel)
   const int kg = wave & 3;                         // this wave's K-quarter: waves w and w + 4 share it (and a SIMD)
 
-  // the first tile's x goes out before the weights: its HBM round trip is the longest latency of the prologue
-  // ---- prefetch of the next tile: dy (wave w rows w, w+8, ...), lin / tanh (rows w, w+8, w+16), h (elementwise map) ----
+  // ---- buffer descriptors of the tensors this kernel streams (out-of-frame pieces are sent past num_records: zeros) ----
   const __amdgpu_buffer_rsrc_t sdy =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, (unsigned)((long)a.B * C * T * 4), 0x00020000);
   const unsigned nbN = (unsigned)((long)a.B * NARROW * T * 4);
@@ -1983,8 +1982,8 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
   const __amdgpu_buffer_rsrc_t sdgate = __builtin_amdgcn_make_buffer_rsrc(a.dgate, 0, nbDA, 0x00020000);
   // ---- prefetch of the next tile, 16 bytes per lane: lane = (row half lane >> 5, float4 index lane & 31); a wave instruction
   // covers two rows.  dy: wave w rows 2 w + half + 16 q; lin / tanh: rows 2 w + half (+ 16: waves 0, 1); h: float4 tid of the
-  // [20][64] tile.  (Round 2 moved these as dword loads + ds_write_b32, one float per lane and instruction: with every MFMA
-  // phase skipped the kernel still took 8 of its 19 us per tile - tools/dgrad_skip_probe.py - all of it issue-bound data movement.)
+  // [20][64] tile.  (Round 2 moved these as dword loads + ds_write_b32, one float per lane and instruction; 16 bytes per lane took
+  // ~2 k cycles out of the staging and copy-out phases of a tile.)
   constexpr int NQY = (CR + 15) / 16, NY4 = (W_dy + DLT + 3) / 4, NA4 = (W_a + DLT + 3) / 4;
   static_assert(NY4 <= 32 && NA4 <= 32, "a row's window fits 32 float4 lanes");
   f32x4 pfy[NQY], pfl[2], pft[2], pfh;
@@ -2254,7 +2253,8 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
     };
 
     // ---- D9: dg[ci][ja] = sum_{tap', o} wt9[tap'][o][ci] * dy[o][ja + tap'], K split in quarters kg.
-    // Channels 0..15: waves 0-3 take column tiles 0..3, waves 4-7 the rest; channels 16..19: waves 4-7, packed tile.
+    // Waves w and w + 4 share K-quarter kg = w & 3 (and a SIMD) and run the same stream: two of the four dense column tiles of
+    // channels 0..15 and half of the packed-tile steps of channels 16..19 each (gated_block_dgrad2_role's ROLE).
     // Software-pipelined loops with scheduling fences: left alone the scheduler hoists ~30 ds_read2 (60 registers) ahead
     // of the MFMAs, which spills - and a scratch reload waits on vmcnt IN ORDER, i.e. on the next tile's whole prefetch.
     if (!(skip & 1)) {
@@ -2363,7 +2363,7 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
     NSC_STAMP(8);
 
     // ---- D15: dh[ci][tt] = sum wt_lr[tap'][c'][ci] * da[c'][tt + tap' d], taps split in quarters kg.
-    // Channels 0..15: waves 0-3 column tiles 0..2, waves 4-7 tile 3; channels 16..19: waves 4-7, packed tile.
+    // Same split as the k9 gradient: two dense column tiles and half of the packed-tile steps per wave.
     if (!(skip & 2)) {
       const float* ab = lin + kq * LDA + l15 + kg * DIL + 32 * hf;
       const float* wb = w15s + kg * W15T + kq * NARROW + l15;
