@@ -56,9 +56,9 @@ __device__ __forceinline__ void nsc_lds_barrier() { asm volatile("s_waitcnt lgkm
 // RELATIVE accuracy near 0 (a 1 - 2 / (exp(2x) + 1) form has 2e-7 absolute error there: the followers' residual inputs are
 // small, and the gradients of a follower step came out 1e-2 off).  14 VALU instructions against ~40 of the library tanhf -
 // whose time next to an fp32 MFMA stream is not hidden (fp32 MFMA runs on the vector ALUs).  The division is v_rcp + mul; the
-// result is clamped to [-1, 1] (the quotient can exceed 1 by an ulp; 1 - th^2 must not go negative).
-__device__ __forceinline__ float nsc_tanh(float x) {
-  x = __builtin_amdgcn_fmed3f(x, -9.f, 9.f);
+// result is clamped to [-1, 1] (the quotient can exceed 1 by an ulp; 1 - th^2 must not go negative); NaN stays NaN.
+__device__ __forceinline__ float nsc_tanh(float x0) {
+  const float x = __builtin_amdgcn_fmed3f(x0, -9.f, 9.f);
   const float x2 = x * x;
   float p = fmaf(x2, -2.76076847742355e-16f, 2.00018790482477e-13f);
   p = fmaf(x2, p, -8.60467152213735e-11f);
@@ -70,7 +70,8 @@ __device__ __forceinline__ float nsc_tanh(float x) {
   float q = fmaf(x2, 1.19825839466702e-06f, 1.18534705686654e-04f);
   q = fmaf(x2, q, 2.26843463243900e-03f);
   q = fmaf(x2, q, 4.89352518554385e-03f);
-  return __builtin_amdgcn_fmed3f(p * __builtin_amdgcn_rcpf(q), -1.f, 1.f);
+  const float r = __builtin_amdgcn_fmed3f(p * __builtin_amdgcn_rcpf(q), -1.f, 1.f);
+  return x0 != x0 ? x0 : r;                 // the clamps would turn a NaN into -1: a diverged run must stay visibly NaN
 }
 
 __device__ __forceinline__ float nsc_apply_act(float v, int act) {

@@ -273,6 +273,14 @@ def test_fast_tanh(lib):
     big = np.abs(x) > 10
     assert np.all(np.abs(th[big] - np.sign(x[big].astype(np.float64))) <= 1.2e-7)
     assert np.array_equal(np.sign(th), np.sign(x.astype(np.float64)))
+    # NaN in, NaN out (the clamps of the rational form must not turn a diverged activation into -1)
+    a2 = np.ones((1, 40, 64), np.float32)
+    a2[0, 20:, ::3] = np.nan
+    ad2 = dev(a2)
+    g2 = torch.empty((1, 20, 64), device="cuda")
+    assert lib.nsc_gate_fwd(ad2.data_ptr(), g2.data_ptr(), 1, 20, 64, _st()) == 0
+    th2 = ad2.cpu().numpy()[0, 20:]
+    assert np.all(np.isnan(th2[:, ::3])) and np.all(np.isfinite(th2[:, 1::3]))
 
 
 def test_glue_kernels(lib):
