@@ -2,6 +2,9 @@
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nsc_amd import _lib
+import os as _os
+if _os.environ.get("NSC_LIB"):
+    _lib.LIB_PATH = _os.path.abspath(_os.environ["NSC_LIB"])
 lib = _lib.load()
 B, C_, T = 128, 100, 256
 x = torch.randn(B, C_, T, device="cuda"); wd = torch.randn(9, C_, device="cuda"); wp = torch.randn(C_, C_, device="cuda") * 0.1
