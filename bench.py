@@ -10,14 +10,20 @@ synthetic 16 kHz frames.  A "step" = one optimizer step over one bat
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (the MFMA implicit-GEMM conv), timed
-live with HIP events on the launch stream over extra instrumented steps of the same workload; `cpu_baseline`
-times the float32 PyTorch-CPU oracle (a port of the reference TF graph - TF itself is not installable) on a
-bounded sample on rank 0 at N=1.
+`python bench.py --gpus N` with N > 1 and no launcher environment starts the N ranks ITSELF: the parent (which never touches
+a GPU) runs `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child process, relays rank 0's JSON line
+and exits with the child's return code.
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel class of the step (the persistent gated-block
+data-gradient kernel, gated_block_dgrad2_kernel, unless another class takes a larger share), timed live with HIP events on
+the launch stream over extra instrumented steps of the same workload; `cpu_baseline` times the float32 PyTorch-CPU oracle
+(a port of the reference TF graph - TF itself is not installable) on a bounded sample on rank 0 at N=1.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -147,6 +153,40 @@ class _NullComm:
         pass
 
 
+def spawn_ranks(n, argv):
+    """--gpus N > 1 without a launcher: start N fresh ranks under torch.distributed.run as a CHILD process (this parent has not
+    initialised a GPU and never does; nothing is exec'ed), relay the child's output and return its exit code."""
+    backend = os.environ.get("NSC_DIST_BACKEND") or "nccl"
+    ndev = torch.cuda.device_count()          # (counting devices does not initialise the GPU on this stack)
+    if backend == "nccl" and ndev < n:
+        print(f"[bench] --gpus {n} needs {n} GPUs for RCCL (one rank per GPU) but this node shows {ndev}; nothing was launched.  "
+              f"(NSC_DIST_BACKEND=gloo shares the visible GPU(s) between ranks: control-flow test only.)", file=sys.stderr)
+        return 2
+    with socket.socket() as so:               # a free rendezvous port on the loopback interface
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL's intra-node transport on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    print(f"[bench] launching {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True)
+    line_json = None
+    for line in proc.stdout:                  # rank 0 prints the ONE JSON line; anything else goes to stderr untouched
+        if line.lstrip().startswith("{") and '"metric"' in line:
+            line_json = line.strip()
+        else:
+            sys.stderr.write(line)
+    rc = proc.wait()
+    if line_json is not None:
+        print(line_json, flush=True)
+    elif rc == 0:
+        print("[bench] the ranks exited with 0 but printed no JSON line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -178,15 +218,19 @@ def main():
     ap.add_argument("--unfused-fwd", action="store_true", help="debug: per-conv forward/backward (no block fusion)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+
     from nsc_amd.dist import Comm
     from nsc_amd.engine import CascadeEngine
     comm = Comm()
-    assert comm.world == args.gpus or comm.world == 1, f"WORLD_SIZE {comm.world} != --gpus {args.gpus}"
-    if args.gpus > 1 and comm.world == 1:
-        raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    if comm.world != args.gpus:
+        raise SystemExit(f"[bench] WORLD_SIZE {comm.world} != --gpus {args.gpus}: launch `python bench.py --gpus N` (it starts the "
+                         f"ranks itself) or torch.distributed.run with --nproc-per-node equal to --gpus")
     ldev = comm.local_rank % torch.cuda.device_count()   # one GPU per rank on a real node; wraps only in single-GPU smoke tests
     torch.cuda.set_device(ldev)
     dev = torch.device("cuda", ldev)
+    comm.preflight(dev)                                  # first contact with RCCL: a checked 4-float all-reduce, clear error
     wl_name, ncodec, strides_c, use_lpc, B_default, mflop_frame = CONFIGS[args.config]
     B = args.batch or B_default
     if args.config != 3:
@@ -258,6 +302,24 @@ def main():
         except Exception as ex:  # fall back to eager launches in this process, say so in the JSON
             print(f"[bench] hipGraph capture failed ({type(ex).__name__}: {ex}); running eagerly", file=sys.stderr)
             graph, seg, launch = None, None, f"eager (capture failed: {type(ex).__name__})"
+    # First contact of the segmented replay with the real backend: one replay under try.  A rank whose replay throws (a
+    # collective that refuses to run between graph launches, a graph that refuses to launch) says so, ALL ranks then agree
+    # - through a collective of their own - to run eagerly in this process.  If the backend itself is broken that agreement
+    # throws too and the rank exits non-zero: nothing is re-exec'ed or restarted once the GPU has been touched.
+    if seg is not None:
+        failed, why = 0.0, ""
+        try:
+            seg.replay()
+            torch.cuda.synchronize()
+        except Exception as ex:
+            failed, why = 1.0, f"{type(ex).__name__}: {ex}"
+            print(f"[bench] rank {comm.rank}: first segmented replay failed ({why}); asking all ranks to run eagerly", file=sys.stderr)
+        if comm.max_float(failed, dev) != 0.0:
+            seg = None
+            launch = "eager (first segmented replay failed" + (f": {why.split(':')[0]}" if why else " on another rank") + ")"
+            torch.cuda.synchronize()
+            step()                           # the eager step must work, or the run ends here with its error
+            torch.cuda.synchronize()
     run = graph.replay if graph is not None else (seg.replay if seg is not None else step)
     # every rank must take the same path (a rank that fell back to eager launches would still be correct, but say so)
     all_same = comm.max_float(0.0 if (graph is not None or seg is not None or args.no_graph) else 1.0, dev) == 0.0
@@ -360,11 +422,11 @@ def main():
         qtrain = dict(kernel=f"quantize_fwd_kernel (training shape: B={Bt}, p not materialised, 8 B/code)",
                       bytes_per_launch=Bt * L * 8, avg_launch_us=round(ust, 2), achieved_gbps=round(Bt * L * 8 / ust / 1e3, 1),
                       note="latency-bound: 262 KB per launch; the roofline record above is the op-surface form at the config-5 batch")
-        qroof = dict(bound="hbm", kernel="quantize_fwd_kernel (p materialised, B=4096 frames)", achieved=round(byts / us / 1e3, 1),
+        qroof = dict(bound="hbm", kernel="quantize_fwd32_wave_kernel (one wave per frame; p materialised, B=4096 frames)", achieved=round(byts / us / 1e3, 1),
                      peak=8000.0, unit="GB/s", frac=round(byts / us / 1e3 / 8000.0, 4),
-                     traffic=traffic.get("quantize_fwd@grid1024"), training_shape=qtrain,
+                     traffic=next((v for k, v in traffic.items() if k.startswith("quantize_fwd_wave@grid")), None), training_shape=qtrain,
                      bytes_per_launch=byts, avg_launch_us=round(us, 2), peak_measured_on_box=5440.0,
-                     note="peak_measured_on_box = write-only stream rate of this box in the kernel's own pattern, 32 KB contiguous per workgroup (tools/write_peak.hip, profiles/r01_onbox_peaks.txt): the kernel writes 32 of every 34 bytes")
+                     note="peak_measured_on_box = write-only stream rate of this box in the kernel's own pattern, 32 KB contiguous per workgroup (tools/write_peak.hip, profiles/archive/r01_onbox_peaks.txt): the kernel writes 32 of every 34 bytes")
 
     # ---- second half of the metric: codec forward us/frame (BASELINE config 5: 2-codec encode+quantise+decode,
     # batch 4096 frames, hipGraph-captured forward), plus the batch-1 latency the reference's eval loop actually pays
@@ -372,7 +434,8 @@ def main():
     if comm.rank == 0 and comm.world == 1 and not args.no_infer:
         def fwd_time(Bi, reps):
             engi = CascadeEngine(Bi, 2, BKD, [[2], [2]], [32, 32], res_scalar=RES_SCALAR, scale_first=True, lpc=True, device=dev)
-            engi.params.copy_(eng.params)
+            engi.set_params(eng.params)
+            engi.refresh_wt()                    # once after loading weights: the forward takes the parameter-image prologue
             engi.keep_activations = False        # encode + quantise + decode only: nothing is kept for a backward pass
             xi = torch.from_numpy(np.tile(x_np, (max(1, Bi // B + 1), 1, 1))[:Bi].copy()).to(dev)
             for _ in range(2):

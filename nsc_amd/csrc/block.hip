@@ -744,7 +744,7 @@ static int launch_block_fwd2(const BlockArgs& a, hipStream_t st) {
   constexpr int CR = 4 * NK1;
   const size_t smem = ((size_t)(CR + NARROW) * 112 + (size_t)3 * NARROW * 80 + (size_t)K15 * NARROW * 48 + (RT9 == 7 ? 728 : 0)) * sizeof(float);
   auto kern = gated_block_fwd2_kernel<RT9, NK1, DIL>;
-  static const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);   // once per instantiation
+  const hipError_t e = NSC_SMEM_ATTR(kern, (int)smem);   // once per instantiation
   NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "gated_block_fwd2: smem attr: %s", hipGetErrorString(e));
   const int tpf = nsc_cdiv(a.T, 64);
   const int ntiles = a.B * tpf;
@@ -789,7 +789,7 @@ extern "C" int nsc_gated_block_fwd(const float* x, const float* w1, const float*
   do {                                                                                                              \
     auto kern = gated_block_fwd_kernel<RT>;                                                                         \
     if (smem > 64 * 1024) {                                                                                         \
-      static const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      const hipError_t e = NSC_SMEM_ATTR(kern, 160 * 1024); \
       NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "gated_block_fwd: smem attr: %s", hipGetErrorString(e));         \
     }                                                                                                               \
     hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, a, ldx, ldg);                                               \
@@ -1281,7 +1281,7 @@ extern "C" int nsc_gated_block_wgrad(const float* x, const float* h, const float
   do {                                                                                                              \
     auto kern = part == 0 ? gated_block_wgrad_kernel<RT, NW_, 0>                                                    \
                           : (part == 1 ? gated_block_wgrad_kernel<RT, NW_, 1> : gated_block_wgrad_kernel<RT, NW_, 2>); \
-    static const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   \
+    const hipError_t e = NSC_SMEM_ATTR(kern, 160 * 1024);   \
     NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "gated_block_wgrad: smem attr: %s", hipGetErrorString(e));         \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW_), smem, st, a, ldn, ldg, ldh);                               \
   } while (0)
@@ -1374,7 +1374,7 @@ static int launch_wgrad_batch(const nsc_block_wgrad_job* jobs, const int* idx, i
   t.njobs = n;
   for (int q = 0; q < n; ++q) t.a[q].slab_stride = stride;
   auto kern = gated_block_wgrad_batch_kernel<RT9>;
-  static const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  const hipError_t e = NSC_SMEM_ATTR(kern, 160 * 1024);
   NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "gated_block_wgrad_batch: smem attr: %s", hipGetErrorString(e));
   hipLaunchKernelGGL(kern, dim3(2 * used), dim3(256), smem, st, t, ldn, ldg);
   NSC_CHECK_LAUNCH("gated_block_wgrad_batch");
@@ -2546,7 +2546,7 @@ static int launch_block_dgrad2(const BlockDgradArgs& a, hipStream_t st) {
                        (size_t)K15 * W15T + (size_t)K9 * w9t) * sizeof(float);
   NSC_REQUIRE(smem <= 160 * 1024, NSC_ERR_UNSUPPORTED, "gated_block_dgrad2: %zu B LDS", smem);
   auto kern = gated_block_dgrad2_kernel<RT9, NK9, DIL, CIN1>;
-  static const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);   // once per instantiation
+  const hipError_t e = NSC_SMEM_ATTR(kern, (int)smem);   // once per instantiation
   NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "gated_block_dgrad2: smem attr: %s", hipGetErrorString(e));
   const int tpf = nsc_cdiv(a.T, 64);
   const int ntiles = a.B * tpf;
@@ -2587,7 +2587,7 @@ extern "C" int nsc_gated_block_dgrad(const float* x, const float* h, const float
 #define LAUNCH_DG(RT)                                                                                               \
   do {                                                                                                              \
     auto kern = gated_block_dgrad_kernel<RT>;                                                                       \
-    static const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   \
+    const hipError_t e = NSC_SMEM_ATTR(kern, 160 * 1024);   \
     NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "gated_block_dgrad: smem attr: %s", hipGetErrorString(e));         \
     hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, a, ldy, lda, ldn);                                          \
   } while (0)

@@ -467,7 +467,7 @@ static int launch_fwd_m32(const nsc_conv_desc* d, const float* x, const float* w
   *taken = smem <= 160 * 1024;
   if (!*taken) return NSC_OK;
   auto kern = conv1d_fwd_m32_kernel<NP, KS>;
-  static const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  const hipError_t e = NSC_SMEM_ATTR(kern, 160 * 1024);
   NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "conv1d_fwd_m32: set smem attr: %s", hipGetErrorString(e));
   dim3 grid(nsc_cdiv(d->Tout, TT), d->B, nsc_cdiv(d->Cout, ROWS));
   hipLaunchKernelGGL(kern, grid, dim3(256 * KS), smem, st, *d, x, w, bias, res, aux, y, ldx, win);
@@ -499,7 +499,7 @@ static int launch_fwd_ks(const nsc_conv_desc* d, const float* x, const float* w,
   NSC_REQUIRE(smem <= 160 * 1024, NSC_ERR_UNSUPPORTED, "conv1d_fwd: x tile %zu B exceeds LDS", smem);
   auto kern = conv1d_fwd_kernel<RT, NC, CIN1, KS, NPRE>;
   if (smem > 64 * 1024) {
-    static const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const hipError_t e = NSC_SMEM_ATTR(kern, 160 * 1024);
     NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "conv1d_fwd: set smem attr: %s", hipGetErrorString(e));
   }
   const int nrt = nsc_cdiv(d->Cout, 16);
@@ -737,7 +737,7 @@ static int launch_cout1_v2(const nsc_conv_desc* d, const float* x, const float* 
   const size_t smem = ((size_t)d->Cin * ldx + (size_t)d->Cin * KP + 8 * TT) * sizeof(float);
   if (smem > 160 * 1024) return 1;     // does not fit: caller falls back to v1
   auto kern = conv1d_cout1_v2_kernel<K, R>;
-  static const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  const hipError_t e = NSC_SMEM_ATTR(kern, 160 * 1024);
   NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "conv1d_cout1_v2: set smem attr: %s", hipGetErrorString(e));
   hipLaunchKernelGGL(kern, dim3(nsc_cdiv(d->Tout, TT), d->B), dim3(512), smem, st, *d, x, w, bias, res, aux, y, ldx);
   NSC_CHECK_LAUNCH("conv1d_cout1_v2");
@@ -764,7 +764,7 @@ extern "C" int nsc_conv1d_cout1_fwd(const nsc_conv_desc* d, const float* x, cons
   const size_t smem = ((size_t)d->Cin * ldx + (size_t)d->K * d->Cin + 128) * sizeof(float);
   NSC_REQUIRE(smem <= 160 * 1024, NSC_ERR_UNSUPPORTED, "conv1d_cout1: tile %zu B exceeds LDS", smem);
   if (smem > 64 * 1024) {
-    static const hipError_t e = hipFuncSetAttribute((const void*)conv1d_cout1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const hipError_t e = NSC_SMEM_ATTR(conv1d_cout1_kernel, 160 * 1024);
     NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "conv1d_cout1: set smem attr: %s", hipGetErrorString(e));
   }
   dim3 grid(nsc_cdiv(d->Tout, 128), d->B);
@@ -1130,7 +1130,7 @@ static int launch_wgrad(const nsc_conv_desc* d, const float* x, const float* dz,
   NSC_REQUIRE(p.smem <= 160 * 1024, NSC_ERR_UNSUPPORTED, "conv1d_wgrad: tiles %zu B exceed LDS", p.smem);
   auto kern = conv1d_wgrad_kernel<RT, CT>;
   if (p.smem > 64 * 1024) {
-    static const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const hipError_t e = NSC_SMEM_ATTR(kern, 160 * 1024);
     NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "conv1d_wgrad: set smem attr: %s", hipGetErrorString(e));
   }
   hipLaunchKernelGGL(kern, dim3(p.gx, p.gy), dim3(512), p.smem, st, *d, x, dz, dw, db, ws, p.slab_stride, flip, p.ldx,
@@ -1253,7 +1253,7 @@ static int launch_cw_class(const nsc_conv_wgrad_job* jobs, const int* idx, const
   t.njobs = n;
   auto kern = conv1d_wgrad_batch_kernel<RT, CT>;
   if (smem > 64 * 1024) {
-    static const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const hipError_t e = NSC_SMEM_ATTR(kern, 160 * 1024);
     NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "conv1d_wgrad_batch: set smem attr: %s", hipGetErrorString(e));
   }
   hipLaunchKernelGGL(kern, dim3(wg), dim3(512), smem, st, t);

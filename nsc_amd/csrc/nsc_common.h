@@ -41,6 +41,25 @@ __device__ __forceinline__ void nsc_lds_barrier() { asm volatile("s_waitcnt lgkm
     }                                         \
   } while (0)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: asked for once per (kernel instantiation,
+// device) - a process that touches a second GPU sets it there too - and a failure is not remembered (the next launch asks again).
+#include <atomic>
+inline hipError_t nsc_smem_attr(const void* kern, int bytes, std::atomic<unsigned long long>& done) {
+  int dv = 0;
+  hipError_t e = hipGetDevice(&dv);
+  if (e != hipSuccess) return e;
+  const bool cached = dv >= 0 && dv < 64;
+  if (cached && ((done.load(std::memory_order_relaxed) >> dv) & 1ull)) return hipSuccess;
+  e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess && cached) done.fetch_or(1ull << dv, std::memory_order_relaxed);
+  return e;
+}
+#define NSC_SMEM_ATTR(kern, bytes)                                             \
+  ([&]() -> hipError_t {                                                       \
+    static std::atomic<unsigned long long> done_{0};                           \
+    return nsc_smem_attr((const void*)(kern), (int)(bytes), done_);            \
+  })()
+
 #define NSC_CHECK_LAUNCH(name)                                                     \
   do {                                                                             \
     hipError_t e__ = hipGetLastError();                                            \

@@ -187,7 +187,9 @@ __global__ __launch_bounds__(256) void quantize_fwd_kernel(const float* __restri
           if (ok[i][j] && p[i][j] > best) { best = p[i][j]; idx = k; }
         }
       idx = grp_argmax<LPC>(best, idx);
-      q = bins[idx];
+      // a NaN code makes every p NaN: no comparison succeeds and idx keeps its sentinel - never index the table with it, and a
+      // diverged run stays visibly NaN (like nsc_tanh)
+      q = (c != c) ? c : bins[min(idx, nb - 1)];
     }
     if (live) {
 #pragma unroll
@@ -448,7 +450,7 @@ __global__ __launch_bounds__(256) void quantize_fwd32_wave_kernel(const float* _
               if (p[i][j] > best) { best = p[i][j]; idx = k; }
             }
           idx = grp_argmax<LPC>(best, idx);
-          q = bins[idx];
+          q = (c != c) ? c : bins[min(idx, NB - 1)];     // NaN in: NaN out, and the sentinel never indexes the table
         }
 #pragma unroll
         for (int i = 0; i < ITER; ++i) {

@@ -239,7 +239,7 @@ template <int RT, int NK>
 int launch_up_fwd(const UpFwdArgs& a, hipStream_t st) {
   const size_t smem = (size_t)2 * 4 * NK * ULD * sizeof(float);
   auto kern = upsample_fwd_kernel<RT, NK>;
-  static const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  const hipError_t e = NSC_SMEM_ATTR(kern, (int)smem);
   NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "upsample_fwd: smem attr: %s", hipGetErrorString(e));
   const int tpf = nsc_cdiv(a.T, UTT);
   static const int skip = NSC_PROBE_INT("NSC_UP_SKIP", 0);   // timing probe (PROBES build only)
@@ -251,7 +251,7 @@ template <int RT, int NK>
 int launch_up_bwd(const UpBwdArgs& a, hipStream_t st) {
   const size_t smem = (size_t)2 * 4 * NK * ULD * sizeof(float);
   auto kern = upsample_bwd_kernel<RT, NK>;
-  static const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  const hipError_t e = NSC_SMEM_ATTR(kern, (int)smem);
   NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "upsample_bwd: smem attr: %s", hipGetErrorString(e));
   const int tpf = nsc_cdiv(a.T, UTT);
   hipLaunchKernelGGL(kern, dim3(a.B * tpf), dim3(512), smem, st, a, tpf);

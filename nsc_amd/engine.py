@@ -588,6 +588,9 @@ class _SegmentRecorder:
         self.mark = self.eng._nlaunch
 
     def cut(self, action):
+        # "empty" is decided from the engine's launch counter: every GPU launch inside a captured step must go through
+        # eng.stream() (a torch op or a raw-stream launch issued here would not be counted and could land in the segment that
+        # replays AFTER the collective)
         if self.eng._nlaunch == self.mark and self.segs:
             self.segs[-1][1].append(action)
             return
@@ -807,6 +810,16 @@ class CascadeEngine:
                 rec.begin()
                 self.train_step(x, target, cfg, lpc_x=lpc_x, comm=comm)
                 rec.finish()
+            except BaseException:
+                # leave the stream out of capture mode and drop the half-built segments, so that the caller's fallback
+                # (eager launches in this process) starts from a clean stream
+                try:
+                    if rec.cur is not None:
+                        rec.cur.capture_end()
+                except Exception:
+                    pass
+                rec.segs.clear()
+                raise
             finally:
                 self._rec = None
         torch.cuda.current_stream().wait_stream(s)
@@ -1011,8 +1024,27 @@ class CascadeEngine:
             out[name] = host[off:off + n].reshape(shape).copy()
         return out
 
-    images_valid = False   # the forward images mirror self.params: set by refresh_wt, cleared by everything that writes params
+    # The forward images mirror self.params.  They are valid iff refresh_wt has run since the last write to the parameters:
+    # writes by this engine's own kernels (Adam) clear the flag, writes through torch (params.copy_, eng.view(name)[...] = ..,
+    # optimizers stepping on views) bump the tensor's version counter, which refresh_wt remembers.  A hipGraph captured with
+    # valid images bakes the image path in: a captured forward must contain refresh_wt() or be re-captured after a weight load.
+    _img_ok = False
+    _img_version = -1
     use_images = True      # fast prologue of the persistent block kernels from the images (False: A/B and tests)
+
+    @property
+    def images_valid(self):
+        return self._img_ok and self.params._version == self._img_version
+
+    @images_valid.setter
+    def images_valid(self, v):
+        self._img_ok = bool(v)
+        self._img_version = self.params._version if v else -1
+
+    def set_params(self, flat):
+        """Overwrite the flat parameter buffer (another engine's .params, a checkpoint) and invalidate everything derived from it."""
+        self.params.copy_(flat)
+        self.images_valid = False
 
     def refresh_wt(self):
         """Rebuild everything derived from the parameters: the flipped / transposed data-gradient kernels and the kernel-ready
@@ -1164,10 +1196,16 @@ class CascadeEngine:
         if grad_allreduce is not None and not self.dp_overlap:
             # one message for everything trainable, after the batched weight-gradient launches at the tail of the step (the
             # launches stay whole: per-codec flushes split them); frozen scopes in front of the first trainable one are not sent
-            lo = min([self.layout.scope_range(f"scope_{i + 1}")[0] for i in range(first_needed, self.N)] +
-                     ([self.layout.scope_range("lpc_quan")[0]] if lpc_rng is not None else []))
-            hi = self.layout.scope_range(f"scope_{self.N}")[1]
-            pending.append(self._collective("async", lambda lo=lo, hi=hi: grad_allreduce(self.grads[lo:hi])))
+            # (the LSF quantizer's two gradients adjoin scope_1: they ride along when scope_1 trains, and travel as a small
+            # message of their own when it is frozen - never the frozen scope's zeros; nothing trainable: nothing is sent)
+            if first_needed < self.N:
+                lo = self.layout.scope_range(f"scope_{first_needed + 1}")[0]
+                hi = self.layout.scope_range(f"scope_{self.N}")[1]
+                if lpc_rng is not None and lpc_rng[1] == lo:
+                    lo, lpc_rng = lpc_rng[0], None
+                pending.append(self._collective("async", lambda lo=lo, hi=hi: grad_allreduce(self.grads[lo:hi])))
+            if lpc_rng is not None:
+                pending.append(self._collective("async", lambda r=lpc_rng: grad_allreduce(self.grads[r[0]:r[1]])))
         if grad_allreduce is not None:
             self._collective("wait", None)
         for w in pending:

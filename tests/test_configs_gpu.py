@@ -54,7 +54,7 @@ def _cfg4_engine(b, device, params=None):
     from nsc_amd.engine import CascadeEngine
     eng = CascadeEngine(b, 4, BKD, [[2, 2]] * 4, [32] * 4, res_scalar=2.0, device=device)
     if params is not None:
-        eng.params.copy_(params)
+        eng.set_params(params)
     eng.refresh_wt()
     return eng
 
@@ -96,7 +96,7 @@ def _cfg5_engine(b, device, params=None):
     eng = CascadeEngine(b, 2, BKD, [[2], [2]], [32, 32], res_scalar=2.0, device=device)
     eng.keep_activations = False
     if params is not None:
-        eng.params.copy_(params)
+        eng.set_params(params)
     return eng
 
 

@@ -379,3 +379,34 @@ def test_three_codec_follower_two_downsamplings():
     for s in ("scope_1", "scope_2"):
         a, b = eng.layout.scope_range(s)
         assert float(eng.grads[a:b].abs().max()) == 0.0
+
+
+def test_parameter_write_after_refresh_invalidates_the_block_images():
+    """refresh_wt -> a direct write to the parameters (params.copy_, a view, set_params) -> forward must NOT decode with
+    the stale kernel-ready images: the forward has to equal the plain entry points on the NEW weights."""
+    B = 4
+    ps_a = make_store(1, [[2]], [32], seed=1)
+    ps_b = make_store(1, [[2]], [32], seed=2)
+    x = synth_frames(B, seed=3)
+    xd = torch.tensor(x, dtype=torch.float32, device=dev()).transpose(1, 2).contiguous()
+    ref = _engine(B, 1, [[2]], [32], ps_b)
+    ref.use_images = False
+    want = ref.forward(xd, 1.0, True).clone()
+    for how in ("copy_", "view", "set_params", "load_named"):
+        eng = _engine(B, 1, [[2]], [32], ps_a)             # refresh_wt has run: images valid for weights A
+        assert eng.images_valid
+        if how == "copy_":
+            eng.params.copy_(ref.params)
+        elif how == "view":
+            for name in eng.layout.entries:
+                eng.view(name).copy_(ref.view(name))
+        elif how == "set_params":
+            eng.set_params(ref.params)
+        else:
+            eng.load_named(ps_b.params)
+        assert not eng.images_valid, how
+        got = eng.forward(xd, 1.0, True)
+        assert torch.equal(got, want), how
+        eng.refresh_wt()
+        assert eng.images_valid
+        assert torch.equal(eng.forward(xd, 1.0, True), want), how + " after refresh"

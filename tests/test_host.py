@@ -325,3 +325,34 @@ def test_epoch_rows_shard_like_a_single_process_at_the_global_batch():
     assert np.array_equal(p0, np.arange(n))                       # epoch 0 reads the matrix in file order like the reference
     assert not np.array_equal(epoch_permutation(n, seed, 1, p0.copy()), np.arange(n))
     assert np.array_equal(epoch_permutation(n, seed, 1, np.arange(n)), epoch_permutation(n, seed, 1, np.arange(n)))
+
+
+def test_bench_starts_its_own_ranks_when_asked_for_more_than_one_gpu():
+    """`python bench.py --gpus N` without a launcher environment must start the N ranks itself.  On this CPU
+    box: with the RCCL backend and no GPU the parent refuses with a clear message and rc 2 (nothing launched); with
+    NSC_DIST_BACKEND=gloo it launches torch.distributed.run as a child, whose ranks fail for lack of a GPU - the parent relays
+    the failure as a non-zero rc and prints no JSON line."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "NSC_DIST_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True,
+                       env=env, timeout=300)
+    if torch.cuda.device_count() < 2:
+        assert r.returncode == 2 and "needs 2 GPUs" in r.stderr and "{" not in r.stdout
+    env["NSC_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert "launching 2 ranks" in r.stderr
+    if not torch.cuda.is_available():
+        assert r.returncode != 0 and '"metric"' not in r.stdout
+
+
+def test_comm_refuses_rccl_with_fewer_gpus_than_local_ranks(monkeypatch):
+    """First-contact robustness: RCCL with two ranks on one device fails deep inside the first collective; Comm says so up front."""
+    from nsc_amd import dist as D
+    monkeypatch.setenv("RANK", "0"); monkeypatch.setenv("WORLD_SIZE", "2"); monkeypatch.setenv("LOCAL_RANK", "0")
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "2")
+    monkeypatch.setattr(D.torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(D.torch.cuda, "device_count", lambda: 1)
+    with pytest.raises(RuntimeError, match="one GPU per local rank"):
+        D.Comm(backend="nccl")

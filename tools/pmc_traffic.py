@@ -56,7 +56,9 @@ for pat, tag in CLASSES:
 # per launch SHAPE for the kernels that run at more than one grid size in the profiled command
 ftg, fcg = read("pass3", "FETCH_SIZE", True)
 wtg, wcg = read("pass4", "WRITE_SIZE", True)
-for pat, tag in (("quantize_fwd_kernel", "quantize_fwd"), ("gated_block_dgrad2", "block_dgrad"), ("gated_block_fwd2", "block_fwd")):
+# (the op-surface quantizer forward at inference batch sizes is quantize_fwd32_wave_kernel: bench.py's roofline_quantizer record)
+for pat, tag in (("quantize_fwd_kernel", "quantize_fwd"), ("quantize_fwd32_wave_kernel", "quantize_fwd_wave"),
+                 ("gated_block_dgrad2", "block_dgrad"), ("gated_block_fwd2", "block_fwd")):
     grids = sorted({k.split("@grid")[1] for k in ftg if pat in k})
     for g in grids:
         fk = [k for k in ftg if pat in k and k.endswith("@grid" + g)]
