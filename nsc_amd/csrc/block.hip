@@ -333,41 +333,43 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
     // lane's register fragments laid out [wave][group of 4][lane][4], so that the whole prologue is ~30 coalesced 16-byte
     // loads per lane instead of ~115 dword loads with index arithmetic (a memory instruction costs the issuing wave 60-100
     // cycles whatever its width: the prologue was 9-13 k cycles of a 40-70 us launch).
+    // Round 4: (1) the k15 gate kernels (w2s, 57.6 KB: a quarter of the image) are not read before phase 2 of the first tile -
+    // they go straight into LDS by LDS-DMA issued AFTER the wait below (see gated_block_dgrad2_role) and land under phases 0 / 1;
+    // (2) fragments that several waves hold in common are ONE copy in the image, fetched by all of them (the second fetch of a
+    // line is an L1 hit or merges with the first): group A = W1 fragments + b1 (per row tile of h: 2 copies), group B = k9
+    // fragments + b9 (per phase-3 row tile: 6 | 4 copies), group C = the gate biases of a wave's two phase-2 jobs (per wave).
+    // 240 -> 170 KB of L2 -> CU traffic per workgroup at C = 100, of which 110 KB are waited for before the first MFMA.
     const f32x4* img4 = reinterpret_cast<const f32x4*>(a.img);
-    constexpr int NA4 = K15 * NARROW * LDW / 4, NE4 = (NA4 + 511) / 512;
-    constexpr int NFR = NK1 + K9 * 5 + 16, NF4 = (NFR + 3) / 4;
-    f32x4 tA[NE4], fr[NF4];
+    constexpr int NA4 = K15 * NARROW * LDW / 4, NP4 = RT9 == 7 ? W9P / 4 : 0;
+    constexpr int NFA = NK1 + 4, NF4A = (NFA + 3) / 4, NF4B = (K9 * 5 + 4 + 3) / 4, NF4C = 2, NVB = RT9 == 7 ? 6 : 4;
+    f32x4 fa[NF4A], fb[NF4B], fc[NF4C];
+    const f32x4* fbase = img4 + NA4 + NP4 + lane;
 #pragma unroll
-    for (int i = 0; i < NE4; ++i) tA[i] = img4[min(tid + 512 * i, NA4 - 1)];
-    const f32x4* fp = img4 + NA4 + wave * NF4 * 64 + lane;
+    for (int g = 0; g < NF4A; ++g) fa[g] = fbase[(r1 * NF4A + g) * 64];
 #pragma unroll
-    for (int g = 0; g < NF4; ++g) fr[g] = fp[g * 64];
+    for (int g = 0; g < NF4B; ++g) fb[g] = fbase[(2 * NF4A + rt3 * NF4B + g) * 64];
+#pragma unroll
+    for (int g = 0; g < NF4C; ++g) fc[g] = fbase[(2 * NF4A + NVB * NF4B + wave * NF4C + g) * 64];
     f32x4 tP = {0.f, 0.f, 0.f, 0.f};
-    if (RT9 == 7 && tid < W9P / 4) tP = img4[NA4 + 8 * NF4 * 64 + tid];
-#pragma unroll
-    for (int i = 0; i < NE4; ++i)
-      if (tid + 512 * i < NA4) reinterpret_cast<f32x4*>(w2s)[tid + 512 * i] = tA[i];
+    if (RT9 == 7 && tid < W9P / 4) tP = img4[NA4 + tid];
     if (RT9 == 7 && tid < W9P / 4) reinterpret_cast<f32x4*>(w9p)[tid] = tP;
-#define NSC_FR(f) fr[(f) / 4][(f) % 4]
 #pragma unroll
-    for (int u = 0; u < NK1; ++u) w1r[u] = NSC_FR(u);
+    for (int u = 0; u < NK1; ++u) w1r[u] = fa[u / 4][u % 4];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) b1r[reg] = fa[(NK1 + reg) / 4][(NK1 + reg) % 4];
 #pragma unroll
     for (int tap = 0; tap < K9; ++tap)
 #pragma unroll
-      for (int u = 0; u < 5; ++u) w9r[tap][u] = NSC_FR(NK1 + tap * 5 + u);
+      for (int u = 0; u < 5; ++u) w9r[tap][u] = fb[(tap * 5 + u) / 4][(tap * 5 + u) % 4];
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      b1r[reg] = NSC_FR(NK1 + 45 + reg);
-      b9r[reg] = NSC_FR(NK1 + 49 + reg);
-    }
+    for (int reg = 0; reg < 4; ++reg) b9r[reg] = fb[(45 + reg) / 4][(45 + reg) % 4];
 #pragma unroll
     for (int e = 0; e < 2; ++e)
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        blr[e][u] = NSC_FR(NK1 + 53 + 2 * e + u);
-        brr[e][u] = NSC_FR(NK1 + 57 + 2 * e + u);
+        blr[e][u] = fc[0][2 * e + u];
+        brr[e][u] = fc[1][2 * e + u];
       }
-#undef NSC_FR
   } else {
   // Every load below uses a CLAMPED index instead of a mask: pad rows of A (output channels >= 20 / >= C) only feed
   // output rows that are never stored, and pad k-rows (ci >= C) multiply x rows that phase 0 writes as zeros, so any
@@ -419,6 +421,21 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
 
 
   nsc_wait_vmem();   // weights (and the first tile) are in: no vmcnt guards on register operands inside the loop
+  // the k15 gate kernels by LDS-DMA (image path; see gated_block_dgrad2_role): the youngest vector-memory operations when the tile
+  // loop starts, waited for by hand before the first tile's phase 2
+  const bool dma2 = a.img != nullptr;
+  if (dma2) {
+    constexpr int NA4 = K15 * NARROW * LDW / 4, NG2 = (NA4 + 511) / 512;
+    const unsigned lds2 = (unsigned)(unsigned long long)w2s;
+#pragma unroll
+    for (int i = 0; i < NG2; ++i) {
+      if (tid + 512 * i < NA4) {
+        const f32x4* gp = reinterpret_cast<const f32x4*>(a.img) + tid + 512 * i;
+        const unsigned m0v = lds2 + (unsigned)((i * 8 + wave) * 1024);
+        asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp), "s"(m0v) : "memory", "m0");
+      }
+    }
+  }
   NSC_STAMP(33);
   for (int tile = first; tile < last; ++tile) {
     const int b = tile / tpf, t0 = (tile - b * tpf) * TT;
@@ -518,6 +535,9 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
       }
     }
     NSC_STAMP(37);
+    // (first tile on the image path: the LDS-DMA of the k15 gate kernels has had phases 0 and 1 to land; nothing younger is
+    // outstanding in the spread form - the next tile's x loads go out inside phase 2)
+    if (dma2 && tile == first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     nsc_lds_barrier();
     NSC_STAMP(38);
 
@@ -2063,29 +2083,39 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
   constexpr int NC1 = RT9 == 7 ? 4 : 2;
   float w1r[5];
   if (a.img) {
-    // FAST prologue from the engine's kernel-ready image (see gated_block_fwd2_kernel): the LDS image of w15s | w9ps as it
-    // stands, then every lane's k9 / 1x1 fragments [wave][group of 4][lane][4]: ~24 coalesced 16-byte loads per lane
-    // instead of ~95 dword loads with index arithmetic (the prologue was 12-17 k cycles of a 47-85 us launch).
+    // FAST prologue from the engine's kernel-ready image (see gated_block_fwd2_kernel).  Round 4: only what the FIRST MFMA phase
+    // needs is waited for here - the k9^T fragments, the packed k9 table (w9ps, through registers) and the first tile.  The k15
+    // table (w15s, 48 KB: a quarter of the image) is not read before the first k15-gradient phase: it goes straight into LDS by
+    // LDS-DMA (global_load_lds_dwordx4, no registers) issued AFTER the wait below and lands under the first k9-gradient phase.
+    // The fragments of waves w and w + 4 (same K-quarter) are ONE copy in the image: both waves fetch the same lines (the
+    // second fetch is an L1 hit or merges with the first) - the per-wave copies were 131 KB of L2 -> CU traffic per workgroup,
+    // x 256 workgroups bursting at once, the prologue is bound by exactly that.
     const f32x4* img4 = reinterpret_cast<const f32x4*>(a.img);
-    const int nA4 = (K15 * W15T + K9 * w9t) / 4;
-    constexpr int NE4 = (K15 * W15T + K9 * (4 * 4 * NK9 + 8) + 4 * 512 - 1) / (4 * 512);
-    constexpr int NFR = K9 * (NJ9 - 1) + 3 + 5, NF4 = (NFR + 3) / 4;
-    f32x4 tA[NE4], fr[NF4];
-#pragma unroll
+    constexpr int N15_4 = K15 * W15T / 4;
+    const int n9_4 = K9 * w9t / 4;
+    constexpr int NE9 = (K9 * (4 * 4 * NK9 + 8) / 4 + 511) / 512;
+    constexpr int NFS = K9 * (NJ9 - 1) + 3, NF4S = (NFS + 3) / 4, NF4W = 2;
+    f32x4 t9[NE9], fr[NF4S], fw[NF4W];
 #if defined(NSC_EXP) && (NSC_EXP & 2)
-    for (int i = 0; i < NE4; ++i) tA[i] = (f32x4){0.f, 0.f, 0.f, (float)tid};
-    const f32x4* fp = img4 + nA4 + wave * NF4 * 64 + lane;
 #pragma unroll
-    for (int g = 0; g < NF4; ++g) fr[g] = (f32x4){0.f, 0.f, (float)g, (float)tid};
+    for (int i = 0; i < NE9; ++i) t9[i] = (f32x4){0.f, 0.f, 0.f, (float)tid};
+#pragma unroll
+    for (int g = 0; g < NF4S; ++g) fr[g] = (f32x4){0.f, 0.f, (float)g, (float)tid};
+#pragma unroll
+    for (int g = 0; g < NF4W; ++g) fw[g] = (f32x4){0.f, 0.f, (float)g, (float)tid};
 #else
-    for (int i = 0; i < NE4; ++i) tA[i] = img4[min(tid + 512 * i, nA4 - 1)];
-    const f32x4* fp = img4 + nA4 + wave * NF4 * 64 + lane;
 #pragma unroll
-    for (int g = 0; g < NF4; ++g) fr[g] = fp[g * 64];
+    for (int i = 0; i < NE9; ++i) t9[i] = img4[N15_4 + min(tid + 512 * i, n9_4 - 1)];
+    const f32x4* fps = img4 + N15_4 + n9_4 + kg * NF4S * 64 + lane;
+#pragma unroll
+    for (int g = 0; g < NF4S; ++g) fr[g] = fps[g * 64];
+    const f32x4* fpw = img4 + N15_4 + n9_4 + 4 * NF4S * 64 + wave * NF4W * 64 + lane;
+#pragma unroll
+    for (int g = 0; g < NF4W; ++g) fw[g] = fpw[g * 64];
 #endif
 #pragma unroll
-    for (int i = 0; i < NE4; ++i)
-      if (tid + 512 * i < nA4) reinterpret_cast<f32x4*>(w15s)[tid + 512 * i] = tA[i];
+    for (int i = 0; i < NE9; ++i)
+      if (tid + 512 * i < n9_4) reinterpret_cast<f32x4*>(w9ps)[tid + 512 * i] = t9[i];
 #define NSC_FR(f) fr[(f) / 4][(f) % 4]
 #pragma unroll
     for (int tp = 0; tp < K9; ++tp)
@@ -2093,9 +2123,9 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
       for (int j = 0; j < NJ9 - 1; ++j) w9r[tp][j] = NSC_FR(tp * (NJ9 - 1) + j);
 #pragma unroll
     for (int i = 0; i < 3; ++i) w9x[i] = NSC_FR(K9 * (NJ9 - 1) + i);
-#pragma unroll
-    for (int s5 = 0; s5 < 5; ++s5) w1r[s5] = CIN1 ? 0.f : NSC_FR(K9 * (NJ9 - 1) + 3 + s5);
 #undef NSC_FR
+#pragma unroll
+    for (int s5 = 0; s5 < 5; ++s5) w1r[s5] = CIN1 ? 0.f : fw[s5 / 4][s5 % 4];
   } else {
   // ---- once per workgroup: weights -> registers / LDS (clamped indices: pad k-rows meet zero rows of the staged
   // tiles; only k-steps / taps past the end need a real zero) ----
@@ -2154,13 +2184,32 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
   float w1c[CIN1 ? NARROW : 1];
   if (CIN1) {
     // (with an image: the 20 taps follow the fragment region)
-    const float* w1p = a.img ? a.img + (K15 * W15T + K9 * w9t) + 8 * 64 * 4 * ((K9 * (NJ9 - 1) + 3 + 5 + 3) / 4) : a.wt1;
+    const float* w1p = a.img ? a.img + (K15 * W15T + K9 * w9t) + 64 * 4 * (4 * ((K9 * (NJ9 - 1) + 3 + 3) / 4) + 8 * 2) : a.wt1;
 #pragma unroll
     for (int c = 0; c < NARROW; ++c) w1c[c] = w1p[c];
   }
 
 
   nsc_wait_vmem();   // weights (and the first tile) are in: no vmcnt guards on register operands inside the loop
+  // the k15 table by LDS-DMA (image path): 16 bytes per lane, 1 KiB per wave instruction, destination m0 + lane * 16.  Hidden in
+  // inline asm: hipcc would otherwise wait vmcnt(0) for it at the next use of any ordinary load's result and at every barrier.
+  // Issued after the wait above (it is the YOUNGEST vector-memory operation when the tile loop starts) and waited for by hand at
+  // the end of the first tile's k9-gradient phase.
+  const bool dma15 = a.img != nullptr;
+  if (dma15) {
+#if !(defined(NSC_EXP) && (NSC_EXP & 2))
+    constexpr int N15_4 = K15 * W15T / 4, NG15 = (N15_4 + 511) / 512;
+    const unsigned lds15 = (unsigned)(unsigned long long)w15s;
+#pragma unroll
+    for (int i = 0; i < NG15; ++i) {
+      if (tid + 512 * i < N15_4) {
+        const f32x4* gp = reinterpret_cast<const f32x4*>(a.img) + tid + 512 * i;
+        const unsigned m0v = lds15 + (unsigned)((i * 8 + wave) * 1024);
+        asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp), "s"(m0v) : "memory", "m0");
+      }
+    }
+#endif
+  }
   NSC_STAMP(1);
   for (int tile = first; tile < last; ++tile) {
     const int b = tile / tpf, t0 = (tile - b * tpf) * TT;
@@ -2286,7 +2335,14 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) ppk[reg * PSW + col] = pk[0][reg] + pk[1][reg];
       } else {
+#if defined(NSC_EXP) && (NSC_EXP & 32)
+        // timing experiment (wrong values): what an EDGE-started chain would save - a fresh tile at t = 0 needs no dg left of the
+        // frame, i.e. one dense column tile less at dilation 2 (78 of 92 columns: 5 tiles instead of 6; dilation 1: 71 of 78, still 5)
+        constexpr int NCTE = DIL == 2 ? NCTA - 1 : NCTA;
+        constexpr int NA = (NCTE + 1) / 2, NMINE = hf == 0 ? NA : NCTE - NA, CB = hf == 0 ? 0 : NA * 16;
+#else
         constexpr int NA = (NCTA + 1) / 2, NMINE = hf == 0 ? NA : NCTA - NA, CB = hf == 0 ? 0 : NA * 16;
+#endif
         {
           f32x4 acc[NMINE];
 #pragma unroll
@@ -2312,6 +2368,12 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
       }
     }
     NSC_STAMP(5);
+    if (dma15 && tile == first) {
+      // the k15 table's LDS-DMA has had the whole k9-gradient phase to land.  Vector-memory operations retire in order: the only
+      // younger ones are the NQY dy prefetch loads of the hooks above (spread form), so vmcnt(NQY) = "the DMA is in LDS".
+      if (spread) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQY) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     nsc_lds_barrier();
     NSC_STAMP(6);
 
@@ -2328,7 +2390,11 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
       asm volatile("" : "+v"(tid_g));
       auto glu = [&](auto fresh_c) {
         constexpr bool FR = decltype(fresh_c)::value;
+#if defined(NSC_EXP) && (NSC_EXP & 32)
+        constexpr int j_lo = FR ? 0 : 2 * Hh, ncol = FR ? (DIL == 2 ? WA16 - 16 : WA16) : TT, st_lo = FR ? Hh : 2 * Hh;
+#else
         constexpr int j_lo = FR ? 0 : 2 * Hh, ncol = FR ? WA16 : TT, st_lo = FR ? Hh : 2 * Hh;
+#endif
         constexpr int NIT = (NARROW * ncol + 511) / 512;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -2640,12 +2706,16 @@ extern "C" long nsc_gated_block_image_floats(int which, int C, int Cin, int dil)
   int rt9, nk;
   if (!img_shape(which, C, Cin, dil, &rt9, &nk)) return 0;
   if (which == 0) {
+    // [300][48] k15 gate kernels | (C = 100: [9][20][4] + 4 packed-tile weights, 728) | group A [2][nf4a] | group B [6 | 4][13] |
+    // group C [8][2], each x [64 lanes][4]
     const int nk1 = Cin == 1 ? 1 : nk;
-    return (long)K15 * NARROW * 48 + 8L * 64 * 4 * ((nk1 + K9 * 5 + 16 + 3) / 4) + (rt9 == 7 ? 728 : 0);
+    return (long)K15 * NARROW * 48 + (rt9 == 7 ? 728 : 0) + 64L * 4 * (2 * ((nk1 + 4 + 3) / 4) + (rt9 == 7 ? 6 : 4) * 13 + 8 * 2);
   }
   if (which == 1) {
     const int w9t = C * 4 + (((C * 4) & 15) == 8 ? 0 : 8), nj = (nk + 3) / 4 - 1;
-    return (long)K15 * W15T + (long)K9 * w9t + 8L * 64 * 4 * ((K9 * nj + 3 + 5 + 3) / 4) + (Cin == 1 ? NARROW : 0);
+    // [15][808] k15 table | [9][w9t] packed k9 table | k9^T fragments, ONE copy per K-quarter [4][nf4s][64][4] | 1x1^T fragments
+    // per wave [8][2][64][4] | (Cin = 1: the 20 taps)
+    return (long)K15 * W15T + (long)K9 * w9t + 64L * 4 * (4 * ((K9 * nj + 3 + 3) / 4) + 8 * 2) + (Cin == 1 ? NARROW : 0);
   }
   return 0;
 }
@@ -2665,30 +2735,37 @@ extern "C" int nsc_gated_block_image_index(int which, int C, int Cin, int dil, c
       const int c = mn((r >> 4) * 8 + (ii >> 2) * 2 + (ii & 1), NARROW - 1);
       idx[e] = (int)(((ii & 2) ? wr : wl) + row * NARROW + c);
     }
-    const int nfr = nk1 + K9 * 5 + 16, nf4 = (nfr + 3) / 4;
-    const long baseB = (long)K15 * NARROW * LDW;
-    for (int wave = 0; wave < 8; ++wave) {
-      const int r1 = wave >> 2, rt3 = rt9 == 7 ? (wave < 4 ? wave : 4 + ((wave - 4) >> 1)) : (wave & 3);    // gated_block_fwd2_kernel's job table
-      int jrt[2];
-      for (int e = 0; e < 2; ++e) { const int q = wave + 8 * e; jrt[e] = (q < 15 ? q : wave) % 3; }
-      for (int lane = 0; lane < 64; ++lane) {
-        const int l15 = lane & 15, kq = lane >> 4;
-        for (int f = 0; f < nfr; ++f) {
-          long src;
-          if (f < nk1) src = w1 + (long)mn(4 * f + kq, Cin - 1) * NARROW + mn(r1 * 16 + l15, NARROW - 1);
-          else if (f < nk1 + 45) { const int t = f - nk1, tap = t / 5, u = t % 5; src = w9 + (long)(tap * NARROW + 4 * u + kq) * C + mn(rt3 * 16 + l15, C - 1); }
-          else if (f < nk1 + 49) src = b1 + mn(r1 * 16 + kq * 4 + (f - nk1 - 45), NARROW - 1);
-          else if (f < nk1 + 53) src = b9 + mn(rt3 * 16 + kq * 4 + (f - nk1 - 49), C - 1);
-          else if (f < nk1 + 57) { const int t = f - nk1 - 53; src = bl + mn(jrt[t >> 1] * 8 + kq * 2 + (t & 1), NARROW - 1); }
-          else { const int t = f - nk1 - 57; src = br + mn(jrt[t >> 1] * 8 + kq * 2 + (t & 1), NARROW - 1); }
-          idx[baseB + ((long)(wave * nf4 + f / 4) * 64 + lane) * 4 + (f & 3)] = (int)src;
-        }
-      }
-    }
+    const long baseP = (long)K15 * NARROW * LDW;
     if (rt9 == 7) {          // packed tile of channels 96..99: [9][20][4] weights, 4 biases
-      const long baseP = baseB + 8L * 64 * 4 * nf4;
       for (int e = 0; e < K9 * NARROW * 4; ++e) idx[baseP + e] = (int)(w9 + (long)(e >> 2) * C + 96 + (e & 3));
       for (int e = 0; e < 4; ++e) idx[baseP + K9 * NARROW * 4 + e] = (int)(b9 + 96 + e);
+    }
+    const int nfa = nk1 + 4, nf4a = (nfa + 3) / 4, nf4b = 13, nf4c = 2, nvb = rt9 == 7 ? 6 : 4;
+    const long baseA = baseP + (rt9 == 7 ? 728 : 0), baseB = baseA + 2L * nf4a * 256, baseC = baseB + (long)nvb * nf4b * 256;
+    for (int lane = 0; lane < 64; ++lane) {
+      const int l15 = lane & 15, kq = lane >> 4;
+      for (int r1 = 0; r1 < 2; ++r1)             // group A: a wave's row tile of h (waves 0-3: channels 0..15, waves 4-7: 16..19 + padding)
+        for (int f = 0; f < nfa; ++f) {
+          const long src = f < nk1 ? w1 + (long)mn(4 * f + kq, Cin - 1) * NARROW + mn(r1 * 16 + l15, NARROW - 1)
+                                   : b1 + mn(r1 * 16 + kq * 4 + (f - nk1), NARROW - 1);
+          idx[baseA + ((long)(r1 * nf4a + f / 4) * 64 + lane) * 4 + (f & 3)] = (int)src;
+        }
+      for (int rt3 = 0; rt3 < nvb; ++rt3)        // group B: a phase-3 row tile (gated_block_fwd2_kernel's job table)
+        for (int f = 0; f < 49; ++f) {
+          long src;
+          if (f < 45) { const int tap = f / 5, u = f % 5; src = w9 + (long)(tap * NARROW + 4 * u + kq) * C + mn(rt3 * 16 + l15, C - 1); }
+          else src = b9 + mn(rt3 * 16 + kq * 4 + (f - 45), C - 1);
+          idx[baseB + ((long)(rt3 * nf4b + f / 4) * 64 + lane) * 4 + (f & 3)] = (int)src;
+        }
+      for (int wave = 0; wave < 8; ++wave) {     // group C: gate biases of the wave's two phase-2 jobs
+        int jrt[2];
+        for (int e = 0; e < 2; ++e) { const int q = wave + 8 * e; jrt[e] = (q < 15 ? q : wave) % 3; }
+        for (int f = 0; f < 8; ++f) {
+          const int t = f & 3;
+          const long src = (f < 4 ? bl : br) + mn(jrt[t >> 1] * 8 + kq * 2 + (t & 1), NARROW - 1);
+          idx[baseC + ((long)(wave * nf4c + f / 4) * 64 + lane) * 4 + (f & 3)] = (int)src;
+        }
+      }
     }
     return NSC_OK;
   }
@@ -2702,23 +2779,30 @@ extern "C" int nsc_gated_block_image_index(int which, int C, int Cin, int dil, c
   for (int e = 0; e < K9 * C * 4; ++e)
     idx[base9 + (long)(e / (4 * C)) * w9t + (e % (4 * C))] = (int)(wt9 + (long)(e >> 2) * NARROW + 16 + (e & 3));
   const long baseB = base9 + (long)K9 * w9t;
-  const int nfr = K9 * nj + 3 + 5, nf4 = (nfr + 3) / 4;
-  for (int wave = 0; wave < 8; ++wave) {
-    const int kg = wave & 3, rt1 = rt9 == 7 ? mn(wave, 6) : (wave & 3);
+  const int nfs = K9 * nj + 3, nf4s = (nfs + 3) / 4, nf4w = 2;
+  // k9^T fragments: waves kg and kg + 4 share a K-quarter and read the same copy
+  for (int kg = 0; kg < 4; ++kg)
     for (int lane = 0; lane < 64; ++lane) {
       const int l15 = lane & 15, kq = lane >> 4;
-      for (int f = 0; f < nfr; ++f) {
+      for (int f = 0; f < nfs; ++f) {
         long src;
         if (f < K9 * nj) { const int tp = f / nj, j = f % nj; src = wt9 + ((long)tp * C + mn(4 * (kg + 4 * j) + kq, C - 1)) * NARROW + l15; }
-        else if (f < K9 * nj + 3) { const int i = f - K9 * nj; src = wt9 + ((long)mn(kg + 4 * i, K9 - 1) * C + mn(4 * (nk - 1) + kq, C - 1)) * NARROW + l15; }
-        else if (Cin == 1) continue;                       // (the 1x1 gradient of a one-channel input is a dot product)
-        else { const int s5 = f - K9 * nj - 3; src = wt1 + (long)(s5 * 4 + kq) * C + mn(rt1 * 16 + l15, C - 1); }
-        idx[baseB + ((long)(wave * nf4 + f / 4) * 64 + lane) * 4 + (f & 3)] = (int)src;
+        else { const int i = f - K9 * nj; src = wt9 + ((long)mn(kg + 4 * i, K9 - 1) * C + mn(4 * (nk - 1) + kq, C - 1)) * NARROW + l15; }
+        idx[baseB + ((long)(kg * nf4s + f / 4) * 64 + lane) * 4 + (f & 3)] = (int)src;
       }
     }
-  }
+  const long baseW = baseB + 4L * nf4s * 64 * 4;
+  if (Cin != 1)                                            // (the 1x1 gradient of a one-channel input is a dot product)
+    for (int wave = 0; wave < 8; ++wave) {
+      const int rt1 = rt9 == 7 ? mn(wave, 6) : (wave & 3);
+      for (int lane = 0; lane < 64; ++lane) {
+        const int l15 = lane & 15, kq = lane >> 4;
+        for (int s5 = 0; s5 < 5; ++s5)
+          idx[baseW + ((long)(wave * nf4w + s5 / 4) * 64 + lane) * 4 + (s5 & 3)] = (int)(wt1 + (long)(s5 * 4 + kq) * C + mn(rt1 * 16 + l15, C - 1));
+      }
+    }
   if (Cin == 1)
-    for (int c = 0; c < NARROW; ++c) idx[baseB + 8L * 64 * 4 * nf4 + c] = (int)(wt1 + c);
+    for (int c = 0; c < NARROW; ++c) idx[baseW + 8L * nf4w * 64 * 4 + c] = (int)(wt1 + c);
   return NSC_OK;
 }
 

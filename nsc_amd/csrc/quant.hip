@@ -7,6 +7,7 @@
 // d(bins) are accumulated in registers across a frame, merged with LDS float atomics, then one global
 // atomic per bin per workgroup.
 #include "nsc_common.h"
+#include <type_traits>
 #include <algorithm>
 
 #define QEPS 1e-20f
@@ -49,6 +50,17 @@ __device__ __forceinline__ float grp_max(float v) {
   if constexpr (LPC >= 64) v = fmaxf(v, __shfl_xor(v, 32, 64));
   return v;
 }
+
+#define NSC_MIN_DPP(v, ctrl)                                                                                   \
+  asm volatile("s_nop 1\n\tv_min_f32_dpp %0, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(v) : "0"(v))
+template <int LPC>
+__device__ __forceinline__ float grp_min8(float v) {      // LPC <= 8 (the wave-per-frame kernel)
+  if constexpr (LPC >= 2) NSC_MIN_DPP(v, "quad_perm:[1,0,3,2]");
+  if constexpr (LPC >= 4) NSC_MIN_DPP(v, "quad_perm:[2,3,0,1]");
+  if constexpr (LPC >= 8) NSC_MIN_DPP(v, "row_half_mirror");
+  return v;
+}
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // Computes this lane's p values for code c.  Returns d_k = |c-b_k| in dist[], p in p[].
 template <int LPC, int ITER>
@@ -386,7 +398,10 @@ template <bool SOFT, int LPC>
 __global__ __launch_bounds__(256) void quantize_fwd32_wave_kernel(const float* __restrict__ code, const float* __restrict__ alpha_p,
                                                                   const float* __restrict__ bins, float on, int L,
                                                                   float* __restrict__ p_out, float* __restrict__ out,
-                                                                  float* __restrict__ quan_out, float* __restrict__ hist, int B) {
+                                                                  float* __restrict__ quan_out, float* __restrict__ hist, int B,
+                                                                  int nostore) {
+  // nostore (probes build only, NSC_QUANT_NO_STORE=1; 0 in the shipped library): the p stores are issued against an EMPTY
+  // buffer descriptor and dropped by the bounds check - the kernel's arithmetic without its 1-KiB stores reaching memory
   constexpr int NB = 32, ITER = NB / (4 * LPC), CPW = 64 / LPC, NPASS = 64 / CPW;
   __shared__ float sh[NB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -409,71 +424,135 @@ __global__ __launch_bounds__(256) void quantize_fwd32_wave_kernel(const float* _
 #pragma unroll
     for (int j = 0; j < 4; ++j) hacc[i][j] = 0.f;
   const int nwaves = gridDim.x * 4, w0 = blockIdx.x * 4 + wave;
+  // fast path of the pass (alpha <= 0, see below): ah = |alpha| log2(e) / 2 and this lane's bins as float pairs
+  const bool fast = alpha <= 0.f;                           // wave-uniform (NaN alpha: the generic path keeps it visible)
+  const float ahalf = -0.5f * 1.4426950408889634f * alpha;
+  f32x2 bp[ITER][2];
+#pragma unroll
+  for (int i = 0; i < ITER; ++i)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) bp[i][h] = (f32x2){bv[i][2 * h], bv[i][2 * h + 1]};
   const int nch = L >> 6;                                   // chunks of 64 codes per frame (L is a multiple of 64 here)
   // lane X of the wave keeps the quantised code of chunk element X: at pass X / CPW it picks it from a lane of group X % CPW
   const int pick_idx = ((lane % CPW) * LPC) * 4, pick_pass = lane / CPW;
-  const __amdgpu_buffer_rsrc_t sp = __builtin_amdgcn_make_buffer_rsrc(p_out, 0, (unsigned)((long)B * L * NB * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t sp = __builtin_amdgcn_make_buffer_rsrc(p_out, 0, nostore ? 0u : (unsigned)((long)B * L * NB * 4), 0x00020000);
   float vn = w0 < B ? code[(long)w0 * L + lane] : 0.f;      // first chunk of the first frame
-  for (int f = w0; f < B; f += nwaves) {
-    float qacc = 0.f;
-    for (int ch = 0; ch < nch; ++ch) {
-      const float v = vn;
-      {   // next chunk (of this frame or of the wave's next frame): in flight during the passes below
-        const int chn = ch + 1 < nch ? ch + 1 : 0;
-        const long fn = ch + 1 < nch ? f : (f + nwaves < B ? f + nwaves : f);
-        vn = code[fn * L + chn * 64 + lane];
-      }
-      float outv = 0.f;
-      const long cbase = (long)f * L + ch * 64;
-#pragma unroll
-      for (int it = 0; it < NPASS; ++it) {
-        // code of this pass's group gc: element it * CPW + gc of the chunk
-        const float c = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((it * CPW + gc) * 4, __builtin_bit_cast(int, v)));
-        float dist[ITER][4], p[ITER][4];
-        softmax_bins<LPC, ITER>(c, alpha, bv, ok, dist, p);
-        float q;
-        if (SOFT) {
-          float s_ = 0.f;
-#pragma unroll
-          for (int i = 0; i < ITER; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) s_ = fmaf(p[i][j], bv[i][j], s_);
-          q = grp_sum<LPC>(s_);
-        } else {
-          float best = -1.f;
-          int idx = 0x7fffffff;
-#pragma unroll
-          for (int i = 0; i < ITER; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int k = (i * LPC + gl) * 4 + j;
-              if (p[i][j] > best) { best = p[i][j]; idx = k; }
-            }
-          idx = grp_argmax<LPC>(best, idx);
-          q = (c != c) ? c : bins[min(idx, NB - 1)];     // NaN in: NaN out, and the sentinel never indexes the table
+  // (the frame loop is instantiated twice and the wave-uniform choice made once, outside it)
+  auto frames = [&](auto fast_c) {
+    constexpr bool FAST = decltype(fast_c)::value;
+    for (int f = w0; f < B; f += nwaves) {
+      float qacc = 0.f;
+      for (int ch = 0; ch < nch; ++ch) {
+        const float v = vn;
+        {   // next chunk (of this frame or of the wave's next frame): in flight during the passes below
+          const int chn = ch + 1 < nch ? ch + 1 : 0;
+          const long fn = ch + 1 < nch ? f : (f + nwaves < B ? f + nwaves : f);
+          vn = code[fn * L + chn * 64 + lane];
         }
-#pragma unroll
-        for (int i = 0; i < ITER; ++i) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            hacc[i][j] += p[i][j];
-            qacc += __builtin_amdgcn_sqrtf(p[i][j] + QEPS);
+        float outv = 0.f;
+        const long cbase = (long)f * L + ch * 64;
+  #pragma unroll
+        for (int it = 0; it < NPASS; ++it) {
+          // code of this pass's group gc: element it * CPW + gc of the chunk
+          const float c = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((it * CPW + gc) * 4, __builtin_bit_cast(int, v)));
+          float p[ITER][4];
+          float qsum;                                   // this lane's share of sum_k sqrt(p_k + eps)
+          if constexpr (FAST) {
+            // ROUND 4.  With its p stores dropped this kernel still took 25.5 of its 29 us (tools/quant_time.py, NSC_QUANT_NO_STORE):
+            // it was bound by VALU issue - 17 instruction slots per bin, two of them quarter-rate transcendentals (v_exp for p,
+            // v_sqrt for the quan_loss term) - not by HBM.  For alpha <= 0 (the reference's regime: init -300, and the only one
+            // in which the soft assignment approaches a hard one) the pass is restated so that ONE transcendental per bin is left
+            // and most of the rest runs on packed fp32 (v_pk_*: two floats per lane and instruction):
+            //   x_k = ah (c - b_k)  (ah = |alpha| log2(e) / 2 >= 0, so |x_k| = ah |c - b_k| bit for bit: codes at EQUAL distance
+            //   from two bins still tie exactly and the hard assignment keeps tf.nn.top_k's lowest index)   M = min_k |x_k|
+            //   t_k = 2^(M - |x_k|)  = sqrt of the softmax numerator;  S = sum_k t_k^2
+            //   p_k = t_k^2 / S      sqrt(p_k) = t_k rsqrt(S)          (sqrt(p + 1e-20) - sqrt(p) <= 1e-10: dropped)
+            // abs / neg ride on source modifiers.  p differs from the exp / rcp form by rounding only (~3 ulp).
+            const f32x2 c2 = {c, c}, ah2 = {ahalf, ahalf};
+            f32x2 x[ITER][2];
+            float mn = INFINITY;
+  #pragma unroll
+            for (int i = 0; i < ITER; ++i)
+  #pragma unroll
+              for (int h = 0; h < 2; ++h) {
+                x[i][h] = (c2 - bp[i][h]) * ah2;
+                mn = fminf(mn, fminf(fabsf(x[i][h][0]), fabsf(x[i][h][1])));
+              }
+            mn = grp_min8<LPC>(mn);
+            f32x2 t[ITER][2], s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
+  #pragma unroll
+            for (int i = 0; i < ITER; ++i)
+  #pragma unroll
+              for (int h = 0; h < 2; ++h) {
+                t[i][h] = (f32x2){__builtin_amdgcn_exp2f(mn - fabsf(x[i][h][0])), __builtin_amdgcn_exp2f(mn - fabsf(x[i][h][1]))};
+                s1 += t[i][h];
+                s2 = __builtin_elementwise_fma(t[i][h], t[i][h], s2);
+              }
+            const float S = grp_sum<LPC>(s2[0] + s2[1]);
+            const float inv = __builtin_amdgcn_rcpf(S);
+            qsum = (s1[0] + s1[1]) * __builtin_amdgcn_rsqf(S);
+            const f32x2 inv2 = {inv, inv};
+  #pragma unroll
+            for (int i = 0; i < ITER; ++i)
+  #pragma unroll
+              for (int h = 0; h < 2; ++h) {
+                const f32x2 pp = (t[i][h] * inv2) * t[i][h];
+                p[i][2 * h] = pp[0];
+                p[i][2 * h + 1] = pp[1];
+              }
+          } else {
+            float dist[ITER][4];
+            softmax_bins<LPC, ITER>(c, alpha, bv, ok, dist, p);
+            qsum = 0.f;
+  #pragma unroll
+            for (int i = 0; i < ITER; ++i)
+  #pragma unroll
+              for (int j = 0; j < 4; ++j) qsum += __builtin_amdgcn_sqrtf(p[i][j] + QEPS);
           }
-          // ONE 16-byte store per lane and float4 group (a plain float4 assignment was split into a 12-byte and a 4-byte store
-          // in half of the unrolled passes, where the allocator had not kept the four values in consecutive registers)
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, (f32x4){p[i][0], p[i][1], p[i][2], p[i][3]}), sp,
-                                                 (int)((cbase + it * CPW + gc) * (NB * 4) + (i * LPC + gl) * 16), 0, 0);
+          qacc += qsum;
+          float q;
+          if (SOFT) {
+            float s_ = 0.f;
+  #pragma unroll
+            for (int i = 0; i < ITER; ++i)
+  #pragma unroll
+              for (int j = 0; j < 4; ++j) s_ = fmaf(p[i][j], bv[i][j], s_);
+            q = grp_sum<LPC>(s_);
+          } else {
+            float best = -1.f;
+            int idx = 0x7fffffff;
+  #pragma unroll
+            for (int i = 0; i < ITER; ++i)
+  #pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const int k = (i * LPC + gl) * 4 + j;
+                if (p[i][j] > best) { best = p[i][j]; idx = k; }
+              }
+            idx = grp_argmax<LPC>(best, idx);
+            q = (c != c) ? c : bins[min(idx, NB - 1)];     // NaN in: NaN out, and the sentinel never indexes the table
+          }
+  #pragma unroll
+          for (int i = 0; i < ITER; ++i) {
+  #pragma unroll
+            for (int j = 0; j < 4; ++j) hacc[i][j] += p[i][j];
+            // ONE 16-byte store per lane and float4 group (a plain float4 assignment was split into a 12-byte and a 4-byte store
+            // in half of the unrolled passes, where the allocator had not kept the four values in consecutive registers)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, (f32x4){p[i][0], p[i][1], p[i][2], p[i][3]}), sp,
+                                                   (int)((cbase + it * CPW + gc) * (NB * 4) + (i * LPC + gl) * 16), 0, 0);
+          }
+          // the group's quantised code travels to lane it * CPW + gc
+          const float o = (1.f - on) * c + on * q;
+          const float t = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(pick_idx, __builtin_bit_cast(int, o)));
+          outv = pick_pass == it ? t : outv;
         }
-        // the group's quantised code travels to lane it * CPW + gc
-        const float o = (1.f - on) * c + on * q;
-        const float t = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(pick_idx, __builtin_bit_cast(int, o)));
-        outv = pick_pass == it ? t : outv;
+        out[cbase + lane] = outv;
       }
-      out[cbase + lane] = outv;
+      qacc = wave_sum(qacc);
+      if (quan_out && lane == 0) quan_out[f] = qacc / (float)L;
     }
-    qacc = wave_sum(qacc);
-    if (quan_out && lane == 0) quan_out[f] = qacc / (float)L;
-  }
+  };
+  if (fast) frames(std::true_type{});
+  else frames(std::false_type{});
 #pragma unroll
   for (int i = 0; i < ITER; ++i)
 #pragma unroll
@@ -538,7 +617,7 @@ extern "C" int nsc_quantize_fwd(const float* code, const float* alpha, const flo
     }
 #endif
 #define QWAVE(SOFT_, LPC_) hipLaunchKernelGGL((quantize_fwd32_wave_kernel<SOFT_, LPC_>), dim3(grid), dim3(256), 0, st, code, alpha, bins, \
-                                              is_quan_on, L, p_out, out, quan_out, hist, B)
+                                              is_quan_on, L, p_out, out, quan_out, hist, B, NSC_PROBE_INT("NSC_QUANT_NO_STORE", 0))
     if (NSC_PROBE_INT("NSC_QLPC", 8) == 8) { if (soft) QWAVE(true, 8); else QWAVE(false, 8); }
     else { if (soft) QWAVE(true, 4); else QWAVE(false, 4); }
 #undef QWAVE

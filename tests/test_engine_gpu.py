@@ -388,7 +388,7 @@ def test_parameter_write_after_refresh_invalidates_the_block_images():
     ps_a = make_store(1, [[2]], [32], seed=1)
     ps_b = make_store(1, [[2]], [32], seed=2)
     x = synth_frames(B, seed=3)
-    xd = torch.tensor(x, dtype=torch.float32, device=dev()).transpose(1, 2).contiguous()
+    xd = dev(x.transpose(0, 2, 1))
     ref = _engine(B, 1, [[2]], [32], ps_b)
     ref.use_images = False
     want = ref.forward(xd, 1.0, True).clone()

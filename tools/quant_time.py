@@ -16,10 +16,15 @@ def run(soft, p, outq, qv, hist):
     _lib.check(lib.nsc_quantize_fwd(code.data_ptr(), alpha.data_ptr(), bins.data_ptr(), 1.0, soft, Bq, L, nb, p.data_ptr(), outq.data_ptr(),
                                     qv.data_ptr(), hist.data_ptr(), st), "q")
 res = {}
+ONLY = os.environ.get("NSC_QT_ONLY")      # run one variant only (for rocprofv3 --pmc passes: one kernel shape per process)
 for variant, env in (("workgroup per frame", {"NSC_QUANT_WG": "1"}), ("wave per frame, grid 512 (shipped)", {}), ("wave per frame, grid 1024", {"NSC_QWGRID": "1024"}), ("wave per frame, 4 lanes/code, grid 512", {"NSC_QLPC": "4"}),
+                     ("wave per frame, p stores dropped (compute only)", {"NSC_QUANT_NO_STORE": "1"}),
+                     ("wave per frame, 4 lanes/code, stores dropped", {"NSC_QLPC": "4", "NSC_QUANT_NO_STORE": "1"}),
                      ("write-only probe, same geometry", {"NSC_QUANT_WRITE_ONLY": "1"}), ("write-only probe, nontemporal", {"NSC_QUANT_WRITE_ONLY": "2"}),
                      ("wave per frame, grid 512 (again)", {})):
-    for k in ("NSC_QUANT_WG", "NSC_QWGRID", "NSC_QUANT_WRITE_ONLY", "NSC_QLPC"):
+    if ONLY and ONLY not in variant:
+        continue
+    for k in ("NSC_QUANT_WG", "NSC_QWGRID", "NSC_QUANT_WRITE_ONLY", "NSC_QLPC", "NSC_QUANT_NO_STORE"):
         os.environ.pop(k, None)
     os.environ.update(env)
     outs = []
@@ -42,9 +47,11 @@ for variant, env in (("workgroup per frame", {"NSC_QUANT_WG": "1"}), ("wave per 
     us = sorted(ts)[len(ts) // 2]
     byts = Bq * L * (4 + 4 * nb + 4)
     print(f"{variant:44s}: {us:6.2f} us (min {min(ts):6.2f})  {byts / us / 1e6:5.2f} TB/s  = {byts / us / 1e6 / 8:.3f} of 8 TB/s", flush=True)
+if ONLY:
+    sys.exit(0)
 base = res["workgroup per frame"]
 for k, v in res.items():
-    if "probe" in k:
+    if "probe" in k or "dropped" in k:
         continue
     d = [max(float((a - b).abs().max()) for a, b in zip(v[s][:3], base[s][:3])) for s in (0, 1)]
     dh = [float(((v[s][3] - base[s][3]).abs() / base[s][3].abs().clamp_min(1)).max()) for s in (0, 1)]
