@@ -63,6 +63,20 @@ int nsc_conv1d_fwd(const nsc_conv_desc* d, const float* x, const float* w, const
 /* Cout == 1 special case (k55 C->1 convs, nsc_module:236,255-259): VALU dot products. Same epilogue. */
 int nsc_conv1d_cout1_fwd(const nsc_conv_desc* d, const float* x, const float* w, const float* bias,
                          const float* res, const float* aux, float* y, void* stream);
+/* the same conv followed by an elementwise chain on its [B,1,Tout] result v (each step was a launch of its own: nsc_cascade_step
+ * behind a codec's output conv - cmrl.py:49-94: decoded (+)= dec / rs, next input = rs (x - decoded) -, nsc_axpby behind the first
+ * conv's data gradient):   out2 = pa * p_in + pb * v   (p_in nullable: pb * v);   out3 = qa * q_in + qb * out2   (out3 nullable).
+ * out2 may alias p_in, out3 must not alias an input.  chain nullable = nsc_conv1d_cout1_fwd. */
+typedef struct nsc_cout1_chain {
+  const float* p_in;
+  float* out2;
+  float pa, pb;
+  const float* q_in;
+  float* out3;
+  float qa, qb;
+} nsc_cout1_chain;
+int nsc_conv1d_cout1_fwd_chain(const nsc_conv_desc* d, const float* x, const float* w, const float* bias, const float* res,
+                               const float* aux, float* y, const nsc_cout1_chain* chain, void* stream);
 /* weight gradient: dw[k,i,o] += sum_{b,t} xin[b,i,t*stride+k*dil-padL] * dz[b,o,t];  db[o] += sum dz (db nullable).
  * flip_taps=1 writes tap k to row K-1-k (used when x/dz roles are swapped for Cout==1 convs). */
 int nsc_conv1d_wgrad(const nsc_conv_desc* d, const float* x, const float* dz, float* dw, float* db,
@@ -279,6 +293,11 @@ int nsc_rfft512(const float* sig, int B, float* re, float* im, float* mag, void*
 int nsc_adam_tf1_step(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
                       float eps, int t, const int* t_dev, void* stream);
 int nsc_increment(int* counter, void* stream);
+/* opening of a training step in one launch (the engine's sess.run(trainop) prologue, neural_speech_coding_module.py:455-458 has
+ * no counterpart - TF zeroes nothing and keeps no flipped kernels): dst[e] = idx[e] >= 0 ? src[idx[e]] : 0 for e < n (nsc_gather:
+ * the data-gradient kernels and parameter images); zero[0, zero_n) = 0 (gradients + histograms; 16-byte aligned, zero_n % 4 == 0);
+ * counter[0] += 1 when non-null (the Adam step counter nsc_adam_tf1_step reads at the end of the step). */
+int nsc_step_begin(const float* src, const int* idx, float* dst, long n, float* zero, long zero_n, int* counter, void* stream);
 
 /* ---- LPC front / back end of the collaborative-quantisation path (replaces the tf.py_func bodies of
  *      lpc_utilities.py: `lsf2poly_after_quan` :28-33, `lpc_analysis_get_residual` :37-77, `lpc_synthesizer_tr` :137-156;

@@ -70,6 +70,7 @@ PROTOTYPES = {
     "nsc_rfft512": [_P, _I, _P, _P, _P, _P],
     "nsc_adam_tf1_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _P, _P],
     "nsc_increment": [_P, _P],
+    "nsc_step_begin": [_P, _P, _P, _L, _P, _L, _P, _P],
     "nsc_frame_utterance": [_P, _L, _P, _P, _I, _P],
     "nsc_overlap_add": [_P, _I, _P, _P, _P],
     "nsc_lsf2poly": [_P, _P, _I, _I, _P],
@@ -88,6 +89,12 @@ class ConvWgradJob(C.Structure):
                 ("flip_taps", C.c_int)]
 
 
+class Cout1Chain(C.Structure):
+    """include/nsc_hip.h: struct nsc_cout1_chain"""
+    _fields_ = [("p_in", C.c_void_p), ("out2", C.c_void_p), ("pa", C.c_float), ("pb", C.c_float),
+                ("q_in", C.c_void_p), ("out3", C.c_void_p), ("qa", C.c_float), ("qb", C.c_float)]
+
+
 class SumJob(C.Structure):
     """include/nsc_hip.h: struct nsc_sum_job"""
     _fields_ = [("x", C.c_void_p), ("out", C.c_void_p), ("n", C.c_long)]
@@ -98,6 +105,7 @@ class EntropyJob(C.Structure):
     _fields_ = [("hist", C.c_void_p), ("ent", C.c_void_p), ("ghist", C.c_void_p), ("nb", C.c_int)]
 
 
+PROTOTYPES["nsc_conv1d_cout1_fwd_chain"] = [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, C.POINTER(Cout1Chain), _P]
 PROTOTYPES["nsc_sum_all_batch"] = [C.POINTER(SumJob), _I, _P]
 PROTOTYPES["nsc_entropy_from_hist_batch"] = [C.POINTER(EntropyJob), _I, _P]
 PROTOTYPES["nsc_gated_block_wgrad_batch"] = [C.POINTER(BlockWgradJob), _I, _I, _I, _I, _P, _L, _P]

@@ -637,7 +637,7 @@ __global__ __launch_bounds__(512) void conv1d_cout1_v2_kernel(nsc_conv_desc d, c
                                                               const float* __restrict__ bias,
                                                               const float* __restrict__ res,
                                                               const float* __restrict__ aux, float* __restrict__ y,
-                                                              int ldx) {
+                                                              int ldx, nsc_cout1_chain ch) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int TT = 64 * R, KP = (K + 3) & ~3, NWIN = (R + KP - 1 + 3) & ~3;
   static_assert(NWIN % R == 0, "window is read in R-float vectors");
@@ -647,6 +647,9 @@ __global__ __launch_bounds__(512) void conv1d_cout1_v2_kernel(nsc_conv_desc d, c
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.y, t0 = blockIdx.x * TT;
+  // (Round 4 tried consuming the rows one at a time in load order - a wave computes exactly the channels it loads, so a row needs no
+  // workgroup barrier and the later rows' latency could run under the earlier rows' FMAs: the 13-fold unrolled body measured the same
+  // at B = 128 (17.4 / 11.4 / 18.7 us against 16.1 / 11.4 / 19.1) and 40 % SLOWER at B = 4096 (328 vs 236 us); not kept.)
   {
     // whole x tile in flight at once: wave w owns rows w, w+8, ...; raw buffer loads, out-of-frame columns -> 0 by the
     // hardware bounds check (a batched-by-8 staging loop spent 5 memory round trips here: 25 of the kernel's 50 us)
@@ -723,15 +726,22 @@ __global__ __launch_bounds__(512) void conv1d_cout1_v2_kernel(nsc_conv_desc d, c
       if (d.res_mode) v += res[idx];
       v = nsc_apply_act(v, d.act);
       if (d.mul_mode) v *= nsc_act_grad_from_out(aux[idx], d.mul_mode);
-      if (d.accumulate) y[idx] += v;
-      else y[idx] = v;
+      if (d.accumulate) v += y[idx];
+      y[idx] = v;
+      // elementwise chain on the [B,1,T] result (nsc_conv1d_cout1_fwd_chain): the cascade step behind a codec's output conv, the
+      // running sum / next codec's output gradient behind the first conv's data gradient - each was a launch of its own
+      if (ch.out2) {
+        const float o2 = ch.p_in ? fmaf(ch.pb, v, ch.pa * ch.p_in[idx]) : ch.pb * v;
+        ch.out2[idx] = o2;
+        if (ch.out3) ch.out3[idx] = fmaf(ch.qa, ch.q_in[idx], ch.qb * o2);
+      }
     }
   }
 }
 
 template <int K, int R>
 static int launch_cout1_v2(const nsc_conv_desc* d, const float* x, const float* w, const float* bias, const float* res,
-                           const float* aux, float* y, hipStream_t st) {
+                           const float* aux, float* y, hipStream_t st, const nsc_cout1_chain& ch) {
   constexpr int TT = 64 * R, KP = (K + 3) & ~3, NWIN = (R + KP - 1 + 3) & ~3;
   const int ldx = (TT + NWIN - R + 3) & ~3;
   const size_t smem = ((size_t)d->Cin * ldx + (size_t)d->Cin * KP + 8 * TT) * sizeof(float);
@@ -739,15 +749,29 @@ static int launch_cout1_v2(const nsc_conv_desc* d, const float* x, const float* 
   auto kern = conv1d_cout1_v2_kernel<K, R>;
   const hipError_t e = NSC_SMEM_ATTR(kern, 160 * 1024);
   NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "conv1d_cout1_v2: set smem attr: %s", hipGetErrorString(e));
-  hipLaunchKernelGGL(kern, dim3(nsc_cdiv(d->Tout, TT), d->B), dim3(512), smem, st, *d, x, w, bias, res, aux, y, ldx);
+  hipLaunchKernelGGL(kern, dim3(nsc_cdiv(d->Tout, TT), d->B), dim3(512), smem, st, *d, x, w, bias, res, aux, y, ldx, ch);
   NSC_CHECK_LAUNCH("conv1d_cout1_v2");
   return NSC_OK;
 }
 
-extern "C" int nsc_conv1d_cout1_fwd(const nsc_conv_desc* d, const float* x, const float* w, const float* bias,
-                                    const float* res, const float* aux, float* y, void* stream) {
+// elementwise chain behind a Cout = 1 conv, for the shapes the register-tiled kernel does not serve
+__global__ void cout1_chain_kernel(const float* __restrict__ v, nsc_cout1_chain ch, long n) {
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    const float o2 = ch.p_in ? fmaf(ch.pb, v[e], ch.pa * ch.p_in[e]) : ch.pb * v[e];
+    ch.out2[e] = o2;
+    if (ch.out3) ch.out3[e] = fmaf(ch.qa, ch.q_in[e], ch.qb * o2);
+  }
+}
+
+extern "C" int nsc_conv1d_cout1_fwd_chain(const nsc_conv_desc* d, const float* x, const float* w, const float* bias,
+                                          const float* res, const float* aux, float* y, const nsc_cout1_chain* chain,
+                                          void* stream) {
   int rc = check_desc(d, "nsc_conv1d_cout1_fwd");
   if (rc) return rc;
+  nsc_cout1_chain ch;
+  memset(&ch, 0, sizeof(ch));
+  if (chain) ch = *chain;
+  NSC_REQUIRE(!ch.out3 || (ch.out2 && ch.q_in), NSC_ERR_BAD_ARG, "nsc_conv1d_cout1_fwd_chain: out3 needs out2 and q_in");
   NSC_REQUIRE(d->Cout == 1 && d->out_mode == 0, NSC_ERR_BAD_ARG, "nsc_conv1d_cout1_fwd: needs Cout == 1, plain store");
   NSC_REQUIRE(x && w && y, NSC_ERR_BAD_ARG, "nsc_conv1d_cout1_fwd: null x/w/y");
   NSC_REQUIRE(!(d->res_mode && !res) && !(d->mul_mode && !aux), NSC_ERR_BAD_ARG, "nsc_conv1d_cout1_fwd: null res/aux");
@@ -755,8 +779,8 @@ extern "C" int nsc_conv1d_cout1_fwd(const nsc_conv_desc* d, const float* x, cons
   if (!v1_only && d->K == 55 && d->dil == 1 && d->stride == 1 && !d->in_up && d->Cin >= 8 && d->Cin <= 104) {
     // R outputs per lane: 4 when that still gives every CU a workgroup, else 2
     const bool r4 = (long)d->B * nsc_cdiv(d->Tout, 256) >= 256;
-    const int rc2 = r4 ? launch_cout1_v2<55, 4>(d, x, w, bias, res, aux, y, (hipStream_t)stream)
-                       : launch_cout1_v2<55, 2>(d, x, w, bias, res, aux, y, (hipStream_t)stream);
+    const int rc2 = r4 ? launch_cout1_v2<55, 4>(d, x, w, bias, res, aux, y, (hipStream_t)stream, ch)
+                       : launch_cout1_v2<55, 2>(d, x, w, bias, res, aux, y, (hipStream_t)stream, ch);
     if (rc2 <= 0) return rc2;          // launched (0) or failed (<0); 1 = tile does not fit LDS -> v1 below
   }
   int ldx = 127 * d->stride + (d->K - 1) * d->dil + 1;
@@ -770,7 +794,17 @@ extern "C" int nsc_conv1d_cout1_fwd(const nsc_conv_desc* d, const float* x, cons
   dim3 grid(nsc_cdiv(d->Tout, 128), d->B);
   hipLaunchKernelGGL(conv1d_cout1_kernel, grid, dim3(256), smem, (hipStream_t)stream, *d, x, w, bias, res, aux, y, ldx);
   NSC_CHECK_LAUNCH("conv1d_cout1");
+  if (ch.out2) {                       // (other shapes: the chain as a launch of its own)
+    const long n = (long)d->B * d->Tout;
+    hipLaunchKernelGGL(cout1_chain_kernel, dim3(std::min<long>(4096, nsc_cdiv(n, 256))), dim3(256), 0, (hipStream_t)stream, y, ch, n);
+    NSC_CHECK_LAUNCH("cout1_chain");
+  }
   return NSC_OK;
+}
+
+extern "C" int nsc_conv1d_cout1_fwd(const nsc_conv_desc* d, const float* x, const float* w, const float* bias,
+                                    const float* res, const float* aux, float* y, void* stream) {
+  return nsc_conv1d_cout1_fwd_chain(d, x, w, bias, res, aux, y, nullptr, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -997,8 +1031,9 @@ struct ConvReduceJob {
   float *dw, *db;
   int nslabs, K, Cin, Cout, n, flip;
 };
+#define NSC_CR_MAXJ 16   // jobs per reduce launch: ONE reduce serves all kernel classes of a step (round 4; it ran once per class)
 struct ConvReduceBatch {
-  ConvReduceJob j[NSC_CW_MAXJ];
+  ConvReduceJob j[NSC_CR_MAXJ];
 };
 // 1024 threads = 64 consecutive elements x 16 slab groups (one wave each; its loads are whole 256-B lines): the slabs of an
 // element are summed by 16 waves in parallel (a single thread walking all of them is a ~100-load dependent chain),
@@ -1007,7 +1042,7 @@ __global__ __launch_bounds__(1024) void conv_slab_reduce_batch_kernel(ConvReduce
   __shared__ float part[16][64];
   ConvReduceJob jb = t.j[0];
 #pragma unroll
-  for (int q = 1; q < NSC_CW_MAXJ; ++q)
+  for (int q = 1; q < NSC_CR_MAXJ; ++q)
     if (q == (int)blockIdx.y) jb = t.j[q];
   const int nW = jb.K * jb.Cin * jb.Cout;
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
@@ -1220,17 +1255,34 @@ static void cw_split(const CwPlan* c, int n, int* gx) {
   }
 }
 
+// the slab reductions of a step: collected class by class, launched once (or every NSC_CR_MAXJ jobs)
+struct CwReduceQueue {
+  ConvReduceBatch r;
+  int n = 0, nmax = 0;
+  long off = 0;              // floats of the workspace handed out so far: the slabs of ALL classes coexist until the reduce
+  int flush(hipStream_t st) {
+    if (n == 0) return NSC_OK;
+    hipLaunchKernelGGL(conv_slab_reduce_batch_kernel, dim3(std::min(512, nsc_cdiv(nmax, 64)), n), dim3(1024), 0, st, r);
+    NSC_CHECK_LAUNCH("conv_slab_reduce_batch");
+    n = 0; nmax = 0;
+    return NSC_OK;
+  }
+};
+
 template <int RT, int CT>
 static int launch_cw_class(const nsc_conv_wgrad_job* jobs, const int* idx, const CwPlan* cp, int n, float* workspace,
-                           long workspace_floats, hipStream_t st) {
+                           long workspace_floats, hipStream_t st, CwReduceQueue& rq) {
   ConvWgradBatch t;
-  ConvReduceBatch r;
   memset(&t, 0, sizeof(t));
-  memset(&r, 0, sizeof(r));
   int gx[NSC_CW_MAXJ];
   cw_split(cp, n, gx);
-  long off = 0;
-  int wg = 0, nmax = 0;
+  if (rq.n + n > NSC_CR_MAXJ) {
+    int rc = rq.flush(st);
+    if (rc) return rc;
+  }
+  ConvReduceBatch& r = rq.r;
+  long off = rq.off;
+  int wg = 0, nmax = rq.nmax;
   size_t smem = 0;
   for (int q = 0; q < n; ++q) {
     const nsc_conv_wgrad_job& jb = jobs[idx[q]];
@@ -1239,7 +1291,7 @@ static int launch_cw_class(const nsc_conv_wgrad_job* jobs, const int* idx, const
     dv.slab = workspace + off; dv.slab_stride = cp[q].stride;
     dv.flip = jb.flip_taps; dv.ldx = cp[q].p.ldx; dv.win = cp[q].p.win; dv.nchunk_t = cp[q].p.nchunk_t;
     dv.gx = gx[q]; dv.gy = cp[q].gy; dv.wg0 = wg;
-    ConvReduceJob& rj = r.j[q];
+    ConvReduceJob& rj = r.j[rq.n + q];
     rj.slab = dv.slab; rj.stride = dv.slab_stride; rj.dw = jb.dw; rj.db = jb.db; rj.nslabs = gx[q];
     rj.K = jb.d.K; rj.Cin = jb.d.Cin; rj.Cout = jb.d.Cout; rj.flip = jb.flip_taps;
     rj.n = (jb.d.K * jb.d.Cin + (jb.db ? 1 : 0)) * jb.d.Cout;
@@ -1258,14 +1310,15 @@ static int launch_cw_class(const nsc_conv_wgrad_job* jobs, const int* idx, const
   }
   hipLaunchKernelGGL(kern, dim3(wg), dim3(512), smem, st, t);
   NSC_CHECK_LAUNCH("conv1d_wgrad_batch");
-  hipLaunchKernelGGL(conv_slab_reduce_batch_kernel, dim3(std::min(512, nsc_cdiv(nmax, 64)), n), dim3(1024), 0, st, r);
-  NSC_CHECK_LAUNCH("conv_slab_reduce_batch");
+  rq.n += n;
+  rq.nmax = nmax;
+  rq.off = off;
   return NSC_OK;
 }
 
 static int cw_dispatch(int rt, int ct, const nsc_conv_wgrad_job* jobs, const int* idx, const CwPlan* cp, int n, float* ws,
-                       long wsf, hipStream_t st) {
-#define CW(RT_, CT_) if (rt == RT_ && ct == CT_) return launch_cw_class<RT_, CT_>(jobs, idx, cp, n, ws, wsf, st)
+                       long wsf, hipStream_t st, CwReduceQueue& rq) {
+#define CW(RT_, CT_) if (rt == RT_ && ct == CT_) return launch_cw_class<RT_, CT_>(jobs, idx, cp, n, ws, wsf, st, rq)
   CW(1, 1); CW(1, 2); CW(1, 3); CW(1, 4); CW(1, 7); CW(2, 1); CW(2, 2); CW(2, 3); CW(2, 4); CW(2, 7); CW(4, 7);
 #undef CW
   nsc_set_error("nsc_conv1d_wgrad_batch: no kernel for class (%d, %d)", rt, ct);
@@ -1295,13 +1348,11 @@ static int cw_for_each_class(const nsc_conv_wgrad_job* jobs, int njobs, F f) {
 
 extern "C" long nsc_conv1d_wgrad_batch_workspace(const nsc_conv_wgrad_job* jobs, int njobs) {
   if (!jobs || njobs <= 0) return 0;
-  long need = 0;
+  long need = 0;       // the slabs of every class live until the one reduce at the end: the SUM over the classes
   cw_for_each_class(jobs, njobs, [&](int, int, const int*, const CwPlan* cp, int n) {
     int gx[NSC_CW_MAXJ];
     cw_split(cp, n, gx);
-    long off = 0;
-    for (int q = 0; q < n; ++q) off += (long)gx[q] * cp[q].stride;
-    need = std::max(need, off);
+    for (int q = 0; q < n; ++q) need += (long)gx[q] * cp[q].stride;
     return 0;
   });
   return need;
@@ -1317,9 +1368,13 @@ extern "C" int nsc_conv1d_wgrad_batch(const nsc_conv_wgrad_job* jobs, int njobs,
     NSC_REQUIRE(jobs[j].d.Cout <= 112, NSC_ERR_UNSUPPORTED, "nsc_conv1d_wgrad_batch: job %d: Cout %d > 112", j, jobs[j].d.Cout);
   }
   hipStream_t st = (hipStream_t)stream;
-  return cw_for_each_class(jobs, njobs, [&](int rt, int ct, const int* idx, const CwPlan* cp, int n) {
-    return cw_dispatch(rt, ct, jobs, idx, cp, n, workspace, workspace_floats, st);
+  CwReduceQueue rq;
+  memset(&rq.r, 0, sizeof(rq.r));
+  int rc = cw_for_each_class(jobs, njobs, [&](int rt, int ct, const int* idx, const CwPlan* cp, int n) {
+    return cw_dispatch(rt, ct, jobs, idx, cp, n, workspace, workspace_floats, st, rq);
   });
+  if (rc) return rc;
+  return rq.flush(st);
 }
 
 // ------------------------------------------------------------------------------------------------

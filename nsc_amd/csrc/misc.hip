@@ -180,6 +180,48 @@ __global__ __launch_bounds__(256) void depthwise_bwd_dw4_kernel(const float* __r
     atomicAdd(dwd + k * C + c, red[0][k] + red[1][k] + red[2][k] + red[3][k]);
   }
 }
+// Round 4: the weight gradient WITHOUT the LDS row.  The two kernels above stage each x row in LDS and pay K LDS reads per FMA-row
+// plus two barriers and a global round trip per group of frames (20 us for 26 MB at B = 128, C = 100, T = 256).  Here a thread owns
+// FOUR consecutive time steps of one (frame, channel) row: three 16-byte loads of x (previous / own / next group: the 12-sample
+// window of a K <= 9 kernel) and one of dy, 4 K FMAs from registers; a workgroup is one channel x NF4 frames, walks the batch
+// grid-stride with every load of its next frames in flight, and ends in one DPP wave sum + K atomics.  T % 4 == 0, K <= 9.
+template <int K>
+__global__ __launch_bounds__(256) void depthwise_bwd_dw_reg_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                   float* __restrict__ dwd, int B, int C, int T) {
+  __shared__ float red[4][K];
+  constexpr int padL = (K - 1) / 2;
+  static_assert(K <= 9 && padL <= 4, "the window is the previous, own and next group of four");
+  const int c = blockIdx.x;
+  const int g4 = T >> 2;                                   // groups of four steps per row
+  const int nitem = B * g4;                                // (frame, group) items of this channel
+  float acc[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) acc[k] = 0.f;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  for (int it = blockIdx.y * 256 + threadIdx.x; it < nitem; it += gridDim.y * 256) {
+    const int b = it / g4, g = it - b * g4;
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x + ((long)b * C + c) * T);
+    const f32x4* dr = reinterpret_cast<const f32x4*>(dy + ((long)b * C + c) * T);
+    const f32x4 xa = g > 0 ? xr[g - 1] : zero, xb = xr[g], xc = g + 1 < g4 ? xr[g + 1] : zero, d = dr[g];
+    const float w[12] = {xa[0], xa[1], xa[2], xa[3], xb[0], xb[1], xb[2], xb[3], xc[0], xc[1], xc[2], xc[3]};
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[k] = fmaf(w[4 + e + k - padL], d[e], acc[k]);     // x[4g + e + k - padL] dy[4g + e]
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const float s_ = wave_sum(acc[k]);
+    if (lane == 0) red[wave][k] = s_;
+  }
+  __syncthreads();
+  if (threadIdx.x < K) {
+    const int k = threadIdx.x;
+    atomicAdd(dwd + k * C + c, (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]));
+  }
+}
+
 extern "C" int nsc_depthwise_bwd(const float* x, const float* wd, const float* dy, float* dx, float* dwd, int B, int C,
                                  int T, int K, void* stream) {
   NSC_REQUIRE(x && wd && dy && B > 0 && C > 0 && T > 0 && K > 0, NSC_ERR_BAD_ARG, "nsc_depthwise_bwd: bad args");
@@ -195,7 +237,12 @@ extern "C" int nsc_depthwise_bwd(const float* x, const float* wd, const float* d
     NSC_CHECK_LAUNCH("depthwise_bwd_dx");
   }
   if (dwd) {
-    if (T + 16 <= 768)
+    static const bool no_reg = NSC_PROBE_SET("NSC_DW_NO_REG");     // A/B switch for profiling
+    if (K == 9 && (T & 3) == 0 && !no_reg && ((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0) {
+      // ~2 workgroups of one channel per CU-slot: enough loads in flight, few same-address atomics (gy per element)
+      const int gy = std::max(1, std::min(nsc_cdiv(B * (T / 4), 256), std::max(1, 2048 / C)));
+      hipLaunchKernelGGL(depthwise_bwd_dw_reg_kernel<9>, dim3(C, gy), dim3(256), 0, (hipStream_t)stream, x, dy, dwd, B, C, T);
+    } else if (T + 16 <= 768)
       hipLaunchKernelGGL(depthwise_bwd_dw4_kernel, dim3(C, nsc_cdiv(B, DWB_NF)), dim3(256),
                          DWB_NF * (T + 16) * sizeof(float), (hipStream_t)stream, x, dy, dwd, B, C, T, K);
     else
@@ -502,6 +549,33 @@ extern "C" int nsc_gather(const float* src, const int* idx, float* dst, long n, 
   hipLaunchKernelGGL(gather_kernel, dim3(std::min<long>(2048, nsc_cdiv(n, 256))), dim3(256), 0, (hipStream_t)stream,
                      src, idx, dst, n);
   NSC_CHECK_LAUNCH("gather");
+  return NSC_OK;
+}
+
+// The three launches that open a training step in ONE (round 4): dst = gather(src, idx) as above; zero[0, zn) = 0 (the gradients and
+// histograms, 16-byte aligned, zn % 4 == 0); counter[0] += 1 (the optimizer's step counter, read by the Adam launch at the END of the
+// step: nothing between here and there touches it).  The zeroing used to be a runtime memset node and the increment a one-thread
+// kernel - each a dispatch of ~5 us in the step's graph.
+__global__ void step_begin_kernel(const float* __restrict__ src, const int* __restrict__ idx, float* __restrict__ dst, long n,
+                                  float* __restrict__ zero, long zn4, int* __restrict__ counter, int gather_blocks) {
+  if ((int)blockIdx.x < gather_blocks) {
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gather_blocks * blockDim.x)
+      dst[e] = idx[e] >= 0 ? src[max(idx[e], 0)] : 0.f;
+    if (counter && blockIdx.x == 0 && threadIdx.x == 0) counter[0] += 1;
+  } else {
+    const int zb = gridDim.x - gather_blocks;
+    f32x4* z4 = reinterpret_cast<f32x4*>(zero);
+    for (long e = (blockIdx.x - gather_blocks) * (long)blockDim.x + threadIdx.x; e < zn4; e += (long)zb * blockDim.x)
+      z4[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+}
+extern "C" int nsc_step_begin(const float* src, const int* idx, float* dst, long n, float* zero, long zero_n, int* counter,
+                              void* stream) {
+  NSC_REQUIRE(src && idx && dst && n > 0 && zero && zero_n > 0, NSC_ERR_BAD_ARG, "nsc_step_begin: bad args");
+  NSC_REQUIRE((zero_n & 3) == 0 && ((uintptr_t)zero & 15) == 0, NSC_ERR_BAD_ARG, "nsc_step_begin: the zeroed range must be 16-byte aligned and a multiple of 4 floats");
+  const int gb = (int)std::min<long>(2048, nsc_cdiv(n, 256)), zb = (int)std::min<long>(512, nsc_cdiv(zero_n / 4, 256));
+  hipLaunchKernelGGL(step_begin_kernel, dim3(gb + zb), dim3(256), 0, (hipStream_t)stream, src, idx, dst, n, zero, zero_n / 4, counter, gb);
+  NSC_CHECK_LAUNCH("step_begin");
   return NSC_OK;
 }
 

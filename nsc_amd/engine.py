@@ -99,13 +99,19 @@ class _Conv:
         """Algorithmic FLOPs of one pass over this layer (2*MAC), identical for fwd, dgrad and wgrad."""
         return 2.0 * self.eng.B * self.Tout * self.Cout * self.K * self.Cin
 
-    def fwd(self, x, y, act="none", res=None, res_mode=0, out_mode=0):
+    def fwd(self, x, y, act="none", res=None, res_mode=0, out_mode=0, chain=None):
+        """chain (Cout = 1 only): a _lib.Cout1Chain applied elementwise to the [B,1,T] result in the conv's own epilogue."""
         e = self.eng
         d = self.desc(act=KIND_ACT[act], res_mode=res_mode, out_mode=out_mode)
-        fn = e.lib.nsc_conv1d_cout1_fwd if self.Cout == 1 else e.lib.nsc_conv1d_fwd
         tok = e.prof_begin("conv_cout1" if self.Cout == 1 else "conv_mfma", self.flops())
-        check(fn(C.byref(d), x.data_ptr(), self._p(e.p_ptr, self.w_off), self._p(e.p_ptr, self.b_off),
-                 _lib.ptr(res), None, y.data_ptr(), e.stream()), f"conv fwd {self.name}")
+        if self.Cout == 1:
+            check(e.lib.nsc_conv1d_cout1_fwd_chain(C.byref(d), x.data_ptr(), self._p(e.p_ptr, self.w_off), self._p(e.p_ptr, self.b_off),
+                                                   _lib.ptr(res), None, y.data_ptr(), C.byref(chain) if chain is not None else None,
+                                                   e.stream()), f"conv fwd {self.name}")
+        else:
+            assert chain is None
+            check(e.lib.nsc_conv1d_fwd(C.byref(d), x.data_ptr(), self._p(e.p_ptr, self.w_off), self._p(e.p_ptr, self.b_off),
+                                       _lib.ptr(res), None, y.data_ptr(), e.stream()), f"conv fwd {self.name}")
         e.prof_end(tok)
 
     def poly_ok(self):
@@ -127,8 +133,9 @@ class _Conv:
                     out[tp, :, par::2] = src[k].T          # [Co, Ci]
         return out.reshape(-1).astype(np.int32)
 
-    def dgrad(self, dz, dx, res=None, res_mode=0, mul_kind="none", aux=None):
-        """dx = conv^T(dz) (+res) (* act'(aux)); runs the forward kernel on the flipped/transposed weights."""
+    def dgrad(self, dz, dx, res=None, res_mode=0, mul_kind="none", aux=None, chain=None):
+        """dx = conv^T(dz) (+res) (* act'(aux)); runs the forward kernel on the flipped/transposed weights.
+        chain (Cin = 1 only): a _lib.Cout1Chain applied to the [B,1,T] result in the kernel's epilogue."""
         e = self.eng
         if self.poly_ok() and e.poly_dgrad:
             d = ConvDesc(B=e.B, Cin=self.Cout, Cout=2 * self.Cin, Tin=self.Tout, Tout=self.Tout, K=5, dil=1, stride=1, padL=2,
@@ -143,10 +150,15 @@ class _Conv:
         d = ConvDesc(B=e.B, Cin=self.Cout, Cout=self.Cin, Tin=self.Tout, Tout=self.Tin, K=self.K, dil=self.dil,
                      stride=1, padL=padl, act=0, res_mode=res_mode, mul_mode=KIND_MUL[mul_kind], out_mode=0,
                      in_up=1 if self.stride == 2 else 0, accumulate=0)
-        fn = e.lib.nsc_conv1d_cout1_fwd if self.Cin == 1 else e.lib.nsc_conv1d_fwd
         tok = e.prof_begin("conv_cout1" if self.Cin == 1 else "conv_mfma", self.flops())
-        check(fn(C.byref(d), dz.data_ptr(), self._p(e.wt_ptr, self.w_off), None, _lib.ptr(res),
-                 _lib.ptr(aux) if mul_kind != "none" else None, dx.data_ptr(), e.stream()), f"conv dgrad {self.name}")
+        if self.Cin == 1:
+            check(e.lib.nsc_conv1d_cout1_fwd_chain(C.byref(d), dz.data_ptr(), self._p(e.wt_ptr, self.w_off), None, _lib.ptr(res),
+                                                   _lib.ptr(aux) if mul_kind != "none" else None, dx.data_ptr(),
+                                                   C.byref(chain) if chain is not None else None, e.stream()), f"conv dgrad {self.name}")
+        else:
+            assert chain is None
+            check(e.lib.nsc_conv1d_fwd(C.byref(d), dz.data_ptr(), self._p(e.wt_ptr, self.w_off), None, _lib.ptr(res),
+                                       _lib.ptr(aux) if mul_kind != "none" else None, dx.data_ptr(), e.stream()), f"conv dgrad {self.name}")
         e.prof_end(tok)
 
     def wgrad(self, x, dz):
@@ -435,7 +447,8 @@ class _Codec:
         return out + self.dec_tail
 
     # -------------------------------------------------------------------------------------------
-    def forward(self, x, is_quan_on, soft, want_p=False):
+    def forward(self, x, is_quan_on, soft, want_p=False, chain=None):
+        """chain: elementwise follow-up of the decoded frame in the output conv's epilogue (the cascade step)."""
         e, s = self.eng, self.scope
         B = e.B
         self.x_in = x
@@ -491,7 +504,7 @@ class _Codec:
             h = blk.fwd(h)
         self.dec_feat = h
         self.dec = e.buf(s + ".dec", (B, 1, frame_length))
-        self.dec_out.fwd(h, self.dec, "none")
+        self.dec_out.fwd(h, self.dec, "none", chain=chain)
         return self.dec
 
     def entropy(self):
@@ -503,7 +516,7 @@ class _Codec:
                                           e.stream()), "entropy_from_hist")
         return self.ent
 
-    def backward(self, ddec, c_quan, ent_scale, need_dx=False):
+    def backward(self, ddec, c_quan, ent_scale, need_dx=False, chain=None):
         """ddec [B,1,512] = dL/d dec.  c_quan: coefficient on sum_b quan_loss[b]; ent_scale: coefficient on the
         entropy scalar (tau * global batch).  Accumulates parameter grads; returns dL/dx_in if need_dx."""
         e, s = self.eng, self.scope
@@ -569,7 +582,7 @@ class _Codec:
         self.in_conv.wgrad(self.x_in, dz)
         if need_dx:
             dx = e.buf(s + ".dx_in", (B, 1, frame_length))
-            self.in_conv.dgrad(dz, dx)
+            self.in_conv.dgrad(dz, dx, chain=chain)
             return dx
         return None
 
@@ -767,6 +780,8 @@ class CascadeEngine:
     # ---- block weight gradients deferred to the end of the backward pass and produced by ONE persistent launch per
     # block width (nsc_gated_block_wgrad_batch): per-block launches walk only 2-4 tiles per workgroup at batch 128, so
     # their prologue, accumulator flush and slab reduction cost more than the MFMA work itself.
+    fused_chain = True   # the cascade step / output-gradient arithmetic between codecs rides in the epilogue of the Cout = 1 convs
+                         # (nsc_conv1d_cout1_fwd_chain) instead of nsc_cascade_step / nsc_axpby launches
     poly_dgrad = True    # stride-2 data gradients in polyphase form (half the MFMAs of the zero-upsampled form)
     fused_up = True      # decoder up-sampling stage as one kernel per direction (nsc_upsample_fwd / _bwd)
     batch_wgrad = True
@@ -1081,15 +1096,21 @@ class CascadeEngine:
             self.xin.append(xin)
             keep = self.keep_activations
             self.keep_activations = keep and i >= first_needed
+            sc = (1.0 / rs) if scaled else 1.0
+            # decoded (+)= sc * dec, and the next codec's input rs * (x - decoded): in the epilogue of the codec's output conv
+            # (fused_chain; otherwise nsc_cascade_step, one launch per codec)
+            xin_next = self.buf(f"xin{i + 1}", (B, 1, frame_length)) if i + 1 < self.N else None
+            chain = None
+            if self.fused_chain:
+                chain = _lib.Cout1Chain(self.decoded.data_ptr() if i > 0 else None, self.decoded.data_ptr(), 1.0, sc,
+                                        x.data_ptr() if xin_next is not None else None, _lib.ptr(xin_next), rs, -rs)
             try:
-                dec = c.forward(xin, is_quan_on, soft, want_p)
+                dec = c.forward(xin, is_quan_on, soft, want_p, chain=chain)
             finally:
                 self.keep_activations = keep
-            sc = (1.0 / rs) if scaled else 1.0
-            # decoded (+)= sc * dec, and the next codec's input rs * (x - decoded), in one launch
-            xin_next = self.buf(f"xin{i + 1}", (B, 1, frame_length)) if i + 1 < self.N else None
-            check(self.lib.nsc_cascade_step(dec.data_ptr(), self.decoded.data_ptr(), int(i > 0), x.data_ptr(), _lib.ptr(xin_next),
-                                            sc, rs, n, self.stream()), "cascade_step")
+            if chain is None:
+                check(self.lib.nsc_cascade_step(dec.data_ptr(), self.decoded.data_ptr(), int(i > 0), x.data_ptr(), _lib.ptr(xin_next),
+                                                sc, rs, n, self.stream()), "cascade_step")
         if self.lpc and lpc_x is not None:
             # LSF quantizer (nsc_module:993-1005): only its soft assignment enters the loss (py_func has no grad)
             L, nb = lpc_x.shape[1], len(lpc_coeff_lsf_bins)
@@ -1134,6 +1155,7 @@ class CascadeEngine:
         ents = self.entropies()
         n = B * frame_length
         dsum = None  # running sum over later codecs of dL/dxin_j
+        ddec_ready = False
         pending = []
         # LSF quantizer first: its loss terms do not depend on the codecs' backward pass, and its two gradients then travel in
         # the same all-reduce message as scope_1 (adjacent in the flat buffer) instead of a third one
@@ -1160,7 +1182,9 @@ class CascadeEngine:
             sc = (1.0 / rs) if scaled else 1.0
             ddec = self.buf(f"ddec{i}", (B, 1, frame_length))
             # d yhat_i = G - rs * sum_{j>i} dxin_j ; d dec_i = d yhat_i * sc   (G already carries gsc)
-            if dsum is None:
+            if ddec_ready:
+                pass                                   # written by the previous codec's input-conv data gradient (fused_chain)
+            elif dsum is None:
                 if sc == gsc:
                     ddec = G
                 else:
@@ -1169,10 +1193,21 @@ class CascadeEngine:
                 check(self.lib.nsc_axpby(G.data_ptr(), dsum.data_ptr(), ddec.data_ptr(), sc / gsc, -rs * sc, n, self.stream()),
                       "axpby")
             need_dx = i > first_needed
+            chain, ddec_ready = None, False
+            if need_dx and self.fused_chain:
+                # S_i = S_{i+1} + dxin_i and d dec_{i-1} = sc' G / gsc - rs sc' S_i, both in the epilogue of this codec's
+                # input-conv data gradient (they were one or two nsc_axpby launches)
+                sc_prev = (1.0 / rs) if ((i - 1 > 0) or self.scale_first) else 1.0
+                S = self.buf(f"dsum{i}", (B, 1, frame_length))
+                chain = _lib.Cout1Chain(dsum.data_ptr() if dsum is not None else None, S.data_ptr(), 1.0, 1.0,
+                                        G.data_ptr(), self.buf(f"ddec{i - 1}", (B, 1, frame_length)).data_ptr(),
+                                        sc_prev / gsc, -rs * sc_prev)
             if trainable[i]:
-                dx = c.backward(ddec, c_quan[i], c_ent[i] * Bg, need_dx=need_dx)
+                dx = c.backward(ddec, c_quan[i], c_ent[i] * Bg, need_dx=need_dx, chain=chain)
             else:
                 raise NotImplementedError("a frozen codec between trainable ones is not a reference configuration")
+            if chain is not None:
+                dsum, ddec_ready = S, True
             if grad_allreduce is not None and self.dp_overlap:
                 # data parallel: this codec's gradients are complete once its deferred weight gradients have run; send them
                 # now, under the backward pass of the earlier codecs (scope = one contiguous range of the flat buffer)
@@ -1182,7 +1217,7 @@ class CascadeEngine:
                 if lpc_rng is not None and lpc_rng[1] == a:
                     a, lpc_rng = lpc_rng[0], None
                 pending.append(self._collective("async", lambda a=a, b=b: grad_allreduce(self.grads[a:b])))
-            if need_dx:
+            if need_dx and chain is None:
                 if dsum is None:
                     dsum = dx
                 else:
@@ -1253,11 +1288,13 @@ class CascadeEngine:
         finally:
             self._leave()
 
-    def adam_step(self, scopes, lr, slot=1, beta1=0.9, beta2=0.999, eps=1e-8):
-        """TF1 Adam on the flat ranges of the given scopes (independent state per optimizer slot)."""
+    def adam_step(self, scopes, lr, slot=1, beta1=0.9, beta2=0.999, eps=1e-8, counted=False):
+        """TF1 Adam on the flat ranges of the given scopes (independent state per optimizer slot).
+        counted: the device step counter of this slot was already advanced for this step (train_step does it in nsc_step_begin)."""
         st = self.adam[slot]
         st["t"] += 1   # host mirror; the kernel reads the device counter so a captured graph stays valid
-        check(self.lib.nsc_increment(st["t_dev"].data_ptr(), self.stream()), "increment")
+        if not counted:
+            check(self.lib.nsc_increment(st["t_dev"].data_ptr(), self.stream()), "increment")
         # adjacent scopes are adjacent ranges of the flat buffers: merge them (one launch for the joint step)
         ranges = []
         for sc in scopes:
@@ -1287,8 +1324,12 @@ class CascadeEngine:
             self._leave()
 
     def _train_step(self, x, target, cfg, lpc_x, comm):
-        check(self.lib.nsc_zero(self.g_ptr, self._gh_floats, self.stream()), "zero grads + hists")   # ONE memset node
-        self.refresh_wt()
+        # ONE launch opens the step: zero gradients + histograms, rebuild the data-gradient kernels / parameter images (refresh_wt),
+        # advance the optimizer's device step counter (read by the Adam launch at the end of this step)
+        slot = cfg.get("slot", 1)
+        check(self.lib.nsc_step_begin(self.p_ptr, self.wt_idx.data_ptr(), self.wt_ptr, self.wt.numel(), self.g_ptr, self._gh_floats,
+                                      self.adam[slot]["t_dev"].data_ptr(), self.stream()), "step_begin")
+        self.images_valid = True
         self.forward(x, cfg["is_quan_on"], True, lpc_x=lpc_x, hists_clean=True,
                      first_needed=min([i for i, t in enumerate(cfg["trainable"]) if t], default=self.N))
         gb = self.B * (comm.world if comm else 1)
@@ -1307,5 +1348,5 @@ class CascadeEngine:
             train_lpc = cfg.get("c_quan_lpc", 0.0) != 0.0 or cfg.get("c_ent_lpc", 0.0) != 0.0
         if self.lpc and train_lpc:
             scopes = ["lpc_quan"] + scopes
-        self.adam_step(scopes, cfg["lr"], cfg.get("slot", 1))
+        self.adam_step(scopes, cfg["lr"], slot, counted=True)
         return terms
