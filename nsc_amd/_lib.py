@@ -70,6 +70,8 @@ PROTOTYPES = {
     "nsc_rfft512": [_P, _I, _P, _P, _P, _P],
     "nsc_adam_tf1_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _P, _P],
     "nsc_increment": [_P, _P],
+    "nsc_gated_block_pair_fwd_img": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
+    "nsc_gated_block_pair_dgrad_img": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
     "nsc_step_begin": [_P, _P, _P, _L, _P, _L, _P, _P],
     "nsc_frame_utterance": [_P, _L, _P, _P, _I, _P],
     "nsc_overlap_add": [_P, _I, _P, _P, _P],
@@ -111,6 +113,7 @@ PROTOTYPES["nsc_entropy_from_hist_batch"] = [C.POINTER(EntropyJob), _I, _P]
 PROTOTYPES["nsc_gated_block_wgrad_batch"] = [C.POINTER(BlockWgradJob), _I, _I, _I, _I, _P, _L, _P]
 PROTOTYPES["nsc_conv1d_wgrad_batch"] = [C.POINTER(ConvWgradJob), _I, _P, _L, _P]
 EXPORTS = sorted(list(PROTOTYPES) + ["nsc_version", "nsc_last_error", "nsc_gated_block_wgrad_workspace", "nsc_gated_block_image_floats",
+                  "nsc_gated_block_pair_flag_ints",
                   "nsc_conv1d_wgrad_workspace", "nsc_gated_block_wgrad_batch_workspace",
                   "nsc_conv1d_wgrad_batch_workspace"])
 

@@ -245,8 +245,57 @@ __global__ __launch_bounds__(512) void gated_block_fwd_kernel(BlockArgs a, int l
 // while the current tile computes.  Built for the shapes the codec uses (C = 4*NK1 rounded, dil 1|2); other shapes
 // take v1.
 // -----------------------------------------------------------------------------------------------------
-template <int RT9, int NK1, int DIL>
-__global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int ntiles, int tpf, int skip) {
+// ---- neighbour flags of a PAIR launch (one launch = two blocks of a stack, the second reads what the first wrote) ----
+// The second block's tiles of workgroup w need columns its neighbours w - 1 / w + 1 produced in the first block (the halo of
+// its first / last tile); every other input of those tiles is the workgroup's own.  So instead of a kernel boundary - all 256
+// workgroups drained, a dispatch, and every workgroup's weight prologue and first tile exposed again - a workgroup publishes
+// "my first-block tiles are in memory" (agent-scope release: its L2 is written back) and, before the first x / dy load of the
+// second block, waits for its two neighbours' flags (agent-scope acquire: stale lines invalidated).  All workgroups of the launch
+// are co-resident (grid <= CUs, one workgroup per CU by LDS: the launcher checks), so the wait cannot deadlock; it is bounded
+// anyway and counts a time-out in flags[gridDim.x] (results are then wrong; the engine checks the counter).
+// Flags are zeroed by the caller before the launch (the engine: in the step's opening launch).
+// Memory model (gfx950, one L2 per XCD, the L2s not coherent with each other).  An agent-scope FENCE pair writes back and
+// INVALIDATES a whole L2 per workgroup: measured, every pair launch 55 us slower than its two blocks launched one by one (the 32
+// workgroups of an XCD keep emptying the L2 the others work from).  A write-back alone (buffer_wbl2 sc1 per wave, no invalidation)
+// still cost 15-20 us per pair launch (timing builds EXP=64 / 128: profiles/r04b_pair_launch_experiments.txt).  So only what
+// crosses workgroups is made coherent, operation by operation:
+//   * the first block's tensor that the second block reads leaves through WRITE-THROUGH stores (sc0 sc1: in memory once acknowledged);
+//   * publish: every wave waits for its stores (vmcnt), barrier, one relaxed agent-scope store (sc1) sets the flag;
+//   * wait: relaxed agent-scope loads of the flag (sc1: from memory), no fence;
+//   * the second block reads that tensor with sc0 sc1 loads (served from memory / the memory-side Infinity Cache, never from an
+//     L1 / L2 line) - its only input that another workgroup wrote in this launch.
+#if defined(NSC_EXP) && (NSC_EXP & 128)
+#define NSC_AUX_COHERENT 0        /* timing experiment (NOT coherent): ordinary loads */
+#else
+#define NSC_AUX_COHERENT 0x11     /* raw buffer load aux bits on gfx940+: bit 0 = sc0, bit 4 = sc1 */
+#endif
+__device__ __forceinline__ void nsc_pair_publish(int* flags) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's write-through stores are acknowledged: they are in memory
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(flags + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void nsc_pair_wait(int* flags) {
+  if (threadIdx.x < 2) {
+    const int nb = (int)blockIdx.x + (threadIdx.x == 0 ? -1 : 1);
+    if (nb >= 0 && nb < (int)gridDim.x) {
+      int it = 0;
+      while (__hip_atomic_load(flags + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+        __builtin_amdgcn_s_sleep(4);
+        if (++it > (1 << 20)) {                       // ~0.1 s: never in a healthy launch
+          atomicAdd(flags + gridDim.x, 1);
+          break;
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// PAIRED: this body runs as the SECOND block of a pair launch: it waits for the neighbours' flags before its first x load
+// FIRST: this body runs as the FIRST block of a pair launch: its output leaves through write-through stores (sc0 sc1: in memory
+// when acknowledged), so that publishing needs no write-back of the whole L2
+template <int RT9, int NK1, int DIL, bool PAIRED, bool FIRST = false>
+__device__ __forceinline__ void gated_block_fwd2_body(const BlockArgs& a, int ntiles, int tpf, int skip, int* flags) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int TT = 64, H = 4 + 7 * DIL, WX = TT + 2 * H, WGW = TT + 8, LDX = 112, LDG = 80, CR = 4 * NK1, LDW = 48;
   constexpr int NCT1 = (WX + 15) / 16;      // column tiles of the h tile (7 at dil 2, 6 at dil 1)
@@ -277,6 +326,8 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
   f32x4 pf4[NQ4];
   const __amdgpu_buffer_rsrc_t sx =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (unsigned)((long)a.B * Cin * T * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t sout =
+      __builtin_amdgcn_make_buffer_rsrc(a.out, 0, FIRST ? (unsigned)((long)a.B * a.C * T * 4) : 0u, 0x00020000);
   const int pi4 = lane & 31, phalf = lane >> 5;
   int pf_vo = 0;
   auto pf_setup = [&](int tile) {
@@ -291,7 +342,7 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
   // lanes' offset goes out of range; the staging step writes zeros there either way)
   auto pf1 = [&](int q) {
     const int vo = (q == NQ4 - 1 && 2 * wave + phalf + 16 * q >= Cin) ? 0x7ffffff0 : pf_vo;
-    pf4[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(sx, vo, q * 16 * T * 4, 0));
+    pf4[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(sx, vo, q * 16 * T * 4, PAIRED ? NSC_AUX_COHERENT : 0));
   };
   auto prefetch = [&](int tile) {
     pf_setup(tile);
@@ -304,7 +355,7 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
   // element is produced by the same instruction sequence in both modes, so the output bits do not depend on the mode.
   const int first = (int)((long)blockIdx.x * ntiles / gridDim.x), last = (int)((long)(blockIdx.x + 1) * ntiles / gridDim.x);
   NSC_STAMP(32);
-  prefetch(first);
+  if (!PAIRED) prefetch(first);          // (a paired body: after the neighbours' flags, below - the weights do not wait for them)
   // ---- once per workgroup: weights -> LDS / registers ----
   const int r1 = wave >> 2;
   float w1r[NK1];
@@ -420,6 +471,10 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
   }
 
 
+  if (PAIRED) {
+    nsc_pair_wait(flags);                // the first block's output around this workgroup's tiles is in memory
+    prefetch(first);
+  }
   nsc_wait_vmem();   // weights (and the first tile) are in: no vmcnt guards on register operands inside the loop
   // the k15 gate kernels by LDS-DMA (image path; see gated_block_dgrad2_role): the youngest vector-memory operations when the tile
   // loop starts, waited for by hand before the first tile's phase 2
@@ -675,6 +730,14 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
     int lane3 = lane;
     asm volatile("" : "+v"(lane3));
     const int l15p = lane3 & 15, kqp = lane3 >> 4;
+    // (first block of a pair launch: the output is written through to memory, see nsc_pair_publish)
+    auto out_store = [&](float v, int b_, int o, int t) {
+      if constexpr (FIRST) {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), sout, ((b_ * C + o) * T + t) * 4, 0, NSC_AUX_COHERENT);
+      } else {
+        a.out[((long)b_ * C + o) * T + t] = v;
+      }
+    };
     // dense job: this wave's row tile, NC column tiles from ct0 on (weights in registers)
     auto dense3 = [&](auto nc_c, int ct0) {
       constexpr int NC = decltype(nc_c)::value;
@@ -703,7 +766,7 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
 #endif
             float v = acc[c][reg] + b9r[reg] + xs[(NK1 == 1 ? 0 : o) * LDX + H + tt];   // Cin = 1: broadcast residual
             if (!a.flat) v = v > 0.f ? v : NSC_LRELU_ALPHA * v;
-            a.out[((long)b * C + o) * T + t] = v;
+            out_store(v, b, o, t);
           }
         }
       }
@@ -734,7 +797,7 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
           const int o = 96 + reg;
           float v = acc0[reg] + acc1[reg] + w9p[K9 * NARROW * 4 + reg] + xs[(NK1 == 1 ? 0 : o) * LDX + H + tt];
           if (!a.flat) v = v > 0.f ? v : NSC_LRELU_ALPHA * v;
-          a.out[((long)b * C + o) * T + t] = v;
+          out_store(v, b, o, t);
         }
       }
     };
@@ -757,6 +820,20 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
     NSC_STAMP(42);
   }
   NSC_STAMP(43);
+}
+
+template <int RT9, int NK1, int DIL>
+__global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int ntiles, int tpf, int skip) {
+  gated_block_fwd2_body<RT9, NK1, DIL, false>(a, ntiles, tpf, skip, nullptr);
+}
+
+// Two consecutive blocks of a stack (dilation 1 then 2, the reference's `_stack_bottleneck_blocks`: neural_speech_coding_module.py
+// :183-217) in ONE launch: see nsc_pair_publish / nsc_pair_wait.  a1.x must be a0.out.
+template <int RT9, int NK1>
+__global__ __launch_bounds__(512) void gated_block_fwd2_pair_kernel(BlockArgs a0, BlockArgs a1, int ntiles, int tpf, int* flags) {
+  gated_block_fwd2_body<RT9, NK1, 1, false, true>(a0, ntiles, tpf, 0, nullptr);
+  nsc_pair_publish(flags);
+  gated_block_fwd2_body<RT9, NK1, 2, true>(a1, ntiles, tpf, 0, flags);
 }
 
 template <int RT9, int NK1, int DIL>
@@ -1947,8 +2024,10 @@ __device__ __forceinline__ void d15_packed(const float* w15s, const float* da, i
 // got the matrix pipe only when the dense one had finished and then ran alone, latency-bound (per-wave stamps: 9.8 k cycles
 // dense, 13.4 k packed, of which the SIMD idled ~3 k; k15 gradient at dil 2: 7.8 k / 12.0 k).  With identical streams on both
 // waves of a SIMD each fills the other's LDS waits and both end together.
-template <int RT9, int NK9, int DIL, bool CIN1, int ROLE>
-__device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a, int ntiles, int tpf, int skip) {
+// PAIRED: second block of a pair launch (nsc_pair_publish / nsc_pair_wait): its dy is what the first block's body wrote as dx
+// FIRST: first block of a pair launch: dx leaves through write-through stores (see gated_block_fwd2_body)
+template <int RT9, int NK9, int DIL, bool CIN1, int ROLE, bool PAIRED = false, bool FIRST = false>
+__device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a, int ntiles, int tpf, int skip, int* flags = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int TT = 64, Hh = 7 * DIL, W_a = TT + 2 * Hh, W_dy = W_a + 8, NCTA = (W_a + 15) / 16, CR = 4 * NK9;
   // LDY / LDA == 14 (mod 32): the two channel rows a 32-lane group reads sit 14 banks apart.  The packed tiles walk time
@@ -1998,6 +2077,7 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
   // da / dgate: two views of one [B][da_rows][T] tensor (dgate = da + 20 T) or two [B][20][T] tensors: the range check of either
   // resource covers what is addressable from its base
   const unsigned nbDA = (unsigned)(((long)a.B * a.da_rows - (a.da_rows == NARROW ? 0 : NARROW)) * T * 4);
+  const __amdgpu_buffer_rsrc_t sdxo = __builtin_amdgcn_make_buffer_rsrc(a.dx, 0, FIRST ? (unsigned)((long)a.B * C * T * 4) : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t sdlin = __builtin_amdgcn_make_buffer_rsrc(a.da, 0, nbDA, 0x00020000);
   const __amdgpu_buffer_rsrc_t sdgate = __builtin_amdgcn_make_buffer_rsrc(a.dgate, 0, nbDA, 0x00020000);
   // ---- prefetch of the next tile, 16 bytes per lane: lane = (row half lane >> 5, float4 index lane & 31); a wave instruction
@@ -2046,7 +2126,8 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
   // 112 rows fetched for 100.  Only the last q of a wave can reach them: those lanes' offset goes out of range.)
   auto pf_dy1 = [&](int q) {
     const int vo = (q == NQY - 1 && 2 * wave + phalf + 16 * q >= C) ? OOB : pf_vy;
-    pfy[q] = bld4(sdy, vo, (pf_b * C + 2 * wave + 16 * q) * T * 4);
+    pfy[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(sdy, vo, (pf_b * C + 2 * wave + 16 * q) * T * 4,
+                                                                             PAIRED ? NSC_AUX_COHERENT : 0));
   };
   auto pf_a1 = [&](int i) {                                    // i = 0..4: lin rows, tanh rows, lin rows + 16, tanh rows + 16, h
     const int so = (pf_b * NARROW + 2 * wave + 16 * (i >> 1)) * T * 4;
@@ -2073,7 +2154,7 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
   NSC_STAMP(0);
   pf_setup(first, false);
 #if !(defined(NSC_EXP) && (NSC_EXP & 1))
-  prefetch_dy();
+  if (!PAIRED) prefetch_dy();            // (a paired body: after the neighbours' flags, below)
   prefetch_a();
 #endif
   static_assert(NK9 == 4 * (NJ9 - 1) + 1, "left-over channel group is shared out by tap");
@@ -2190,6 +2271,10 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
   }
 
 
+  if (PAIRED) {
+    nsc_pair_wait(flags);                // the first block's dx around this workgroup's tiles is in memory
+    prefetch_dy();
+  }
   nsc_wait_vmem();   // weights (and the first tile) are in: no vmcnt guards on register operands inside the loop
   // the k15 table by LDS-DMA (image path): 16 bytes per lane, 1 KiB per wave instruction, destination m0 + lane * 16.  Hidden in
   // inline asm: hipcc would otherwise wait vmcnt(0) for it at the next use of any ordinary load's result and at every barrier.
@@ -2579,7 +2664,10 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
               for (int e = 0; e < 4; ++e) v[e] *= (xv[q][e] > 0.f ? 1.f : NSC_LRELU_ALPHA);
             }
             float* gp = a.dx + ((long)b * C + r) * T + tx;
-            if (tvec) {
+            if constexpr (FIRST) {                           // written through to memory: the pair's second block reads it
+              const int bo = ((b * C + r) * T + tx) * 4;
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, v), sdxo, bo, 0, NSC_AUX_COHERENT);   // (pair launches: T % 4 == 0)
+            } else if (tvec) {
               *reinterpret_cast<f32x4*>(gp) = v;
             } else {
   #pragma unroll
@@ -2601,6 +2689,21 @@ template <int RT9, int NK9, int DIL, bool CIN1 = false>
 __global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs a, int ntiles, int tpf, int skip) {
   if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 8) == 0) gated_block_dgrad2_role<RT9, NK9, DIL, CIN1, 0>(a, ntiles, tpf, skip);
   else gated_block_dgrad2_role<RT9, NK9, DIL, CIN1, 1>(a, ntiles, tpf, skip);
+}
+
+// the data-path backward of two consecutive blocks of a stack in ONE launch: the dilation-2 block first, then the dilation-1
+// block on the dx it wrote (a0.dy must be a1.dx)
+template <int RT9, int NK9>
+__global__ __launch_bounds__(512) void gated_block_dgrad2_pair_kernel(BlockDgradArgs a1, BlockDgradArgs a0, int ntiles, int tpf, int* flags) {
+  if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 8) == 0) {
+    gated_block_dgrad2_role<RT9, NK9, 2, false, 0, false, true>(a1, ntiles, tpf, 0);
+    nsc_pair_publish(flags);
+    gated_block_dgrad2_role<RT9, NK9, 1, false, 0, true>(a0, ntiles, tpf, 0, flags);
+  } else {
+    gated_block_dgrad2_role<RT9, NK9, 2, false, 1, false, true>(a1, ntiles, tpf, 0);
+    nsc_pair_publish(flags);
+    gated_block_dgrad2_role<RT9, NK9, 1, false, 1, true>(a0, ntiles, tpf, 0, flags);
+  }
 }
 
 template <int RT9, int NK9, int DIL, bool CIN1 = false>
@@ -2804,6 +2907,103 @@ extern "C" int nsc_gated_block_image_index(int which, int C, int Cin, int dil, c
   if (Cin == 1)
     for (int c = 0; c < NARROW; ++c) idx[baseW + 8L * nf4w * 64 * 4 + c] = (int)(wt1 + c);
   return NSC_OK;
+}
+
+// ---- pair launches: two consecutive blocks of a stack (dilations 1, 2; C -> C both) in one launch ----
+static int nsc_cu_count() {
+  static std::atomic<int> cached[64];
+  int dv = 0;
+  if (hipGetDevice(&dv) != hipSuccess || dv < 0 || dv >= 64) return 0;
+  int n = cached[dv].load(std::memory_order_relaxed);
+  if (n == 0) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dv) != hipSuccess) return 0;
+    cached[dv].store(n, std::memory_order_relaxed);
+  }
+  return n;
+}
+extern "C" int nsc_gated_block_pair_flag_ints(void) { return 256 + 1; }     // flags of up to 256 workgroups + the time-out counter
+
+template <int RT9, int NK1>
+static int launch_block_fwd2_pair(const BlockArgs& a0, const BlockArgs& a1, int* flags, hipStream_t st) {
+  constexpr int CR = 4 * NK1;
+  const size_t smem = ((size_t)(CR + NARROW) * 112 + (size_t)3 * NARROW * 80 + (size_t)K15 * NARROW * 48 + (RT9 == 7 ? 728 : 0)) * sizeof(float);
+  auto kern = gated_block_fwd2_pair_kernel<RT9, NK1>;
+  const hipError_t e = NSC_SMEM_ATTR(kern, (int)smem);
+  NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "gated_block_fwd2_pair: smem attr: %s", hipGetErrorString(e));
+  const int tpf = nsc_cdiv(a0.T, 64);
+  const int ntiles = a0.B * tpf;
+  const int grid = std::min(ntiles, 256);
+  // every workgroup of the launch must be resident at once (they wait for each other): one per CU (LDS), so grid <= CUs
+  NSC_REQUIRE(grid <= nsc_cu_count(), NSC_ERR_UNSUPPORTED, "gated_block_fwd2_pair: %d workgroups > %d CUs", grid, nsc_cu_count());
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, a0, a1, ntiles, tpf, flags);
+  NSC_CHECK_LAUNCH("gated_block_fwd2_pair");
+  return NSC_OK;
+}
+
+extern "C" int nsc_gated_block_pair_fwd_img(const float* img0, const float* img1, const float* x, float* out0, float* h0, float* lin0,
+                                            float* th0, float* g0, float* out1, float* h1, float* lin1, float* th1, float* g1, int B,
+                                            int C, int T, int flat1, int* flags, void* stream) {
+  NSC_REQUIRE(img0 && img1 && x && out0 && out1 && flags, NSC_ERR_BAD_ARG, "nsc_gated_block_pair_fwd_img: null pointer");
+  NSC_REQUIRE(B > 0 && T > 0, NSC_ERR_BAD_ARG, "nsc_gated_block_pair_fwd_img: bad sizes");
+  NSC_REQUIRE(C == 100 || C == 50 || C == 25, NSC_ERR_UNSUPPORTED, "nsc_gated_block_pair_fwd_img: C %d", C);
+  NSC_REQUIRE((T & 3) == 0 && (long)B * C * T * 4 < (1L << 31), NSC_ERR_UNSUPPORTED,
+              "nsc_gated_block_pair_fwd_img: needs T %% 4 == 0 and a tensor below 2 GB (T %d, B %d): launch the blocks one by one", T, B);
+  NSC_REQUIRE((((uintptr_t)img0 | (uintptr_t)img1) & 15) == 0, NSC_ERR_BAD_ARG, "nsc_gated_block_pair_fwd_img: images must be 16-byte aligned");
+  NSC_REQUIRE((!(lin0 || th0 || g0) || (lin0 && th0 && g0)) && (!(lin1 || th1 || g1) || (lin1 && th1 && g1)), NSC_ERR_BAD_ARG,
+              "nsc_gated_block_pair_fwd_img: lin/th/g outputs must be given together");
+  BlockArgs a0{B, C, T, 1, 0, x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, out0, h0, lin0, th0, g0, C, img0};
+  BlockArgs a1{B, C, T, 2, flat1, out0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, out1, h1, lin1, th1, g1, C, img1};
+  hipStream_t st = (hipStream_t)stream;
+  if (C == 100) return launch_block_fwd2_pair<7, 25>(a0, a1, flags, st);
+  if (C == 25) return launch_block_fwd2_pair<4, 7>(a0, a1, flags, st);
+  return launch_block_fwd2_pair<4, 13>(a0, a1, flags, st);
+}
+
+template <int RT9, int NK9>
+static int launch_block_dgrad2_pair(const BlockDgradArgs& a1, const BlockDgradArgs& a0, int* flags, hipStream_t st) {
+  size_t smem = 0;
+  for (int dil = 1; dil <= 2; ++dil) {             // the larger of the two bodies' LDS layouts (dilation 2)
+    const int WA16 = ((64 + 14 * dil + 15) / 16) * 16;
+    const size_t partsz = std::max((size_t)4 * NARROW * (WA16 + 4), (size_t)4 * NK9 * 68);
+    const int w9t = a0.C * 4 + (((a0.C * 4) & 15) == 8 ? 0 : 8);
+    smem = std::max(smem, ((size_t)4 * NK9 * 110 + (size_t)2 * NARROW * 110 + (size_t)NARROW * 80 + partsz + (size_t)K15 * W15T +
+                           (size_t)K9 * w9t) * sizeof(float));
+  }
+  NSC_REQUIRE(smem <= 160 * 1024, NSC_ERR_UNSUPPORTED, "gated_block_dgrad2_pair: %zu B LDS", smem);
+  auto kern = gated_block_dgrad2_pair_kernel<RT9, NK9>;
+  const hipError_t e = NSC_SMEM_ATTR(kern, (int)smem);
+  NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "gated_block_dgrad2_pair: smem attr: %s", hipGetErrorString(e));
+  const int tpf = nsc_cdiv(a0.T, 64);
+  const int ntiles = a0.B * tpf;
+  const int grid = std::min(ntiles, 256);
+  NSC_REQUIRE(grid <= nsc_cu_count(), NSC_ERR_UNSUPPORTED, "gated_block_dgrad2_pair: %d workgroups > %d CUs", grid, nsc_cu_count());
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, a1, a0, ntiles, tpf, flags);
+  NSC_CHECK_LAUNCH("gated_block_dgrad2_pair");
+  return NSC_OK;
+}
+
+// block 1 = the dilation-2 block (runs first: dy1 in, dx1 out), block 0 = the dilation-1 block in front of it (its dy is dx1)
+extern "C" int nsc_gated_block_pair_dgrad_img(const float* img1, const float* x1, const float* h1, const float* lin1, const float* th1,
+                                              const float* dy1, float* dx1, float* da1, float* dz1_1, const float* img0,
+                                              const float* x0, const float* h0, const float* lin0, const float* th0, float* dx0,
+                                              float* da0, float* dz1_0, int B, int C, int T, int in_act0, int* flags, void* stream) {
+  NSC_REQUIRE(img1 && x1 && h1 && lin1 && th1 && dy1 && dx1 && da1 && dz1_1 && img0 && x0 && h0 && lin0 && th0 && dx0 && da0 && dz1_0 && flags,
+              NSC_ERR_BAD_ARG, "nsc_gated_block_pair_dgrad_img: null pointer");
+  NSC_REQUIRE(B > 0 && T > 0, NSC_ERR_BAD_ARG, "nsc_gated_block_pair_dgrad_img: bad sizes");
+  NSC_REQUIRE(C == 100 || C == 50 || C == 25, NSC_ERR_UNSUPPORTED, "nsc_gated_block_pair_dgrad_img: C %d", C);
+  NSC_REQUIRE((T & 3) == 0 && (long)B * C * T * 4 < (1L << 31), NSC_ERR_UNSUPPORTED,
+              "nsc_gated_block_pair_dgrad_img: needs T %% 4 == 0 and a tensor below 2 GB (T %d, B %d): launch the blocks one by one", T, B);
+  NSC_REQUIRE((((uintptr_t)img0 | (uintptr_t)img1) & 15) == 0, NSC_ERR_BAD_ARG, "nsc_gated_block_pair_dgrad_img: images must be 16-byte aligned");
+  NSC_REQUIRE(in_act0 == NSC_ACT_NONE || in_act0 == NSC_ACT_LRELU, NSC_ERR_BAD_ARG, "nsc_gated_block_pair_dgrad_img: in_act0");
+  // the dilation-2 block's input is the dilation-1 block's lrelu output: its dx carries lrelu'(x1)
+  BlockDgradArgs a1{B, C, T, 2, NSC_ACT_LRELU, x1, h1, lin1, th1, dy1, nullptr, nullptr, nullptr, nullptr, dx1, da1, dz1_1,
+                    da1 + (long)NARROW * T, 2 * NARROW, img1};
+  BlockDgradArgs a0{B, C, T, 1, in_act0, x0, h0, lin0, th0, dx1, nullptr, nullptr, nullptr, nullptr, dx0, da0, dz1_0,
+                    da0 + (long)NARROW * T, 2 * NARROW, img0};
+  hipStream_t st = (hipStream_t)stream;
+  if (C == 100) return launch_block_dgrad2_pair<7, 25>(a1, a0, flags, st);
+  if (C == 25) return launch_block_dgrad2_pair<4, 9>(a1, a0, flags, st);
+  return launch_block_dgrad2_pair<4, 13>(a1, a0, flags, st);
 }
 
 // The two persistent kernels on an image (shapes of the codec only: C in {100, 50, 25}, Cin in {C, 1}, dil in {1, 2}).

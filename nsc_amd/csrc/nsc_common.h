@@ -7,6 +7,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));   // accumulator of v_mfma_f32_32x32x2_f32
+typedef int i32x4_t __attribute__((ext_vector_type(4)));     // payload type of the 16-byte raw buffer stores
 
 #define NSC_LRELU_ALPHA 0.2f
 

@@ -388,7 +388,6 @@ __global__ __launch_bounds__(256) void quantize_bwd_kernel(
 // instruction, hands them to the 8-lane groups through the cross-lane network (ds_bpermute), collects the 64 quantised
 // codes the same way and stores them with ONE instruction, reduces quan_loss inside the wave - no barrier in the frame
 // loop - and the 1-KiB float4 stores of p are all that is left per pass.
-typedef int i32x4_t __attribute__((ext_vector_type(4)));
 // LPC lanes share a code (ITER = 8 / LPC float4 groups of bins per lane).  LPC = 8 ships (p bit-equal to the workgroup kernel).
 // LPC = 4 (probes library, NSC_QLPC=4: 16 codes per pass, two DPP steps per reduction, ~320 instead of ~560 lane-instructions
 // per code) measured NO faster (4.6-5.1 vs 4.8-5.1 TB/s), as did single 16-byte stores instead of the 12 + 4-byte splits the

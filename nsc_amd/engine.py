@@ -437,6 +437,71 @@ class _Codec:
         self.dec_tail, C_ = stack(C_, T)
         self.dec_out = _Conv(eng, scope, 55, C_, 1, 1, 1, T)
 
+    # ---- a stack of blocks (one resolution): the dil-1 / dil-2 pair of C -> C blocks runs as ONE launch when it can ----
+    def _pair_ok(self, blocks):
+        e = self.eng
+        if not (e.fused_pairs and e.fused_fwd and e.fused_dgrad and e.use_images and len(blocks) == 2):
+            return False
+        b0, b1 = blocks
+        return (b0.Cin == b0.wide == b1.Cin == b1.wide and b0.wide in (100, 50, 25) and b0.cl.dil == 1 and b1.cl.dil == 2 and
+                b0.narrow == 20 and b0.c9.K == 9 and b0.img_fwd_off is not None and b1.img_fwd_off is not None and
+                b0.img_bwd_off is not None and b1.img_bwd_off is not None and not b0.flat and b0.T % 4 == 0 and
+                e.B * b0.wide * b0.T * 4 < 2 ** 31 and
+                min(e.B * ((b0.T + 63) // 64), 256) <= e.cu_count)
+
+    def stack_fwd(self, blocks, h):
+        e = self.eng
+        if not (self._pair_ok(blocks) and e.images_valid):
+            for blk in blocks:
+                h = blk.fwd(h)
+            return h
+        b0, b1 = blocks
+        B, n, T = e.B, b0.narrow, b0.T
+        for blk, xin in ((b0, h), (b1, None)):
+            u = blk.uid
+            blk.x = xin
+            blk.h = e.buf(u + ".h", (B, n, T)); blk.lin = e.buf(u + ".lin", (B, n, T))
+            blk.th = e.buf(u + ".th", (B, n, T)); blk.g = e.buf(u + ".g", (B, n, T))
+            blk.out = e.buf(u + ".out", (B, blk.wide, T))
+        b1.x = b0.out
+        save = e.keep_activations
+        sv = lambda blk: [t.data_ptr() if save else None for t in (blk.h, blk.lin, blk.th, blk.g)]
+        fl = sum(c.flops() for blk in blocks for c in (blk.c1, blk.cl, blk.cr, blk.c9))
+        tok = e.prof_begin("block_fwd", fl)
+        check(e.lib.nsc_gated_block_pair_fwd_img(e.wt_ptr + 4 * b0.img_fwd_off, e.wt_ptr + 4 * b1.img_fwd_off, h.data_ptr(),
+                                                 b0.out.data_ptr(), *sv(b0), b1.out.data_ptr(), *sv(b1), B, b0.wide, T, int(b1.flat),
+                                                 e.pair_flags(), e.stream()), "gated_block_pair_fwd_img")
+        e.prof_end(tok)
+        return b1.out
+
+    def stack_bwd(self, blocks, dz, in_kind_first, in_kind_rest="lrelu"):
+        """Backward through a stack: dz = dL/d(pre-activation of the last block's output).  in_kind_first: what produced the
+        first block's input.  Returns dL/d(pre-activation of that producer)."""
+        e = self.eng
+        if not (self._pair_ok(blocks) and e.batch_wgrad and e.fused_wgrad and in_kind_first in ("lrelu", "none")):
+            for j in range(len(blocks) - 1, -1, -1):
+                dz = blocks[j].bwd(dz, in_kind_rest if j > 0 else in_kind_first)
+            return dz
+        b0, b1 = blocks
+        B, n, T = e.B, b0.narrow, b0.T
+        bufs = {}
+        for blk in blocks:
+            u = blk.uid
+            bufs[blk] = (e.buf(u + ".dx", (B, blk.Cin, T)), e.buf(u + ".da", (B, 2 * n, T)), e.buf(u + ".dh", (B, n, T)))
+        (dx0, da0, dh0), (dx1, da1, dh1) = bufs[b0], bufs[b1]
+        fl = sum(c.flops() for blk in blocks for c in (blk.c1, blk.cl, blk.cr, blk.c9))
+        tok = e.prof_begin("block_dgrad", fl)
+        P = lambda t: t.data_ptr()
+        check(e.lib.nsc_gated_block_pair_dgrad_img(e.wt_ptr + 4 * b1.img_bwd_off, P(b1.x), P(b1.h), P(b1.lin), P(b1.th), P(dz), P(dx1),
+                                                   P(da1), P(dh1), e.wt_ptr + 4 * b0.img_bwd_off, P(b0.x), P(b0.h), P(b0.lin),
+                                                   P(b0.th), P(dx0), P(da0), P(dh0), B, b0.wide, T, KIND_ACT[in_kind_first],
+                                                   e.pair_flags(), e.stream()), "gated_block_pair_dgrad_img")
+        e.prof_end(tok)
+        for blk, dzb, da, dh in ((b1, dz, da1, dh1), (b0, dx1, da0, dh0)):
+            e.defer_block_wgrad(blk, dzb, da, dh, e.g_ptr + 4 * blk.c1.w_off,
+                                blk.c1.flops() + blk.cl.flops() + blk.cr.flops() + blk.c9.flops())
+        return dx0
+
     def all_blocks(self):
         out = []
         for blocks, _ in self.enc_stages:
@@ -457,14 +522,12 @@ class _Codec:
         h = self.h0
         self.down_out = []
         for i, (blocks, down) in enumerate(self.enc_stages):
-            for blk in blocks:
-                h = blk.fwd(h)
+            h = self.stack_fwd(blocks, h)
             d = e.buf(f"{s}.down{i}", (B, down.Cout, down.Tout))
             down.fwd(h, d, "lrelu")
             self.down_out.append((h, d))
             h = d
-        for blk in self.enc_tail:
-            h = blk.fwd(h)
+        h = self.stack_fwd(self.enc_tail, h)
         self.enc_feat = h
         self.code = e.buf(s + ".code", (B, 1, self.L))
         self.enc_out.fwd(h, self.code, "tanh")
@@ -500,8 +563,7 @@ class _Codec:
                 pw.fwd(dwo, up, "lrelu", out_mode=1)
             self.up_saved.append((h, dwo, up))
             h = up
-        for blk in self.dec_tail:
-            h = blk.fwd(h)
+        h = self.stack_fwd(self.dec_tail, h)
         self.dec_feat = h
         self.dec = e.buf(s + ".dec", (B, 1, frame_length))
         self.dec_out.fwd(h, self.dec, "none", chain=chain)
@@ -525,9 +587,7 @@ class _Codec:
         dz = e.buf(s + ".d_decfeat", tuple(self.dec_feat.shape))
         self.dec_out.wgrad(self.dec_feat, ddec)
         self.dec_out.dgrad(ddec, dz)  # dec_feat comes from a flat block: no activation gradient
-        for j in range(len(self.dec_tail) - 1, -1, -1):
-            in_kind = "lrelu" if j > 0 else ("lrelu" if self.dec_stages else "none")
-            dz = self.dec_tail[j].bwd(dz, in_kind)
+        dz = self.stack_bwd(self.dec_tail, dz, "lrelu" if self.dec_stages else "none")
         for i in range(len(self.dec_stages) - 1, -1, -1):
             blocks, dw_off, pw, T, C_ = self.dec_stages[i]
             xin, dwo, up = self.up_saved[i]
@@ -568,17 +628,14 @@ class _Codec:
         self.enc_out.wgrad(self.enc_feat, dcode)
         dz = e.buf(s + ".d_encfeat", tuple(self.enc_feat.shape))
         self.enc_out.dgrad(dcode, dz)
-        for j in range(len(self.enc_tail) - 1, -1, -1):
-            dz = self.enc_tail[j].bwd(dz, "lrelu")   # input of block 0 is the lrelu output of the down conv / in conv
+        dz = self.stack_bwd(self.enc_tail, dz, "lrelu")   # input of block 0 is the lrelu output of the down conv / in conv
         for i in range(len(self.enc_stages) - 1, -1, -1):
             blocks, down = self.enc_stages[i]
             hin, dout = self.down_out[i]
             down.wgrad(hin, dz)
             dzi = e.buf(f"{s}.d_down{i}", tuple(hin.shape))
             down.dgrad(dz, dzi)                       # hin comes from a flat block
-            dz = dzi
-            for j in range(len(blocks) - 1, -1, -1):
-                dz = blocks[j].bwd(dz, "lrelu")
+            dz = self.stack_bwd(blocks, dzi, "lrelu")
         self.in_conv.wgrad(self.x_in, dz)
         if need_dx:
             dx = e.buf(s + ".dx_in", (B, 1, frame_length))
@@ -675,10 +732,18 @@ class CascadeEngine:
         # gradients and, right behind them, every quantizer's soft histogram live in ONE allocation padded to 64 KB: a
         # training step clears both with a single aligned memset (an unaligned size costs a second fill dispatch for the tail)
         nh = sum(nb_ for nb_ in num_bins) + 4 * len(lpc_coeff_lsf_bins)
-        self._gh_floats = (n + nh + 16383) // 16384 * 16384
+        # ... and the neighbour flags of the pair launches (int32 behind the same memset): one slot per pair launch of a step
+        self.cu_count = torch.cuda.get_device_properties(self.device).multi_processor_count
+        self._flag_ints = int(self.lib.nsc_gated_block_pair_flag_ints())
+        npairs = sum(len(c.enc_stages) + 2 for c in self.codecs)              # enc stages + enc tail + dec tail (at most)
+        self._flag_slots = 2 * npairs
+        nfl = (self._flag_ints + 3) // 4 * 4 * self._flag_slots
+        self._gh_floats = (n + nh + nfl + 16383) // 16384 * 16384
         self._gh = torch.zeros(self._gh_floats, **f32)
         self.grads = self._gh[:n]
         self._hist_flat = self._gh[n:n + nh]
+        self._flags = self._gh[n + nh:n + nh + nfl].view(torch.int32)
+        self._flag_next = 0
         self._hist_slots, self._hist_used = {}, 0
         # wt = flipped/transposed kernels of every conv at the same offsets as the parameters, followed by one extra
         # region per gated block holding the two k15 gate kernels concatenated along their OUTPUT channels
@@ -780,6 +845,8 @@ class CascadeEngine:
     # ---- block weight gradients deferred to the end of the backward pass and produced by ONE persistent launch per
     # block width (nsc_gated_block_wgrad_batch): per-block launches walk only 2-4 tiles per workgroup at batch 128, so
     # their prologue, accumulator flush and slab reduction cost more than the MFMA work itself.
+    fused_pairs = True   # the dil-1 / dil-2 blocks of a stack in ONE launch (nsc_gated_block_pair_fwd_img / _dgrad_img: neighbour flags
+                         # between workgroups instead of a kernel boundary); False: one launch per block
     fused_chain = True   # the cascade step / output-gradient arithmetic between codecs rides in the epilogue of the Cout = 1 convs
                          # (nsc_conv1d_cout1_fwd_chain) instead of nsc_cascade_step / nsc_axpby launches
     poly_dgrad = True    # stride-2 data gradients in polyphase form (half the MFMAs of the zero-upsampled form)
@@ -960,6 +1027,20 @@ class CascadeEngine:
             out[tag] = (n + 1, ms + a.elapsed_time(b), f + fl)
         return out
 
+    def pair_flags(self):
+        """Pointer to the next zeroed flag slot of this step / forward (reset in forward(); zeroed by the step's opening launch, or
+        by forward() itself outside a training step)."""
+        k = self._flag_next
+        assert k < self._flag_slots, "more pair launches than flag slots"
+        self._flag_next += 1
+        stride = (self._flag_ints + 3) // 4 * 4
+        return self._flags.data_ptr() + 4 * stride * k
+
+    def pair_timeouts(self):
+        """Number of neighbour waits that timed out since the flags were last zeroed (must be 0)."""
+        stride = (self._flag_ints + 3) // 4 * 4
+        return int(self._flags.view(self._flag_slots, stride)[:, self._flag_ints - 1].sum().item())
+
     def hist_view(self, key, nb):
         """[nb] slice of the flat histogram buffer (codecs' 32-bin and the LSF quantizer's 256-bin histograms side by side)."""
         if key not in self._hist_slots:
@@ -1079,6 +1160,9 @@ class CascadeEngine:
         B, rs = self.B, self.res_scalar
         assert tuple(x.shape) == (B, 1, frame_length) and x.dtype == torch.float32 and x.is_contiguous()
         self._hist_clean = bool(hists_clean)
+        self._flag_next = 0
+        if not hists_clean and self.fused_pairs:      # (a training step's opening launch has zeroed the pair flags already)
+            check(self.lib.nsc_zero(self._flags.data_ptr(), self._flags.numel(), self.stream()), "zero pair flags")
         self.x = x
         n = B * frame_length
         self.decoded = self.buf("decoded", (B, 1, frame_length))
