@@ -160,17 +160,17 @@ int nsc_gated_block_dgrad_img(const float* img, const float* x, const float* h, 
  *      flags: nsc_gated_block_pair_flag_ints() ints, ZEROED by the caller before each launch; flags[256] counts waits that timed
  *      out (must stay 0; results are undefined otherwise).
  *   fwd:   x -> block 0 (dil 1, lrelu out) -> out0 -> block 1 (dil 2, flat1) -> out1; saved activations h / lin / th / g of each
- *          block nullable (together).
+ *          block nullable (together).  Cin0 = C, or 1: block 0 is the first block of a decoder stage (x [B,1,T], image of Cin = 1).
  *   dgrad: block 1 first (dy1 -> dx1, da1 [B,40,T], dz1_1), then block 0 on dy = dx1 (-> dx0, da0, dz1_0); in_act0 = activation
- *          that produced block 0's input. */
+ *          that produced block 0's input (Cin0 = 1: none; x0 unused, dx0 [B,1,T], da0 = dlin | dgate as one [B,40,T] tensor). */
 int nsc_gated_block_pair_flag_ints(void);
 int nsc_gated_block_pair_fwd_img(const float* img0, const float* img1, const float* x, float* out0, float* h0, float* lin0,
                                  float* th0, float* g0, float* out1, float* h1, float* lin1, float* th1, float* g1, int B, int C,
-                                 int T, int flat1, int* flags, void* stream);
+                                 int Cin0, int T, int flat1, int* flags, void* stream);
 int nsc_gated_block_pair_dgrad_img(const float* img1, const float* x1, const float* h1, const float* lin1, const float* th1,
                                    const float* dy1, float* dx1, float* da1, float* dz1_1, const float* img0, const float* x0,
                                    const float* h0, const float* lin0, const float* th0, float* dx0, float* da0, float* dz1_0,
-                                   int B, int C, int T, int in_act0, int* flags, void* stream);
+                                   int B, int C, int Cin0, int T, int in_act0, int* flags, void* stream);
 
 /* Persistent weight-gradient kernel of one gated block: all eight parameter gradients (accumulated) from the saved
  * activations x [B,C,T], h, g [B,20,T] and the data-path gradients dy [B,C,T], da [B,40,T] (= dlin | dgate, the

@@ -829,11 +829,12 @@ __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int 
 
 // Two consecutive blocks of a stack (dilation 1 then 2, the reference's `_stack_bottleneck_blocks`: neural_speech_coding_module.py
 // :183-217) in ONE launch: see nsc_pair_publish / nsc_pair_wait.  a1.x must be a0.out.
-template <int RT9, int NK1>
+// (NK1A = 1: the first block has ONE input channel - the first stack of a decoder, whose input is the quantised code)
+template <int RT9, int NK1A, int NK1B>
 __global__ __launch_bounds__(512) void gated_block_fwd2_pair_kernel(BlockArgs a0, BlockArgs a1, int ntiles, int tpf, int* flags) {
-  gated_block_fwd2_body<RT9, NK1, 1, false, true>(a0, ntiles, tpf, 0, nullptr);
+  gated_block_fwd2_body<RT9, NK1A, 1, false, true>(a0, ntiles, tpf, 0, nullptr);
   nsc_pair_publish(flags);
-  gated_block_fwd2_body<RT9, NK1, 2, true>(a1, ntiles, tpf, 0, flags);
+  gated_block_fwd2_body<RT9, NK1B, 2, true>(a1, ntiles, tpf, 0, flags);
 }
 
 template <int RT9, int NK1, int DIL>
@@ -2693,16 +2694,17 @@ __global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs 
 
 // the data-path backward of two consecutive blocks of a stack in ONE launch: the dilation-2 block first, then the dilation-1
 // block on the dx it wrote (a0.dy must be a1.dx)
-template <int RT9, int NK9>
+// (CIN1B: the dilation-1 block in front has ONE input channel)
+template <int RT9, int NK9, bool CIN1B>
 __global__ __launch_bounds__(512) void gated_block_dgrad2_pair_kernel(BlockDgradArgs a1, BlockDgradArgs a0, int ntiles, int tpf, int* flags) {
   if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 8) == 0) {
     gated_block_dgrad2_role<RT9, NK9, 2, false, 0, false, true>(a1, ntiles, tpf, 0);
     nsc_pair_publish(flags);
-    gated_block_dgrad2_role<RT9, NK9, 1, false, 0, true>(a0, ntiles, tpf, 0, flags);
+    gated_block_dgrad2_role<RT9, NK9, 1, CIN1B, 0, true>(a0, ntiles, tpf, 0, flags);
   } else {
     gated_block_dgrad2_role<RT9, NK9, 2, false, 1, false, true>(a1, ntiles, tpf, 0);
     nsc_pair_publish(flags);
-    gated_block_dgrad2_role<RT9, NK9, 1, false, 1, true>(a0, ntiles, tpf, 0, flags);
+    gated_block_dgrad2_role<RT9, NK9, 1, CIN1B, 1, true>(a0, ntiles, tpf, 0, flags);
   }
 }
 
@@ -2923,11 +2925,11 @@ static int nsc_cu_count() {
 }
 extern "C" int nsc_gated_block_pair_flag_ints(void) { return 256 + 1; }     // flags of up to 256 workgroups + the time-out counter
 
-template <int RT9, int NK1>
+template <int RT9, int NK1A, int NK1B>
 static int launch_block_fwd2_pair(const BlockArgs& a0, const BlockArgs& a1, int* flags, hipStream_t st) {
-  constexpr int CR = 4 * NK1;
+  constexpr int CR = 4 * (NK1A > NK1B ? NK1A : NK1B);
   const size_t smem = ((size_t)(CR + NARROW) * 112 + (size_t)3 * NARROW * 80 + (size_t)K15 * NARROW * 48 + (RT9 == 7 ? 728 : 0)) * sizeof(float);
-  auto kern = gated_block_fwd2_pair_kernel<RT9, NK1>;
+  auto kern = gated_block_fwd2_pair_kernel<RT9, NK1A, NK1B>;
   const hipError_t e = NSC_SMEM_ATTR(kern, (int)smem);
   NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "gated_block_fwd2_pair: smem attr: %s", hipGetErrorString(e));
   const int tpf = nsc_cdiv(a0.T, 64);
@@ -2942,7 +2944,7 @@ static int launch_block_fwd2_pair(const BlockArgs& a0, const BlockArgs& a1, int*
 
 extern "C" int nsc_gated_block_pair_fwd_img(const float* img0, const float* img1, const float* x, float* out0, float* h0, float* lin0,
                                             float* th0, float* g0, float* out1, float* h1, float* lin1, float* th1, float* g1, int B,
-                                            int C, int T, int flat1, int* flags, void* stream) {
+                                            int C, int Cin0, int T, int flat1, int* flags, void* stream) {
   NSC_REQUIRE(img0 && img1 && x && out0 && out1 && flags, NSC_ERR_BAD_ARG, "nsc_gated_block_pair_fwd_img: null pointer");
   NSC_REQUIRE(B > 0 && T > 0, NSC_ERR_BAD_ARG, "nsc_gated_block_pair_fwd_img: bad sizes");
   NSC_REQUIRE(C == 100 || C == 50 || C == 25, NSC_ERR_UNSUPPORTED, "nsc_gated_block_pair_fwd_img: C %d", C);
@@ -2951,15 +2953,21 @@ extern "C" int nsc_gated_block_pair_fwd_img(const float* img0, const float* img1
   NSC_REQUIRE((((uintptr_t)img0 | (uintptr_t)img1) & 15) == 0, NSC_ERR_BAD_ARG, "nsc_gated_block_pair_fwd_img: images must be 16-byte aligned");
   NSC_REQUIRE((!(lin0 || th0 || g0) || (lin0 && th0 && g0)) && (!(lin1 || th1 || g1) || (lin1 && th1 && g1)), NSC_ERR_BAD_ARG,
               "nsc_gated_block_pair_fwd_img: lin/th/g outputs must be given together");
-  BlockArgs a0{B, C, T, 1, 0, x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, out0, h0, lin0, th0, g0, C, img0};
+  NSC_REQUIRE(Cin0 == C || Cin0 == 1, NSC_ERR_BAD_ARG, "nsc_gated_block_pair_fwd_img: Cin0 must be C or 1 (got %d)", Cin0);
+  BlockArgs a0{B, C, T, 1, 0, x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, out0, h0, lin0, th0, g0, Cin0, img0};
   BlockArgs a1{B, C, T, 2, flat1, out0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, out1, h1, lin1, th1, g1, C, img1};
   hipStream_t st = (hipStream_t)stream;
-  if (C == 100) return launch_block_fwd2_pair<7, 25>(a0, a1, flags, st);
-  if (C == 25) return launch_block_fwd2_pair<4, 7>(a0, a1, flags, st);
-  return launch_block_fwd2_pair<4, 13>(a0, a1, flags, st);
+  if (Cin0 == 1) {
+    if (C == 100) return launch_block_fwd2_pair<7, 1, 25>(a0, a1, flags, st);
+    if (C == 25) return launch_block_fwd2_pair<4, 1, 7>(a0, a1, flags, st);
+    return launch_block_fwd2_pair<4, 1, 13>(a0, a1, flags, st);
+  }
+  if (C == 100) return launch_block_fwd2_pair<7, 25, 25>(a0, a1, flags, st);
+  if (C == 25) return launch_block_fwd2_pair<4, 7, 7>(a0, a1, flags, st);
+  return launch_block_fwd2_pair<4, 13, 13>(a0, a1, flags, st);
 }
 
-template <int RT9, int NK9>
+template <int RT9, int NK9, bool CIN1B>
 static int launch_block_dgrad2_pair(const BlockDgradArgs& a1, const BlockDgradArgs& a0, int* flags, hipStream_t st) {
   size_t smem = 0;
   for (int dil = 1; dil <= 2; ++dil) {             // the larger of the two bodies' LDS layouts (dilation 2)
@@ -2970,7 +2978,7 @@ static int launch_block_dgrad2_pair(const BlockDgradArgs& a1, const BlockDgradAr
                            (size_t)K9 * w9t) * sizeof(float));
   }
   NSC_REQUIRE(smem <= 160 * 1024, NSC_ERR_UNSUPPORTED, "gated_block_dgrad2_pair: %zu B LDS", smem);
-  auto kern = gated_block_dgrad2_pair_kernel<RT9, NK9>;
+  auto kern = gated_block_dgrad2_pair_kernel<RT9, NK9, CIN1B>;
   const hipError_t e = NSC_SMEM_ATTR(kern, (int)smem);
   NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "gated_block_dgrad2_pair: smem attr: %s", hipGetErrorString(e));
   const int tpf = nsc_cdiv(a0.T, 64);
@@ -2986,9 +2994,12 @@ static int launch_block_dgrad2_pair(const BlockDgradArgs& a1, const BlockDgradAr
 extern "C" int nsc_gated_block_pair_dgrad_img(const float* img1, const float* x1, const float* h1, const float* lin1, const float* th1,
                                               const float* dy1, float* dx1, float* da1, float* dz1_1, const float* img0,
                                               const float* x0, const float* h0, const float* lin0, const float* th0, float* dx0,
-                                              float* da0, float* dz1_0, int B, int C, int T, int in_act0, int* flags, void* stream) {
-  NSC_REQUIRE(img1 && x1 && h1 && lin1 && th1 && dy1 && dx1 && da1 && dz1_1 && img0 && x0 && h0 && lin0 && th0 && dx0 && da0 && dz1_0 && flags,
-              NSC_ERR_BAD_ARG, "nsc_gated_block_pair_dgrad_img: null pointer");
+                                              float* da0, float* dz1_0, int B, int C, int Cin0, int T, int in_act0, int* flags,
+                                              void* stream) {
+  NSC_REQUIRE(img1 && x1 && h1 && lin1 && th1 && dy1 && dx1 && da1 && dz1_1 && img0 && (x0 || Cin0 == 1) && h0 && lin0 && th0 && dx0 && da0 &&
+                  dz1_0 && flags, NSC_ERR_BAD_ARG, "nsc_gated_block_pair_dgrad_img: null pointer");
+  NSC_REQUIRE(Cin0 == C || (Cin0 == 1 && in_act0 == NSC_ACT_NONE), NSC_ERR_BAD_ARG,
+              "nsc_gated_block_pair_dgrad_img: Cin0 must be C, or 1 with in_act0 none (got %d, %d)", Cin0, in_act0);
   NSC_REQUIRE(B > 0 && T > 0, NSC_ERR_BAD_ARG, "nsc_gated_block_pair_dgrad_img: bad sizes");
   NSC_REQUIRE(C == 100 || C == 50 || C == 25, NSC_ERR_UNSUPPORTED, "nsc_gated_block_pair_dgrad_img: C %d", C);
   NSC_REQUIRE((T & 3) == 0 && (long)B * C * T * 4 < (1L << 31), NSC_ERR_UNSUPPORTED,
@@ -2998,12 +3009,17 @@ extern "C" int nsc_gated_block_pair_dgrad_img(const float* img1, const float* x1
   // the dilation-2 block's input is the dilation-1 block's lrelu output: its dx carries lrelu'(x1)
   BlockDgradArgs a1{B, C, T, 2, NSC_ACT_LRELU, x1, h1, lin1, th1, dy1, nullptr, nullptr, nullptr, nullptr, dx1, da1, dz1_1,
                     da1 + (long)NARROW * T, 2 * NARROW, img1};
-  BlockDgradArgs a0{B, C, T, 1, in_act0, x0, h0, lin0, th0, dx1, nullptr, nullptr, nullptr, nullptr, dx0, da0, dz1_0,
+  BlockDgradArgs a0{B, C, T, 1, in_act0, Cin0 == 1 ? dx1 : x0, h0, lin0, th0, dx1, nullptr, nullptr, nullptr, nullptr, dx0, da0, dz1_0,
                     da0 + (long)NARROW * T, 2 * NARROW, img0};
   hipStream_t st = (hipStream_t)stream;
-  if (C == 100) return launch_block_dgrad2_pair<7, 25>(a1, a0, flags, st);
-  if (C == 25) return launch_block_dgrad2_pair<4, 9>(a1, a0, flags, st);
-  return launch_block_dgrad2_pair<4, 13>(a1, a0, flags, st);
+  if (Cin0 == 1) {
+    if (C == 100) return launch_block_dgrad2_pair<7, 25, true>(a1, a0, flags, st);
+    if (C == 25) return launch_block_dgrad2_pair<4, 9, true>(a1, a0, flags, st);
+    return launch_block_dgrad2_pair<4, 13, true>(a1, a0, flags, st);
+  }
+  if (C == 100) return launch_block_dgrad2_pair<7, 25, false>(a1, a0, flags, st);
+  if (C == 25) return launch_block_dgrad2_pair<4, 9, false>(a1, a0, flags, st);
+  return launch_block_dgrad2_pair<4, 13, false>(a1, a0, flags, st);
 }
 
 // The two persistent kernels on an image (shapes of the codec only: C in {100, 50, 25}, Cin in {C, 1}, dil in {1, 2}).

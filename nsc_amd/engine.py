@@ -443,7 +443,8 @@ class _Codec:
         if not (e.fused_pairs and e.fused_fwd and e.fused_dgrad and e.use_images and len(blocks) == 2):
             return False
         b0, b1 = blocks
-        return (b0.Cin == b0.wide == b1.Cin == b1.wide and b0.wide in (100, 50, 25) and b0.cl.dil == 1 and b1.cl.dil == 2 and
+        return ((b0.Cin == b0.wide or (b0.Cin == 1 and e.batch_cin1_wgrad)) and b0.wide == b1.Cin == b1.wide and
+                b0.wide in (100, 50, 25) and b0.cl.dil == 1 and b1.cl.dil == 2 and
                 b0.narrow == 20 and b0.c9.K == 9 and b0.img_fwd_off is not None and b1.img_fwd_off is not None and
                 b0.img_bwd_off is not None and b1.img_bwd_off is not None and not b0.flat and b0.T % 4 == 0 and
                 e.B * b0.wide * b0.T * 4 < 2 ** 31 and
@@ -469,8 +470,8 @@ class _Codec:
         fl = sum(c.flops() for blk in blocks for c in (blk.c1, blk.cl, blk.cr, blk.c9))
         tok = e.prof_begin("block_fwd", fl)
         check(e.lib.nsc_gated_block_pair_fwd_img(e.wt_ptr + 4 * b0.img_fwd_off, e.wt_ptr + 4 * b1.img_fwd_off, h.data_ptr(),
-                                                 b0.out.data_ptr(), *sv(b0), b1.out.data_ptr(), *sv(b1), B, b0.wide, T, int(b1.flat),
-                                                 e.pair_flags(), e.stream()), "gated_block_pair_fwd_img")
+                                                 b0.out.data_ptr(), *sv(b0), b1.out.data_ptr(), *sv(b1), B, b0.wide, b0.Cin, T,
+                                                 int(b1.flat), e.pair_flags(), e.stream()), "gated_block_pair_fwd_img")
         e.prof_end(tok)
         return b1.out
 
@@ -478,7 +479,8 @@ class _Codec:
         """Backward through a stack: dz = dL/d(pre-activation of the last block's output).  in_kind_first: what produced the
         first block's input.  Returns dL/d(pre-activation of that producer)."""
         e = self.eng
-        if not (self._pair_ok(blocks) and e.batch_wgrad and e.fused_wgrad and in_kind_first in ("lrelu", "none")):
+        if not (self._pair_ok(blocks) and e.batch_wgrad and e.fused_wgrad and in_kind_first in ("lrelu", "none") and
+                (blocks[0].Cin > 1 or in_kind_first == "none")):
             for j in range(len(blocks) - 1, -1, -1):
                 dz = blocks[j].bwd(dz, in_kind_rest if j > 0 else in_kind_first)
             return dz
@@ -494,7 +496,7 @@ class _Codec:
         P = lambda t: t.data_ptr()
         check(e.lib.nsc_gated_block_pair_dgrad_img(e.wt_ptr + 4 * b1.img_bwd_off, P(b1.x), P(b1.h), P(b1.lin), P(b1.th), P(dz), P(dx1),
                                                    P(da1), P(dh1), e.wt_ptr + 4 * b0.img_bwd_off, P(b0.x), P(b0.h), P(b0.lin),
-                                                   P(b0.th), P(dx0), P(da0), P(dh0), B, b0.wide, T, KIND_ACT[in_kind_first],
+                                                   P(b0.th), P(dx0), P(da0), P(dh0), B, b0.wide, b0.Cin, T, KIND_ACT[in_kind_first],
                                                    e.pair_flags(), e.stream()), "gated_block_pair_dgrad_img")
         e.prof_end(tok)
         for blk, dzb, da, dh in ((b1, dz, da1, dh1), (b0, dx1, da0, dh0)):
@@ -546,8 +548,7 @@ class _Codec:
         h = self.qcode
         self.up_saved = []
         for i, (blocks, dw_off, pw, T, C_) in enumerate(self.dec_stages):
-            for blk in blocks:
-                h = blk.fwd(h)
+            h = self.stack_fwd(blocks, h)
             dwo = e.buf(f"{s}.dw{i}", (B, C_, T))
             up = e.buf(f"{s}.up{i}", (B, C_ // 2, T * 2))
             if e.fused_up and C_ in (100, 50) and B * C_ * T < 2 ** 29:    # (32-bit buffer offsets in the fused kernels)
@@ -609,13 +610,7 @@ class _Codec:
                 pw.dgrad(dzp, ddw)
                 check(e.lib.nsc_depthwise_bwd(xin.data_ptr(), e.p_ptr + 4 * dw_off, ddw.data_ptr(), dxu.data_ptr(),
                                               e.g_ptr + 4 * dw_off, B, C_, T, 9, e.stream()), "depthwise_bwd")
-            dz = dxu
-            for j in range(len(blocks) - 1, -1, -1):
-                if j > 0:
-                    in_kind = "lrelu"
-                else:
-                    in_kind = "none" if i == 0 else "lrelu"   # stage 0 input is the quantized code
-                dz = blocks[j].bwd(dz, in_kind)
+            dz = self.stack_bwd(blocks, dxu, "none" if i == 0 else "lrelu")   # stage 0 input is the quantized code
         dq = dz  # [B,1,L]: dL/d qcode
         # quantizer (+ fused quan / entropy loss gradients), returns dL/d(pre-tanh code)
         dcode = e.buf(s + ".dcode", (B, 1, self.L))
@@ -735,7 +730,7 @@ class CascadeEngine:
         # ... and the neighbour flags of the pair launches (int32 behind the same memset): one slot per pair launch of a step
         self.cu_count = torch.cuda.get_device_properties(self.device).multi_processor_count
         self._flag_ints = int(self.lib.nsc_gated_block_pair_flag_ints())
-        npairs = sum(len(c.enc_stages) + 2 for c in self.codecs)              # enc stages + enc tail + dec tail (at most)
+        npairs = sum(len(c.enc_stages) + len(c.dec_stages) + 2 for c in self.codecs)    # enc / dec stages + enc tail + dec tail
         self._flag_slots = 2 * npairs
         nfl = (self._flag_ints + 3) // 4 * 4 * self._flag_slots
         self._gh_floats = (n + nh + nfl + 16383) // 16384 * 16384

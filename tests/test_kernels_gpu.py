@@ -1093,21 +1093,23 @@ def test_block_kernels_on_parameter_images_equal_the_plain_entry_points(lib, C_,
         assert torch.equal(a, b) and bool(torch.isfinite(a).all())
 
 
-@pytest.mark.parametrize("C_,T,B", [(100, 256, 3), (100, 512, 2), (50, 512, 3), (50, 200, 3), (25, 128, 5), (100, 132, 3), (25, 68, 3),
-                                    (100, 256, 128), (50, 512, 128), (100, 64, 300)])
-def test_pair_launches_equal_two_single_launches(lib, C_, T, B):
+@pytest.mark.parametrize("C_,T,B,Cin0", [(100, 256, 3, 100), (100, 512, 2, 100), (50, 512, 3, 50), (50, 200, 3, 50), (25, 128, 5, 25),
+                                         (100, 132, 3, 100), (25, 68, 3, 25), (100, 256, 128, 100), (50, 512, 128, 50), (100, 64, 300, 100),
+                                         (100, 256, 3, 1), (100, 256, 128, 1), (50, 512, 5, 1), (25, 128, 70, 1)])
+def test_pair_launches_equal_two_single_launches(lib, C_, T, B, Cin0):
     """nsc_gated_block_pair_fwd_img / _dgrad_img (the dil-1 and dil-2 block of a stack in ONE launch, neighbour flags between the
     workgroups instead of a kernel boundary) produce the same bits as the two blocks launched one after the other - at sizes
     with one tile per workgroup, with chains inside a frame, with more tiles than workgroups, and at the headline batch; no
     neighbour wait may time out (flags[256] == 0).  Run three times: the result must not depend on workgroup timing.
     (T % 4 == 0: other lengths are refused with NSC_ERR_UNSUPPORTED and the engine launches the blocks one by one.)"""
     import ctypes as C
-    rng = np.random.default_rng(C_ + T + B)
+    rng = np.random.default_rng(C_ + T + B + Cin0)
     f = lambda *sh: (0.1 * rng.standard_normal(sh)).astype(np.float32)
     nfl = int(lib.nsc_gated_block_pair_flag_ints())
     blocks = []
     for dil in (1, 2):
-        w = [f(1, C_, 20), f(20), f(15, 20, 20), f(20), f(15, 20, 20), f(20), f(9, 20, C_), f(C_)]
+        Ci = Cin0 if dil == 1 else C_                 # (Cin0 = 1: the first block of a decoder stage)
+        w = [f(1, Ci, 20), f(20), f(15, 20, 20), f(20), f(15, 20, 20), f(20), f(9, 20, C_), f(C_)]
         flat = np.concatenate([a.reshape(-1) for a in w])
         offs = np.concatenate([[0], np.cumsum([a.size for a in w])[:-1]]).astype(np.int64)
         wt = [np.ascontiguousarray(w[i][::-1].transpose(0, 2, 1)) for i in (0, 2, 4, 6)]
@@ -1115,29 +1117,29 @@ def test_pair_launches_equal_two_single_launches(lib, C_, T, B):
         toffs = np.concatenate([[0], np.cumsum([a.size for a in wt])[:-1]]).astype(np.int64)
         imgs = []
         for which, src, o in ((0, dev(flat), offs), (1, dev(tflat), toffs)):
-            n = int(lib.nsc_gated_block_image_floats(which, C_, C_, dil))
+            n = int(lib.nsc_gated_block_image_floats(which, C_, Ci, dil))
             idx = np.empty(n, np.int32)
-            assert lib.nsc_gated_block_image_index(which, C_, C_, dil, (C.c_long * len(o))(*[int(v) for v in o]),
+            assert lib.nsc_gated_block_image_index(which, C_, Ci, dil, (C.c_long * len(o))(*[int(v) for v in o]),
                                                    idx.ctypes.data_as(C.c_void_p)) == 0, lib.nsc_last_error()
             img = torch.empty(n, device="cuda")
             assert lib.nsc_gather(src.data_ptr(), torch.tensor(idx, device="cuda").data_ptr(), img.data_ptr(), n, _st()) == 0
             imgs.append(img)
         blocks.append(imgs)
     (f0, b0), (f1, b1) = blocks
-    x = dev(rng.standard_normal((B, C_, T)).astype(np.float32))
+    x = dev(rng.standard_normal((B, Cin0, T)).astype(np.float32))
     nan = lambda *sh: torch.full(sh, float("nan"), device="cuda")
     P = lambda t: t.data_ptr()
     # ---- forward ----
     o0, o1 = nan(B, C_, T), nan(B, C_, T)
     s0, s1 = [nan(B, 20, T) for _ in range(4)], [nan(B, 20, T) for _ in range(4)]
-    assert lib.nsc_gated_block_fwd_img(P(f0), P(x), P(o0), *[P(t) for t in s0], B, C_, C_, T, 1, 0, _st()) == 0, lib.nsc_last_error()
+    assert lib.nsc_gated_block_fwd_img(P(f0), P(x), P(o0), *[P(t) for t in s0], B, C_, Cin0, T, 1, 0, _st()) == 0, lib.nsc_last_error()
     assert lib.nsc_gated_block_fwd_img(P(f1), P(o0), P(o1), *[P(t) for t in s1], B, C_, C_, T, 2, 1, _st()) == 0, lib.nsc_last_error()
     torch.cuda.synchronize()
     for rep in range(3):
         p0, p1 = nan(B, C_, T), nan(B, C_, T)
         q0, q1 = [nan(B, 20, T) for _ in range(4)], [nan(B, 20, T) for _ in range(4)]
         flags = torch.zeros(nfl, dtype=torch.int32, device="cuda")
-        assert lib.nsc_gated_block_pair_fwd_img(P(f0), P(f1), P(x), P(p0), *[P(t) for t in q0], P(p1), *[P(t) for t in q1], B, C_, T, 1,
+        assert lib.nsc_gated_block_pair_fwd_img(P(f0), P(f1), P(x), P(p0), *[P(t) for t in q0], P(p1), *[P(t) for t in q1], B, C_, Cin0, T, 1,
                                                 P(flags), _st()) == 0, lib.nsc_last_error()
         torch.cuda.synchronize()
         assert int(flags[256]) == 0, "a neighbour wait timed out"
@@ -1149,18 +1151,20 @@ def test_pair_launches_equal_two_single_launches(lib, C_, T, B):
     t0_, t1_ = (torch.tanh(dev(rng.standard_normal((B, 20, T)).astype(np.float32))) for _ in range(2))
     x1 = dev(rng.standard_normal((B, C_, T)).astype(np.float32))
     dx1, da1, dz1 = nan(B, C_, T), nan(B, 40, T), nan(B, 20, T)
-    dx0, da0, dz0 = nan(B, C_, T), nan(B, 40, T), nan(B, 20, T)
+    dx0, da0, dz0 = nan(B, Cin0, T), nan(B, 40, T), nan(B, 20, T)
+    act0 = 0 if Cin0 == 1 else 2
     assert lib.nsc_gated_block_dgrad_img(P(b1), P(x1), P(h1), P(l1), P(t1_), P(dy), P(dx1), P(da1), P(da1) + 80 * T, P(dz1), B, C_, C_, T, 2,
                                          2, 40, _st()) == 0, lib.nsc_last_error()
-    assert lib.nsc_gated_block_dgrad_img(P(b0), P(x), P(h0), P(l0), P(t0_), P(dx1), P(dx0), P(da0), P(da0) + 80 * T, P(dz0), B, C_, C_, T, 1,
-                                         2, 40, _st()) == 0, lib.nsc_last_error()
+    assert lib.nsc_gated_block_dgrad_img(P(b0), None if Cin0 == 1 else P(x), P(h0), P(l0), P(t0_), P(dx1), P(dx0), P(da0), P(da0) + 80 * T,
+                                         P(dz0), B, C_, Cin0, T, 1, act0, 40, _st()) == 0, lib.nsc_last_error()
     torch.cuda.synchronize()
     for rep in range(3):
         e1, a1, z1 = nan(B, C_, T), nan(B, 40, T), nan(B, 20, T)
-        e0, a0, z0 = nan(B, C_, T), nan(B, 40, T), nan(B, 20, T)
+        e0, a0, z0 = nan(B, Cin0, T), nan(B, 40, T), nan(B, 20, T)
         flags = torch.zeros(nfl, dtype=torch.int32, device="cuda")
-        assert lib.nsc_gated_block_pair_dgrad_img(P(b1), P(x1), P(h1), P(l1), P(t1_), P(dy), P(e1), P(a1), P(z1), P(b0), P(x), P(h0), P(l0),
-                                                  P(t0_), P(e0), P(a0), P(z0), B, C_, T, 2, P(flags), _st()) == 0, lib.nsc_last_error()
+        assert lib.nsc_gated_block_pair_dgrad_img(P(b1), P(x1), P(h1), P(l1), P(t1_), P(dy), P(e1), P(a1), P(z1), P(b0),
+                                                  None if Cin0 == 1 else P(x), P(h0), P(l0), P(t0_), P(e0), P(a0), P(z0), B, C_, Cin0, T, act0,
+                                                  P(flags), _st()) == 0, lib.nsc_last_error()
         torch.cuda.synchronize()
         assert int(flags[256]) == 0, "a neighbour wait timed out"
         for a, b in zip([dx1, da1, dz1, dx0, da0, dz0], [e1, a1, z1, e0, a0, z0]):
