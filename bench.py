@@ -338,6 +338,9 @@ def main():
         comm.barrier()
         pass_ms.append(1e3 * comm.max_float(time.perf_counter() - t0, dev) / args.steps)
     ms_step = float(np.median(pass_ms))
+    pair_to = eng.pair_timeouts()            # neighbour waits of the pair launches that timed out in the last step: must be 0
+    if pair_to:
+        raise SystemExit(f"[bench] {pair_to} neighbour wait(s) of a pair launch timed out: results invalid")
     dt = ms_step * 1e-3 * args.steps
     fps = comm.world * B * args.steps / dt
 
@@ -484,7 +487,7 @@ def main():
                                    ("+RCCL grad all-reduce(sum)" if comm.world > 1 else ""),
                        "batch_per_gpu": B, "global_batch": B * comm.world, "frame": 512,
                        "parallelism": f"dp{comm.world}", "launch": launch, "all_ranks_same_launch": all_same,
-                       "c_abi_calls_per_step": calls_per_step,
+                       "c_abi_calls_per_step": calls_per_step, "pair_launches": bool(eng.fused_pairs), "pair_launch_timeouts": pair_to,
                        "grad_message": (("one per trainable scope, under the backward pass" if eng.dp_overlap else
                                          "one at the tail of the step") if dcomm is not None else None),
                        "streams": "one (weight gradients batched at the tail of the step)",

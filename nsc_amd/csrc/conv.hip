@@ -334,8 +334,44 @@ __global__ __launch_bounds__(256 * KS) void conv1d_fwd_m32_kernel(nsc_conv_desc 
   const int b = blockIdx.y, t0 = blockIdx.x * TT, row0 = blockIdx.z * ROWS;
   const int Cin4 = (d.Cin + 3) & ~3, Cout = d.Cout;
   const int Tin_virt = d.in_up ? 2 * d.Tin : d.Tin;
-  nsc_stage_rows<4 * KS, NSC_CONV_U>(xs, ldx, Cin4, d.Cin, win, x + (long)b * d.Cin * d.Tin, d.Tin, t0 * d.stride - d.padL,
-                                     Tin_virt, d.in_up, wave8, lane);
+  if (!d.in_up && Cin4 <= 104 && ldx <= 320 && KS == 2) {
+    // Round 4: the whole x tile in flight at once (13 rows x 5 column blocks of dword buffer loads per lane, zeros outside the frame
+    // from the bounds check), then the LDS stores: ONE memory round trip.  nsc_stage_rows batches U rows per round trip - ten round
+    // trips for the 100 x 263 tile of the stride-2 conv, 10.5 of its 76 us with nothing to overlap them.
+    constexpr int NQ = 13, NJ = 5;
+    const __amdgpu_buffer_rsrc_t sx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0,
+                                                                        (unsigned)((long)d.B * d.Cin * d.Tin * 4), 0x00020000);
+    float v[NQ][NJ];
+    const int u0 = t0 * d.stride - d.padL;
+#pragma unroll
+    for (int jb = 0; jb < NJ; ++jb) {
+      const int j = jb * 64 + lane, u = u0 + j;
+      const int vo = (j < win && u >= 0 && u < d.Tin) ? u * 4 : 0x7ffffff0;
+      if (jb * 64 < ldx) {                       // wave-uniform
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const int r = wave8 + 8 * q;
+          if (8 * q < Cin4)                      // wave-uniform guard: only the row groups this shape has
+            v[q][jb] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                     sx, r < d.Cin ? vo : 0x7ffffff0, (b * d.Cin + min(r, d.Cin - 1)) * d.Tin * 4, 0));
+        }
+      }
+    }
+#pragma unroll
+    for (int jb = 0; jb < NJ; ++jb) {
+      const int j = jb * 64 + lane;
+      if (j < ldx) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const int r = wave8 + 8 * q;
+          if (r < Cin4) xs[r * ldx + j] = v[q][jb];
+        }
+      }
+    }
+  } else {
+    nsc_stage_rows<4 * KS, NSC_CONV_U>(xs, ldx, Cin4, d.Cin, win, x + (long)b * d.Cin * d.Tin, d.Tin, t0 * d.stride - d.padL,
+                                       Tin_virt, d.in_up, wave8, lane);
+  }
   __syncthreads();
 
   f32x16 acc[NP];

@@ -531,6 +531,9 @@ class neuralSpeechCodingModule(object):
                 nsteps += 1
             torch.cuda.synchronize()
             elapsed = time.perf_counter() - start
+            if nsteps and eng.pair_timeouts():
+                raise RuntimeError("a neighbour wait of a pair launch timed out (gated-block stack kernels): results invalid; "
+                                   "set CascadeEngine.fused_pairs = False")
             self._epochs_done += 1
             self._perm = epoch_permutation(self._tr_data.shape[0], self._seed, self._epochs_done, self._perm)   # nsc_module:460
             # ---- validation signal (nsc_module:462-470; the loops themselves are out of scope) ----
