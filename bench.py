@@ -360,9 +360,9 @@ def main():
     eng.overlap_wgrad = ov
     # dominant kernel = the instrumented kernel class with the largest share of the step
     KERNELS = {"conv_mfma": "conv1d_fwd_kernel / conv1d_fwd_m32_kernel (convs outside gated blocks: forward + data gradients)",
-               "block_fwd": "gated_block_fwd2_kernel (persistent weight-stationary gated block forward)",
+               "block_fwd": "gated_block_fwd2_pair_kernel / gated_block_fwd2_kernel (persistent weight-stationary gated block forward; the two blocks of a stack per launch)",
                "block_wgrad": "gated_block_wgrad_batch_kernel + slab_reduce_batch_kernel (all blocks' weight gradients, one launch per width)",
-               "block_dgrad": "gated_block_dgrad2_kernel (persistent weight-stationary gated block data-path backward)",
+               "block_dgrad": "gated_block_dgrad2_pair_kernel / gated_block_dgrad2_kernel (persistent weight-stationary gated block data-path backward; the two blocks of a stack per launch)",
                "wgrad_mfma": "conv1d_wgrad_batch_kernel + conv_slab_reduce_batch_kernel (weight gradients of the convs outside gated blocks)"}
     roof, by_kernel = None, {}
     traffic = {}
@@ -428,8 +428,8 @@ def main():
         qroof = dict(bound="hbm", kernel="quantize_fwd32_wave_kernel (one wave per frame; p materialised, B=4096 frames)", achieved=round(byts / us / 1e3, 1),
                      peak=8000.0, unit="GB/s", frac=round(byts / us / 1e3 / 8000.0, 4),
                      traffic=next((v for k, v in traffic.items() if k.startswith("quantize_fwd_wave@grid")), None), training_shape=qtrain,
-                     bytes_per_launch=byts, avg_launch_us=round(us, 2), peak_measured_on_box=5440.0,
-                     note="peak_measured_on_box = write-only stream rate of this box in the kernel's own pattern, 32 KB contiguous per workgroup (tools/write_peak.hip, profiles/archive/r01_onbox_peaks.txt): the kernel writes 32 of every 34 bytes")
+                     bytes_per_launch=byts, avg_launch_us=round(us, 2), peak_measured_on_box=6800.0,
+                     note="peak_measured_on_box = a write-only probe in the kernel's own grid and store geometry (probes library, tools/quant_time.py, profiles/r04a_quantizer_variants.txt): the kernel writes 32 of every 34 bytes; with its stores dropped the kernel's arithmetic alone takes 23.6 us (VALU-bound, not HBM-bound)")
 
     # ---- second half of the metric: codec forward us/frame (BASELINE config 5: 2-codec encode+quantise+decode,
     # batch 4096 frames, hipGraph-captured forward), plus the batch-1 latency the reference's eval loop actually pays
