@@ -729,6 +729,12 @@ class CascadeEngine:
         nh = sum(nb_ for nb_ in num_bins) + 4 * len(lpc_coeff_lsf_bins)
         # ... and the neighbour flags of the pair launches (int32 behind the same memset): one slot per pair launch of a step
         self.cu_count = torch.cuda.get_device_properties(self.device).multi_processor_count
+        # Pair launches need every workgroup of a launch resident at once, i.e. the GPU to this process (the deployment model: one
+        # process per GPU).  Ranks that SHARE a device (tests: more local ranks than GPUs, gloo) would interleave two such launches,
+        # neither complete: their neighbour waits would run into the time-out.  They launch the blocks one by one.
+        lws = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+        if lws > torch.cuda.device_count():
+            self.fused_pairs = False
         self._flag_ints = int(self.lib.nsc_gated_block_pair_flag_ints())
         npairs = sum(len(c.enc_stages) + len(c.dec_stages) + 2 for c in self.codecs)    # enc / dec stages + enc tail + dec tail
         self._flag_slots = 2 * npairs
