@@ -288,7 +288,8 @@ __device__ __forceinline__ void nsc_pair_wait(int* flags) {
       }
     }
   }
-  __syncthreads();
+  nsc_lds_barrier();      // (not __syncthreads(): its vmcnt(0) would drain the second block's weight loads, which were issued before
+                          //  this wait precisely so that they and the first tile's loads - issued right after it - are in flight together)
 }
 
 // PAIRED: this body runs as the SECOND block of a pair launch: it waits for the neighbours' flags before its first x load
