@@ -1259,6 +1259,103 @@ extern "C" int nsc_conv1d_wgrad(const nsc_conv_desc* d, const float* x, const fl
   return nsc_conv1d_wgrad_ws(d, x, dz, dw, db, flip_taps, nullptr, 0, stream);
 }
 
+// ---- weight gradient of a ONE-INPUT-CHANNEL conv (the k55 1 -> C input convs of the codecs), round 4 ----
+//   dW[tap][o] = sum_{b,t} x[b, t + tap - padL] dz[b, o, t]      db[o] = sum_{b,t} dz[b, o, t]
+// In conv_wgrad_body the rows of the GEMM are (tap, ci): with one input channel that is 56 rows - four of the eight waves have a row
+// tile, each workgroup sees 2 chunks, and the launch is all prologue, flush and slab traffic (30 us for 0.7 GFLOP and 26 MB).  Here the
+// roles are swapped: rows = OUTPUT CHANNELS (one 16-row tile per wave: 7 of 8 busy at C = 100), columns = taps (4 tiles; column K is
+// the bias: B = 1), reduction over time.  The k index of a step is mapped to time as t = t_blk + 16 kq + ks, so a lane's A operands of
+// 16 consecutive k-steps are 16 consecutive floats of its dz row: four 16-byte loads straight into registers, no LDS for dz at all;
+// B is the x window in LDS, consecutive lanes consecutive addresses.  A workgroup walks chunks of 256 steps; partial dW^T leaves to
+// the job's slab in the layout conv_slab_reduce_batch_kernel expects ([tap][o], bias row behind the taps).
+#define NSC_CW1_MAXJ 4
+struct Cin1WgradJob {
+  const float *x, *dz;
+  float* slab;
+  long slab_stride;
+  int B, Cout, T, K, padL, nrows, gx, wg0;
+};
+struct Cin1WgradBatch {
+  Cin1WgradJob j[NSC_CW1_MAXJ];
+  int njobs;
+};
+__global__ __launch_bounds__(512) void conv1d_wgrad_cin1_kernel(Cin1WgradBatch tb) {
+  __shared__ float xs[320];
+  int jq = 0;
+#pragma unroll
+  for (int q = 1; q < NSC_CW1_MAXJ; ++q)
+    if (q < tb.njobs && (int)blockIdx.x >= tb.j[q].wg0) jq = q;
+  Cin1WgradJob jb = tb.j[0];
+#pragma unroll
+  for (int q = 1; q < NSC_CW1_MAXJ; ++q)
+    if (q == jq) jb = tb.j[q];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, kq = lane >> 4;
+  const int wl = blockIdx.x - jb.wg0;
+  const int nchunk_t = jb.T >> 8, nchunks = jb.B * nchunk_t;
+  const bool busy = wave * 16 < jb.Cout;
+  const int o = wave * 16 + l15;
+  const __amdgpu_buffer_rsrc_t sz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(jb.dz), 0, (unsigned)((long)jb.B * jb.Cout * jb.T * 4), 0x00020000);
+  f32x4 acc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // column tile 3 holds taps 48..63: the real ones, the bias column (tap == K: B = 1) and zero columns - a per-lane constant
+  const int tap3 = 48 + l15;
+  const float one3 = (tap3 == jb.K && jb.nrows > jb.K) ? 1.f : 0.f;
+  const bool real3 = tap3 < jb.K;
+  for (int chunk = wl; chunk < nchunks; chunk += jb.gx) {
+    const int b = chunk / nchunk_t, t0 = (chunk - b * nchunk_t) << 8;
+    // this lane's dz row, 16 consecutive steps per 64-step block: the chunk's 16 loads go out before anything else
+    f32x4 a4[4][4];
+    const int vo = (busy && o < jb.Cout) ? ((b * jb.Cout + o) * jb.T + t0 + 16 * kq) * 4 : 0x7ffffff0;
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        a4[blk][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(sz, vo, (64 * blk + 4 * i) * 4, 0));
+    __syncthreads();                               // the previous chunk's window reads are done
+    if (tid < 320) {
+      const int u = t0 - jb.padL + tid;
+      xs[tid] = (u >= 0 && u < jb.T) ? jb.x[(long)b * jb.T + u] : 0.f;
+    }
+    __syncthreads();
+    if (busy) {
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk) {
+        const float* xb = xs + 64 * blk + 16 * kq + l15;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+          const float a = a4[blk][ks >> 2][ks & 3];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xb[ks + 16 * c], acc[c], 0, 0, 0);
+          const float b3 = real3 ? xb[ks + 48] : one3;
+          acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b3, acc[3], 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (!busy) return;
+  float* sl = jb.slab + (long)wl * jb.slab_stride;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int tap = 16 * c + l15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int oo = wave * 16 + kq * 4 + r;
+      if (oo < jb.Cout && tap < jb.nrows) sl[(long)tap * jb.Cout + oo] = acc[c][r];
+    }
+  }
+}
+static bool cw_is_cin1(const nsc_conv_wgrad_job& jb) {
+  static const bool off = NSC_PROBE_SET("NSC_CW_NO_CIN1");        // A/B switch for profiling
+  const nsc_conv_desc& d = jb.d;
+  return !off && d.Cin == 1 && d.stride == 1 && d.dil == 1 && !d.in_up && d.Tin == d.Tout && (d.Tout & 255) == 0 && d.K + (jb.db ? 1 : 0) <= 64 &&
+         d.K >= 48 && d.Cout <= 112 && d.padL <= 63 && (long)d.B * d.Cout * d.Tout * 4 < (1L << 31) && (((uintptr_t)jb.dz) & 15) == 0;
+}
+static int cw_cin1_gx(const nsc_conv_wgrad_job& jb) { return std::max(1, std::min(256, jb.d.B * (jb.d.Tout >> 8))); }
+static long cw_cin1_stride(const nsc_conv_wgrad_job& jb) { return (((long)(jb.d.K + (jb.db ? 1 : 0)) * jb.d.Cout) + 63) & ~63L; }
+
 // ---- host side of the batched form ----
 struct CwPlan { int rt, ct, gy, nchunks; long stride; size_t smem; double weight; WgradPlan p; };
 
@@ -1283,7 +1380,11 @@ static void cw_split(const CwPlan* c, int n, int* gx) {
   size_t smem = 0;
   double tot = 0;
   for (int q = 0; q < n; ++q) { smem = std::max(smem, c[q].smem); tot += c[q].weight; }
-  const int budget = smem <= 76 * 1024 ? 512 : 256;
+  static const int budget_probe = NSC_PROBE_INT("NSC_CW_BUDGET", 0);      // tuning probe (probes build only)
+  // one workgroup per CU for every class: with two per CU (512) the small-LDS classes ran 2 chunks per workgroup and their prologue,
+  // flush and slab traffic outweighed the overlap (class <1,7> of the headline step: 73.3 us at 512, 67.4 at 256, 84.4 at 384 / 1024)
+  const int budget = budget_probe ? budget_probe : 256;
+  (void)smem;
   for (int q = 0; q < n; ++q) {
     int g = (int)(budget * c[q].weight / tot / c[q].gy + 0.5);
     g = std::min(g, std::max(1, c[q].nchunks / 2));
@@ -1385,6 +1486,15 @@ static int cw_for_each_class(const nsc_conv_wgrad_job* jobs, int njobs, F f) {
 extern "C" long nsc_conv1d_wgrad_batch_workspace(const nsc_conv_wgrad_job* jobs, int njobs) {
   if (!jobs || njobs <= 0) return 0;
   long need = 0;       // the slabs of every class live until the one reduce at the end: the SUM over the classes
+  nsc_conv_wgrad_job rest[256];
+  int nrest = 0;
+  for (int j = 0; j < njobs && j < 256; ++j) {
+    if (cw_is_cin1(jobs[j])) need += (long)cw_cin1_gx(jobs[j]) * cw_cin1_stride(jobs[j]);
+    else rest[nrest++] = jobs[j];
+  }
+  jobs = rest;
+  njobs = nrest;
+  if (njobs == 0) return need;
   cw_for_each_class(jobs, njobs, [&](int, int, const int*, const CwPlan* cp, int n) {
     int gx[NSC_CW_MAXJ];
     cw_split(cp, n, gx);
@@ -1406,6 +1516,46 @@ extern "C" int nsc_conv1d_wgrad_batch(const nsc_conv_wgrad_job* jobs, int njobs,
   hipStream_t st = (hipStream_t)stream;
   CwReduceQueue rq;
   memset(&rq.r, 0, sizeof(rq.r));
+  NSC_REQUIRE(njobs <= 256, NSC_ERR_UNSUPPORTED, "nsc_conv1d_wgrad_batch: more than 256 jobs");
+  // the one-input-channel k55 convs first: their own kernel (conv1d_wgrad_cin1_kernel), up to NSC_CW1_MAXJ jobs per launch
+  nsc_conv_wgrad_job rest[256];
+  int nrest = 0;
+  {
+    Cin1WgradBatch tb;
+    memset(&tb, 0, sizeof(tb));
+    int wg = 0;
+    auto flush1 = [&]() -> int {
+      if (tb.njobs == 0) return NSC_OK;
+      hipLaunchKernelGGL(conv1d_wgrad_cin1_kernel, dim3(wg), dim3(512), 0, st, tb);
+      NSC_CHECK_LAUNCH("conv1d_wgrad_cin1");
+      memset(&tb, 0, sizeof(tb));
+      wg = 0;
+      return NSC_OK;
+    };
+    for (int j = 0; j < njobs; ++j) {
+      const nsc_conv_wgrad_job& jb = jobs[j];
+      if (!cw_is_cin1(jb)) { rest[nrest++] = jb; continue; }
+      if (tb.njobs == NSC_CW1_MAXJ) { int rc1 = flush1(); if (rc1) return rc1; }
+      if (rq.n == NSC_CR_MAXJ) { int rc1 = flush1(); if (rc1) return rc1; rc1 = rq.flush(st); if (rc1) return rc1; }
+      const int gx = cw_cin1_gx(jb), nrows = jb.d.K + (jb.db ? 1 : 0);
+      const long stride = cw_cin1_stride(jb);
+      NSC_REQUIRE(rq.off + (long)gx * stride <= workspace_floats, NSC_ERR_BAD_ARG, "nsc_conv1d_wgrad_batch: workspace %ld floats too small", workspace_floats);
+      Cin1WgradJob& q = tb.j[tb.njobs++];
+      q.x = jb.x; q.dz = jb.dz; q.slab = workspace + rq.off; q.slab_stride = stride; q.B = jb.d.B; q.Cout = jb.d.Cout; q.T = jb.d.Tout; q.K = jb.d.K;
+      q.padL = jb.d.padL; q.nrows = nrows; q.gx = gx; q.wg0 = wg;
+      wg += gx;
+      ConvReduceJob& rj = rq.r.j[rq.n++];
+      rj.slab = q.slab; rj.stride = stride; rj.dw = jb.dw; rj.db = jb.db; rj.nslabs = gx; rj.K = jb.d.K; rj.Cin = 1; rj.Cout = jb.d.Cout;
+      rj.flip = jb.flip_taps; rj.n = nrows * jb.d.Cout;
+      rq.nmax = std::max(rq.nmax, rj.n);
+      rq.off += (long)gx * stride;
+    }
+    int rc1 = flush1();
+    if (rc1) return rc1;
+  }
+  jobs = rest;
+  njobs = nrest;
+  if (njobs == 0) return rq.flush(st);
   int rc = cw_for_each_class(jobs, njobs, [&](int rt, int ct, const int* idx, const CwPlan* cp, int n) {
     return cw_dispatch(rt, ct, jobs, idx, cp, n, workspace, workspace_floats, st, rq);
   });

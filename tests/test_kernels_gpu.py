@@ -1169,3 +1169,42 @@ def test_pair_launches_equal_two_single_launches(lib, C_, T, B, Cin0):
         assert int(flags[256]) == 0, "a neighbour wait timed out"
         for a, b in zip([dx1, da1, dz1, dx0, da0, dz0], [e1, a1, z1, e0, a0, z0]):
             assert torch.equal(a, b) and bool(torch.isfinite(a).all()), ("dgrad", rep)
+
+
+@pytest.mark.parametrize("B", [2, 128])
+def test_conv_wgrad_batch_with_one_input_channel_convs(lib, B):
+    """nsc_conv1d_wgrad_batch over the headline step's job mix - two k55 1 -> 100 input convs (their own swapped-role kernel:
+    rows = output channels, columns = taps, the bias as column K), a k55 1 -> 50 conv WITHOUT a bias, a T not a multiple of 256
+    (stays on the generic kernel), a pointwise 100 -> 100 conv and a k55 100 -> 1 conv - against float64 on the host; gradients
+    ACCUMULATE into dw / db (started from a non-zero value); taps flipped for one job."""
+    import ctypes as C
+    from nsc_amd._lib import ConvWgradJob
+    rng = np.random.default_rng(B)
+    # (Cin, Cout, T, K, padL, bias, flip)
+    specs = [(1, 100, 512, 55, 27, True, 0), (1, 100, 512, 55, 27, True, 1), (1, 50, 256, 55, 27, False, 0), (1, 100, 320, 55, 27, True, 0),
+             (100, 100, 256, 1, 0, True, 0), (100, 1, 256, 55, 27, True, 0)]
+    jobs, refs, outs = [], [], []
+    for (Cin, Cout, T, K, padL, bias, flip) in specs:
+        x = rng.standard_normal((B, Cin, T)).astype(np.float32)
+        dz = rng.standard_normal((B, Cout, T)).astype(np.float32)
+        dw0 = rng.standard_normal((K, Cin, Cout)).astype(np.float32)
+        db0 = rng.standard_normal((Cout,)).astype(np.float32)
+        xp = np.pad(x.astype(np.float64), ((0, 0), (0, 0), (padL, K)))
+        dwr = np.stack([np.einsum("bit,bot->io", xp[:, :, k:k + T], dz.astype(np.float64)) for k in range(K)], 0)
+        if flip:
+            dwr = dwr[::-1]
+        refs.append((dw0 + dwr, db0 + dz.astype(np.float64).sum((0, 2))))
+        xd, dzd, dwd, dbd = dev(x), dev(dz), dev(dw0), dev(db0)
+        outs.append((dwd, dbd, bias))
+        d = _desc(B=B, Cin=Cin, Cout=Cout, Tin=T, Tout=T, K=K, padL=padL)
+        jobs.append((ConvWgradJob(d, xd.data_ptr(), dzd.data_ptr(), dwd.data_ptr(), dbd.data_ptr() if bias else None, flip), xd, dzd))
+    arr = (ConvWgradJob * len(jobs))(*[j[0] for j in jobs])
+    lib.nsc_conv1d_wgrad_batch_workspace.restype = C.c_long
+    need = int(lib.nsc_conv1d_wgrad_batch_workspace(arr, len(jobs)))
+    ws = torch.full((need,), float("nan"), device="cuda")
+    assert lib.nsc_conv1d_wgrad_batch(arr, len(jobs), ws.data_ptr(), need, _st()) == 0, lib.nsc_last_error()
+    torch.cuda.synchronize()
+    for (dwd, dbd, bias), (dwr, dbr), sp in zip(outs, refs, specs):
+        assert_close(dwd.cpu().numpy(), dwr, tol=2e-5, what=f"dW of {sp}")
+        if bias:
+            assert_close(dbd.cpu().numpy(), dbr, tol=2e-5, what=f"db of {sp}")
