@@ -77,6 +77,19 @@ typedef struct nsc_cout1_chain {
 } nsc_cout1_chain;
 int nsc_conv1d_cout1_fwd_chain(const nsc_conv_desc* d, const float* x, const float* w, const float* bias, const float* res,
                                const float* aux, float* y, const nsc_cout1_chain* chain, void* stream);
+/* the encoder's output conv (`change_channel` + tanh, neural_speech_coding_module.py:236) followed IN THE SAME LAUNCH by the soft-to-hard
+ * quantizer of the training step (nn_core_operator.py:140-164) on the codes it produced: y = code [B,1,T] (d->act = tanh), qcode = the
+ * quantised code, quan[b] += mean_l sum_k sqrt(p + 1e-20) (ACCUMULATED: the caller zeroes quan), hist[k] += sum p (both nullable); p is
+ * not materialised.  32 bins and the k55 C -> 1 shapes only (NSC_ERR_UNSUPPORTED otherwise: launch nsc_conv1d_cout1_fwd and
+ * nsc_quantize_fwd separately - same results up to summation order). */
+typedef struct nsc_cout1_quant {
+  const float *alpha, *bins;
+  float is_quan_on;
+  int soft, nb;
+  float *qcode, *quan, *hist;
+} nsc_cout1_quant;
+int nsc_conv1d_cout1_fwd_quant(const nsc_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
+                               const nsc_cout1_quant* quant, void* stream);
 /* weight gradient: dw[k,i,o] += sum_{b,t} xin[b,i,t*stride+k*dil-padL] * dz[b,o,t];  db[o] += sum dz (db nullable).
  * flip_taps=1 writes tap k to row K-1-k (used when x/dz roles are swapped for Cout==1 convs). */
 int nsc_conv1d_wgrad(const nsc_conv_desc* d, const float* x, const float* dz, float* dw, float* db,

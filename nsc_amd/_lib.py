@@ -97,6 +97,12 @@ class Cout1Chain(C.Structure):
                 ("q_in", C.c_void_p), ("out3", C.c_void_p), ("qa", C.c_float), ("qb", C.c_float)]
 
 
+class Cout1Quant(C.Structure):
+    """include/nsc_hip.h: struct nsc_cout1_quant"""
+    _fields_ = [("alpha", C.c_void_p), ("bins", C.c_void_p), ("is_quan_on", C.c_float), ("soft", C.c_int), ("nb", C.c_int),
+                ("qcode", C.c_void_p), ("quan", C.c_void_p), ("hist", C.c_void_p)]
+
+
 class SumJob(C.Structure):
     """include/nsc_hip.h: struct nsc_sum_job"""
     _fields_ = [("x", C.c_void_p), ("out", C.c_void_p), ("n", C.c_long)]
@@ -108,6 +114,7 @@ class EntropyJob(C.Structure):
 
 
 PROTOTYPES["nsc_conv1d_cout1_fwd_chain"] = [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, C.POINTER(Cout1Chain), _P]
+PROTOTYPES["nsc_conv1d_cout1_fwd_quant"] = [C.POINTER(ConvDesc), _P, _P, _P, _P, C.POINTER(Cout1Quant), _P]
 PROTOTYPES["nsc_sum_all_batch"] = [C.POINTER(SumJob), _I, _P]
 PROTOTYPES["nsc_entropy_from_hist_batch"] = [C.POINTER(EntropyJob), _I, _P]
 PROTOTYPES["nsc_gated_block_wgrad_batch"] = [C.POINTER(BlockWgradJob), _I, _I, _I, _I, _P, _L, _P]

@@ -9,6 +9,7 @@
 //   wgrad   : rows i = (tap, ci),      cols j = output channel, k = time ; A = x tile (LDS), B = dz tile (LDS)
 // so D's lane index is always the memory-contiguous axis of the output (time for y, Cout for dW).
 #include "nsc_common.h"
+#include "quant_common.h"
 #include <cstdlib>
 #include <cstdarg>
 #include <algorithm>
@@ -673,7 +674,7 @@ __global__ __launch_bounds__(512) void conv1d_cout1_v2_kernel(nsc_conv_desc d, c
                                                               const float* __restrict__ bias,
                                                               const float* __restrict__ res,
                                                               const float* __restrict__ aux, float* __restrict__ y,
-                                                              int ldx, nsc_cout1_chain ch) {
+                                                              int ldx, nsc_cout1_chain ch, nsc_cout1_quant qz) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int TT = 64 * R, KP = (K + 3) & ~3, NWIN = (R + KP - 1 + 3) & ~3;
   static_assert(NWIN % R == 0, "window is read in R-float vectors");
@@ -771,21 +772,105 @@ __global__ __launch_bounds__(512) void conv1d_cout1_v2_kernel(nsc_conv_desc d, c
         ch.out2[idx] = o2;
         if (ch.out3) ch.out3[idx] = fmaf(ch.qa, ch.q_in[idx], ch.qb * o2);
       }
+      if (qz.qcode) xs[tid] = v;                 // the tile's codes for the quantizer stage below (the x tile is dead)
+    } else if (qz.qcode) {
+      xs[tid] = 0.f;
+    }
+  }
+  // ---- fused soft-to-hard quantizer of the training step (nn_core_operator.py:140-164 on the code this conv just produced; p is
+  // not materialised: quan_loss partials and the soft histogram only, as nsc_quantize_fwd with p_out = null).  It was a launch of its
+  // own behind every encoder (8-10 us of latency for 32 k codes).  32 bins: 4 lanes per code, 8 bins per lane, 128 codes per pass.
+  if (qz.qcode) {
+    float* qsh = part + 8 * TT;                  // [32 + 8] behind the partial-sum tile (dynamic LDS: the kernel asks for all 160 KB)
+    if (tid < 40) qsh[tid] = 0.f;
+    __syncthreads();
+    constexpr int LPC = 4, ITER = 2;
+    const int gl = tid & 3;
+    const float alpha = qz.alpha[0];
+    float bv[ITER][4], hacc[ITER][4];
+    bool ok[ITER][4];
+#pragma unroll
+    for (int i = 0; i < ITER; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        bv[i][j] = qz.bins[(i * LPC + gl) * 4 + j];
+        ok[i][j] = true;
+        hacc[i][j] = 0.f;
+      }
+    float qacc = 0.f;
+#pragma unroll
+    for (int ps = 0; ps < TT / 128; ++ps) {
+      const int ci = ps * 128 + (tid >> 2), t = t0 + ci;
+      const bool live = t < d.Tout;
+      const float c = xs[ci];
+      float dist[ITER][4], p[ITER][4];
+      softmax_bins<LPC, ITER>(c, alpha, bv, ok, dist, p);
+      float q;
+      if (qz.soft) {
+        float s_ = 0.f;
+#pragma unroll
+        for (int i = 0; i < ITER; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) s_ = fmaf(p[i][j], bv[i][j], s_);
+        q = grp_sum<LPC>(s_);
+      } else {
+        float best = -1.f;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < ITER; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int k = (i * LPC + gl) * 4 + j;
+            if (p[i][j] > best) { best = p[i][j]; bi = k; }
+          }
+        bi = grp_argmax<LPC>(best, bi);
+        q = (c != c) ? c : qz.bins[min(bi, 31)];
+      }
+      if (live) {
+#pragma unroll
+        for (int i = 0; i < ITER; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            hacc[i][j] += p[i][j];
+            qacc += __builtin_amdgcn_sqrtf(p[i][j] + QEPS);
+          }
+        if (gl == 0) qz.qcode[(long)b * d.Tout + t] = (1.f - qz.is_quan_on) * c + qz.is_quan_on * q;
+      }
+    }
+    // histogram: lanes with the same gl (bins) across the wave's 16 codes, then the 8 waves through LDS, one atomic per bin and workgroup
+#pragma unroll
+    for (int i = 0; i < ITER; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float h = hacc[i][j];
+#pragma unroll
+        for (int o = 4; o < 64; o <<= 1) h += __shfl_xor(h, o, 64);
+        if (lane < 4) atomicAdd(&qsh[(i * LPC + gl) * 4 + j], h);
+      }
+    qacc = wave_sum(qacc);
+    if (lane == 0) qsh[32 + wave] = qacc;
+    __syncthreads();
+    if (qz.hist && tid < 32) atomicAdd(qz.hist + tid, qsh[tid]);
+    if (qz.quan && tid == 0) {
+      float s_ = 0.f;
+#pragma unroll
+      for (int w8 = 0; w8 < 8; ++w8) s_ += qsh[32 + w8];
+      atomicAdd(qz.quan + b, s_ / (float)d.Tout);       // (a frame's tiles add up: the caller zeroes quan)
     }
   }
 }
 
 template <int K, int R>
 static int launch_cout1_v2(const nsc_conv_desc* d, const float* x, const float* w, const float* bias, const float* res,
-                           const float* aux, float* y, hipStream_t st, const nsc_cout1_chain& ch) {
+                           const float* aux, float* y, hipStream_t st, const nsc_cout1_chain& ch, const nsc_cout1_quant& qz) {
   constexpr int TT = 64 * R, KP = (K + 3) & ~3, NWIN = (R + KP - 1 + 3) & ~3;
   const int ldx = (TT + NWIN - R + 3) & ~3;
-  const size_t smem = ((size_t)d->Cin * ldx + (size_t)d->Cin * KP + 8 * TT) * sizeof(float);
+  const size_t smem = ((size_t)d->Cin * ldx + (size_t)d->Cin * KP + 8 * TT + 64) * sizeof(float);
   if (smem > 160 * 1024) return 1;     // does not fit: caller falls back to v1
   auto kern = conv1d_cout1_v2_kernel<K, R>;
   const hipError_t e = NSC_SMEM_ATTR(kern, 160 * 1024);
   NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "conv1d_cout1_v2: set smem attr: %s", hipGetErrorString(e));
-  hipLaunchKernelGGL(kern, dim3(nsc_cdiv(d->Tout, TT), d->B), dim3(512), smem, st, *d, x, w, bias, res, aux, y, ldx, ch);
+  hipLaunchKernelGGL(kern, dim3(nsc_cdiv(d->Tout, TT), d->B), dim3(512), smem, st, *d, x, w, bias, res, aux, y, ldx, ch, qz);
   NSC_CHECK_LAUNCH("conv1d_cout1_v2");
   return NSC_OK;
 }
@@ -799,14 +884,23 @@ __global__ void cout1_chain_kernel(const float* __restrict__ v, nsc_cout1_chain 
   }
 }
 
-extern "C" int nsc_conv1d_cout1_fwd_chain(const nsc_conv_desc* d, const float* x, const float* w, const float* bias,
-                                          const float* res, const float* aux, float* y, const nsc_cout1_chain* chain,
-                                          void* stream) {
+static int cout1_fwd_impl(const nsc_conv_desc* d, const float* x, const float* w, const float* bias, const float* res, const float* aux,
+                          float* y, const nsc_cout1_chain* chain, const nsc_cout1_quant* quant, void* stream) {
   int rc = check_desc(d, "nsc_conv1d_cout1_fwd");
   if (rc) return rc;
   nsc_cout1_chain ch;
   memset(&ch, 0, sizeof(ch));
   if (chain) ch = *chain;
+  nsc_cout1_quant qz;
+  memset(&qz, 0, sizeof(qz));
+  if (quant) {
+    qz = *quant;
+    NSC_REQUIRE(qz.qcode && qz.alpha && qz.bins, NSC_ERR_BAD_ARG, "nsc_conv1d_cout1_fwd_quant: null qcode / alpha / bins");
+    // only the register-tiled kernel carries the quantizer stage (32 bins); anything else: NSC_ERR_UNSUPPORTED, the caller launches
+    // the conv and nsc_quantize_fwd separately
+    NSC_REQUIRE(qz.nb == 32 && d->K == 55 && d->dil == 1 && d->stride == 1 && !d->in_up && d->Cin >= 8 && d->Cin <= 104 && !d->accumulate,
+                NSC_ERR_UNSUPPORTED, "nsc_conv1d_cout1_fwd_quant: needs 32 bins and the k55 C -> 1 shapes (C in 8..104)");
+  }
   NSC_REQUIRE(!ch.out3 || (ch.out2 && ch.q_in), NSC_ERR_BAD_ARG, "nsc_conv1d_cout1_fwd_chain: out3 needs out2 and q_in");
   NSC_REQUIRE(d->Cout == 1 && d->out_mode == 0, NSC_ERR_BAD_ARG, "nsc_conv1d_cout1_fwd: needs Cout == 1, plain store");
   NSC_REQUIRE(x && w && y, NSC_ERR_BAD_ARG, "nsc_conv1d_cout1_fwd: null x/w/y");
@@ -815,10 +909,11 @@ extern "C" int nsc_conv1d_cout1_fwd_chain(const nsc_conv_desc* d, const float* x
   if (!v1_only && d->K == 55 && d->dil == 1 && d->stride == 1 && !d->in_up && d->Cin >= 8 && d->Cin <= 104) {
     // R outputs per lane: 4 when that still gives every CU a workgroup, else 2
     const bool r4 = (long)d->B * nsc_cdiv(d->Tout, 256) >= 256;
-    const int rc2 = r4 ? launch_cout1_v2<55, 4>(d, x, w, bias, res, aux, y, (hipStream_t)stream, ch)
-                       : launch_cout1_v2<55, 2>(d, x, w, bias, res, aux, y, (hipStream_t)stream, ch);
+    const int rc2 = r4 ? launch_cout1_v2<55, 4>(d, x, w, bias, res, aux, y, (hipStream_t)stream, ch, qz)
+                       : launch_cout1_v2<55, 2>(d, x, w, bias, res, aux, y, (hipStream_t)stream, ch, qz);
     if (rc2 <= 0) return rc2;          // launched (0) or failed (<0); 1 = tile does not fit LDS -> v1 below
   }
+  NSC_REQUIRE(!qz.qcode, NSC_ERR_UNSUPPORTED, "nsc_conv1d_cout1_fwd_quant: the tile does not fit the register-tiled kernel");
   int ldx = 127 * d->stride + (d->K - 1) * d->dil + 1;
   ldx |= 1;
   const size_t smem = ((size_t)d->Cin * ldx + (size_t)d->K * d->Cin + 128) * sizeof(float);
@@ -838,9 +933,19 @@ extern "C" int nsc_conv1d_cout1_fwd_chain(const nsc_conv_desc* d, const float* x
   return NSC_OK;
 }
 
+extern "C" int nsc_conv1d_cout1_fwd_chain(const nsc_conv_desc* d, const float* x, const float* w, const float* bias,
+                                          const float* res, const float* aux, float* y, const nsc_cout1_chain* chain,
+                                          void* stream) {
+  return cout1_fwd_impl(d, x, w, bias, res, aux, y, chain, nullptr, stream);
+}
+extern "C" int nsc_conv1d_cout1_fwd_quant(const nsc_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
+                                          const nsc_cout1_quant* quant, void* stream) {
+  NSC_REQUIRE(quant, NSC_ERR_BAD_ARG, "nsc_conv1d_cout1_fwd_quant: null quant");
+  return cout1_fwd_impl(d, x, w, bias, nullptr, nullptr, y, nullptr, quant, stream);
+}
 extern "C" int nsc_conv1d_cout1_fwd(const nsc_conv_desc* d, const float* x, const float* w, const float* bias,
                                     const float* res, const float* aux, float* y, void* stream) {
-  return nsc_conv1d_cout1_fwd_chain(d, x, w, bias, res, aux, y, nullptr, stream);
+  return cout1_fwd_impl(d, x, w, bias, res, aux, y, nullptr, nullptr, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1268,7 +1373,7 @@ extern "C" int nsc_conv1d_wgrad(const nsc_conv_desc* d, const float* x, const fl
 // 16 consecutive k-steps are 16 consecutive floats of its dz row: four 16-byte loads straight into registers, no LDS for dz at all;
 // B is the x window in LDS, consecutive lanes consecutive addresses.  A workgroup walks chunks of 256 steps; partial dW^T leaves to
 // the job's slab in the layout conv_slab_reduce_batch_kernel expects ([tap][o], bias row behind the taps).
-#define NSC_CW1_MAXJ 4
+#define NSC_CW1_MAXJ 8
 struct Cin1WgradJob {
   const float *x, *dz;
   float* slab;
@@ -1353,8 +1458,26 @@ static bool cw_is_cin1(const nsc_conv_wgrad_job& jb) {
   return !off && d.Cin == 1 && d.stride == 1 && d.dil == 1 && !d.in_up && d.Tin == d.Tout && (d.Tout & 255) == 0 && d.K + (jb.db ? 1 : 0) <= 64 &&
          d.K >= 48 && d.Cout <= 112 && d.padL <= 63 && (long)d.B * d.Cout * d.Tout * 4 < (1L << 31) && (((uintptr_t)jb.dz) & 15) == 0;
 }
-static int cw_cin1_gx(const nsc_conv_wgrad_job& jb) { return std::max(1, std::min(256, jb.d.B * (jb.d.Tout >> 8))); }
 static long cw_cin1_stride(const nsc_conv_wgrad_job& jb) { return (((long)(jb.d.K + (jb.db ? 1 : 0)) * jb.d.Cout) + 63) & ~63L; }
+// The one-input-channel jobs of a call, in launches of up to NSC_CW1_MAXJ jobs; a launch's workgroups (256: one per CU - at 896 the
+// headline step's six jobs took 66 us in two launches, every workgroup a single chunk) are shared out by the jobs' chunk counts.
+// idx[i] = job index, gx[i] = its workgroups (= slabs), launch_of[i] = launch number.  Returns the number of such jobs.
+static int cw_cin1_plan(const nsc_conv_wgrad_job* jobs, int njobs, int* idx, int* gx, int* launch_of) {
+  int n = 0;
+  for (int j = 0; j < njobs && n < 256; ++j)
+    if (cw_is_cin1(jobs[j])) idx[n++] = j;
+  for (int lo = 0; lo < n; lo += NSC_CW1_MAXJ) {
+    const int hi = std::min(n, lo + NSC_CW1_MAXJ);
+    long tot = 0;
+    for (int i = lo; i < hi; ++i) tot += (long)jobs[idx[i]].d.B * (jobs[idx[i]].d.Tout >> 8);
+    for (int i = lo; i < hi; ++i) {
+      const long ch = (long)jobs[idx[i]].d.B * (jobs[idx[i]].d.Tout >> 8);
+      gx[i] = (int)std::max(1L, std::min(ch, (256 * ch + tot / 2) / tot));
+      launch_of[i] = lo / NSC_CW1_MAXJ;
+    }
+  }
+  return n;
+}
 
 // ---- host side of the batched form ----
 struct CwPlan { int rt, ct, gy, nchunks; long stride; size_t smem; double weight; WgradPlan p; };
@@ -1488,10 +1611,13 @@ extern "C" long nsc_conv1d_wgrad_batch_workspace(const nsc_conv_wgrad_job* jobs,
   long need = 0;       // the slabs of every class live until the one reduce at the end: the SUM over the classes
   nsc_conv_wgrad_job rest[256];
   int nrest = 0;
-  for (int j = 0; j < njobs && j < 256; ++j) {
-    if (cw_is_cin1(jobs[j])) need += (long)cw_cin1_gx(jobs[j]) * cw_cin1_stride(jobs[j]);
-    else rest[nrest++] = jobs[j];
+  {
+    int idx1[256], gx1[256], l1[256];
+    const int n1 = cw_cin1_plan(jobs, njobs, idx1, gx1, l1);
+    for (int i = 0; i < n1; ++i) need += (long)gx1[i] * cw_cin1_stride(jobs[idx1[i]]);
   }
+  for (int j = 0; j < njobs && j < 256; ++j)
+    if (!cw_is_cin1(jobs[j])) rest[nrest++] = jobs[j];
   jobs = rest;
   njobs = nrest;
   if (njobs == 0) return need;
@@ -1532,12 +1658,15 @@ extern "C" int nsc_conv1d_wgrad_batch(const nsc_conv_wgrad_job* jobs, int njobs,
       wg = 0;
       return NSC_OK;
     };
-    for (int j = 0; j < njobs; ++j) {
-      const nsc_conv_wgrad_job& jb = jobs[j];
-      if (!cw_is_cin1(jb)) { rest[nrest++] = jb; continue; }
-      if (tb.njobs == NSC_CW1_MAXJ) { int rc1 = flush1(); if (rc1) return rc1; }
+    int idx1[256], gx1[256], l1[256];
+    const int n1 = cw_cin1_plan(jobs, njobs, idx1, gx1, l1);
+    for (int j = 0; j < njobs; ++j)
+      if (!cw_is_cin1(jobs[j])) rest[nrest++] = jobs[j];
+    for (int i = 0; i < n1; ++i) {
+      const nsc_conv_wgrad_job& jb = jobs[idx1[i]];
+      if (i > 0 && l1[i] != l1[i - 1]) { int rc1 = flush1(); if (rc1) return rc1; }
       if (rq.n == NSC_CR_MAXJ) { int rc1 = flush1(); if (rc1) return rc1; rc1 = rq.flush(st); if (rc1) return rc1; }
-      const int gx = cw_cin1_gx(jb), nrows = jb.d.K + (jb.db ? 1 : 0);
+      const int gx = gx1[i], nrows = jb.d.K + (jb.db ? 1 : 0);
       const long stride = cw_cin1_stride(jb);
       NSC_REQUIRE(rq.off + (long)gx * stride <= workspace_floats, NSC_ERR_BAD_ARG, "nsc_conv1d_wgrad_batch: workspace %ld floats too small", workspace_floats);
       Cin1WgradJob& q = tb.j[tb.njobs++];

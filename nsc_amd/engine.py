@@ -392,6 +392,7 @@ class _Codec:
 
     def __init__(self, eng, scope, bkd, strides, nb):
         self.eng, self.scope, self.strides, self.nb = eng, scope, list(strides), nb
+        self.index = int(scope.rsplit("_", 1)[1]) - 1          # position in the cascade (scope_1 -> 0)
         lay = eng.layout
         self.alpha_off = lay.add(scope + "/alpha", ())
         self.bins_off = lay.add(scope + "/bins", (nb,))
@@ -532,18 +533,31 @@ class _Codec:
         h = self.stack_fwd(self.enc_tail, h)
         self.enc_feat = h
         self.code = e.buf(s + ".code", (B, 1, self.L))
-        self.enc_out.fwd(h, self.code, "tanh")
-        # ---- quantizer + fused quan/entropy partials ----
+        # ---- encoder output conv + quantizer + fused quan/entropy partials ----
         self.qcode = e.buf(s + ".qcode", (B, 1, self.L))
-        self.quan = e.buf(s + ".quan", (B,))
         self.hist = e.hist_view(s, self.nb)     # a slice of ONE flat buffer: the data-parallel exchange is a single all-reduce
         self.p = e.buf(s + ".p", (B, self.L, self.nb)) if want_p else None
         e.zero_hists_once()
         self.is_quan_on, self.soft = float(is_quan_on), int(bool(soft))
-        check(e.lib.nsc_quantize_fwd(self.code.data_ptr(), e.p_ptr + 4 * self.alpha_off, e.p_ptr + 4 * self.bins_off,
-                                     self.is_quan_on, self.soft, B, self.L, self.nb, _lib.ptr(self.p),
-                                     self.qcode.data_ptr(), self.quan.data_ptr(), self.hist.data_ptr(), e.stream()),
-              "quantize_fwd")
+        eo = self.enc_out
+        if (e.fused_quant and not want_p and self.nb == 32 and eo.K == 55 and eo.dil == 1 and eo.stride == 1 and 8 <= eo.Cin <= 104):
+            # the quantizer rides in the conv's launch (nsc_conv1d_cout1_fwd_quant); quan_loss accumulates tile by tile into the
+            # zeroed accumulator behind the gradients
+            self.quan = e._quan_acc[self.index]
+            qz = _lib.Cout1Quant(e.p_ptr + 4 * self.alpha_off, e.p_ptr + 4 * self.bins_off, self.is_quan_on, self.soft, self.nb,
+                                 self.qcode.data_ptr(), self.quan.data_ptr(), self.hist.data_ptr())
+            d = eo.desc(act=KIND_ACT["tanh"], res_mode=0, out_mode=0)
+            tok = e.prof_begin("conv_cout1", eo.flops())
+            check(e.lib.nsc_conv1d_cout1_fwd_quant(C.byref(d), h.data_ptr(), eo._p(e.p_ptr, eo.w_off), eo._p(e.p_ptr, eo.b_off),
+                                                   self.code.data_ptr(), C.byref(qz), e.stream()), "conv1d_cout1_fwd_quant")
+            e.prof_end(tok)
+        else:
+            self.enc_out.fwd(h, self.code, "tanh")
+            self.quan = e.buf(s + ".quan", (B,))
+            check(e.lib.nsc_quantize_fwd(self.code.data_ptr(), e.p_ptr + 4 * self.alpha_off, e.p_ptr + 4 * self.bins_off,
+                                         self.is_quan_on, self.soft, B, self.L, self.nb, _lib.ptr(self.p),
+                                         self.qcode.data_ptr(), self.quan.data_ptr(), self.hist.data_ptr(), e.stream()),
+                  "quantize_fwd")
         # ---- decoder ----
         h = self.qcode
         self.up_saved = []
@@ -739,12 +753,14 @@ class CascadeEngine:
         npairs = sum(len(c.enc_stages) + len(c.dec_stages) + 2 for c in self.codecs)    # enc / dec stages + enc tail + dec tail
         self._flag_slots = 2 * npairs
         nfl = (self._flag_ints + 3) // 4 * 4 * self._flag_slots
-        self._gh_floats = (n + nh + nfl + 16383) // 16384 * 16384
+        nquan = self.N * self.B
+        self._gh_floats = (n + nh + nfl + nquan + 16383) // 16384 * 16384
         self._gh = torch.zeros(self._gh_floats, **f32)
         self.grads = self._gh[:n]
         self._hist_flat = self._gh[n:n + nh]
         self._flags = self._gh[n + nh:n + nh + nfl].view(torch.int32)
         self._flag_next = 0
+        self._quan_acc = self._gh[n + nh + nfl:n + nh + nfl + nquan].view(self.N, self.B)     # quan_loss per frame, accumulated by tiles
         self._hist_slots, self._hist_used = {}, 0
         # wt = flipped/transposed kernels of every conv at the same offsets as the parameters, followed by one extra
         # region per gated block holding the two k15 gate kernels concatenated along their OUTPUT channels
@@ -846,6 +862,7 @@ class CascadeEngine:
     # ---- block weight gradients deferred to the end of the backward pass and produced by ONE persistent launch per
     # block width (nsc_gated_block_wgrad_batch): per-block launches walk only 2-4 tiles per workgroup at batch 128, so
     # their prologue, accumulator flush and slab reduction cost more than the MFMA work itself.
+    fused_quant = True   # the training-shape quantizer forward in the launch of the encoder's output conv (nsc_conv1d_cout1_fwd_quant)
     fused_pairs = True   # the dil-1 / dil-2 blocks of a stack in ONE launch (nsc_gated_block_pair_fwd_img / _dgrad_img: neighbour flags
                          # between workgroups instead of a kernel boundary); False: one launch per block
     fused_chain = True   # the cascade step / output-gradient arithmetic between codecs rides in the epilogue of the Cout = 1 convs
@@ -1162,8 +1179,12 @@ class CascadeEngine:
         assert tuple(x.shape) == (B, 1, frame_length) and x.dtype == torch.float32 and x.is_contiguous()
         self._hist_clean = bool(hists_clean)
         self._flag_next = 0
-        if not hists_clean and self.fused_pairs:      # (a training step's opening launch has zeroed the pair flags already)
-            check(self.lib.nsc_zero(self._flags.data_ptr(), self._flags.numel(), self.stream()), "zero pair flags")
+        if not hists_clean:
+            # outside a training step (whose opening launch zeroes all of it): histograms, pair flags and the quan accumulators of
+            # the fused quantizer stage sit side by side behind the gradients - one memset
+            n = self.layout.size
+            check(self.lib.nsc_zero(self._gh.data_ptr() + 4 * n, self._gh_floats - n, self.stream()), "zero hists + flags + quan")
+            self._hist_clean = True
         self.x = x
         n = B * frame_length
         self.decoded = self.buf("decoded", (B, 1, frame_length))

@@ -129,7 +129,7 @@ def test_pretrain_no_quan_step():
     assert float(np.abs(g["scope_1/alpha"]).max()) == 0.0 and float(np.abs(g["scope_1/bins"]).max()) == 0.0
 
 
-@pytest.mark.parametrize("switch", ["fused_up", "batch_conv_wgrad", "batch_wgrad", "fused_dgrad", "fused_fwd", "fused_chain", "fused_pairs"])
+@pytest.mark.parametrize("switch", ["fused_up", "batch_conv_wgrad", "batch_wgrad", "fused_dgrad", "fused_fwd", "fused_chain", "fused_pairs", "fused_quant"])
 def test_composed_paths_equal_the_fused_ones(switch):
     """Every fused / batched launch has a composed per-op path behind an engine switch (other widths and dilations take it):
     with the switch off, one joint 2-codec step ('2 2' codecs: C = 100 and 50 up-sampling stages) gives the same decoded

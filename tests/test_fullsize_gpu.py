@@ -151,44 +151,50 @@ def _grad_report(mine, g64, g32, what, only=None):
     return rep
 
 
-# Recorded ceilings (round 4, MI355X; profiles/r04b_grad_ratios_{joint,follower}.json hold the measured values): 4x what was achieved (floor 2e-5), so a
-# regression from 5e-6 to 4e-4 fails here even though it would pass the 5e-4 / 4x-fp32-CPU bound above.
-GRAD_CEILING = {'follower': {'block 1x1 bias': 2e-05,
-              'block 1x1 kernel': 2e-05,
-              'block 1x1, one input channel bias': 2e-05,
-              'block 1x1, one input channel kernel': 2e-05,
-              'block k15 gate bias': 2e-05,
-              'block k15 gate kernel': 2e-05,
-              'block k9 bias': 2e-05,
-              'block k9 kernel': 2e-05,
-              'k55 1 -> C bias': 2e-05,
-              'k55 1 -> C kernel': 2e-05,
-              'k55 C -> 1 bias': 2e-05,
-              'k55 C -> 1 kernel': 2e-05,
-              'k9 100 -> 100 (down-sampling) bias': 2e-05,
-              'k9 100 -> 100 (down-sampling) kernel': 2e-05,
-              'quantizer alpha / bins': 2e-05,
-              'separable conv bias': 2e-05,
-              'separable conv depthwise_kernel': 2e-05,
-              'separable conv pointwise_kernel': 2e-05},
- 'joint': {'block 1x1 bias': 3e-05,
-           'block 1x1 kernel': 2.9e-05,
+# Recorded ceilings (round 4, MI355X; profiles/r04b_grad_ratios_{joint,follower}.json hold the measured values): 4x what was achieved,
+# floor 1e-4, so a regression from 5e-6 to 4e-4 fails here even though it would pass the 5e-4 / 4x-fp32-CPU bound above.  Why a floor of
+# 1e-4 and not of 2e-5: ONE activation within fp32 noise of the leaky-relu kink takes the other slope as soon as anything upstream rounds
+# differently, and that single element moves a bias gradient by its whole contribution.  Measured: the follower step's encoder gradients
+# sit at 0.9e-6 of float64 - and at 5.12e-5 (down-sampling conv of scope_2; 1.9e-5 on the k15 kernels) both when the input frames are
+# perturbed by 1e-7 relative and when the quantizer forward runs fused in the C -> 1 conv's launch (4-lane instead of 8-lane groups:
+# 1e-7 on the soft codes); the forward is equally accurate in all three runs (decoded 4.2e-8 rms of float64).  The float32 CPU oracle is
+# at 5.2e-5 on the same tensor.
+GRAD_CEILING = {'follower': {'block 1x1 bias': 0.0001,
+              'block 1x1 kernel': 0.0001,
+              'block 1x1, one input channel bias': 0.0001,
+              'block 1x1, one input channel kernel': 0.0001,
+              'block k15 gate bias': 0.0001,
+              'block k15 gate kernel': 0.0001,
+              'block k9 bias': 0.0001,
+              'block k9 kernel': 0.0001,
+              'k55 1 -> C bias': 0.0001,
+              'k55 1 -> C kernel': 0.0001,
+              'k55 C -> 1 bias': 0.0001,
+              'k55 C -> 1 kernel': 0.0001,
+              'k9 100 -> 100 (down-sampling) bias': 0.0001,
+              'k9 100 -> 100 (down-sampling) kernel': 0.0001,
+              'quantizer alpha / bins': 0.0001,
+              'separable conv bias': 0.0001,
+              'separable conv depthwise_kernel': 0.0001,
+              'separable conv pointwise_kernel': 0.0001},
+ 'joint': {'block 1x1 bias': 0.0001,
+           'block 1x1 kernel': 0.0001,
            'block 1x1, one input channel bias': 0.00049,
-           'block 1x1, one input channel kernel': 8.3e-05,
+           'block 1x1, one input channel kernel': 0.0001,
            'block k15 gate bias': 0.00027,
            'block k15 gate kernel': 0.00026,
            'block k9 bias': 0.00055,
            'block k9 kernel': 0.00053,
-           'k55 1 -> C bias': 3e-05,
+           'k55 1 -> C bias': 0.0001,
            'k55 1 -> C kernel': 0.00026,
-           'k55 C -> 1 bias': 3.1e-05,
-           'k55 C -> 1 kernel': 2.5e-05,
-           'k9 100 -> 100 (down-sampling) bias': 2.9e-05,
-           'k9 100 -> 100 (down-sampling) kernel': 2.9e-05,
-           'quantizer alpha / bins': 2e-05,
-           'separable conv bias': 4.9e-05,
-           'separable conv depthwise_kernel': 2e-05,
-           'separable conv pointwise_kernel': 4.8e-05}}
+           'k55 C -> 1 bias': 0.0001,
+           'k55 C -> 1 kernel': 0.0001,
+           'k9 100 -> 100 (down-sampling) bias': 0.0001,
+           'k9 100 -> 100 (down-sampling) kernel': 0.0001,
+           'quantizer alpha / bins': 0.0001,
+           'separable conv bias': 0.0001,
+           'separable conv depthwise_kernel': 0.0001,
+           'separable conv pointwise_kernel': 0.0001}}
 
 
 def _check_ceilings(rep, what):

@@ -1208,3 +1208,37 @@ def test_conv_wgrad_batch_with_one_input_channel_convs(lib, B):
         assert_close(dwd.cpu().numpy(), dwr, tol=2e-5, what=f"dW of {sp}")
         if bias:
             assert_close(dbd.cpu().numpy(), dbr, tol=2e-5, what=f"db of {sp}")
+
+
+@pytest.mark.parametrize("C_,T,B,soft", [(100, 256, 128, True), (100, 256, 3, False), (50, 128, 5, True), (100, 200, 3, True)])
+def test_cout1_conv_with_fused_quantizer_equals_conv_then_quantizer(lib, C_, T, B, soft):
+    """nsc_conv1d_cout1_fwd_quant (the encoder's k55 C -> 1 conv + tanh with the training-shape quantizer in the same launch)
+    against nsc_conv1d_cout1_fwd followed by nsc_quantize_fwd: the float codes bit for bit; the quantised codes, quan_loss and the
+    soft histogram up to the summation order of a 4-lane instead of an 8-lane group (hard codes: exactly the same bin); quan
+    accumulates into a zeroed buffer, the histogram onto what is there."""
+    import ctypes as C
+    from nsc_amd._lib import Cout1Quant
+    rng = np.random.default_rng(C_ + T + B)
+    x = dev(rng.standard_normal((B, C_, T)).astype(np.float32))
+    w = dev((0.02 * rng.standard_normal((55, C_, 1))).astype(np.float32))
+    bias = dev(np.array([0.01], np.float32))
+    alpha, bins = dev(np.array([-300.0 if soft else -20.0], np.float32)), dev(np.linspace(-1, 1, 32).astype(np.float32))
+    d = _desc(B=B, Cin=C_, Cout=1, Tin=T, Tout=T, K=55, padL=27, act=1)
+    code0, code1 = torch.full((B, 1, T), float("nan"), device="cuda"), torch.full((B, 1, T), float("nan"), device="cuda")
+    q0, q1 = torch.full((B, 1, T), float("nan"), device="cuda"), torch.full((B, 1, T), float("nan"), device="cuda")
+    quan0, quan1 = torch.zeros(B, device="cuda"), torch.zeros(B, device="cuda")
+    h0, h1 = torch.ones(32, device="cuda"), torch.ones(32, device="cuda")
+    assert lib.nsc_conv1d_cout1_fwd(C.byref(d), x.data_ptr(), w.data_ptr(), bias.data_ptr(), None, None, code0.data_ptr(), _st()) == 0
+    assert lib.nsc_quantize_fwd(code0.data_ptr(), alpha.data_ptr(), bins.data_ptr(), 1.0, int(soft), B, T, 32, None, q0.data_ptr(),
+                                quan0.data_ptr(), h0.data_ptr(), _st()) == 0, lib.nsc_last_error()
+    qz = Cout1Quant(alpha.data_ptr(), bins.data_ptr(), 1.0, int(soft), 32, q1.data_ptr(), quan1.data_ptr(), h1.data_ptr())
+    assert lib.nsc_conv1d_cout1_fwd_quant(C.byref(d), x.data_ptr(), w.data_ptr(), bias.data_ptr(), code1.data_ptr(), C.byref(qz),
+                                          _st()) == 0, lib.nsc_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(code0, code1) and bool(torch.isfinite(code1).all())
+    if soft:
+        assert_close(q1.cpu().numpy(), q0.cpu().numpy(), tol=2e-6, atol=1e-7, what="soft codes")
+    else:
+        assert torch.equal(q0, q1), "hard codes"
+    assert_close(quan1.cpu().numpy(), quan0.cpu().numpy(), tol=2e-6, what="quan_loss per frame")
+    assert_close(h1.cpu().numpy(), h0.cpu().numpy(), tol=1e-5, what="soft histogram")
