@@ -10,6 +10,7 @@
 // so D's lane index is always the memory-contiguous axis of the output (time for y, Cout for dW).
 #include "nsc_common.h"
 #include "quant_common.h"
+#include <type_traits>
 #include <cstdlib>
 #include <cstdarg>
 #include <algorithm>
@@ -1409,29 +1410,36 @@ __global__ __launch_bounds__(512) void conv1d_wgrad_cin1_kernel(Cin1WgradBatch t
   const int tap3 = 48 + l15;
   const float one3 = (tap3 == jb.K && jb.nrows > jb.K) ? 1.f : 0.f;
   const bool real3 = tap3 < jb.K;
-  for (int chunk = wl; chunk < nchunks; chunk += jb.gx) {
-    const int b = chunk / nchunk_t, t0 = (chunk - b * nchunk_t) << 8;
-    // this lane's dz row, 16 consecutive steps per 64-step block: the chunk's 16 loads go out before anything else
-    f32x4 a4[4][4];
+  // this lane's dz row, 16 consecutive steps per 64-step block: a chunk's 16 loads; the NEXT chunk's go out before this chunk's MFMAs
+  // (register double buffer) and the barriers order LDS traffic only, so the loads stay in flight across them
+  f32x4 a4[2][4][4];
+  auto load_a = [&](int chunk, int buf) {
+    const int cc = chunk < nchunks ? chunk : wl;             // past the end: a harmless re-read
+    const int b = cc / nchunk_t, t0 = (cc - b * nchunk_t) << 8;
     const int vo = (busy && o < jb.Cout) ? ((b * jb.Cout + o) * jb.T + t0 + 16 * kq) * 4 : 0x7ffffff0;
 #pragma unroll
     for (int blk = 0; blk < 4; ++blk)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        a4[blk][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(sz, vo, (64 * blk + 4 * i) * 4, 0));
-    __syncthreads();                               // the previous chunk's window reads are done
+        a4[buf][blk][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(sz, vo, (64 * blk + 4 * i) * 4, 0));
+  };
+  auto run_chunk = [&](int chunk, auto buf_c) {
+    constexpr int BUF = decltype(buf_c)::value;
+    const int b = chunk / nchunk_t, t0 = (chunk - b * nchunk_t) << 8;
+    nsc_lds_barrier();                             // the previous chunk's window reads are done
     if (tid < 320) {
       const int u = t0 - jb.padL + tid;
       xs[tid] = (u >= 0 && u < jb.T) ? jb.x[(long)b * jb.T + u] : 0.f;
     }
-    __syncthreads();
+    nsc_lds_barrier();
+    load_a(chunk + jb.gx, BUF ^ 1);
     if (busy) {
 #pragma unroll
       for (int blk = 0; blk < 4; ++blk) {
         const float* xb = xs + 64 * blk + 16 * kq + l15;
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
-          const float a = a4[blk][ks >> 2][ks & 3];
+          const float a = a4[BUF][blk][ks >> 2][ks & 3];
 #pragma unroll
           for (int c = 0; c < 3; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xb[ks + 16 * c], acc[c], 0, 0, 0);
           const float b3 = real3 ? xb[ks + 48] : one3;
@@ -1439,6 +1447,11 @@ __global__ __launch_bounds__(512) void conv1d_wgrad_cin1_kernel(Cin1WgradBatch t
         }
       }
     }
+  };
+  load_a(wl, 0);
+  for (int chunk = wl; chunk < nchunks; chunk += 2 * jb.gx) {
+    run_chunk(chunk, std::integral_constant<int, 0>{});
+    if (chunk + jb.gx < nchunks) run_chunk(chunk + jb.gx, std::integral_constant<int, 1>{});
   }
   if (!busy) return;
   float* sl = jb.slab + (long)wl * jb.slab_stride;
