@@ -5,6 +5,7 @@ if len(sys.argv) > 1:
     import torch
     from nsc_amd import _lib
     from nsc_amd._lib import ConvDesc
+    _lib.LIB_PATH = os.path.abspath(os.environ.get("NSC_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "nsc_amd", "libnsc_hip_probes.so")))
     lib = _lib.load()
     st = torch.cuda.current_stream().cuda_stream
     B, T = 128, 512
