@@ -56,6 +56,47 @@ __device__ __forceinline__ void conv_store_rows(const nsc_conv_desc& d, const fl
   if (d.out_mode == 1) {
     // sub-pixel shuffle: output row (ch >> 1) interleaves LDS rows 2c, 2c+1 in time, so a wave still writes whole lines;
     // residual / aux (if any) are laid out like the OUTPUT [B, Cout/2, 2 Tout]
+    if ((d.Tout & 1) == 0 && (LDO & 1) == 0 && ((uintptr_t)y & 15) == 0 && (!d.res_mode || ((uintptr_t)res & 15) == 0) &&
+        (!d.mul_mode || ((uintptr_t)aux & 15) == 0)) {
+      // 16 bytes per lane: four consecutive output steps = two steps of LDS row 2c interleaved with two of row 2c + 1
+      constexpr int L4 = 2 * TTc / 4, RPI = 64 / L4 > 0 ? 64 / L4 : 1;       // float4 per output row (2 TTc steps)
+      static_assert(L4 <= 64, "an output row's float4s fit a wave");
+      const int sub = lane / L4, q4 = lane - sub * L4;
+      const int t2 = 2 * t0 + 4 * q4;
+      for (int orb = wave8 * RPI; 2 * orb < nrow; orb += NWV * RPI) {
+        const int orow = orb + sub;
+        if (2 * orow >= nrow || t2 >= 2 * d.Tout) continue;
+        const int och = (rt0 * 16 >> 1) + orow;
+        const bool has1 = 2 * orow + 1 < nrow;
+        const float b0 = bias ? bias[rt0 * 16 + 2 * orow] : 0.f;
+        const float b1 = (bias && has1) ? bias[rt0 * 16 + 2 * orow + 1] : 0.f;
+        const float2 e0 = *reinterpret_cast<const float2*>(os + (2 * orow) * LDO + 2 * q4);
+        const float2 e1 = has1 ? *reinterpret_cast<const float2*>(os + (2 * orow + 1) * LDO + 2 * q4) : make_float2(0.f, 0.f);
+        f32x4 v = {e0.x + b0, e1.x + b1, e0.y + b0, e1.y + b1};
+        const long oidx = ((long)b * (Cout >> 1) + och) * (2L * d.Tout) + t2;
+        f32x4 rv = {0.f, 0.f, 0.f, 0.f}, av = {0.f, 0.f, 0.f, 0.f};
+        if (d.res_mode == 1) rv = *reinterpret_cast<const f32x4*>(res + oidx);
+        else if (d.res_mode == 2) rv = *reinterpret_cast<const f32x4*>(res + (long)b * 2 * d.Tout + t2);
+        if (d.mul_mode) av = *reinterpret_cast<const f32x4*>(aux + oidx);
+        f32x4* yp = reinterpret_cast<f32x4*>(y + oidx);
+        const f32x4 y0 = d.accumulate ? *yp : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float u = v[e];
+          if (d.res_mode) u += rv[e];
+          u = nsc_apply_act(u, d.act);
+          if (d.mul_mode) u *= nsc_act_grad_from_out(av[e], d.mul_mode);
+          v[e] = u + y0[e];
+        }
+        if (has1) {
+          *yp = v;
+        } else {                                   // (an odd channel count: the last output row has its even steps only)
+          y[oidx] = v[0];
+          y[oidx + 2] = v[2];
+        }
+      }
+      return;
+    }
     for (int orow = wave8; 2 * orow < nrow; orow += NWV) {
       const int och = (rt0 * 16 >> 1) + orow;
       const float b0 = bias ? bias[rt0 * 16 + 2 * orow] : 0.f;
@@ -74,6 +115,41 @@ __device__ __forceinline__ void conv_store_rows(const nsc_conv_desc& d, const fl
         if (d.accumulate) y[oidx] += v;
         else y[oidx] = v;
       }
+    }
+    return;
+  }
+  // Round 4: 16 bytes per lane where the rows allow it (T % 4 == 0, 16-byte aligned tensors): a wave instruction moves 64 / (TTc / 4) whole
+  // rows - a quarter of the LDS reads and global stores of the dword form below (the k55 1 -> C conv spent 15 of its 23 us in launch +
+  // this epilogue: 26 MB of row stores).
+  if ((d.Tout & 3) == 0 && (LDO & 3) == 0 && ((uintptr_t)y & 15) == 0 && (!d.res_mode || ((uintptr_t)res & 15) == 0) &&
+      (!d.mul_mode || ((uintptr_t)aux & 15) == 0)) {
+    constexpr int L4 = TTc / 4, RPI = 64 / L4;
+    static_assert(L4 <= 64 && 64 % L4 == 0, "a row's float4s divide the wave");
+    const int sub = lane / L4, q4 = lane - sub * L4;
+    const int t = t0 + 4 * q4;
+    for (int rowb = wave8 * RPI; rowb < nrow; rowb += NWV * RPI) {
+      const int row = rowb + sub;
+      if (row >= nrow || t >= d.Tout) continue;
+      const int ch = rt0 * 16 + row;
+      const float bv = bias ? bias[ch] : 0.f;
+      f32x4 v = *reinterpret_cast<const f32x4*>(os + row * LDO + 4 * q4);
+      const long idx = ((long)b * Cout + ch) * d.Tout + t;
+      f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+      if (d.res_mode == 1) rv = *reinterpret_cast<const f32x4*>(res + idx);
+      else if (d.res_mode == 2) rv = *reinterpret_cast<const f32x4*>(res + (long)b * d.Tout + t);
+      f32x4 av = {0.f, 0.f, 0.f, 0.f};
+      if (d.mul_mode) av = *reinterpret_cast<const f32x4*>(aux + idx);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float u = v[e] + bv;
+        if (d.res_mode) u += rv[e];
+        u = nsc_apply_act(u, d.act);
+        if (d.mul_mode) u *= nsc_act_grad_from_out(av[e], d.mul_mode);
+        v[e] = u;
+      }
+      f32x4* yp = reinterpret_cast<f32x4*>(y + idx);
+      if (d.accumulate) v += *yp;
+      *yp = v;
     }
     return;
   }
