@@ -269,6 +269,15 @@ __global__ __launch_bounds__(512) void gated_block_fwd_kernel(BlockArgs a, int l
 #else
 #define NSC_AUX_COHERENT 0x11     /* raw buffer load aux bits on gfx940+: bit 0 = sc0, bit 4 = sc1 */
 #endif
+// Cache policy of the streaming traffic of the forward / data-gradient kernels (profiles/r04h_store_flavours.txt).  Stores of
+// tensors nobody reads before the backward pass / the tail of the step (saved activations, da, dz1) are NONTEMPORAL: they do not sit
+// dirty in the eight L2s until the end-of-kernel write-back (-1.0 % of the step; written through with sc0 sc1: -0.5 %).  The tile
+// prefetch loads are nontemporal too (-0.7 %).  Measured and not kept: the block's main output (out / dx, read by the next launch)
+// nontemporal (+-0); nontemporal operand loads in the weight-gradient kernels (+0.3 %) and in the convs outside the blocks (+-0.1 %).
+#define NSC_AUX_LATE 2            /* raw buffer aux bits: bit 1 = nt */
+#define NSC_AUX_STREAM 2
+__device__ __forceinline__ void nsc_store4_late(float* gp, const f32x4& v) { __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(gp)); }
+
 __device__ __forceinline__ void nsc_pair_publish(int* flags) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's write-through stores are acknowledged: they are in memory
   __syncthreads();
@@ -343,7 +352,7 @@ __device__ __forceinline__ void gated_block_fwd2_body(const BlockArgs& a, int nt
   // lanes' offset goes out of range; the staging step writes zeros there either way)
   auto pf1 = [&](int q) {
     const int vo = (q == NQ4 - 1 && 2 * wave + phalf + 16 * q >= Cin) ? 0x7ffffff0 : pf_vo;
-    pf4[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(sx, vo, q * 16 * T * 4, PAIRED ? NSC_AUX_COHERENT : 0));
+    pf4[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(sx, vo, q * 16 * T * 4, PAIRED ? NSC_AUX_COHERENT : NSC_AUX_STREAM));
   };
   auto prefetch = [&](int tile) {
     pf_setup(tile);
@@ -602,7 +611,7 @@ __device__ __forceinline__ void gated_block_fwd2_body(const BlockArgs& a, int nt
     const bool tvec = (T & 3) == 0;
     auto store4 = [&](float* gp, const f32x4& v, int t) {
       if (tvec) {
-        if (t < T) *reinterpret_cast<f32x4*>(gp) = v;
+        if (t < T) nsc_store4_late(gp, v);
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -2092,7 +2101,7 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
   const int pi4 = lane & 31, phalf = lane >> 5;
   const bool tvec = (T & 3) == 0;                  // rows are 16-byte aligned: float4 pieces never straddle a row end
   auto bld4 = [](const __amdgpu_buffer_rsrc_t& r, int voff, int soff) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, NSC_AUX_STREAM));
   };
   auto bld = [](const __amdgpu_buffer_rsrc_t& r, int voff, int soff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
@@ -2129,7 +2138,7 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
   auto pf_dy1 = [&](int q) {
     const int vo = (q == NQY - 1 && 2 * wave + phalf + 16 * q >= C) ? OOB : pf_vy;
     pfy[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(sdy, vo, (pf_b * C + 2 * wave + 16 * q) * T * 4,
-                                                                             PAIRED ? NSC_AUX_COHERENT : 0));
+                                                                             PAIRED ? NSC_AUX_COHERENT : NSC_AUX_STREAM));
   };
   auto pf_a1 = [&](int i) {                                    // i = 0..4: lin rows, tanh rows, lin rows + 16, tanh rows + 16, h
     const int so = (pf_b * NARROW + 2 * wave + 16 * (i >> 1)) * T * 4;
@@ -2503,8 +2512,8 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
             *pt = dgt;
             const int t = t0 - Hh + ja;
             const int vo = (ja >= st_lo && ja < st_hi && t < T) ? (c * T + t) * 4 : OOB;
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, dl_), sdlin, vo, sda, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, dgt), sdgate, vo, sda, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, dl_), sdlin, vo, sda, NSC_AUX_LATE);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, dgt), sdgate, vo, sda, NSC_AUX_LATE);
           }
         }
       };
@@ -2591,7 +2600,7 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
       *reinterpret_cast<f32x4*>(dhs + c * LDN + tt) = v;
       float* gp = a.dz1 + ((long)b * NARROW + c) * T + t;
       if (tvec) {
-        if (t < T) *reinterpret_cast<f32x4*>(gp) = v;
+        if (t < T) nsc_store4_late(gp, v);
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
