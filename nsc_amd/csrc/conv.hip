@@ -9,6 +9,9 @@
 //   wgrad   : rows i = (tap, ci),      cols j = output channel, k = time ; A = x tile (LDS), B = dz tile (LDS)
 // so D's lane index is always the memory-contiguous axis of the output (time for y, Cout for dW).
 #include "nsc_common.h"
+// whole-row 16-byte stores of the conv epilogues are nontemporal (conv class 0.416 -> 0.400 ms per step, profiles/r04h_store_flavours.txt;
+// nontemporal 4-byte slab stores of the weight-gradient flush were 6 % slower)
+#define NSC_CONV_ST4(p_, v_) __builtin_nontemporal_store(v_, p_)
 #include "quant_common.h"
 #include <type_traits>
 #include <cstdlib>
@@ -89,7 +92,7 @@ __device__ __forceinline__ void conv_store_rows(const nsc_conv_desc& d, const fl
           v[e] = u + y0[e];
         }
         if (has1) {
-          *yp = v;
+          NSC_CONV_ST4(yp, v);
         } else {                                   // (an odd channel count: the last output row has its even steps only)
           y[oidx] = v[0];
           y[oidx + 2] = v[2];
@@ -149,7 +152,7 @@ __device__ __forceinline__ void conv_store_rows(const nsc_conv_desc& d, const fl
       }
       f32x4* yp = reinterpret_cast<f32x4*>(y + idx);
       if (d.accumulate) v += *yp;
-      *yp = v;
+      NSC_CONV_ST4(yp, v);
     }
     return;
   }

@@ -10,6 +10,8 @@
 // pointwise kernel, NK registers), and the epilogue leaves through LDS as whole shuffled 256-B rows.  64 KB of LDS and
 // <= 128 registers: two workgroups share a CU, so one's loads / stores overlap the other's MFMAs.
 #include "nsc_common.h"
+// the kernels' whole-row stores are nontemporal (up-sampling class 0.103 -> 0.096 ms per step, profiles/r04h_store_flavours.txt)
+#define UP_ST(p_, v_) __builtin_nontemporal_store((float)(v_), p_)
 #include <algorithm>
 #include <type_traits>
 
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(512, 4) void upsample_fwd_kernel(UpFwdArgs a, int t
 #pragma unroll
       for (int k = 0; k < UK; ++k) v = fmaf(xs[r * ULD + lane + k], wr[k * C], v);
       dws[r * ULD + lane] = v;                        // rows >= C: x is zero
-      if (a.dwo && r < C && t0 + lane < T) a.dwo[((long)b * C + r) * T + t0 + lane] = v;
+      if (a.dwo && r < C && t0 + lane < T) UP_ST(a.dwo + ((long)b * C + r) * T + t0 + lane, v);
     }
   }
   nsc_lds_barrier();
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(512, 4) void upsample_fwd_kernel(UpFwdArgs a, int t
     for (int hb = 0; hb < 2; ++hb) {
       const int tl2 = hb * 64 + lane, par = tl2 & 1, tl = tl2 >> 1;
       const int t2 = 2 * t0 + tl2;
-      if (t2 < 2 * T && !(skip & 8)) a.y[((long)b * Ch + oc) * (2L * T) + t2] = os[(2 * oc + par) * ULO + tl];
+      if (t2 < 2 * T && !(skip & 8)) UP_ST(a.y + ((long)b * Ch + oc) * (2L * T) + t2, os[(2 * oc + par) * ULO + tl]);
     }
   }
 }
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(512, 4) void upsample_bwd_kernel(UpBwdArgs a, int t
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     const int r = wave + 8 * q;
-    if (r < C && t0 + lane < T) a.dzp[((long)b * C + r) * T + t0 + lane] = dzs[r * ULD + 4 + lane];
+    if (r < C && t0 + lane < T) UP_ST(a.dzp + ((long)b * C + r) * T + t0 + lane, dzs[r * ULD + 4 + lane]);
   }
   // ---- pointwise^T on the matrix pipe: 80 columns ----
   auto mma = [&](auto nc_tag, int ctb) {
@@ -229,8 +231,8 @@ __global__ __launch_bounds__(512, 4) void upsample_bwd_kernel(UpBwdArgs a, int t
 #pragma unroll
       for (int k = 0; k < UK; ++k) v = fmaf(dr[8 - k], wr[k * C], v);
       const long o = ((long)b * C + r) * T + t0 + lane;
-      a.ddw[o] = dr[4];
-      a.dx[o] = v;
+      UP_ST(a.ddw + o, dr[4]);
+      UP_ST(a.dx + o, v);
     }
   }
 }
