@@ -376,6 +376,7 @@ __device__ __forceinline__ void gated_block_fwd2_body(const BlockArgs& a, int nt
   const int rt3 = RT9 == 7 ? (wave < 4 ? wave : 4 + ((wave - 4) >> 1)) : (wave & 3);
   float w9r[K9][5];
   float b1r[4], b9r[4];
+  float b9l;            // bias of output channel rt3 * 16 + l15: the dense phase-3 jobs run transposed (see out_store4)
   // phase-2 jobs: q -> (row tile q % 3, column tile q / 3); wave w runs q = w and w + 8 (wave 7: a discarded duplicate)
   int jrt[2], jct[2];
   bool jlive[2];
@@ -486,6 +487,14 @@ __device__ __forceinline__ void gated_block_fwd2_body(const BlockArgs& a, int nt
     prefetch(first);
   }
   nsc_wait_vmem();   // weights (and the first tile) are in: no vmcnt guards on register operands inside the loop
+  {
+    // b9r[reg] = b9[rt3 * 16 + 4 kq + reg] (the fragment layout of the image); the transposed phase 3 wants b9[rt3 * 16 + l15]:
+    // lane (kq' = l15 >> 2, any l15') holds it in register l15 & 3
+    float tb[4];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) tb[reg] = __shfl(b9r[reg], (l15 >> 2) * 16, 64);
+    b9l = (l15 & 2) ? ((l15 & 1) ? tb[3] : tb[2]) : ((l15 & 1) ? tb[1] : tb[0]);
+  }
   // the k15 gate kernels by LDS-DMA (image path; see gated_block_dgrad2_role): the youngest vector-memory operations when the tile
   // loop starts, waited for by hand before the first tile's phase 2
   const bool dma2 = a.img != nullptr;
@@ -748,6 +757,21 @@ __device__ __forceinline__ void gated_block_fwd2_body(const BlockArgs& a, int nt
         a.out[((long)b_ * C + o) * T + t] = v;
       }
     };
+    // The dense jobs compute the TRANSPOSED product (the two MFMA operands swapped: rows of D = time, columns = output channels;
+    // both operands keep their lane layout, 16x16x4 fragments of A and B are mirror images): a lane's four accumulator registers
+    // are four CONSECUTIVE steps of one channel and leave as one 16-byte store - 4 store instructions per lane and job instead of 16.
+    auto out_store4 = [&](const f32x4& v, int b_, int o, int t) {
+      float* gp = a.out + ((long)b_ * C + o) * T + t;
+      if constexpr (FIRST) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, v), sout, ((b_ * C + o) * T + t) * 4, 0, NSC_AUX_COHERENT);   // (pairs: T % 4 == 0)
+      } else if (tvec) {
+        *reinterpret_cast<f32x4*>(gp) = v;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (t + e < T) gp[e] = v[e];
+      }
+    };
     // dense job: this wave's row tile, NC column tiles from ct0 on (weights in registers)
     auto dense3 = [&](auto nc_c, int ct0) {
       constexpr int NC = decltype(nc_c)::value;
@@ -760,24 +784,27 @@ __device__ __forceinline__ void gated_block_fwd2_body(const BlockArgs& a, int nt
 #pragma unroll
         for (int u = 0; u < 5; ++u)
 #pragma unroll
-          for (int c = 0; c < NC; ++c) acc[c] = mfma4(w9r[tap][u], gb[4 * u * LDG + c * 16 + tap], acc[c]);
+          for (int c = 0; c < NC; ++c) acc[c] = mfma4(gb[4 * u * LDG + c * 16 + tap], w9r[tap][u], acc[c]);   // (transposed product)
       }
+      const int o = rt3 * 16 + l15p;
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
-        const int tt = (ct0 + c) * 16 + l15p;
+        const int tt = (ct0 + c) * 16 + 4 * kqp;
         const int t = t0 + tt;
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const int o = rt3 * 16 + kqp * 4 + reg;
 #if defined(NSC_EXP) && (NSC_EXP & 16)
-          if (o < C && t < T && a.B < 0) {                 // timing experiment: the output epilogue never stores
+        if (o < C && t < T && a.B < 0) {                   // timing experiment: the output epilogue never stores
 #else
-          if (o < C && t < T) {
+        if (o < C && t < T) {
 #endif
-            float v = acc[c][reg] + b9r[reg] + xs[(NK1 == 1 ? 0 : o) * LDX + H + tt];   // Cin = 1: broadcast residual
-            if (!a.flat) v = v > 0.f ? v : NSC_LRELU_ALPHA * v;
-            out_store(v, b, o, t);
+          const float* xr = xs + (NK1 == 1 ? 0 : o) * LDX + H + tt;             // Cin = 1: broadcast residual
+          f32x4 v;
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) {
+            float u_ = acc[c][reg] + b9l + xr[reg];
+            if (!a.flat) u_ = u_ > 0.f ? u_ : NSC_LRELU_ALPHA * u_;
+            v[reg] = u_;
           }
+          out_store4(v, b, o, t);
         }
       }
     };
