@@ -327,6 +327,9 @@ int nsc_rfft512(const float* sig, int B, float* re, float* im, float* mag, void*
 int nsc_adam_tf1_step(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
                       float eps, int t, const int* t_dev, void* stream);
 int nsc_increment(int* counter, void* stream);
+/* measurement aid (bench.py): 256 one-wave workgroups run a dependent chain of `iters` FMAs; a launch whose duration no cache can
+ * change, bracketed once and twice by events to find what a bracket adds to the launch inside it. */
+int nsc_spin(float* sink, int iters, void* stream);
 /* opening of a training step in one launch (the engine's sess.run(trainop) prologue, neural_speech_coding_module.py:455-458 has
  * no counterpart - TF zeroes nothing and keeps no flipped kernels): dst[e] = idx[e] >= 0 ? src[idx[e]] : 0 for e < n (nsc_gather:
  * the data-gradient kernels and parameter images); zero[0, zero_n) = 0 (gradients + histograms; 16-byte aligned, zero_n % 4 == 0);

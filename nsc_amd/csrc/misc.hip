@@ -483,6 +483,19 @@ extern "C" int nsc_increment(int* counter, void* stream) {
   NSC_CHECK_LAUNCH("increment");
   return NSC_OK;
 }
+// A kernel whose duration does not depend on any cache: 256 workgroups of one wave run a dependent chain of `iters` FMAs (about 8
+// cycles each).  bench.py brackets one and two launches of it with events to measure what an event bracket adds to a launch.
+__global__ void spin_kernel(float* sink, int iters) {
+  float x = (float)threadIdx.x * 1e-3f;
+  for (int i = 0; i < iters; ++i) x = fmaf(x, 0.999f, 0.001f);
+  if (x == 123.456f) sink[0] = x;
+}
+extern "C" int nsc_spin(float* sink, int iters, void* stream) {
+  NSC_REQUIRE(sink && iters > 0, NSC_ERR_BAD_ARG, "nsc_spin: bad args");
+  hipLaunchKernelGGL(spin_kernel, dim3(256), dim3(64), 0, (hipStream_t)stream, sink, iters);
+  NSC_CHECK_LAUNCH("spin");
+  return NSC_OK;
+}
 
 // ---------------- framing / Hann overlap-add (utilities.py:7-39; cmrl.py:595-597) ----------------
 __global__ void frame_utterance_kernel(const float* __restrict__ utt, long n, const float* __restrict__ window,
