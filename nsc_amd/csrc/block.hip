@@ -764,7 +764,7 @@ __device__ __forceinline__ void gated_block_fwd2_body(const BlockArgs& a, int nt
       float* gp = a.out + ((long)b_ * C + o) * T + t;
       if constexpr (FIRST) {
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, v), sout, ((b_ * C + o) * T + t) * 4, 0, NSC_AUX_COHERENT);   // (pairs: T % 4 == 0)
-      } else if (tvec) {
+      } else if (tvec && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0) {      // (rows 16-byte aligned: T % 4 == 0 and an aligned tensor)
         *reinterpret_cast<f32x4*>(gp) = v;
       } else {
 #pragma unroll
