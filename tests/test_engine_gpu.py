@@ -410,3 +410,32 @@ def test_parameter_write_after_refresh_invalidates_the_block_images():
         eng.refresh_wt()
         assert eng.images_valid
         assert torch.equal(eng.forward(xd, 1.0, True), want), how + " after refresh"
+
+
+def test_bench_line_contract():
+    """`python bench.py` (the command the driver runs) prints ONE JSON line with the contract's keys; the live roofline record carries
+    the kernel's average launch time corrected by the event bracket's own overhead (measured in the same run) and stays below the peak."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--no-infer"],
+                         capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["dtype"] == "f32" and d["vs_baseline"] is None
+    assert d["scaling"] == "weak" and d["higher_is_better"] is True and "workload" in d["config"]
+    assert abs(d["value"] - 128 * 1e3 / d["ms_per_step"]) < 0.01 * d["value"]              # frames/s of the whole job
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "avg_launch_us_event_bracket",
+              "event_bracket_overhead_us"):
+        assert k in r, k
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and 0.05 < r["frac"] < 1.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert 0.0 <= r["event_bracket_overhead_us"] <= 10.0
+    assert abs(r["avg_launch_us_event_bracket"] - r["avg_launch_us"] - r["event_bracket_overhead_us"]) < 0.05
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
