@@ -439,3 +439,20 @@ def test_bench_line_contract():
     assert abs(r["avg_launch_us_event_bracket"] - r["avg_launch_us"] - r["event_bracket_overhead_us"]) < 0.05
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
+
+
+@pytest.mark.parametrize("when", ["first", "timed"])
+def test_bench_survives_a_pair_launch_timeout(when):
+    """A neighbour wait of a pair launch that times out (another process or a collective holding compute units) must cost the run
+    its pair launches, not its line: bench.py switches to one launch per block - before capture, or after the timed region and then
+    times again - and says so."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NSC_BENCH_FAKE_PAIR_TIMEOUT=when)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--no-infer",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    c = d["config"]
+    assert c["pair_launches"] is False and c["pair_launch_timeouts"] == 0 and "pair_launches_note" in c, c
+    assert d["value"] > 0 and d["steps"] == 3
