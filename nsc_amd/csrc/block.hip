@@ -664,8 +664,6 @@ __device__ __forceinline__ void gated_block_fwd2_body(const BlockArgs& a, int nt
       const bool two = fresh || wave < 4;                 // wave-uniform: does this wave run a second job?
       f32x4 acc[2];
       acc[0] = acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      f32x4 acc2[2];
-      acc2[0] = acc2[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
       const float* ab0 = w2s + kq * LDW + jrt[0] * 16 + l15;
       const float* ab1 = w2s + kq * LDW + jrt[1] * 16 + l15;
       const float* hb0 = hs + kq * LDX + jct[0] * 16 + l15 + joff;
@@ -686,19 +684,10 @@ __device__ __forceinline__ void gated_block_fwd2_body(const BlockArgs& a, int nt
 #pragma unroll
           for (int u = 0; u < 5; ++u) {
             const int ao = (tap * NARROW + 4 * u) * LDW, ho = 4 * u * LDX + tap * DIL;
-            // (even and odd k-steps on separate accumulators, summed below: consecutive MFMAs of a job are independent and the wave
-            // need not wait out the previous one's latency - step 2.943 -> 2.936 ms, codec forward 6.01 -> 5.97 us/frame)
-            if ((tap * 5 + u) & 1) {
-              acc2[0] = mfma4(ab0[ao], hb0[ho], acc2[0]);
-              acc2[1] = mfma4(ab1[ao], hb1[ho], acc2[1]);
-            } else {
-              acc[0] = mfma4(ab0[ao], hb0[ho], acc[0]);
-              acc[1] = mfma4(ab1[ao], hb1[ho], acc[1]);
-            }
+            acc[0] = mfma4(ab0[ao], hb0[ho], acc[0]);
+            acc[1] = mfma4(ab1[ao], hb1[ho], acc[1]);
           }
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { acc[0][r] += acc2[0][r]; acc[1][r] += acc2[1][r]; }
       } else {
 #pragma unroll
         for (int tap = 0; tap < K15; ++tap) {
@@ -706,12 +695,9 @@ __device__ __forceinline__ void gated_block_fwd2_body(const BlockArgs& a, int nt
 #pragma unroll
           for (int u = 0; u < 5; ++u) {
             const int ao = (tap * NARROW + 4 * u) * LDW, ho = 4 * u * LDX + tap * DIL;
-            if ((tap * 5 + u) & 1) acc[1] = mfma4(ab0[ao], hb0[ho], acc[1]);      // two independent chains, summed below
-            else acc[0] = mfma4(ab0[ao], hb0[ho], acc[0]);
+            acc[0] = mfma4(ab0[ao], hb0[ho], acc[0]);
           }
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[0][r] += acc[1][r];
       }
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
