@@ -204,7 +204,8 @@ long nsc_gated_block_wgrad_workspace(int C);
  * pass (cmrl.py:106-113 / :369-372 only hand them to the optimizer), so a host can defer all of them to the end.
  * Each job's eight gradients must be contiguous in creation order starting at `grads`
  * (dw1 | db1 | dwl | dbl | dwr | dbr | dw9 | db9); they are ACCUMULATED into.  workspace: >=
- * nsc_gated_block_wgrad_batch_workspace(max C) floats, caller-owned. */
+ * nsc_gated_block_wgrad_batch_workspace(max C) floats, caller-owned; with twice that, the launches of the two block widths
+ * (C <= 64 | C > 64) keep their slabs side by side and ONE reduce launch sums both. */
 typedef struct nsc_block_wgrad_job {
   const float *x, *h, *g, *dy, *da, *dz1;
   float* grads;

@@ -1326,15 +1326,19 @@ __global__ __launch_bounds__(256, 2) void gated_block_wgrad_batch_kernel(BlockWg
 
 // per job: grads[range] += sum of its workgroups' slabs; blockIdx.y = job * 2 + half (half 0: everything before dW9 -
 // written by the part-2 workgroups; half 1: dW9 | db9 - written by the part-1 workgroups; both use slabs wg0[j]..wg0[j+1])
-struct SlabReduceBatch {
-  float* grads[NSC_WG_MAXJ];
-  int off9[NSC_WG_MAXJ], range[NSC_WG_MAXJ];
-  int wg0[NSC_WG_MAXJ + 1];
+struct SlabReduceBatch {                         // jobs of BOTH block widths of a step: one launch reduces them all
+  float* grads[2 * NSC_WG_MAXJ];
+  const float* slab[2 * NSC_WG_MAXJ];            // slab 0 of the job's launch
+  long stride[2 * NSC_WG_MAXJ];
+  int off9[2 * NSC_WG_MAXJ], range[2 * NSC_WG_MAXJ];
+  int w0[2 * NSC_WG_MAXJ], w1[2 * NSC_WG_MAXJ];  // the job's workgroup slabs [w0, w1)
 };
-__global__ void slab_reduce_batch_kernel(SlabReduceBatch t, const float* __restrict__ slab, long stride) {
+__global__ void slab_reduce_batch_kernel(SlabReduceBatch t) {
   const int j = blockIdx.y >> 1, half = blockIdx.y & 1;
   const int i0 = half ? t.off9[j] : 0, i1 = half ? t.range[j] : t.off9[j];
-  const int w0 = t.wg0[j], w1 = t.wg0[j + 1];
+  const int w0 = t.w0[j], w1 = t.w1[j];
+  const float* __restrict__ slab = t.slab[j];
+  const long stride = t.stride[j];
   float* g = t.grads[j];
   for (int i = i0 + blockIdx.x * blockDim.x + threadIdx.x; i < i1; i += gridDim.x * blockDim.x) {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -1438,11 +1442,9 @@ extern "C" int nsc_gated_block_wgrad(const float* x, const float* h, const float
 
 template <int RT9>
 static int launch_wgrad_batch(const nsc_block_wgrad_job* jobs, const int* idx, int n, int B, float* workspace,
-                              long workspace_floats, hipStream_t st) {
+                              long workspace_floats, hipStream_t st, SlabReduceBatch& r, int& nr, long& used_floats) {
   BlockWgradBatch t;
-  SlabReduceBatch r;
   memset(&t, 0, sizeof(t));
-  memset(&r, 0, sizeof(r));
   static int skip_env = -1;
   if (skip_env < 0) { skip_env = NSC_PROBE_INT("NSC_WG_SKIP", 0); }
   const int ldn = ld2(64), ldg = ld2(72);
@@ -1467,9 +1469,9 @@ static int launch_wgrad_batch(const nsc_block_wgrad_job* jobs, const int* idx, i
     a.ntiles = B * a.tiles_per_frame;
     a.skip = skip_env;
     total_tiles += a.ntiles;
-    r.grads[q] = jb.grads;
-    r.off9[q] = (int)((long)Cx * NARROW + NARROW + 2L * (K15 * NARROW * NARROW + NARROW));
-    r.range[q] = (int)range;
+    r.grads[nr + q] = jb.grads;
+    r.off9[nr + q] = (int)((long)Cx * NARROW + NARROW + 2L * (K15 * NARROW * NARROW + NARROW));
+    r.range[nr + q] = (int)range;
     const int ldh = ld2(64 + 14 * jb.dil);
     const size_t f1 = (size_t)(C + 2) * ldn + (size_t)C * ldn + (size_t)(NARROW + 2) * ldg + (size_t)3 * NARROW * ldn;
     const size_t f2 = (size_t)(C + 2) * ldn + (size_t)(NARROW + 2) * ldh + (size_t)3 * NARROW * ldn;
@@ -1505,7 +1507,14 @@ static int launch_wgrad_batch(const nsc_block_wgrad_job* jobs, const int* idx, i
   }
   t.wg0[0] = 0;
   for (int q = 0; q < n; ++q) t.wg0[q + 1] = t.wg0[q] + cnt[q];
-  for (int q = 0; q <= n; ++q) r.wg0[q] = t.wg0[q];
+  for (int q = 0; q < n; ++q) {
+    r.w0[nr + q] = t.wg0[q];
+    r.w1[nr + q] = t.wg0[q + 1];
+    r.slab[nr + q] = workspace;
+    r.stride[nr + q] = stride;
+  }
+  nr += n;
+  used_floats = (long)slots * stride;
   t.njobs = n;
   for (int q = 0; q < n; ++q) t.a[q].slab_stride = stride;
   auto kern = gated_block_wgrad_batch_kernel<RT9>;
@@ -1513,8 +1522,13 @@ static int launch_wgrad_batch(const nsc_block_wgrad_job* jobs, const int* idx, i
   NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "gated_block_wgrad_batch: smem attr: %s", hipGetErrorString(e));
   hipLaunchKernelGGL(kern, dim3(2 * used), dim3(256), smem, st, t, ldn, ldg);
   NSC_CHECK_LAUNCH("gated_block_wgrad_batch");
-  hipLaunchKernelGGL(slab_reduce_batch_kernel, dim3(64, 2 * n), dim3(256), 0, st, r, workspace, stride);
+  return NSC_OK;
+}
+static int launch_slab_reduce(SlabReduceBatch& r, int& nr, hipStream_t st) {
+  if (nr == 0) return NSC_OK;
+  hipLaunchKernelGGL(slab_reduce_batch_kernel, dim3(64, 2 * nr), dim3(256), 0, st, r);
   NSC_CHECK_LAUNCH("slab_reduce_batch");
+  nr = 0;
   return NSC_OK;
 }
 
@@ -1526,18 +1540,44 @@ extern "C" int nsc_gated_block_wgrad_batch(const nsc_block_wgrad_job* jobs, int 
   NSC_REQUIRE(narrow == NARROW && k9 == K9, NSC_ERR_UNSUPPORTED, "nsc_gated_block_wgrad_batch: built for narrow=20, k9=9");
   int small[NSC_WG_MAXJ], big[NSC_WG_MAXJ], ns = 0, nb = 0;
   hipStream_t st = (hipStream_t)stream;
+  // One launch per block width, then ONE slab reduce for both - if the workspace holds both launches' slabs side by side (the
+  // engine's does: 2 x nsc_gated_block_wgrad_batch_workspace); with a smaller one the second launch reuses the slabs of the first
+  // after its reduce (two reduce launches, as before round 4).
+  SlabReduceBatch r;
+  memset(&r, 0, sizeof(r));
+  int nr = 0;
+  long ws_used = 0;                    // floats of the workspace that hold slabs not reduced yet
+  auto one = [&](auto rt_c, const int* idx, int& n) -> int {
+    constexpr int RT = decltype(rt_c)::value;
+    long need = 0;
+    for (int q = 0; q < n; ++q) {      // what launch_wgrad_batch will take: 256 slabs of the widest job's parameter range
+      const nsc_block_wgrad_job& jb = jobs[idx[q]];
+      const long Cx = jb.Cin > 0 ? jb.Cin : jb.C;
+      const long range = Cx * NARROW + NARROW + 2L * (K15 * NARROW * NARROW + NARROW) + (long)K9 * NARROW * jb.C + jb.C;
+      need = std::max(need, 256L * ((range + 63) & ~63L));
+    }
+    if (nr && (ws_used + need > workspace_floats || nr + n > 2 * NSC_WG_MAXJ)) {
+      int rc = launch_slab_reduce(r, nr, st);
+      if (rc) return rc;
+      ws_used = 0;
+    }
+    long used = 0;
+    int rc = launch_wgrad_batch<RT>(jobs, idx, n, B, workspace + ws_used, workspace_floats - ws_used, st, r, nr, used);
+    if (rc) return rc;
+    ws_used += used;
+    n = 0;
+    return NSC_OK;
+  };
   auto flush = [&](bool all) -> int {
     if (ns && (all || ns == NSC_WG_MAXJ)) {
-      int rc = launch_wgrad_batch<4>(jobs, small, ns, B, workspace, workspace_floats, st);
+      int rc = one(std::integral_constant<int, 4>{}, small, ns);
       if (rc) return rc;
-      ns = 0;
     }
     if (nb && (all || nb == NSC_WG_MAXJ)) {
-      int rc = launch_wgrad_batch<7>(jobs, big, nb, B, workspace, workspace_floats, st);
+      int rc = one(std::integral_constant<int, 7>{}, big, nb);
       if (rc) return rc;
-      nb = 0;
     }
-    return NSC_OK;
+    return all ? launch_slab_reduce(r, nr, st) : NSC_OK;
   };
   for (int j = 0; j < njobs; ++j) {
     const nsc_block_wgrad_job& jb = jobs[j];

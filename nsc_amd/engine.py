@@ -960,10 +960,12 @@ class CascadeEngine:
             self._wg_keep = []
             return
         jobs = (_lib.BlockWgradJob * len(self._wg_jobs))(*self._wg_jobs)
-        ws = self.wgrad_workspace(slot="batch")   # private: per-conv wgrads may still be running on the side stream
+        # private (per-conv wgrads may still be running on the side stream) and twice the size: the launches of the two block widths
+        # keep their slabs side by side and ONE reduce launch sums both
+        ws = self.wgrad_workspace(slot="batch", mult=2)
         tok = self.prof_begin("block_wgrad", self._wg_flops)
         # main stream: ordered after every data-gradient kernel, and after nothing else that matters (tail of the step)
-        check(self.lib.nsc_gated_block_wgrad_batch(jobs, len(self._wg_jobs), self.B, 20, 9, ws, self._ws_floats,
+        check(self.lib.nsc_gated_block_wgrad_batch(jobs, len(self._wg_jobs), self.B, 20, 9, ws, 2 * self._ws_floats,
                                                    self.stream()), "gated_block_wgrad_batch")
         self.prof_end(tok)
         self._wg_jobs, self._wg_keep, self._wg_flops = [], [], 0.0
@@ -1003,7 +1005,7 @@ class CascadeEngine:
     _side_rr = 0
     side_idx = 0
 
-    def wgrad_workspace(self, slot=0):
+    def wgrad_workspace(self, slot=0, mult=1):
         """Scratch for the store+reduce flush of nsc_gated_block_wgrad / nsc_conv1d_wgrad_ws.  One buffer per slot:
         launches that may run concurrently (different side streams) must not share a slab; launches on one stream are
         ordered.  Sized ONCE for the largest user so it is never reallocated under a running kernel."""
@@ -1019,7 +1021,7 @@ class CascadeEngine:
         key = f"wgrad.ws{slot}"
         ws = self._bufs.get(key)
         if ws is None:
-            ws = torch.empty(self._ws_floats, dtype=torch.float32, device=self.device)
+            ws = torch.empty(mult * self._ws_floats, dtype=torch.float32, device=self.device)
             self._bufs[key] = ws
         return ws.data_ptr()
 
