@@ -2394,9 +2394,13 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
 #pragma unroll
         for (int q = 0; q < NQY; ++q) {
           const int r = 2 * wave + phalf + 16 * q;
-          if (r < CR) {
+          // (only the last q can reach rows past CR; rows past C - what the loads fetched there belongs to the next frame - only
+          // where 16 q + 15 >= C: a scalar test first, most q never run the per-lane select)
+          if (q < NQY - 1 || r < CR) {
             f32x4 v = pfy[q];
-            if (r >= C) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (16 * q + 15 >= C) {
+              if (r >= C) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
             if (!tvec) {                                  // a row ends inside this piece: the rest came from the next row
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = (unsigned)(ty + e) < (unsigned)T ? v[e] : 0.f;
