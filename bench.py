@@ -352,7 +352,7 @@ def main():
             ms.append(1e3 * comm.max_float(time.perf_counter() - t0, dev) / args.steps)
         return ms
     pass_ms = timed_passes()
-    pair_to = eng.pair_timeouts()            # neighbour waits of the pair launches that timed out in the last step: must be 0
+    pair_to = eng.pair_timeouts()            # neighbour waits of the pair launches that timed out in ANY step so far (sticky counter): must be 0
     if comm.max_float(float(pair_to > 0 or fake_to == "timed"), dev) != 0.0:
         # a timed step ran with a neighbour wait that gave up (its results are invalid): all ranks drop the pair launches and the
         # captured graph, and the K steps are timed again with one eager launch per block - a slower line instead of none
@@ -365,8 +365,9 @@ def main():
         for _ in range(2):
             step()
         torch.cuda.synchronize()
+        to_before = pair_to
         pass_ms = timed_passes()
-        pair_to = eng.pair_timeouts()
+        pair_to = eng.pair_timeouts() - to_before
         if pair_to:
             raise SystemExit(f"[bench] {pair_to} neighbour wait(s) timed out with pair launches off: results invalid")
     ms_step = float(np.median(pass_ms))

@@ -170,8 +170,9 @@ int nsc_gated_block_dgrad_img(const float* img, const float* x, const float* h, 
  *      flags before the second block's first load (acquire) - no kernel boundary, no second dispatch, the second block's weight
  *      prologue runs while the neighbours finish.  Requires every workgroup of the launch to be resident (grid = min(tiles, 256) <=
  *      CUs: checked, NSC_ERR_UNSUPPORTED otherwise - launch the blocks one by one then).
- *      flags: nsc_gated_block_pair_flag_ints() ints, ZEROED by the caller before each launch; flags[256] counts waits that timed
- *      out (must stay 0; results are undefined otherwise).
+ *      flags: nsc_gated_block_pair_flag_ints() ints (one per workgroup), ZEROED by the caller before each launch.
+ *      timeouts: ONE caller-owned int the library only ever ADDS to: neighbour waits that gave up (must stay 0; the results of that
+ *      launch are undefined otherwise).  It lives outside whatever the caller zeroes per launch / per step, so a count survives.
  *   fwd:   x -> block 0 (dil 1, lrelu out) -> out0 -> block 1 (dil 2, flat1) -> out1; saved activations h / lin / th / g of each
  *          block nullable (together).  Cin0 = C, or 1: block 0 is the first block of a decoder stage (x [B,1,T], image of Cin = 1).
  *   dgrad: block 1 first (dy1 -> dx1, da1 [B,40,T], dz1_1), then block 0 on dy = dx1 (-> dx0, da0, dz1_0); in_act0 = activation
@@ -179,11 +180,11 @@ int nsc_gated_block_dgrad_img(const float* img, const float* x, const float* h, 
 int nsc_gated_block_pair_flag_ints(void);
 int nsc_gated_block_pair_fwd_img(const float* img0, const float* img1, const float* x, float* out0, float* h0, float* lin0,
                                  float* th0, float* g0, float* out1, float* h1, float* lin1, float* th1, float* g1, int B, int C,
-                                 int Cin0, int T, int flat1, int* flags, void* stream);
+                                 int Cin0, int T, int flat1, int* flags, int* timeouts, void* stream);
 int nsc_gated_block_pair_dgrad_img(const float* img1, const float* x1, const float* h1, const float* lin1, const float* th1,
                                    const float* dy1, float* dx1, float* da1, float* dz1_1, const float* img0, const float* x0,
                                    const float* h0, const float* lin0, const float* th0, float* dx0, float* da0, float* dz1_0,
-                                   int B, int C, int Cin0, int T, int in_act0, int* flags, void* stream);
+                                   int B, int C, int Cin0, int T, int in_act0, int* flags, int* timeouts, void* stream);
 
 /* Persistent weight-gradient kernel of one gated block: all eight parameter gradients (accumulated) from the saved
  * activations x [B,C,T], h, g [B,20,T] and the data-path gradients dy [B,C,T], da [B,40,T] (= dlin | dgate, the

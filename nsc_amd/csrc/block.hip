@@ -14,18 +14,15 @@
 #include <type_traits>
 
 #include "block_args.h"
-
+#include "block_common.h"
 
 #ifdef NSC_PROBES
-// phase stamps of workgroup 0 / wave 0 (s_memtime), read back with nsc_probe_read: profiling builds only
-__device__ unsigned long long nsc_dbg_stamps[128];     // [0, 64): wave 0, [64, 128): wave 4 of workgroup 0
-#define NSC_STAMP(i) do { if (blockIdx.x == 0 && (threadIdx.x & 255) == 0) nsc_dbg_stamps[(threadIdx.x >> 8) * 64 + (i)] = __builtin_readcyclecounter(); } while (0)
 extern "C" int nsc_probe_read(unsigned long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(nsc_dbg_stamps), sizeof(unsigned long long) * 128) == hipSuccess ? 0 : -3;
 }
-#else
-#define NSC_STAMP(i) do { } while (0)
 #endif
+
+
 
 
 
@@ -264,48 +261,11 @@ __global__ __launch_bounds__(512) void gated_block_fwd_kernel(BlockArgs a, int l
 //   * wait: relaxed agent-scope loads of the flag (sc1: from memory), no fence;
 //   * the second block reads that tensor with sc0 sc1 loads (served from memory / the memory-side Infinity Cache, never from an
 //     L1 / L2 line) - its only input that another workgroup wrote in this launch.
-#if defined(NSC_EXP) && (NSC_EXP & 128)
-#define NSC_AUX_COHERENT 0        /* timing experiment (NOT coherent): ordinary loads */
-#else
-#define NSC_AUX_COHERENT 0x11     /* raw buffer load aux bits on gfx940+: bit 0 = sc0, bit 4 = sc1 */
-#endif
-// Cache policy of the streaming traffic of the forward / data-gradient kernels (profiles/r04h_store_flavours.txt).  Stores of
-// tensors nobody reads before the backward pass / the tail of the step (saved activations, da, dz1) are NONTEMPORAL: they do not sit
-// dirty in the eight L2s until the end-of-kernel write-back (-1.0 % of the step; written through with sc0 sc1: -0.5 %).  The tile
-// prefetch loads are nontemporal too (-0.7 %).  Measured and not kept: the block's main output (out / dx, read by the next launch)
-// nontemporal (+-0); nontemporal operand loads in the weight-gradient kernels (+0.3 %) and in the convs outside the blocks (+-0.1 %).
-#define NSC_AUX_LATE 2            /* raw buffer aux bits: bit 1 = nt */
-#define NSC_AUX_STREAM 2
-__device__ __forceinline__ void nsc_store4_late(float* gp, const f32x4& v) { __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(gp)); }
-
-__device__ __forceinline__ void nsc_pair_publish(int* flags) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's write-through stores are acknowledged: they are in memory
-  __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_store(flags + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void nsc_pair_wait(int* flags) {
-  if (threadIdx.x < 2) {
-    const int nb = (int)blockIdx.x + (threadIdx.x == 0 ? -1 : 1);
-    if (nb >= 0 && nb < (int)gridDim.x) {
-      int it = 0;
-      while (__hip_atomic_load(flags + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-        __builtin_amdgcn_s_sleep(4);
-        if (++it > (1 << 20)) {                       // ~0.1 s: never in a healthy launch
-          atomicAdd(flags + gridDim.x, 1);
-          break;
-        }
-      }
-    }
-  }
-  nsc_lds_barrier();      // (not __syncthreads(): its vmcnt(0) would drain the second block's weight loads, which were issued before
-                          //  this wait precisely so that they and the first tile's loads - issued right after it - are in flight together)
-}
-
 // PAIRED: this body runs as the SECOND block of a pair launch: it waits for the neighbours' flags before its first x load
 // FIRST: this body runs as the FIRST block of a pair launch: its output leaves through write-through stores (sc0 sc1: in memory
 // when acknowledged), so that publishing needs no write-back of the whole L2
 template <int RT9, int NK1, int DIL, bool PAIRED, bool FIRST = false>
-__device__ __forceinline__ void gated_block_fwd2_body(const BlockArgs& a, int ntiles, int tpf, int skip, int* flags) {
+__device__ __forceinline__ void gated_block_fwd2_body(const BlockArgs& a, int ntiles, int tpf, int skip, int* flags, int* timeouts) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int TT = 64, H = 4 + 7 * DIL, WX = TT + 2 * H, WGW = TT + 8, LDX = 112, LDG = 80, CR = 4 * NK1, LDW = 48;
   constexpr int NCT1 = (WX + 15) / 16;      // column tiles of the h tile (7 at dil 2, 6 at dil 1)
@@ -483,7 +443,7 @@ __device__ __forceinline__ void gated_block_fwd2_body(const BlockArgs& a, int nt
 
 
   if (PAIRED) {
-    nsc_pair_wait(flags);                // the first block's output around this workgroup's tiles is in memory
+    nsc_pair_wait(flags, timeouts);                // the first block's output around this workgroup's tiles is in memory
     prefetch(first);
   }
   nsc_wait_vmem();   // weights (and the first tile) are in: no vmcnt guards on register operands inside the loop
@@ -861,17 +821,17 @@ __device__ __forceinline__ void gated_block_fwd2_body(const BlockArgs& a, int nt
 
 template <int RT9, int NK1, int DIL>
 __global__ __launch_bounds__(512) void gated_block_fwd2_kernel(BlockArgs a, int ntiles, int tpf, int skip) {
-  gated_block_fwd2_body<RT9, NK1, DIL, false>(a, ntiles, tpf, skip, nullptr);
+  gated_block_fwd2_body<RT9, NK1, DIL, false>(a, ntiles, tpf, skip, nullptr, nullptr);
 }
 
 // Two consecutive blocks of a stack (dilation 1 then 2, the reference's `_stack_bottleneck_blocks`: neural_speech_coding_module.py
 // :183-217) in ONE launch: see nsc_pair_publish / nsc_pair_wait.  a1.x must be a0.out.
 // (NK1A = 1: the first block has ONE input channel - the first stack of a decoder, whose input is the quantised code)
 template <int RT9, int NK1A, int NK1B>
-__global__ __launch_bounds__(512) void gated_block_fwd2_pair_kernel(BlockArgs a0, BlockArgs a1, int ntiles, int tpf, int* flags) {
-  gated_block_fwd2_body<RT9, NK1A, 1, false, true>(a0, ntiles, tpf, 0, nullptr);
+__global__ __launch_bounds__(512) void gated_block_fwd2_pair_kernel(BlockArgs a0, BlockArgs a1, int ntiles, int tpf, int* flags, int* timeouts) {
+  gated_block_fwd2_body<RT9, NK1A, 1, false, true>(a0, ntiles, tpf, 0, nullptr, nullptr);
   nsc_pair_publish(flags);
-  gated_block_fwd2_body<RT9, NK1B, 2, true>(a1, ntiles, tpf, 0, flags);
+  gated_block_fwd2_body<RT9, NK1B, 2, true>(a1, ntiles, tpf, 0, flags, timeouts);
 }
 
 template <int RT9, int NK1, int DIL>
@@ -2105,7 +2065,7 @@ __device__ __forceinline__ void d15_packed(const float* w15s, const float* da, i
 // PAIRED: second block of a pair launch (nsc_pair_publish / nsc_pair_wait): its dy is what the first block's body wrote as dx
 // FIRST: first block of a pair launch: dx leaves through write-through stores (see gated_block_fwd2_body)
 template <int RT9, int NK9, int DIL, bool CIN1, int ROLE, bool PAIRED = false, bool FIRST = false>
-__device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a, int ntiles, int tpf, int skip, int* flags = nullptr) {
+__device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a, int ntiles, int tpf, int skip, int* flags = nullptr, int* timeouts = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int TT = 64, Hh = 7 * DIL, W_a = TT + 2 * Hh, W_dy = W_a + 8, NCTA = (W_a + 15) / 16, CR = 4 * NK9;
   // LDY / LDA == 14 (mod 32): the two channel rows a 32-lane group reads sit 14 banks apart.  The packed tiles walk time
@@ -2350,7 +2310,7 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
 
 
   if (PAIRED) {
-    nsc_pair_wait(flags);                // the first block's dx around this workgroup's tiles is in memory
+    nsc_pair_wait(flags, timeouts);                // the first block's dx around this workgroup's tiles is in memory
     prefetch_dy();
   }
   nsc_wait_vmem();   // weights (and the first tile) are in: no vmcnt guards on register operands inside the loop
@@ -2777,15 +2737,15 @@ __global__ __launch_bounds__(512) void gated_block_dgrad2_kernel(BlockDgradArgs 
 // block on the dx it wrote (a0.dy must be a1.dx)
 // (CIN1B: the dilation-1 block in front has ONE input channel)
 template <int RT9, int NK9, bool CIN1B>
-__global__ __launch_bounds__(512) void gated_block_dgrad2_pair_kernel(BlockDgradArgs a1, BlockDgradArgs a0, int ntiles, int tpf, int* flags) {
+__global__ __launch_bounds__(512) void gated_block_dgrad2_pair_kernel(BlockDgradArgs a1, BlockDgradArgs a0, int ntiles, int tpf, int* flags, int* timeouts) {
   if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 8) == 0) {
     gated_block_dgrad2_role<RT9, NK9, 2, false, 0, false, true>(a1, ntiles, tpf, 0);
     nsc_pair_publish(flags);
-    gated_block_dgrad2_role<RT9, NK9, 1, CIN1B, 0, true>(a0, ntiles, tpf, 0, flags);
+    gated_block_dgrad2_role<RT9, NK9, 1, CIN1B, 0, true>(a0, ntiles, tpf, 0, flags, timeouts);
   } else {
     gated_block_dgrad2_role<RT9, NK9, 2, false, 1, false, true>(a1, ntiles, tpf, 0);
     nsc_pair_publish(flags);
-    gated_block_dgrad2_role<RT9, NK9, 1, CIN1B, 1, true>(a0, ntiles, tpf, 0, flags);
+    gated_block_dgrad2_role<RT9, NK9, 1, CIN1B, 1, true>(a0, ntiles, tpf, 0, flags, timeouts);
   }
 }
 
@@ -3004,10 +2964,10 @@ static int nsc_cu_count() {
   }
   return n;
 }
-extern "C" int nsc_gated_block_pair_flag_ints(void) { return 256 + 1; }     // flags of up to 256 workgroups + the time-out counter
+extern "C" int nsc_gated_block_pair_flag_ints(void) { return NSC_PAIR_MAX_WG; }     // one flag per workgroup of a pair launch
 
 template <int RT9, int NK1A, int NK1B>
-static int launch_block_fwd2_pair(const BlockArgs& a0, const BlockArgs& a1, int* flags, hipStream_t st) {
+static int launch_block_fwd2_pair(const BlockArgs& a0, const BlockArgs& a1, int* flags, int* timeouts, hipStream_t st) {
   constexpr int CR = 4 * (NK1A > NK1B ? NK1A : NK1B);
   const size_t smem = ((size_t)(CR + NARROW) * 112 + (size_t)3 * NARROW * 80 + (size_t)K15 * NARROW * 48 + (RT9 == 7 ? 728 : 0)) * sizeof(float);
   auto kern = gated_block_fwd2_pair_kernel<RT9, NK1A, NK1B>;
@@ -3018,15 +2978,15 @@ static int launch_block_fwd2_pair(const BlockArgs& a0, const BlockArgs& a1, int*
   const int grid = std::min(ntiles, 256);
   // every workgroup of the launch must be resident at once (they wait for each other): one per CU (LDS), so grid <= CUs
   NSC_REQUIRE(grid <= nsc_cu_count(), NSC_ERR_UNSUPPORTED, "gated_block_fwd2_pair: %d workgroups > %d CUs", grid, nsc_cu_count());
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, a0, a1, ntiles, tpf, flags);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, a0, a1, ntiles, tpf, flags, timeouts);
   NSC_CHECK_LAUNCH("gated_block_fwd2_pair");
   return NSC_OK;
 }
 
 extern "C" int nsc_gated_block_pair_fwd_img(const float* img0, const float* img1, const float* x, float* out0, float* h0, float* lin0,
                                             float* th0, float* g0, float* out1, float* h1, float* lin1, float* th1, float* g1, int B,
-                                            int C, int Cin0, int T, int flat1, int* flags, void* stream) {
-  NSC_REQUIRE(img0 && img1 && x && out0 && out1 && flags, NSC_ERR_BAD_ARG, "nsc_gated_block_pair_fwd_img: null pointer");
+                                            int C, int Cin0, int T, int flat1, int* flags, int* timeouts, void* stream) {
+  NSC_REQUIRE(img0 && img1 && x && out0 && out1 && flags && timeouts, NSC_ERR_BAD_ARG, "nsc_gated_block_pair_fwd_img: null pointer");
   NSC_REQUIRE(B > 0 && T > 0, NSC_ERR_BAD_ARG, "nsc_gated_block_pair_fwd_img: bad sizes");
   NSC_REQUIRE(C == 100 || C == 50 || C == 25, NSC_ERR_UNSUPPORTED, "nsc_gated_block_pair_fwd_img: C %d", C);
   NSC_REQUIRE((T & 3) == 0 && (long)B * C * T * 4 < (1L << 31), NSC_ERR_UNSUPPORTED,
@@ -3039,17 +2999,17 @@ extern "C" int nsc_gated_block_pair_fwd_img(const float* img0, const float* img1
   BlockArgs a1{B, C, T, 2, flat1, out0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, out1, h1, lin1, th1, g1, C, img1};
   hipStream_t st = (hipStream_t)stream;
   if (Cin0 == 1) {
-    if (C == 100) return launch_block_fwd2_pair<7, 1, 25>(a0, a1, flags, st);
-    if (C == 25) return launch_block_fwd2_pair<4, 1, 7>(a0, a1, flags, st);
-    return launch_block_fwd2_pair<4, 1, 13>(a0, a1, flags, st);
+    if (C == 100) return launch_block_fwd2_pair<7, 1, 25>(a0, a1, flags, timeouts, st);
+    if (C == 25) return launch_block_fwd2_pair<4, 1, 7>(a0, a1, flags, timeouts, st);
+    return launch_block_fwd2_pair<4, 1, 13>(a0, a1, flags, timeouts, st);
   }
-  if (C == 100) return launch_block_fwd2_pair<7, 25, 25>(a0, a1, flags, st);
-  if (C == 25) return launch_block_fwd2_pair<4, 7, 7>(a0, a1, flags, st);
-  return launch_block_fwd2_pair<4, 13, 13>(a0, a1, flags, st);
+  if (C == 100) return launch_block_fwd2_pair<7, 25, 25>(a0, a1, flags, timeouts, st);
+  if (C == 25) return launch_block_fwd2_pair<4, 7, 7>(a0, a1, flags, timeouts, st);
+  return launch_block_fwd2_pair<4, 13, 13>(a0, a1, flags, timeouts, st);
 }
 
 template <int RT9, int NK9, bool CIN1B>
-static int launch_block_dgrad2_pair(const BlockDgradArgs& a1, const BlockDgradArgs& a0, int* flags, hipStream_t st) {
+static int launch_block_dgrad2_pair(const BlockDgradArgs& a1, const BlockDgradArgs& a0, int* flags, int* timeouts, hipStream_t st) {
   size_t smem = 0;
   for (int dil = 1; dil <= 2; ++dil) {             // the larger of the two bodies' LDS layouts (dilation 2)
     const int WA16 = ((64 + 14 * dil + 15) / 16) * 16;
@@ -3066,7 +3026,7 @@ static int launch_block_dgrad2_pair(const BlockDgradArgs& a1, const BlockDgradAr
   const int ntiles = a0.B * tpf;
   const int grid = std::min(ntiles, 256);
   NSC_REQUIRE(grid <= nsc_cu_count(), NSC_ERR_UNSUPPORTED, "gated_block_dgrad2_pair: %d workgroups > %d CUs", grid, nsc_cu_count());
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, a1, a0, ntiles, tpf, flags);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, a1, a0, ntiles, tpf, flags, timeouts);
   NSC_CHECK_LAUNCH("gated_block_dgrad2_pair");
   return NSC_OK;
 }
@@ -3076,9 +3036,9 @@ extern "C" int nsc_gated_block_pair_dgrad_img(const float* img1, const float* x1
                                               const float* dy1, float* dx1, float* da1, float* dz1_1, const float* img0,
                                               const float* x0, const float* h0, const float* lin0, const float* th0, float* dx0,
                                               float* da0, float* dz1_0, int B, int C, int Cin0, int T, int in_act0, int* flags,
-                                              void* stream) {
+                                              int* timeouts, void* stream) {
   NSC_REQUIRE(img1 && x1 && h1 && lin1 && th1 && dy1 && dx1 && da1 && dz1_1 && img0 && (x0 || Cin0 == 1) && h0 && lin0 && th0 && dx0 && da0 &&
-                  dz1_0 && flags, NSC_ERR_BAD_ARG, "nsc_gated_block_pair_dgrad_img: null pointer");
+                  dz1_0 && flags && timeouts, NSC_ERR_BAD_ARG, "nsc_gated_block_pair_dgrad_img: null pointer");
   NSC_REQUIRE(Cin0 == C || (Cin0 == 1 && in_act0 == NSC_ACT_NONE), NSC_ERR_BAD_ARG,
               "nsc_gated_block_pair_dgrad_img: Cin0 must be C, or 1 with in_act0 none (got %d, %d)", Cin0, in_act0);
   NSC_REQUIRE(B > 0 && T > 0, NSC_ERR_BAD_ARG, "nsc_gated_block_pair_dgrad_img: bad sizes");
@@ -3094,13 +3054,13 @@ extern "C" int nsc_gated_block_pair_dgrad_img(const float* img1, const float* x1
                     da0 + (long)NARROW * T, 2 * NARROW, img0};
   hipStream_t st = (hipStream_t)stream;
   if (Cin0 == 1) {
-    if (C == 100) return launch_block_dgrad2_pair<7, 25, true>(a1, a0, flags, st);
-    if (C == 25) return launch_block_dgrad2_pair<4, 9, true>(a1, a0, flags, st);
-    return launch_block_dgrad2_pair<4, 13, true>(a1, a0, flags, st);
+    if (C == 100) return launch_block_dgrad2_pair<7, 25, true>(a1, a0, flags, timeouts, st);
+    if (C == 25) return launch_block_dgrad2_pair<4, 9, true>(a1, a0, flags, timeouts, st);
+    return launch_block_dgrad2_pair<4, 13, true>(a1, a0, flags, timeouts, st);
   }
-  if (C == 100) return launch_block_dgrad2_pair<7, 25, false>(a1, a0, flags, st);
-  if (C == 25) return launch_block_dgrad2_pair<4, 9, false>(a1, a0, flags, st);
-  return launch_block_dgrad2_pair<4, 13, false>(a1, a0, flags, st);
+  if (C == 100) return launch_block_dgrad2_pair<7, 25, false>(a1, a0, flags, timeouts, st);
+  if (C == 25) return launch_block_dgrad2_pair<4, 9, false>(a1, a0, flags, timeouts, st);
+  return launch_block_dgrad2_pair<4, 13, false>(a1, a0, flags, timeouts, st);
 }
 
 // The two persistent kernels on an image (shapes of the codec only: C in {100, 50, 25}, Cin in {C, 1}, dil in {1, 2}).

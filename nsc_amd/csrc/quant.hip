@@ -18,7 +18,7 @@
 #define NSC_QGRID 1024   // workgroups of the forward kernel (measured at B = 4096: 512 -> 3.7, 768 -> 4.05, 1024 -> 4.08, 1280 -> 3.75, 2048 -> 3.3 TB/s)
 #endif
 
-// Cross-lane exchan*ITER (32 bins on 8 lanes, 256 on 64): every (lane, slot) holds a real bin, so the masks, selects and
+// FULL: nb == 4*LPC*ITER (32 bins on 8 lanes, 256 on 64): every (lane, slot) holds a real bin, so the masks, selects and
 // scalar-store fallbacks fold away (they made ~2/3 of the pass's VALU instructions)
 template <int LPC, int ITER, bool FULL>
 __global__ __launch_bounds__(256) void quantize_fwd_kernel(const float* __restrict__ code,

@@ -472,7 +472,7 @@ class _Codec:
         tok = e.prof_begin("block_fwd", fl)
         check(e.lib.nsc_gated_block_pair_fwd_img(e.wt_ptr + 4 * b0.img_fwd_off, e.wt_ptr + 4 * b1.img_fwd_off, h.data_ptr(),
                                                  b0.out.data_ptr(), *sv(b0), b1.out.data_ptr(), *sv(b1), B, b0.wide, b0.Cin, T,
-                                                 int(b1.flat), e.pair_flags(), e.stream()), "gated_block_pair_fwd_img")
+                                                 int(b1.flat), e.pair_flags(), e.pair_timeouts_ptr(), e.stream()), "gated_block_pair_fwd_img")
         e.prof_end(tok)
         return b1.out
 
@@ -498,7 +498,7 @@ class _Codec:
         check(e.lib.nsc_gated_block_pair_dgrad_img(e.wt_ptr + 4 * b1.img_bwd_off, P(b1.x), P(b1.h), P(b1.lin), P(b1.th), P(dz), P(dx1),
                                                    P(da1), P(dh1), e.wt_ptr + 4 * b0.img_bwd_off, P(b0.x), P(b0.h), P(b0.lin),
                                                    P(b0.th), P(dx0), P(da0), P(dh0), B, b0.wide, b0.Cin, T, KIND_ACT[in_kind_first],
-                                                   e.pair_flags(), e.stream()), "gated_block_pair_dgrad_img")
+                                                   e.pair_flags(), e.pair_timeouts_ptr(), e.stream()), "gated_block_pair_dgrad_img")
         e.prof_end(tok)
         for blk, dzb, da, dh in ((b1, dz, da1, dh1), (b0, dx1, da0, dh0)):
             e.defer_block_wgrad(blk, dzb, da, dh, e.g_ptr + 4 * blk.c1.w_off,
@@ -1056,10 +1056,18 @@ class CascadeEngine:
         stride = (self._flag_ints + 3) // 4 * 4
         return self._flags.data_ptr() + 4 * stride * k
 
+    def pair_timeouts_ptr(self):
+        """The STICKY time-out counter of the pair launches: one int outside everything a step zeroes; the kernels only add to it."""
+        if self._pair_to is None:
+            self._pair_to = torch.zeros(4, dtype=torch.int32, device=self.device)
+        return self._pair_to.data_ptr()
+
     def pair_timeouts(self):
-        """Number of neighbour waits that timed out since the flags were last zeroed (must be 0)."""
-        stride = (self._flag_ints + 3) // 4 * 4
-        return int(self._flags.view(self._flag_slots, stride)[:, self._flag_ints - 1].sum().item())
+        """Neighbour waits of pair launches that timed out since this engine was created (must be 0: the launch that counted one
+        read unpublished data).  Synchronises the device."""
+        return 0 if self._pair_to is None else int(self._pair_to[0].item())
+
+    _pair_to = None
 
     def hist_view(self, key, nb):
         """[nb] slice of the flat histogram buffer (codecs' 32-bin and the LSF quantizer's 256-bin histograms side by side)."""
