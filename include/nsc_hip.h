@@ -186,6 +186,27 @@ int nsc_gated_block_pair_dgrad_img(const float* img1, const float* x1, const flo
                                    const float* h0, const float* lin0, const float* th0, float* dx0, float* da0, float* dz1_0,
                                    int B, int C, int Cin0, int T, int in_act0, int* flags, int* timeouts, void* stream);
 
+/* ---- The same block kernels on the bf16 MATRIX CORES with SPLIT operands (csrc/block_split.hip; replaces the same reference
+ *      function, nn_core_operator.py:82-112).  Every fp32 operand of the two long contractions (both k15 gate convs, the k9 conv:
+ *      94 % of the block's MACs) is split exactly into three bf16 pieces (hi + lo + lo2 = x), six of the nine piece products are
+ *      formed by v_mfma_f32_16x16x32_bf16 and accumulated in fp32: the error class of the fp32 matrix instruction (dropped terms
+ *      <= 2^-24 |a||b|), at 2.7x its rate, with the vector ALU free for the elementwise phases.  The 1x1 conv stays on the exact
+ *      fp32 instruction.  Results agree with nsc_gated_block_fwd_img to fp32 rounding (not bit for bit).
+ *   nsc_gated_block_simage_words(which, C, Cin, dil)   size of the split image in 32-bit words (0: no split kernel for this shape;
+ *                                                      which = 0: forward)
+ *   nsc_gated_block_simage_index(which, ..., offs, idx) index map for nsc_gather / nsc_step_begin, offs as for
+ *      nsc_gated_block_image_index.  Entries carry a MODE in bits 26..29 (so source offsets must stay below 2^26 - 2^20):
+ *      0 = the fp32 value; m > 0 = two bf16 pieces packed in one word, low half from src[i], high half from src[i + stride],
+ *      plane (m - 1) >> 2 (0 hi, 1 lo, 2 lo2), stride {20, 25, 50, 100}[(m - 1) & 3].  nsc_gather understands them.
+ *   nsc_gated_block_fwd_simg / nsc_gated_block_pair_fwd_simg: arguments of nsc_gated_block_fwd_img / _pair_fwd_img. */
+long nsc_gated_block_simage_words(int which, int C, int Cin, int dil);
+int nsc_gated_block_simage_index(int which, int C, int Cin, int dil, const long* offs, int* idx);
+int nsc_gated_block_fwd_simg(const float* img, const float* x, float* out, float* h_out, float* lin_out, float* th_out,
+                             float* g_out, int B, int C, int Cin, int T, int dil, int flat, void* stream);
+int nsc_gated_block_pair_fwd_simg(const float* img0, const float* img1, const float* x, float* out0, float* h0, float* lin0,
+                                  float* th0, float* g0, float* out1, float* h1, float* lin1, float* th1, float* g1, int B, int C,
+                                  int Cin0, int T, int flat1, int* flags, int* timeouts, void* stream);
+
 /* Persistent weight-gradient kernel of one gated block: all eight parameter gradients (accumulated) from the saved
  * activations x [B,C,T], h, g [B,20,T] and the data-path gradients dy [B,C,T], da [B,40,T] (= dlin | dgate, the
  * nsc_glu_bwd_cat output), dz1 [B,20,T] (= dL/d(pre-activation of h)).  Optionally (dx != NULL) it also produces the
@@ -216,6 +237,10 @@ typedef struct nsc_block_wgrad_job {
 } nsc_block_wgrad_job;
 long nsc_gated_block_wgrad_batch_workspace(int Cmax);
 int nsc_gated_block_wgrad_batch(const nsc_block_wgrad_job* jobs, int njobs, int B, int narrow, int k9,
+                                float* workspace, long workspace_floats, void* stream);
+/* nsc_gated_block_wgrad_batch on the bf16 matrix cores with split operands (see nsc_gated_block_fwd_simg): same arguments, same
+ * results to fp32 rounding; jobs it does not serve (T % 4 != 0, tensors not 16-byte aligned) run the exact kernel. */
+int nsc_gated_block_wgrad_batch_split(const nsc_block_wgrad_job* jobs, int njobs, int B, int narrow, int k9,
                                 float* workspace, long workspace_floats, void* stream);
 
 /* ---- separable conv pieces (replaces tf.keras.layers.SeparableConv1D behind nn_core_operator.py:17-21) ---- */

@@ -43,6 +43,9 @@ PROTOTYPES = {
     "nsc_gated_block_fwd_img": [_P] * 7 + [_I] * 6 + [_P],
     "nsc_gated_block_dgrad_img": [_P] * 10 + [_I] * 7 + [_P],
     "nsc_gated_block_image_index": [_I, _I, _I, _I, _P, _P],
+    "nsc_gated_block_simage_index": [_I, _I, _I, _I, _P, _P],
+    "nsc_gated_block_fwd_simg": [_P] * 7 + [_I] * 6 + [_P],
+    "nsc_gated_block_pair_fwd_simg": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
     "nsc_depthwise_fwd": [_P, _P, _P, _I, _I, _I, _I, _P],
     "nsc_depthwise_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "nsc_gate_fwd": [_P, _P, _I, _I, _I, _P],
@@ -119,8 +122,10 @@ PROTOTYPES["nsc_conv1d_cout1_fwd_quant"] = [C.POINTER(ConvDesc), _P, _P, _P, _P,
 PROTOTYPES["nsc_sum_all_batch"] = [C.POINTER(SumJob), _I, _P]
 PROTOTYPES["nsc_entropy_from_hist_batch"] = [C.POINTER(EntropyJob), _I, _P]
 PROTOTYPES["nsc_gated_block_wgrad_batch"] = [C.POINTER(BlockWgradJob), _I, _I, _I, _I, _P, _L, _P]
+PROTOTYPES["nsc_gated_block_wgrad_batch_split"] = [C.POINTER(BlockWgradJob), _I, _I, _I, _I, _P, _L, _P]
 PROTOTYPES["nsc_conv1d_wgrad_batch"] = [C.POINTER(ConvWgradJob), _I, _P, _L, _P]
 EXPORTS = sorted(list(PROTOTYPES) + ["nsc_version", "nsc_last_error", "nsc_gated_block_wgrad_workspace", "nsc_gated_block_image_floats",
+                  "nsc_gated_block_simage_words",
                   "nsc_gated_block_pair_flag_ints",
                   "nsc_conv1d_wgrad_workspace", "nsc_gated_block_wgrad_batch_workspace",
                   "nsc_conv1d_wgrad_batch_workspace"])
@@ -156,6 +161,8 @@ def load():
     lib.nsc_conv1d_wgrad_batch_workspace.restype = C.c_long
     lib.nsc_gated_block_image_floats.argtypes = [C.c_int] * 4
     lib.nsc_gated_block_image_floats.restype = C.c_long
+    lib.nsc_gated_block_simage_words.argtypes = [C.c_int] * 4
+    lib.nsc_gated_block_simage_words.restype = C.c_long
     lib.nsc_version.restype = C.c_int
     lib.nsc_last_error.restype = C.c_char_p
     _lib = lib

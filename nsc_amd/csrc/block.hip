@@ -928,18 +928,6 @@ extern "C" int nsc_gated_block_fwd_cin1(const float* x, const float* w1, const f
 #ifndef NSC_WG_UNROLL
 #define NSC_WG_UNROLL 4   // k-steps of the MFMA loop unrolled together: at 1 every step exposed an LDS round trip (-8 % launch time at 4; 8, 16: same)
 #endif
-struct BlockWgradArgs {
-  int B, C, T, dil;
-  const float *x, *h, *g, *dy, *da, *dz1;   // da [B,40,T] = dlin | dgate
-  const float* wt1;                          // nullable: flipped/transposed 1x1 kernel [20][C]; with dx enables the fused
-  float* dx;                                 //   data gradient dx = (W1^T dz1 + dy) * act'(x)
-  int in_act;
-  float *dw1, *db1, *dwl, *dbl, *dwr, *dbr, *dw9, *db9;   // atomics into the gradients, or (slab != 0) plain stores into
-  int ntiles, tiles_per_frame;                             // this workgroup's private partial slab (same relative layout)
-  long slab_stride;                                        // floats between consecutive workgroups' slabs (0 = atomics)
-  int skip;   // timing-only probe (NSC_WG_SKIP): 1 D1, 2 wgrad MFMA loop, 4 flush, 8 staging loads, 16 staging stores
-  int Cin;    // channels of x (= C, or 1 for the first block of a decoder stage: dW1 is then [1,20] and x one row)
-};
 
 __device__ __forceinline__ void wg_flush(float* p, float v, bool plain) {
   if (plain) *p = v;
@@ -1264,12 +1252,6 @@ __global__ __launch_bounds__(64 * NW, 2) void gated_block_wgrad_kernel(BlockWgra
 // of 2-4, which amortises the prologue, the register-resident accumulators' flush and the slab reduction (14x fewer
 // slabs per block), and removes 4 launches per block.  Workgroup w: part = 1 + (w & 1) (two 4-wave workgroups of
 // different parts share a CU); among the workgroups of a part, job j owns [wg0[j], wg0[j+1]).
-#define NSC_WG_MAXJ 12
-struct BlockWgradBatch {
-  BlockWgradArgs a[NSC_WG_MAXJ];
-  int wg0[NSC_WG_MAXJ + 1];
-  int njobs;
-};
 template <int RT9>
 __global__ __launch_bounds__(256, 2) void gated_block_wgrad_batch_kernel(BlockWgradBatch t, int ldn, int ldg) {
   const int part = 1 + (blockIdx.x & 1), w = blockIdx.x >> 1;
@@ -1402,7 +1384,7 @@ extern "C" int nsc_gated_block_wgrad(const float* x, const float* h, const float
 
 template <int RT9>
 static int launch_wgrad_batch(const nsc_block_wgrad_job* jobs, const int* idx, int n, int B, float* workspace,
-                              long workspace_floats, hipStream_t st, SlabReduceBatch& r, int& nr, long& used_floats) {
+                              long workspace_floats, hipStream_t st, SlabReduceBatch& r, int& nr, long& used_floats, bool split) {
   BlockWgradBatch t;
   memset(&t, 0, sizeof(t));
   static int skip_env = -1;
@@ -1477,6 +1459,8 @@ static int launch_wgrad_batch(const nsc_block_wgrad_job* jobs, const int* idx, i
   used_floats = (long)slots * stride;
   t.njobs = n;
   for (int q = 0; q < n; ++q) t.a[q].slab_stride = stride;
+  // split operands on the bf16 matrix cores (block_split.hip): same job table, slabs and flush layout
+  if (split && nsc_block_wgrad_split_ok(t)) return nsc_launch_block_wgrad_split(t, RT9, used, st);
   auto kern = gated_block_wgrad_batch_kernel<RT9>;
   const hipError_t e = NSC_SMEM_ATTR(kern, 160 * 1024);
   NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "gated_block_wgrad_batch: smem attr: %s", hipGetErrorString(e));
@@ -1494,8 +1478,8 @@ static int launch_slab_reduce(SlabReduceBatch& r, int& nr, hipStream_t st) {
 
 extern "C" long nsc_gated_block_wgrad_batch_workspace(int Cmax) { return nsc_gated_block_wgrad_workspace(Cmax); }
 
-extern "C" int nsc_gated_block_wgrad_batch(const nsc_block_wgrad_job* jobs, int njobs, int B, int narrow, int k9,
-                                           float* workspace, long workspace_floats, void* stream) {
+static int wgrad_batch_impl(const nsc_block_wgrad_job* jobs, int njobs, int B, int narrow, int k9, float* workspace,
+                            long workspace_floats, void* stream, bool split) {
   NSC_REQUIRE(jobs && njobs > 0 && B > 0 && workspace, NSC_ERR_BAD_ARG, "nsc_gated_block_wgrad_batch: bad arguments");
   NSC_REQUIRE(narrow == NARROW && k9 == K9, NSC_ERR_UNSUPPORTED, "nsc_gated_block_wgrad_batch: built for narrow=20, k9=9");
   int small[NSC_WG_MAXJ], big[NSC_WG_MAXJ], ns = 0, nb = 0;
@@ -1522,7 +1506,7 @@ extern "C" int nsc_gated_block_wgrad_batch(const nsc_block_wgrad_job* jobs, int 
       ws_used = 0;
     }
     long used = 0;
-    int rc = launch_wgrad_batch<RT>(jobs, idx, n, B, workspace + ws_used, workspace_floats - ws_used, st, r, nr, used);
+    int rc = launch_wgrad_batch<RT>(jobs, idx, n, B, workspace + ws_used, workspace_floats - ws_used, st, r, nr, used, split);
     if (rc) return rc;
     ws_used += used;
     n = 0;
@@ -1552,6 +1536,17 @@ extern "C" int nsc_gated_block_wgrad_batch(const nsc_block_wgrad_job* jobs, int 
   }
   return flush(true);
 }
+extern "C" int nsc_gated_block_wgrad_batch(const nsc_block_wgrad_job* jobs, int njobs, int B, int narrow, int k9,
+                                           float* workspace, long workspace_floats, void* stream) {
+  return wgrad_batch_impl(jobs, njobs, B, narrow, k9, workspace, workspace_floats, stream, false);
+}
+// the same on the bf16 matrix cores with split operands (block_split.hip); launches whose shapes it does not serve (T % 4 != 0,
+// unaligned tensors, dilation > 2) run the exact kernel
+extern "C" int nsc_gated_block_wgrad_batch_split(const nsc_block_wgrad_job* jobs, int njobs, int B, int narrow, int k9,
+                                                 float* workspace, long workspace_floats, void* stream) {
+  return wgrad_batch_impl(jobs, njobs, B, narrow, k9, workspace, workspace_floats, stream, true);
+}
+
 
 // =====================================================================================================
 // Fused DATA-PATH backward of the gated block (8 waves, ~78 KB LDS -> two workgroups per CU):

@@ -551,11 +551,23 @@ extern "C" int nsc_overlap_add(const float* frames, int nframes, const float* wi
 }
 
 // dst[e] = src[idx[e]], or 0 where idx[e] < 0  (one launch rebuilds every flipped/transposed dgrad weight from the flat
-// parameter buffer; negative entries are the structural zeros of the polyphase stride-2 data-gradient kernels)
+// parameter buffer; negative entries are the structural zeros of the polyphase stride-2 data-gradient kernels).
+// Bits 26..29 of an index = m > 0: the word is two bf16 PIECES of the split-operand images (block_split.hip: nsc_gated_block_simage_index):
+// low half from src[i], high half from src[i + stride], plane (m - 1) >> 2 (0 hi, 1 lo, 2 lo2), stride {20, 25, 50, 100}[(m - 1) & 3].
+__device__ __forceinline__ float gather_word(const float* __restrict__ src, int i) {
+  if (i < 0) return 0.f;
+  const int m = i >> 26;
+  if (m == 0) return src[i];
+  const int base = i & 0x3ffffff, plane = (m - 1) >> 2, sel = (m - 1) & 3;
+  const int stride = sel == 0 ? 20 : (sel == 1 ? 25 : (sel == 2 ? 50 : 100));
+  unsigned pk[3];
+  nsc_split2(src[base], src[base + stride], pk);
+  return __builtin_bit_cast(float, plane == 0 ? pk[0] : (plane == 1 ? pk[1] : pk[2]));
+}
 __global__ void gather_kernel(const float* __restrict__ src, const int* __restrict__ idx, float* __restrict__ dst,
                               long n) {
   for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x)
-    dst[e] = idx[e] >= 0 ? src[max(idx[e], 0)] : 0.f;
+    dst[e] = gather_word(src, idx[e]);
 }
 extern "C" int nsc_gather(const float* src, const int* idx, float* dst, long n, void* stream) {
   NSC_REQUIRE(src && idx && dst && n > 0, NSC_ERR_BAD_ARG, "nsc_gather: bad args");
@@ -573,7 +585,7 @@ __global__ void step_begin_kernel(const float* __restrict__ src, const int* __re
                                   float* __restrict__ zero, long zn4, int* __restrict__ counter, int gather_blocks) {
   if ((int)blockIdx.x < gather_blocks) {
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gather_blocks * blockDim.x)
-      dst[e] = idx[e] >= 0 ? src[max(idx[e], 0)] : 0.f;
+      dst[e] = gather_word(src, idx[e]);
     if (counter && blockIdx.x == 0 && threadIdx.x == 0) counter[0] += 1;
   } else {
     const int zb = gridDim.x - gather_blocks;

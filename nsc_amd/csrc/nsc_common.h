@@ -168,4 +168,19 @@ __device__ __forceinline__ void nsc_stage_rows(float* __restrict__ xs, int ldx, 
     }
   }
 }
+// ---- fp32 -> three bf16 pieces (hi + lo + lo2 = x exactly: 3 x 8 significand bits; round to nearest even) ----
+// Used by the split-operand block kernels (block_split.hip) and by the gather that builds their parameter images (misc.hip).
+typedef __bf16 nsc_bf2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned nsc_cvt2(float a, float b) {          // packed: low half = bf16(a), high half = bf16(b)
+  const nsc_bf2 v = {(__bf16)a, (__bf16)b};                               // v_cvt_pk_bf16_f32; a NaN stays a NaN
+  return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ void nsc_split2(float a, float b, unsigned (&p)[3]) {
+  p[0] = nsc_cvt2(a, b);
+  float ra = a - __builtin_bit_cast(float, p[0] << 16), rb = b - __builtin_bit_cast(float, p[0] & 0xffff0000u);
+  p[1] = nsc_cvt2(ra, rb);
+  ra -= __builtin_bit_cast(float, p[1] << 16);
+  rb -= __builtin_bit_cast(float, p[1] & 0xffff0000u);
+  p[2] = nsc_cvt2(ra, rb);
+}
 static inline int nsc_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -240,7 +240,11 @@ class _Block:
             # the fused backward recomputes the intermediates from x; an inference-only engine never reads them
             save = e.keep_activations
             sv = [t.data_ptr() if save else None for t in (self.h, self.lin, self.th, self.g)]
-            if e.use_images and e.images_valid and self.img_fwd_off is not None:
+            if e.use_images and e.images_valid and e.split_fwd and self.simg_fwd_off is not None:
+                check(e.lib.nsc_gated_block_fwd_simg(e.wt_ptr + 4 * self.simg_fwd_off, x.data_ptr(), self.out.data_ptr(), *sv, B,
+                                                     self.wide, self.Cin, T, self.cl.dil, int(self.flat), e.stream()),
+                      "gated_block_fwd_simg")
+            elif e.use_images and e.images_valid and self.img_fwd_off is not None:
                 check(e.lib.nsc_gated_block_fwd_img(e.wt_ptr + 4 * self.img_fwd_off, x.data_ptr(), self.out.data_ptr(), *sv, B,
                                                     self.wide, self.Cin, T, self.cl.dil, int(self.flat), e.stream()),
                       "gated_block_fwd_img")
@@ -470,9 +474,15 @@ class _Codec:
         sv = lambda blk: [t.data_ptr() if save else None for t in (blk.h, blk.lin, blk.th, blk.g)]
         fl = sum(c.flops() for blk in blocks for c in (blk.c1, blk.cl, blk.cr, blk.c9))
         tok = e.prof_begin("block_fwd", fl)
-        check(e.lib.nsc_gated_block_pair_fwd_img(e.wt_ptr + 4 * b0.img_fwd_off, e.wt_ptr + 4 * b1.img_fwd_off, h.data_ptr(),
-                                                 b0.out.data_ptr(), *sv(b0), b1.out.data_ptr(), *sv(b1), B, b0.wide, b0.Cin, T,
-                                                 int(b1.flat), e.pair_flags(), e.pair_timeouts_ptr(), e.stream()), "gated_block_pair_fwd_img")
+        if e.split_fwd and b0.simg_fwd_off is not None and b1.simg_fwd_off is not None:
+            check(e.lib.nsc_gated_block_pair_fwd_simg(e.wt_ptr + 4 * b0.simg_fwd_off, e.wt_ptr + 4 * b1.simg_fwd_off, h.data_ptr(),
+                                                      b0.out.data_ptr(), *sv(b0), b1.out.data_ptr(), *sv(b1), B, b0.wide, b0.Cin, T,
+                                                      int(b1.flat), e.pair_flags(), e.pair_timeouts_ptr(), e.stream()),
+                  "gated_block_pair_fwd_simg")
+        else:
+            check(e.lib.nsc_gated_block_pair_fwd_img(e.wt_ptr + 4 * b0.img_fwd_off, e.wt_ptr + 4 * b1.img_fwd_off, h.data_ptr(),
+                                                     b0.out.data_ptr(), *sv(b0), b1.out.data_ptr(), *sv(b1), B, b0.wide, b0.Cin, T,
+                                                     int(b1.flat), e.pair_flags(), e.pair_timeouts_ptr(), e.stream()), "gated_block_pair_fwd_img")
         e.prof_end(tok)
         return b1.out
 
@@ -779,10 +789,17 @@ class CascadeEngine:
         # nsc_gated_block_image_index): one forward and one data-gradient image per block, 16-byte aligned, rebuilt by the
         # same gather launch as the flipped kernels
         for b in blocks:
-            b.img_fwd_off = b.img_bwd_off = None
+            b.img_fwd_off = b.img_bwd_off = b.simg_fwd_off = None
             if b.narrow == 20 and b.c9.K == 9:
                 for which, attr in ((0, "img_fwd_off"), (1, "img_bwd_off")):
                     nf = int(self.lib.nsc_gated_block_image_floats(which, int(b.wide), int(b.Cin), int(b.cl.dil)))
+                    if nf > 0:
+                        extra = (n + extra + 3) // 4 * 4 - n
+                        setattr(b, attr, n + extra)
+                        extra += nf
+                # ... and the SPLIT images of the bf16-matrix-core kernels (csrc/block_split.hip): 32-bit words of packed bf16 pieces
+                for which, attr in ((0, "simg_fwd_off"),):
+                    nf = int(self.lib.nsc_gated_block_simage_words(which, int(b.wide), int(b.Cin), int(b.cl.dil)))
                     if nf > 0:
                         extra = (n + extra + 3) // 4 * 4 - n
                         setattr(b, attr, n + extra)
@@ -816,6 +833,13 @@ class CascadeEngine:
                 if which == 1:
                     im = np.where(im >= 0, idx[np.maximum(im, 0)], -1).astype(np.int32)
                 idx[off:off + nf] = im
+            if b.simg_fwd_off is not None:      # split image, straight from the parameters (entries carry a mode in bits 26..29)
+                nf = int(self.lib.nsc_gated_block_simage_words(0, int(b.wide), int(b.Cin), int(b.cl.dil)))
+                offs = [b.c1.w_off, b.c1.b_off, b.cl.w_off, b.cl.b_off, b.cr.w_off, b.cr.b_off, b.c9.w_off, b.c9.b_off]
+                im = np.empty(nf, dtype=np.int32)
+                check(self.lib.nsc_gated_block_simage_index(0, int(b.wide), int(b.Cin), int(b.cl.dil), (C.c_long * len(offs))(*offs),
+                                                            im.ctypes.data_as(C.c_void_p)), "gated_block_simage_index")
+                idx[b.simg_fwd_off:b.simg_fwd_off + nf] = im
         self.wt_idx = torch.from_numpy(idx).to(self.device)
         # two Adam slot sets (no-quan op / quan op) with independent state (nsc_module:922-926)
         self.adam = [dict(m=torch.zeros(n, **f32), v=torch.zeros(n, **f32), t=0,
@@ -863,6 +887,11 @@ class CascadeEngine:
     # block width (nsc_gated_block_wgrad_batch): per-block launches walk only 2-4 tiles per workgroup at batch 128, so
     # their prologue, accumulator flush and slab reduction cost more than the MFMA work itself.
     fused_quant = True   # the training-shape quantizer forward in the launch of the encoder's output conv (nsc_conv1d_cout1_fwd_quant)
+    # Arithmetic of the gated blocks' long contractions: False = the exact fp32 matrix instruction (csrc/block.hip); True = the bf16
+    # matrix cores on operands split into three bf16 pieces, six products, fp32 accumulation (csrc/block_split.hip: fp32-class
+    # error, the vector ALU left free).  NSC_BLOCK_ARITH=exact|split overrides the default for A/B runs.
+    split_fwd = os.environ.get("NSC_BLOCK_ARITH", "exact") == "split"
+    split_wgrad_arith = os.environ.get("NSC_BLOCK_ARITH", "exact") == "split"   # (split_wgrad is the two-light-launches switch above)
     fused_pairs = True   # the dil-1 / dil-2 blocks of a stack in ONE launch (nsc_gated_block_pair_fwd_img / _dgrad_img: neighbour flags
                          # between workgroups instead of a kernel boundary); False: one launch per block
     fused_chain = True   # the cascade step / output-gradient arithmetic between codecs rides in the epilogue of the Cout = 1 convs
@@ -965,8 +994,8 @@ class CascadeEngine:
         ws = self.wgrad_workspace(slot="batch", mult=2)
         tok = self.prof_begin("block_wgrad", self._wg_flops)
         # main stream: ordered after every data-gradient kernel, and after nothing else that matters (tail of the step)
-        check(self.lib.nsc_gated_block_wgrad_batch(jobs, len(self._wg_jobs), self.B, 20, 9, ws, 2 * self._ws_floats,
-                                                   self.stream()), "gated_block_wgrad_batch")
+        fn = self.lib.nsc_gated_block_wgrad_batch_split if self.split_wgrad_arith else self.lib.nsc_gated_block_wgrad_batch
+        check(fn(jobs, len(self._wg_jobs), self.B, 20, 9, ws, 2 * self._ws_floats, self.stream()), "gated_block_wgrad_batch")
         self.prof_end(tok)
         self._wg_jobs, self._wg_keep, self._wg_flops = [], [], 0.0
 

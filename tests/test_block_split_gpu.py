@@ -1,0 +1,199 @@
+"""GPU parity tests of the SPLIT-operand gated-block kernels (csrc/block_split.hip: bf16 matrix cores, every fp32 operand split into
+three bf16 pieces, six products, fp32 accumulation) against the float64 oracle - at the SAME bounds as the exact-fp32 kernels - and
+against the exact kernels themselves (the achieved error of both arms against float64 is reported; the split arm must stay within
+1.5x of the exact arm + a floor of one fp32 rounding of the tensor's scale)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nsc_oracle as O
+from tests._util import assert_close, dev
+from tests.test_kernels_gpu import P, _st, lib  # noqa: F401  (the NaN-poisoning library proxy)
+
+pytestmark = pytest.mark.gpu
+
+
+def _params(rng, Cin, C_):
+    f = lambda *sh: (0.1 * rng.standard_normal(sh)).astype(np.float32)
+    w = [f(1, Cin, 20), f(20), f(15, 20, 20), f(20), f(15, 20, 20), f(20), f(9, 20, C_), f(C_)]
+    flat = np.concatenate([a.reshape(-1) for a in w])
+    offs = np.concatenate([[0], np.cumsum([a.size for a in w])[:-1]]).astype(np.int64)
+    return w, flat, offs
+
+
+def _image(lib, split, which, C_, Cin, dil, src, offs):
+    fn_n = lib.nsc_gated_block_simage_words if split else lib.nsc_gated_block_image_floats
+    fn_i = lib.nsc_gated_block_simage_index if split else lib.nsc_gated_block_image_index
+    n = int(fn_n(which, C_, Cin, dil))
+    assert n > 0
+    idx = np.empty(n, np.int32)
+    assert fn_i(which, C_, Cin, dil, (C.c_long * len(offs))(*[int(o) for o in offs]), idx.ctypes.data_as(C.c_void_p)) == 0, lib.nsc_last_error()
+    img = torch.empty(n, device="cuda")
+    assert lib.nsc_gather(src.data_ptr(), torch.tensor(idx, device="cuda").data_ptr(), img.data_ptr(), n, _st()) == 0
+    return img
+
+
+def _ref_block(x, w, dil, flat):
+    """float64 gated_bottleneck (nn_core_operator.py:82-112) on [B, C, T] tensors; returns h, lin, th, g, out."""
+    w1, b1, wl, bl, wr, br, w9, b9 = [a.astype(np.float64) for a in w]
+    B, Cin, T = x.shape
+    xd = x.astype(np.float64)
+    h = np.einsum("bit,io->bot", xd, w1[0]) + b1[None, :, None]
+    h = np.where(h > 0, h, 0.2 * h)
+
+    def conv(v, k, d):
+        K = k.shape[0]
+        pad = (K - 1) * d
+        pl = pad // 2
+        vp = np.pad(v, ((0, 0), (0, 0), (pl, pad - pl)))
+        return sum(np.einsum("bit,io->bot", vp[:, :, q * d:q * d + T], k[q]) for q in range(K))
+    lin = conv(h, wl, dil) + bl[None, :, None]
+    th = np.tanh(conv(h, wr, dil) + br[None, :, None])
+    g = lin * th
+    y = conv(g, w9, 1) + b9[None, :, None] + xd                      # (Cin = 1: broadcast residual)
+    out = y if flat else np.where(y > 0, y, 0.2 * y)
+    return h, lin, th, g, out
+
+
+_CASES = [(2, 100, 100, 512, 2, 0), (2, 100, 100, 256, 1, 1), (3, 50, 50, 512, 2, 0), (2, 50, 50, 512, 1, 1), (1, 100, 100, 200, 2, 0),
+          (70, 100, 100, 300, 2, 0), (40, 50, 50, 512, 1, 1),
+          # long chains of consecutive tiles (carried h / g columns), crossing frame boundaries
+          (150, 100, 100, 512, 1, 0), (150, 50, 50, 512, 2, 1), (72, 100, 100, 256, 2, 0),
+          # C = 25 (third resolution of '2 2' codecs)
+          (3, 25, 25, 128, 1, 0), (300, 25, 25, 128, 2, 1), (2, 25, 25, 200, 2, 0),
+          # T not a multiple of 4
+          (3, 100, 100, 130, 2, 0), (40, 100, 100, 203, 1, 1), (5, 50, 50, 70, 2, 0), (3, 25, 25, 67, 1, 0),
+          # one input channel (first block of a decoder stage)
+          (2, 100, 1, 256, 1, 0), (3, 100, 1, 300, 2, 0), (2, 50, 1, 130, 1, 0), (70, 50, 1, 512, 2, 0), (5, 25, 1, 128, 2, 1)]
+
+
+@pytest.mark.parametrize("case", _CASES)
+def test_split_gated_block_fwd_matches_the_float64_oracle(lib, case):
+    B, C_, Cin, T, dil, flat = case
+    rng = np.random.default_rng(100 + C_ + T + dil + Cin)
+    w, pflat, offs = _params(rng, Cin, C_)
+    pd = dev(pflat)
+    x = rng.standard_normal((B, Cin, T)).astype(np.float32)
+    xd = dev(x)
+    ref = _ref_block(x, w, dil, flat)
+    res = {}
+    for split in (False, True):
+        img = _image(lib, split, 0, C_, Cin, dil, pd, offs)
+        out = torch.full((B, C_, T), float("nan"), device="cuda")
+        sv = [torch.full((B, 20, T), float("nan"), device="cuda") for _ in range(4)]
+        fn = lib.nsc_gated_block_fwd_simg if split else lib.nsc_gated_block_fwd_img
+        assert fn(img.data_ptr(), xd.data_ptr(), out.data_ptr(), *[t.data_ptr() for t in sv], B, C_, Cin, T, dil, flat, _st()) == 0, lib.nsc_last_error()
+        torch.cuda.synchronize()
+        res[split] = [t.cpu().numpy() for t in sv + [out]]
+        # without the optional outputs: same main output
+        out2 = torch.full((B, C_, T), float("nan"), device="cuda")
+        assert fn(img.data_ptr(), xd.data_ptr(), out2.data_ptr(), None, None, None, None, B, C_, Cin, T, dil, flat, _st()) == 0
+        assert torch.equal(out, out2)
+    names = ["h", "lin", "tanh", "g", "out"]
+    for nm, a, r in zip(names, res[True], ref):
+        assert_close(a, r, what=f"split block {nm} {case}")
+    # error of both arms against float64, relative to the tensor's rms
+    # (rms error within 1.5x of the exact arm; the maximum is one draw of a noisy statistic on the small tensors: 3x)
+    for nm, e_, s_, r in zip(names, res[False], res[True], ref):
+        rms = float(np.sqrt(np.mean(r ** 2)))
+        ee, es = float(np.abs(e_ - r).max()) / rms, float(np.abs(s_ - r).max()) / rms
+        re_, rs = float(np.sqrt(np.mean((e_ - r) ** 2))) / rms, float(np.sqrt(np.mean((s_ - r) ** 2))) / rms
+        print(f"  {nm}: err / rms of the tensor   exact max {ee:.2e} rms {re_:.2e}   split max {es:.2e} rms {rs:.2e}")
+        assert rs <= 1.5 * re_ + 1e-7 and es <= 3.0 * ee + 1e-6, (nm, ee, es, re_, rs)
+
+
+@pytest.mark.parametrize("C_,T,B,Cin0", [(100, 512, 2, 100), (100, 256, 5, 100), (50, 512, 3, 50), (25, 128, 9, 25), (100, 256, 128, 100),
+                                         (50, 512, 128, 50), (100, 256, 3, 1), (100, 256, 128, 1), (50, 512, 5, 1), (25, 128, 70, 1)])
+def test_split_pair_launch_equals_two_single_launches(lib, C_, T, B, Cin0):
+    """nsc_gated_block_pair_fwd_simg (dilation 1 then 2 in ONE launch, neighbour flags) == the two split launches, bit for bit."""
+    rng = np.random.default_rng(C_ + T + B + Cin0)
+    nfl = int(lib.nsc_gated_block_pair_flag_ints())
+    tmo = torch.zeros(4, dtype=torch.int32, device="cuda")
+    imgs = []
+    for dil in (1, 2):
+        Ci = Cin0 if dil == 1 else C_
+        w, pflat, offs = _params(rng, Ci, C_)
+        imgs.append(_image(lib, True, 0, C_, Ci, dil, dev(pflat), offs))
+    f0, f1 = imgs
+    x = dev(rng.standard_normal((B, Cin0, T)).astype(np.float32))
+    nan = lambda *sh: torch.full(sh, float("nan"), device="cuda")
+    Pt = lambda t: t.data_ptr()
+    o0, o1 = nan(B, C_, T), nan(B, C_, T)
+    s0, s1 = [nan(B, 20, T) for _ in range(4)], [nan(B, 20, T) for _ in range(4)]
+    assert lib.nsc_gated_block_fwd_simg(Pt(f0), Pt(x), Pt(o0), *[Pt(t) for t in s0], B, C_, Cin0, T, 1, 0, _st()) == 0, lib.nsc_last_error()
+    assert lib.nsc_gated_block_fwd_simg(Pt(f1), Pt(o0), Pt(o1), *[Pt(t) for t in s1], B, C_, C_, T, 2, 1, _st()) == 0, lib.nsc_last_error()
+    torch.cuda.synchronize()
+    for rep in range(3):
+        p0, p1 = nan(B, C_, T), nan(B, C_, T)
+        q0, q1 = [nan(B, 20, T) for _ in range(4)], [nan(B, 20, T) for _ in range(4)]
+        flags = torch.zeros(nfl, dtype=torch.int32, device="cuda")
+        assert lib.nsc_gated_block_pair_fwd_simg(Pt(f0), Pt(f1), Pt(x), Pt(p0), *[Pt(t) for t in q0], Pt(p1), *[Pt(t) for t in q1], B, C_, Cin0,
+                                                 T, 1, Pt(flags), Pt(tmo), _st()) == 0, lib.nsc_last_error()
+        torch.cuda.synchronize()
+        assert int(tmo[0]) == 0, "a neighbour wait timed out"
+        for a, b in zip([o0, o1] + s0 + s1, [p0, p1] + q0 + q1):
+            assert torch.equal(a, b) and bool(torch.isfinite(a).all()), ("forward", rep)
+
+
+def _wgrad_ref(t, C_, Cx, T, dil):
+    """float64 parameter gradients of one gated block from its saved activations and data-path gradients (block.hip header)."""
+    x, h, g, dy, da, dz1 = [t[k].astype(np.float64) for k in ("x", "h", "g", "dy", "da", "dz1")]
+    gp_ = np.pad(g, ((0, 0), (0, 0), (4, 4)))
+    hp_ = np.pad(h, ((0, 0), (0, 0), (7 * dil, 7 * dil)))
+    dw9 = np.stack([np.einsum("bit,bot->io", gp_[:, :, k:k + T], dy) for k in range(9)], 0)
+    dwl = np.stack([np.einsum("bit,bot->io", hp_[:, :, k * dil:k * dil + T], da[:, :20]) for k in range(15)], 0)
+    dwr = np.stack([np.einsum("bit,bot->io", hp_[:, :, k * dil:k * dil + T], da[:, 20:]) for k in range(15)], 0)
+    dw1 = np.einsum("bit,bot->io", x, dz1)
+    parts = [dw1, dz1.sum((0, 2)), dwl, da[:, :20].sum((0, 2)), dwr, da[:, 20:].sum((0, 2)), dw9, dy.sum((0, 2))]
+    return np.concatenate([p.reshape(-1) for p in parts])
+
+
+@pytest.mark.parametrize("B,shapes", [(6, [(100, 100, 256, 2), (100, 100, 512, 1), (50, 50, 512, 2), (100, 1, 256, 1), (50, 50, 512, 1), (25, 25, 128, 2)]),
+                                      (40, [(100, 100, 256, 1), (50, 1, 512, 2), (25, 25, 128, 1), (100, 100, 512, 2)]),
+                                      (3, [(100, 100, 64, 2), (50, 50, 68, 1), (25, 1, 128, 2)])])
+def test_split_block_wgrad_batch_matches_float64(lib, B, shapes):
+    """nsc_gated_block_wgrad_batch_split (bf16 matrix cores, split operands) against float64 on the host and against the exact kernel:
+    same bound as the exact kernel's test (2e-4 of each tensor's scale), rms error within 1.5x of the exact arm."""
+    from nsc_amd._lib import BlockWgradJob
+    rng = np.random.default_rng(B + len(shapes))
+    lib.nsc_gated_block_wgrad_batch_workspace.restype = C.c_long
+    nws = 2 * lib.nsc_gated_block_wgrad_batch_workspace(100)
+    keep, refs = [], []
+    outs = {False: [], True: []}
+    jobs = {False: [], True: []}
+    for (C_, Cx, T, dil) in shapes:
+        th = {k: rng.standard_normal(s_).astype(np.float32) for k, s_ in
+              dict(x=(B, Cx, T), h=(B, 20, T), g=(B, 20, T), dy=(B, C_, T), da=(B, 40, T), dz1=(B, 20, T)).items()}
+        t = {k: dev(v) for k, v in th.items()}
+        keep.append(t)
+        refs.append(_wgrad_ref(th, C_, Cx, T, dil))
+        n = refs[-1].size
+        for split in (False, True):
+            out = torch.full((n,), 0.5, device="cuda")
+            outs[split].append(out)
+            jobs[split].append(BlockWgradJob(t["x"].data_ptr(), t["h"].data_ptr(), t["g"].data_ptr(), t["dy"].data_ptr(), t["da"].data_ptr(),
+                                             t["dz1"].data_ptr(), out.data_ptr(), C_, T, dil, Cx if Cx != C_ else 0))
+    for split in (False, True):
+        ws = torch.full((nws,), float("nan"), device="cuda")
+        arr = (BlockWgradJob * len(shapes))(*jobs[split])
+        fn = lib.nsc_gated_block_wgrad_batch_split if split else lib.nsc_gated_block_wgrad_batch
+        assert fn(arr, len(shapes), B, 20, 9, ws.data_ptr(), nws, _st()) == 0, lib.nsc_last_error()
+        torch.cuda.synchronize()
+    for i, sh in enumerate(shapes):
+        C_, Cx, T, dil = sh
+        r = refs[i]
+        e_ = outs[False][i].cpu().numpy().astype(np.float64) - 0.5
+        s_ = outs[True][i].cpu().numpy().astype(np.float64) - 0.5
+        sizes = [Cx * 20, 20, 6000, 20, 6000, 20, 180 * C_, C_]
+        o = 0
+        for nm, n in zip(["dw1", "db1", "dwl", "dbl", "dwr", "dbr", "dw9", "db9"], sizes):
+            rr, ee, ss = r[o:o + n], e_[o:o + n], s_[o:o + n]
+            o += n
+            assert_close(ss, rr, tol=2e-4, what=f"split wgrad {nm} job {i} {sh}")
+            rms = float(np.sqrt(np.mean(rr ** 2)))
+            re_, rs = float(np.sqrt(np.mean((ee - rr) ** 2))) / rms, float(np.sqrt(np.mean((ss - rr) ** 2))) / rms
+            print(f"  job {i} {sh} {nm}: rms err / rms  exact {re_:.2e}  split {rs:.2e}")
+            # (the 0.5 the gradients accumulate onto costs both arms the same fp32 rounding of the sum: floor 2e-7 of the tensor's rms)
+            assert rs <= 1.5 * re_ + 2e-7 * max(1.0, 0.5 / rms), (nm, re_, rs)
