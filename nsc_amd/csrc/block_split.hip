@@ -120,8 +120,12 @@ __device__ __forceinline__ void gated_block_fwd3_body(const BlockArgs& a, int nt
   constexpr int TT = SPL_TT, H = G::H, WX = G::WX, WGW = TT + 8, LDX = SPL_LDX, CR = 4 * NK1, NCT1 = G::NCT1;
   constexpr int HPL = G::HPL, GPL = SPL_GPL;
   static_assert(NCT1 * 16 <= LDX && 79 + 14 * DIL < NCT1 * 16, "h tile must cover every column the k15 taps read");
-  float* xs = sm;                                                        // [CR][LDX] fp32
-  u16* hp = reinterpret_cast<u16*>(xs + CR * LDX);                      // [3][HPL]
+  // x tile, fp32 rows.  Physical column 0 of a row is step t0 - H - DLT, a multiple of 4 (DLT in 0..3): the tile lands by LDS-DMA in
+  // aligned 16-byte pieces that lie wholly inside or wholly outside the frame (T % 4 == 0); the logical tile starts DLT columns in.
+  constexpr int DLT = (4 - (H & 3)) & 3;
+  static_assert(WX + DLT <= LDX, "shifted x tile fits its rows");
+  float* xs = sm + DLT;                                                  // [CR][LDX] fp32, column j <-> step t0 - H + j
+  u16* hp = reinterpret_cast<u16*>(sm + CR * LDX);                      // [3][HPL]   (16-byte aligned: from the physical base)
   u16* gp = hp + 3 * HPL;                                               // [3][GPL]
   u16* w2 = gp + 3 * GPL;                                               // gate image
   float* w1s = reinterpret_cast<float*>(w2 + SPL_W2U16 + SPL_W2SLACK);  // [2][NK1][64] fp32 fragments of W1 (registers are what is scarce)
@@ -132,33 +136,38 @@ __device__ __forceinline__ void gated_block_fwd3_body(const BlockArgs& a, int nt
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, kq = lane >> 4;
 
-  // ---- x tile prefetch: exactly gated_block_fwd2_body's ----
-  constexpr int NQ4 = (CR + 15) / 16;
-  f32x4 pf4[NQ4];
+  // ---- x tile: global -> LDS by LDS-DMA (buffer form: 16 bytes per lane to m0 + lane * 16, ZEROS for lanes whose offset is out of
+  // range - tools/blds_check.hip), no registers, no staging pass.  Float4 i of the [CR][28] tile: row i / 28, piece i % 28; rows
+  // past Cin and pieces outside the frame are sent out of range.  The tile of step n + 1 is requested as soon as phase 1 of step n
+  // has read the buffer (the residual of phase 3 comes from memory - an L2 hit: this CU fetched the same lines a tile ago).
+  constexpr int NX4 = CR * (LDX / 4), NDMA = (NX4 + 511) / 512;
+  typedef int rsrc4_t __attribute__((ext_vector_type(4)));
+  const unsigned long long xaddr = (unsigned long long)a.x;
+  const rsrc4_t sxd = {(int)(unsigned)xaddr, (int)((unsigned)(xaddr >> 32) & 0xFFFFu), (int)(unsigned)((long)a.B * Cin * T * 4), 0x00020000};
   const __amdgpu_buffer_rsrc_t sx =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (unsigned)((long)a.B * Cin * T * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t sout =
       __builtin_amdgcn_make_buffer_rsrc(a.out, 0, FIRST ? (unsigned)((long)a.B * a.C * T * 4) : 0u, 0x00020000);
-  const int pi4 = lane & 31, phalf = lane >> 5;
-  int pf_vo = 0;
-  auto pf_setup = [&](int tile) {
+  const unsigned lds_x = (unsigned)(unsigned long long)(nsc_lds_cu16)reinterpret_cast<const u16*>(sm);
+  auto dma_x = [&](int tile) {
     const int tl = __builtin_amdgcn_readfirstlane(tile < ntiles ? tile : 0);
     const int b = tl / tpf, t0 = (tl - b * tpf) * TT;
-    const int OOB = 0x7ffffff0;
-    pf_vo = pi4 < LDX / 4 ? max(((b * Cin + 2 * wave + phalf) * T + t0 - H + 4 * pi4) * 4, 0) : OOB;
-  };
-  auto pf1 = [&](int q) {
-    const int vo = (q == NQ4 - 1 && 2 * wave + phalf + 16 * q >= Cin) ? 0x7ffffff0 : pf_vo;
-    pf4[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(sx, vo, q * 16 * T * 4, PAIRED ? NSC_AUX_COHERENT : NSC_AUX_STREAM));
-  };
-  auto prefetch = [&](int tile) {
-    pf_setup(tile);
 #pragma unroll
-    for (int q = 0; q < NQ4; ++q) pf1(q);
+    for (int n = 0; n < NDMA; ++n) {
+      const int i = tid + 512 * n;
+      if (i < NX4) {
+        const int r = i / (LDX / 4), f = i - r * (LDX / 4);
+        const int tm = t0 - H - DLT + 4 * f;
+        const int vo = (r < Cin && tm >= 0 && tm < T) ? ((b * Cin + r) * T + tm) * 4 : 0x7ffffff0;
+        const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_x + (unsigned)((n * 8 + wave) * 1024));
+        if (PAIRED) asm volatile("s_mov_b32 m0, %2\n\tbuffer_load_dwordx4 %0, %1, 0 offen sc0 sc1 lds" ::"v"(vo), "s"(sxd), "s"(m0v) : "memory", "m0");
+        else asm volatile("s_mov_b32 m0, %2\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(vo), "s"(sxd), "s"(m0v) : "memory", "m0");
+      }
+    }
   };
   const int first = (int)((long)blockIdx.x * ntiles / gridDim.x), last = (int)((long)(blockIdx.x + 1) * ntiles / gridDim.x);
   NSC_STAMP(32);
-  if (!PAIRED) prefetch(first);
+  if (!PAIRED) dma_x(first);
 
   // ---- once per workgroup: the parameter image (nsc_gated_block_simage_index, which = 0) ----
   const int r1 = wave >> 2;
@@ -199,9 +208,10 @@ __device__ __forceinline__ void gated_block_fwd3_body(const BlockArgs& a, int nt
   }
   if (PAIRED) {
     nsc_pair_wait(flags, timeouts);
-    prefetch(first);
+    dma_x(first);
   }
   nsc_wait_vmem();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the compiler does not see the DMA of the first x tile)
   // the gate image by LDS-DMA (16 bytes per lane, no registers): the youngest vector-memory operations when the tile loop starts,
   // waited for by hand before the first tile's phase 2 (see gated_block_fwd2_body)
   {
@@ -211,13 +221,12 @@ __device__ __forceinline__ void gated_block_fwd3_body(const BlockArgs& a, int nt
     for (int i = 0; i < NG2; ++i) {
       if (tid + 512 * i < N2_4) {
         const f32x4* gptr = reinterpret_cast<const f32x4*>(a.img) + tid + 512 * i;
-        const unsigned m0v = lds2 + (unsigned)((i * 8 + wave) * 1024);
+        const unsigned m0v = __builtin_amdgcn_readfirstlane(lds2 + (unsigned)((i * 8 + wave) * 1024));
         asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(m0v) : "memory", "m0");
       }
     }
   }
   NSC_STAMP(33);
-  const bool tvec = (T & 3) == 0;
   for (int tile = first; tile < last; ++tile) {
     const int b = tile / tpf, t0 = (tile - b * tpf) * TT;
     const bool fresh = tile == first || t0 == 0;                                   // workgroup-uniform
@@ -227,49 +236,30 @@ __device__ __forceinline__ void gated_block_fwd3_body(const BlockArgs& a, int nt
       // carried columns (the planes move as 32-bit words): g [64, 72) -> [0, 8); h [72, 2H + 64) -> [8, 2H) (dilation 2: rows
       // [36, H + 32) -> [4, H) of either parity half)
       constexpr int NGW = 8 * NARROW / 2, NHW = (2 * H - 8) * NARROW / 2 / DIL, NHALF = DIL;
-      for (int e = tid; e < 3 * (NGW + NHALF * NHW); e += 512) {
+      constexpr int NCW = 3 * (NGW + NHALF * NHW), NCI = (NCW + 511) / 512;
+      // (all reads first, then all writes: one LDS round trip instead of one per pass of the loop)
+      unsigned cv[NCI];
+      unsigned* cdst[NCI];
+#pragma unroll
+      for (int it = 0; it < NCI; ++it) {
+        const int e = min(tid + 512 * it, NCW - 1);
         const int p = e / (NGW + NHALF * NHW), r = e - p * (NGW + NHALF * NHW);
         if (r < NGW) {
-          unsigned* q = reinterpret_cast<unsigned*>(gp + p * GPL) + r;
-          q[0] = q[TT * NARROW / 2];
+          cdst[it] = reinterpret_cast<unsigned*>(gp + p * GPL) + r;
+          cv[it] = cdst[it][TT * NARROW / 2];
         } else {
           const int rr = r - NGW, hf = rr / NHW, i = rr - hf * NHW;
-          unsigned* q = reinterpret_cast<unsigned*>(hp + p * HPL + hf * G::HHALF) + (8 / DIL) * NARROW / 2 + i;
-          q[0] = q[(TT / DIL) * NARROW / 2];
+          cdst[it] = reinterpret_cast<unsigned*>(hp + p * HPL + hf * G::HHALF) + (8 / DIL) * NARROW / 2 + i;
+          cv[it] = cdst[it][(TT / DIL) * NARROW / 2];
         }
       }
-    }
-    // ---- phase 0: prefetched x tile -> LDS (fp32 rows) ----
-    if (pi4 < LDX / 4) {
-      const int tb = t0 - H + 4 * pi4;
-      const bool m0 = (unsigned)tb < (unsigned)T, m1 = (unsigned)(tb + 1) < (unsigned)T;
-      const bool m2 = (unsigned)(tb + 2) < (unsigned)T, m3 = (unsigned)(tb + 3) < (unsigned)T;
-      const bool clamped = b == 0 && wave == 0 && phalf == 0 && tb < 0 && tb > -4;
 #pragma unroll
-      for (int q = 0; q < NQ4; ++q) {
-        const int r = 2 * wave + phalf + 16 * q;
-        if (r < CR) {
-          f32x4 v = pf4[q];
-          if (clamped) {
-            const f32x4 w = v;
-            const int sh = -tb;
-            v[1] = sh == 1 ? w[0] : 0.f;
-            v[2] = sh == 1 ? w[1] : (sh == 2 ? w[0] : 0.f);
-            v[3] = sh == 1 ? w[2] : (sh == 2 ? w[1] : w[0]);
-          }
-          const bool live = r < Cin;
-          v[0] = live && m0 ? v[0] : 0.f;
-          v[1] = live && m1 ? v[1] : 0.f;
-          v[2] = live && m2 ? v[2] : 0.f;
-          v[3] = live && m3 ? v[3] : 0.f;
-          *reinterpret_cast<f32x4*>(xs + r * LDX + 4 * pi4) = v;
-        }
-      }
+      for (int it = 0; it < NCI; ++it)
+        if (tid + 512 * it < NCW) *cdst[it] = cv[it];
     }
     NSC_STAMP(35);
-    nsc_lds_barrier();
+    nsc_lds_barrier();           // the x tile is in LDS (waited for in the previous tile's phase 3 / the prologue), the carried columns moved
     NSC_STAMP(36);
-    pf_setup(tile + 1 < last ? tile + 1 : tile);
 
     // ---- phase 1 (exact fp32): h = lrelu(W1 x + b1) -> the three bf16 planes; kept for the backward pass from the accumulators ----
     {
@@ -325,6 +315,7 @@ __device__ __forceinline__ void gated_block_fwd3_body(const BlockArgs& a, int nt
     if (tile == first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the gate image has landed
     nsc_lds_barrier();
     NSC_STAMP(38);
+    if (tile + 1 < last) dma_x(tile + 1);     // phase 1 was the last reader of the x tile: the next one lands under phases 2 and 3
 
     // ---- phase 2: both k15 gate convs on the matrix cores; gate; g -> the three bf16 planes ----
     {
@@ -333,10 +324,6 @@ __device__ __forceinline__ void gated_block_fwd3_body(const BlockArgs& a, int nt
       acc[0] = acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
       // image row of this lane in row tile rt: rt * 16 + l15 (rows 40..47 of the third tile: don't-care rows, never stored)
       const u16* wl_ = w2 + (kq * SPL_W2ROWS + l15) * 8;
-      auto hook = [&](int s) {                                           // the next tile's x: one load per k-step
-        if (s >= 1 && s - 1 < NQ4) pf1(s - 1);
-      };
-      static_assert(NQ4 < SPL_KS2, "one x load per k-step");
       int jj0, jj1 = 0, rt0, rt1 = 0;
       bool two;
       // Software-pipelined by hand (hipcc issues a k-step's LDS reads, waits, then its MFMAs - every step exposed a full LDS round
@@ -368,7 +355,6 @@ __device__ __forceinline__ void gated_block_fwd3_body(const BlockArgs& a, int nt
         for (int u = 0; u < 2 * SPL_KS2; ++u) {
           if (u + 1 < 2 * SPL_KS2) fetch_a(u + 1, (u + 1) & 1);
           if ((u & 1) && (u >> 1) + 1 < SPL_KS2) fetch_b((u >> 1) + 1, ((u >> 1) + 1) & 1);
-          if (!(u & 1)) hook(u >> 1);
           __builtin_amdgcn_sched_barrier(0);
           acc[u & 1] = mfma_split6(aa[u & 1], bb[(u >> 1) & 1], acc[u & 1]);
           __builtin_amdgcn_sched_barrier(0);
@@ -400,8 +386,7 @@ __device__ __forceinline__ void gated_block_fwd3_body(const BlockArgs& a, int nt
 #pragma unroll
           for (int u = 0; u < 2 * SPL_KS2; ++u) {
             if (u + 1 < 2 * SPL_KS2) fetch(u + 1, (u + 1) & 1);
-            if (!(u & 1)) hook(u >> 1);
-            __builtin_amdgcn_sched_barrier(0);
+              __builtin_amdgcn_sched_barrier(0);
             acc[u & 1] = mfma_split6(aa[u & 1], bb[u & 1], acc[u & 1]);
             __builtin_amdgcn_sched_barrier(0);
           }
@@ -417,7 +402,6 @@ __device__ __forceinline__ void gated_block_fwd3_body(const BlockArgs& a, int nt
 #pragma unroll
           for (int s_ = 0; s_ < SPL_KS2; ++s_) {
             if (s_ + 1 < SPL_KS2) fetch(s_ + 1, (s_ + 1) & 1);
-            hook(s_);
             __builtin_amdgcn_sched_barrier(0);
             acc[0] = mfma_split6(aa[s_ & 1], bb[s_ & 1], acc[0]);
             __builtin_amdgcn_sched_barrier(0);
@@ -470,12 +454,8 @@ __device__ __forceinline__ void gated_block_fwd3_body(const BlockArgs& a, int nt
       float* gptr = a.out + ((long)b_ * C + o) * T + t;
       if constexpr (FIRST) {
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, v), sout, ((b_ * C + o) * T + t) * 4, 0, NSC_AUX_COHERENT);   // (pairs: T % 4 == 0)
-      } else if (tvec && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0) {
-        *reinterpret_cast<f32x4*>(gptr) = v;
       } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (t + e < T) gptr[e] = v[e];
+        *reinterpret_cast<f32x4*>(gptr) = v;                             // (T % 4 == 0 and a 16-byte aligned tensor: checked by the launcher)
       }
     };
     auto dense3 = [&](auto nc_c, int ct0) {
@@ -483,6 +463,15 @@ __device__ __forceinline__ void gated_block_fwd3_body(const BlockArgs& a, int nt
       f32x4 acc[NC];
 #pragma unroll
       for (int c = 0; c < NC; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      // the residual x[o][t .. t + 3] from memory (the LDS tile already belongs to the next step): requested before the MFMA loop
+      const int o = rt3 * 16 + l15p;
+      f32x4 xr4[NC];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int t = t0 + (ct0 + c) * 16 + 4 * kqp;
+        const int vo = (o < C && t < T) ? ((b * Cin + (NK1 == 1 ? 0 : o)) * T + t) * 4 : 0x7ffffff0;       // Cin = 1: broadcast residual
+        xr4[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(sx, vo, 0, PAIRED ? NSC_AUX_COHERENT : 0));
+      }
       // (software-pipelined by hand like phase 2: step i = (k-step i / NC, column tile i % NC); opaque bases per plane and pair of
       // column tiles: the offsets of a pair's fragments - up to 640 + 320 + 8 bytes - fit the 8-bit offset fields)
       nsc_lds_cu16 gb[3][(NC + 1) / 2];
@@ -504,17 +493,19 @@ __device__ __forceinline__ void gated_block_fwd3_body(const BlockArgs& a, int nt
         acc[i % NC] = mfma_split6(gf[i & 1], w9a[i / NC], acc[i % NC]);   // (A = g: rows of D are time)
         __builtin_amdgcn_sched_barrier(0);
       }
-      const int o = rt3 * 16 + l15p;
+      // Every vector-memory operation this wave has issued so far has completed - the next x tile's DMA (which the compiler does not
+      // see) among them: the loop-end barrier then means "the x tile is in LDS".  Everything outstanding here is old (the DMA and the
+      // residual went out before ~150 MFMAs), the output stores below are not waited for.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         const int tt = (ct0 + c) * 16 + 4 * kqp;
         const int t = t0 + tt;
         if (o < C && t < T) {
-          const float* xr = xs + (NK1 == 1 ? 0 : o) * LDX + H + tt;             // Cin = 1: broadcast residual
           f32x4 v;
 #pragma unroll
           for (int reg = 0; reg < 4; ++reg) {
-            float u_ = acc[c][reg] + b9l + xr[reg];
+            float u_ = acc[c][reg] + b9l + xr4[c][reg];
             if (!a.flat) u_ = u_ > 0.f ? u_ : NSC_LRELU_ALPHA * u_;
             v[reg] = u_;
           }
@@ -524,6 +515,7 @@ __device__ __forceinline__ void gated_block_fwd3_body(const BlockArgs& a, int nt
     };
     if (RT9 == 7) {
       if (wave < 7) dense3(std::integral_constant<int, 4>{}, 0);
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (wave 7 has no phase-3 job: its share of the DMA)
     } else {
       dense3(std::integral_constant<int, 2>{}, 2 * (wave >> 2));
     }
@@ -675,6 +667,8 @@ extern "C" int nsc_gated_block_fwd_simg(const float* img, const float* x, float*
   NSC_REQUIRE(nsc_gated_block_simage_words(0, C, Cin, dil) > 0, NSC_ERR_UNSUPPORTED,
               "nsc_gated_block_fwd_simg: no split kernel for C %d, Cin %d, dil %d", C, Cin, dil);
   NSC_REQUIRE(((uintptr_t)img & 15) == 0, NSC_ERR_BAD_ARG, "nsc_gated_block_fwd_simg: image must be 16-byte aligned");
+  NSC_REQUIRE((T & 3) == 0 && (((uintptr_t)x | (uintptr_t)out) & 15) == 0 && (long)B * C * T * 4 < (1L << 31), NSC_ERR_UNSUPPORTED,
+              "nsc_gated_block_fwd_simg: needs T %% 4 == 0, 16-byte aligned x / out and tensors below 2 GB (T %d, B %d): use nsc_gated_block_fwd_img", T, B);
   NSC_REQUIRE(!(lin_out || th_out || g_out) || (lin_out && th_out && g_out), NSC_ERR_BAD_ARG,
               "nsc_gated_block_fwd_simg: lin/th/g outputs must be given together");
   BlockArgs a{B, C, T, dil, flat, x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, out, h_out, lin_out,
@@ -699,6 +693,7 @@ extern "C" int nsc_gated_block_pair_fwd_simg(const float* img0, const float* img
   NSC_REQUIRE((T & 3) == 0 && (long)B * C * T * 4 < (1L << 31), NSC_ERR_UNSUPPORTED,
               "nsc_gated_block_pair_fwd_simg: needs T %% 4 == 0 and a tensor below 2 GB (T %d, B %d): launch the blocks one by one", T, B);
   NSC_REQUIRE((((uintptr_t)img0 | (uintptr_t)img1) & 15) == 0, NSC_ERR_BAD_ARG, "nsc_gated_block_pair_fwd_simg: images must be 16-byte aligned");
+  NSC_REQUIRE((((uintptr_t)x | (uintptr_t)out0 | (uintptr_t)out1) & 15) == 0, NSC_ERR_UNSUPPORTED, "nsc_gated_block_pair_fwd_simg: x / out must be 16-byte aligned");
   NSC_REQUIRE((!(lin0 || th0 || g0) || (lin0 && th0 && g0)) && (!(lin1 || th1 || g1) || (lin1 && th1 && g1)), NSC_ERR_BAD_ARG,
               "nsc_gated_block_pair_fwd_simg: lin/th/g outputs must be given together");
   NSC_REQUIRE(Cin0 == C || Cin0 == 1, NSC_ERR_BAD_ARG, "nsc_gated_block_pair_fwd_simg: Cin0 must be C or 1 (got %d)", Cin0);
@@ -787,8 +782,14 @@ __device__ __forceinline__ void block_wgrad_split_body(const BlockWgradArgs& a, 
   u16* dzp = dap + 3 * PLA;
   u16* hpl = dzp + 3 * PLZ;
   // ---- accumulators: row tiles {w, w + 4, ...} of every product ----
-  constexpr int R9 = PART == 1 ? 3 : 1, NC9 = PART == 1 ? RT9 : 1, RLR = PART == 2 ? 5 : 1, R1 = PART == 2 ? 2 : 1;
-  f32x4 g9[R9][NC9], glr[RLR][3], g1[R1][2], gb[2];
+  constexpr int R9 = PART == 1 ? 3 : 1, NC9 = PART == 1 ? RT9 : 1, RLR = PART == 2 ? 5 : 1, R1 = PART == 2 ? (RT9 + 3) / 4 : 1;
+  f32x4 g9[R9][NC9], glr[RLR][3], g1[R1][2];
+  // bias gradients (sums over time of dy | da | dz1): every thread adds up the float4 pieces it stages (rows crow + 16 q), the 16
+  // threads of a row meet once at the end - exact fp32, and no wave-dependent branch inside the MFMA loop
+  float bsum[RT9], bsa[3], bsz[2];
+#pragma unroll
+  for (int q = 0; q < RT9; ++q) bsum[q] = 0.f;
+  bsa[0] = bsa[1] = bsa[2] = bsz[0] = bsz[1] = 0.f;
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int r = 0; r < R9; ++r)
@@ -800,8 +801,6 @@ __device__ __forceinline__ void block_wgrad_split_body(const BlockWgradArgs& a, 
     for (int c = 0; c < 3; ++c) glr[r][c] = z4;
 #pragma unroll
   for (int r = 0; r < R1; ++r) g1[r][0] = g1[r][1] = z4;
-  gb[0] = gb[1] = z4;
-  const bf16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
 
   // ---- staging: the next tile's windows travel as 16-byte loads into registers during this tile's MFMA loop ----
   const int OOB = 0x7ffffff0;
@@ -857,6 +856,7 @@ __device__ __forceinline__ void block_wgrad_split_body(const BlockWgradArgs& a, 
     for (int q = 0; q < RT9; ++q) {
       const int r = crow + 16 * q;
       if (r < (PART == 1 ? C : Cx)) wsp_put_ct(PART == 1 ? dyp : xp, PART == 1 ? PLY : PLX, r * LDT + 4 * cf4, rc[q]);
+      if (PART == 1) bsum[q] += (rc[q][0] + rc[q][1]) + (rc[q][2] + rc[q][3]);      // (rows past C were not fetched: zeros)
     }
     if (PART == 2) {
 #pragma unroll
@@ -865,6 +865,10 @@ __device__ __forceinline__ void block_wgrad_split_body(const BlockWgradArgs& a, 
 #pragma unroll
       for (int q = 0; q < 2; ++q)
         if (crow + 16 * q < NARROW) wsp_put_ct(dzp, PLZ, (crow + 16 * q) * LDT + 4 * cf4, rz[q]);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) bsa[q] += (ra[q][0] + ra[q][1]) + (ra[q][2] + ra[q][3]);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) bsz[q] += (rz[q][0] + rz[q][1]) + (rz[q][2] + rz[q][3]);
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -917,11 +921,6 @@ __device__ __forceinline__ void block_wgrad_split_body(const BlockWgradArgs& a, 
           for (int p = 0; p < 3; ++p) bf[p] = ld_frag16(dyp + p * PLY + c * 16 * LDT + ctb + 32 * s);
 #pragma unroll
           for (int r = 0; r < R9; ++r) g9[r][c] = mfma_split6(af[r], bf, g9[r][c]);
-          // bias gradient db9 = sum_t dy: column tile c belongs to wave c & 3 (its slot c >> 2)
-          if ((c & 3) == wave) {
-#pragma unroll
-            for (int p = 2; p >= 0; --p) gb[c >> 2] = mfma_bf(ones, bf[p], gb[c >> 2]);
-          }
         }
       } else {
         bf16x8 bd[3][3];
@@ -931,23 +930,16 @@ __device__ __forceinline__ void block_wgrad_split_body(const BlockWgradArgs& a, 
           for (int p = 0; p < 3; ++p) bd[c][p] = ld_frag16(dap + p * PLA + c * 16 * LDT + ctb + 32 * s);
 #pragma unroll
         for (int r = 0; r < RLR; ++r) {
-          if (wave + 4 * r < 19) {                                    // 19 row tiles of (tap, ci): wave 3 has four
-            bf16x8 af[3];
+          // (19 row tiles of (tap, ci): the twentieth - wave 3, r = 4 - reads rows past the last tap: a product nobody stores, and
+          // a loop without a wave-dependent branch)
+          bf16x8 af[3];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
-              const u16* q0 = hpl + p * PLH + htr + s * hks + r * 64;
-              af[p] = ld_frag_tr(q0, q0 + hhf);
-            }
-#pragma unroll
-            for (int c = 0; c < 3; ++c) glr[r][c] = mfma_split6(af, bd[c], glr[r][c]);
+          for (int p = 0; p < 3; ++p) {
+            const u16* q0 = hpl + p * PLH + htr + s * hks + r * 64;
+            af[p] = ld_frag_tr(q0, q0 + hhf);
           }
-        }
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {                                 // dbl | dbr = sum_t da: column tile c belongs to wave c
-          if (wave == c) {
-#pragma unroll
-            for (int p = 2; p >= 0; --p) gb[0] = mfma_bf(ones, bd[c][p], gb[0]);
-          }
+          for (int c = 0; c < 3; ++c) glr[r][c] = mfma_split6(af, bd[c], glr[r][c]);
         }
         bf16x8 bz[2][3];
 #pragma unroll
@@ -955,20 +947,12 @@ __device__ __forceinline__ void block_wgrad_split_body(const BlockWgradArgs& a, 
 #pragma unroll
           for (int p = 0; p < 3; ++p) bz[c][p] = ld_frag16(dzp + p * PLZ + c * 16 * LDT + ctb + 32 * s);
 #pragma unroll
-        for (int r = 0; r < R1; ++r) {
-          if ((wave + 4 * r) * 16 < Cx) {
-            bf16x8 af[3];
+        for (int r = 0; r < R1; ++r) {                                // (row tiles past Cx: products nobody stores)
+          bf16x8 af[3];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) af[p] = ld_frag16(xp + p * PLX + (wave + 4 * r) * 16 * LDT + ctb + 32 * s);
+          for (int p = 0; p < 3; ++p) af[p] = ld_frag16(xp + p * PLX + (wave + 4 * r) * 16 * LDT + ctb + 32 * s);
 #pragma unroll
-            for (int c = 0; c < 2; ++c) g1[r][c] = mfma_split6(af, bz[c], g1[r][c]);
-          }
-        }
-        if (wave == 3) {                                              // db1 = sum_t dz1
-#pragma unroll
-          for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int p = 2; p >= 0; --p) gb[c] = mfma_bf(ones, bz[c][p], gb[c]);
+          for (int c = 0; c < 2; ++c) g1[r][c] = mfma_split6(af, bz[c], g1[r][c]);
         }
       }
     }
@@ -989,12 +973,11 @@ __device__ __forceinline__ void block_wgrad_split_body(const BlockWgradArgs& a, 
           if (o < C) a.dw9[so + (long)kk * C + o] = g9[r][cc][reg];
         }
       }
-    if (kq == 0) {                                                    // row 0 of the ones product
 #pragma unroll
-      for (int sl = 0; sl < 2; ++sl) {
-        const int o = (wave + 4 * sl) * 16 + l15;
-        if (wave + 4 * sl < RT9 && o < C) a.db9[so + o] = gb[sl][0];
-      }
+    for (int q = 0; q < RT9; ++q) {                                   // db9: the 16 threads of a row (lanes 16 g .. 16 g + 15)
+      float v = bsum[q];
+      v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+      if (cf4 == 0 && crow + 16 * q < C) a.db9[so + crow + 16 * q] = v;
     }
   } else {
 #pragma unroll
@@ -1010,10 +993,13 @@ __device__ __forceinline__ void block_wgrad_split_body(const BlockWgradArgs& a, 
           else if (c < 2 * NARROW) a.dwr[so + kk * NARROW + c - NARROW] = glr[r][ct][reg];
         }
       }
-    if (kq == 0 && wave < 3) {
-      const int c = wave * 16 + l15;
-      if (c < NARROW) a.dbl[so + c] = gb[0][0];
-      else if (c < 2 * NARROW) a.dbr[so + c - NARROW] = gb[0][0];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      float v = bsa[q];
+      v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+      const int c = crow + 16 * q;
+      if (cf4 == 0 && c < NARROW) a.dbl[so + c] = v;
+      else if (cf4 == 0 && c < 2 * NARROW) a.dbr[so + c - NARROW] = v;
     }
 #pragma unroll
     for (int r = 0; r < R1; ++r)
@@ -1027,12 +1013,11 @@ __device__ __forceinline__ void block_wgrad_split_body(const BlockWgradArgs& a, 
           if (o < NARROW) a.dw1[so + ci * NARROW + o] = g1[r][c][reg];
         }
       }
-    if (kq == 0 && wave == 3) {
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const int o = c * 16 + l15;
-        if (o < NARROW) a.db1[so + o] = gb[c][0];
-      }
+    for (int q = 0; q < 2; ++q) {
+      float v = bsz[q];
+      v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+      if (cf4 == 0 && crow + 16 * q < NARROW) a.db1[so + crow + 16 * q] = v;
     }
   }
 }

@@ -240,7 +240,7 @@ class _Block:
             # the fused backward recomputes the intermediates from x; an inference-only engine never reads them
             save = e.keep_activations
             sv = [t.data_ptr() if save else None for t in (self.h, self.lin, self.th, self.g)]
-            if e.use_images and e.images_valid and e.split_fwd and self.simg_fwd_off is not None:
+            if e.use_images and e.images_valid and e.split_fwd and self.simg_fwd_off is not None and T % 4 == 0:
                 check(e.lib.nsc_gated_block_fwd_simg(e.wt_ptr + 4 * self.simg_fwd_off, x.data_ptr(), self.out.data_ptr(), *sv, B,
                                                      self.wide, self.Cin, T, self.cl.dil, int(self.flat), e.stream()),
                       "gated_block_fwd_simg")
