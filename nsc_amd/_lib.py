@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnsc_hip.so")
+# NSC_LIB_PATH: another build of the library (A/B runs of tools/ and tests; the shipped path is the in-tree libnsc_hip.so)
+LIB_PATH = os.environ.get("NSC_LIB_PATH") or os.path.join(_HERE, "libnsc_hip.so")
 
 ACT_NONE, ACT_TANH, ACT_LRELU = 0, 1, 2
 
@@ -45,6 +46,7 @@ PROTOTYPES = {
     "nsc_gated_block_image_index": [_I, _I, _I, _I, _P, _P],
     "nsc_gated_block_simage_index": [_I, _I, _I, _I, _P, _P],
     "nsc_gated_block_fwd_simg": [_P] * 7 + [_I] * 6 + [_P],
+    "nsc_gated_block_dgrad_simg": [_P] * 10 + [_I] * 7 + [_P],
     "nsc_gated_block_pair_fwd_simg": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
     "nsc_depthwise_fwd": [_P, _P, _P, _I, _I, _I, _I, _P],
     "nsc_depthwise_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],

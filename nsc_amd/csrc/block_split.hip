@@ -42,14 +42,26 @@ typedef unsigned short u16;
 __device__ __forceinline__ f32x4 mfma_bf(const bf16x8& a, const bf16x8& b, const f32x4& c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
-// the six products of one k-step, smallest first
+// the six products of one k-step, smallest first (NSC_SPLIT_ORDER = 1: largest first - an A/B switch of the build, same error class)
+#ifndef NSC_SPLIT_ORDER
+#define NSC_SPLIT_ORDER 0
+#endif
 __device__ __forceinline__ f32x4 mfma_split6(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x4 c) {
+#if NSC_SPLIT_ORDER == 0
   c = mfma_bf(a[1], b[1], c);
   c = mfma_bf(a[0], b[2], c);
   c = mfma_bf(a[2], b[0], c);
   c = mfma_bf(a[0], b[1], c);
   c = mfma_bf(a[1], b[0], c);
   c = mfma_bf(a[0], b[0], c);
+#else
+  c = mfma_bf(a[0], b[0], c);
+  c = mfma_bf(a[1], b[0], c);
+  c = mfma_bf(a[0], b[1], c);
+  c = mfma_bf(a[2], b[0], c);
+  c = mfma_bf(a[0], b[2], c);
+  c = mfma_bf(a[1], b[1], c);
+#endif
   return c;
 }
 // a fragment (8 bf16) from LDS: 8-byte aligned (activation planes: ds_read2_b64) / 16-byte aligned (weight images: ds_read_b128)
@@ -540,26 +552,32 @@ __global__ __launch_bounds__(512) void gated_block_fwd3_pair_kernel(BlockArgs a0
 // =====================================================================================================
 // Split parameter images.  An image is an array of 32-bit WORDS built by nsc_gather / nsc_step_begin from the flat parameter
 // buffer (misc.hip: gather_word): idx[w] < 0 -> 0; bits 26..29 = 0 -> the fp32 value src[idx]; = m > 0 -> two bf16 PIECES packed,
-// low half of src[i], high half of src[i + stride], plane = (m - 1) >> 2 (0 hi, 1 lo, 2 lo2), stride = {20, 25, 50, 100}[(m - 1) & 3]
-// (the two k of a word are neighbours in the reduction index, whose source stride is the kernel's Cout).
+// low half of src[i], high half of src[i + stride], plane = (m - 1) / 5 (0 hi, 1 lo, 2 lo2), stride = {20, 25, 50, 100, 1}[(m - 1) % 5]
+// (the two k of a word are neighbours in the reduction index: the source stride is the kernel's Cout in the forward, 1 in the
+// data gradients, whose reduction runs over the output channel of the [K][Cin][Cout] kernels).
 //   which = 0 (forward): gate image [10][3][4][40][4 words] (+ 32 words of zeros) | group A [2][nf4a][64][4] fp32 (W1 fragments + b1,
 //   as in nsc_gated_block_image_index) | group B per phase-3 row tile: [6][3][64][4 words] k9 fragments + [64][4] (word 0: b9 of the lane's
 //   channel) | group C [8][2][64][4] fp32: gate biases of the wave's two phase-2 jobs.
 // =====================================================================================================
 static bool simg_shape(int which, int C, int Cin, int dil, int* rt9, int* nk) {
-  if (which != 0) return false;
+  if (which != 0 && which != 1) return false;
+  if (which == 1 && !(Cin == C && (C == 100 || C == 50))) return false;      // data gradient: gated_block_dgrad3_kernel's shapes
   if (!(dil == 1 || dil == 2) || !(C == 100 || C == 50 || C == 25) || !(Cin == C || Cin == 1)) return false;
   *rt9 = C == 100 ? 7 : 4;
   *nk = C == 100 ? 25 : (C == 50 ? 13 : 7);
   return true;
 }
 static int simg_mode(int plane, int stride) {
-  const int sel = stride == 20 ? 0 : (stride == 25 ? 1 : (stride == 50 ? 2 : 3));
-  return (1 + plane * 4 + sel) << 26;
+  const int sel = stride == 20 ? 0 : (stride == 25 ? 1 : (stride == 50 ? 2 : (stride == 100 ? 3 : 4)));   // (4: stride 1)
+  return (1 + plane * 5 + sel) << 26;
 }
 extern "C" long nsc_gated_block_simage_words(int which, int C, int Cin, int dil) {
   int rt9, nk;
   if (!simg_shape(which, C, Cin, dil, &rt9, &nk)) return 0;
+  if (which == 1) {
+    const int cp = (C + 3) & ~3, nks9 = (K9 * cp + 31) / 32, nks15 = (K15 * 2 * NARROW + 31) / 32, nct = (C + 15) / 16;
+    return 256L * 3 * (2 * nks9 + 2 * nks15 + nct);
+  }
   const int nk1 = Cin == 1 ? 1 : nk;
   const long n2 = (SPL_W2U16 + SPL_W2SLACK) / 2;
   return n2 + 256L * (2 * ((nk1 + 4 + 3) / 4) + (rt9 == 7 ? 7 : 4) * (SPL_KS3 * 3 + 1) + 8 * 2);
@@ -575,6 +593,39 @@ extern "C" int nsc_gated_block_simage_index(int which, int C, int Cin, int dil, 
   const long w1 = offs[0], b1 = offs[1], wl = offs[2], bl = offs[3], wr = offs[4], br = offs[5], w9 = offs[6], b9 = offs[7];
   for (long i = 0; i < 8; ++i)
     NSC_REQUIRE(offs[i] >= 0 && offs[i] < (1L << 26) - (1L << 20), NSC_ERR_UNSUPPORTED, "nsc_gated_block_simage_index: offset %ld does not fit 26 bits", offs[i]);
+  if (which == 1) {
+    // Data gradient (gated_block_dgrad3_kernel).  B fragments: lane (n = l15: column = input channel ci of the k9 | k15 kernel,
+    // output channel co of the 1x1), k = 32 s + 8 kq + 2 jw (+ 1), straight from the PARAMETERS (offs as for which = 0):
+    //   k9:  k = tap' * CP + o   -> w9[8 - tap'][ci][o]           (CP = C rounded to 4: the pad slots are zeros)
+    //   k15: k = tap' * 40 + c'  -> (c' < 20 ? wl : wr)[14 - tap'][ci][c' % 20]
+    //   1x1: k = c (< 20)        -> w1[co][c]
+    const int cp = (C + 3) & ~3, nks9 = (K9 * cp + 31) / 32, nks15 = (K15 * 2 * NARROW + 31) / 32, nct = (C + 15) / 16;
+    const long base15 = 256L * 3 * 2 * nks9, base1 = base15 + 256L * 3 * 2 * nks15;
+    for (int lane = 0; lane < 64; ++lane) {
+      const int l15 = lane & 15, kq = lane >> 4;
+      for (int p = 0; p < 3; ++p)
+        for (int jw = 0; jw < 4; ++jw) {
+          for (int s = 0; s < nks9; ++s)
+            for (int ct = 0; ct < 2; ++ct) {
+              const int k = 32 * s + 8 * kq + 2 * jw, tp = k / cp, o = k - tp * cp, ci = ct * 16 + l15;
+              if (tp < K9 && o < C && ci < NARROW)
+                idx[(((long)(s * 2 + ct) * 3 + p) * 64 + lane) * 4 + jw] = (int)(w9 + ((long)(K9 - 1 - tp) * NARROW + ci) * C + o) | simg_mode(p, 1);
+            }
+          for (int s = 0; s < nks15; ++s)
+            for (int ct = 0; ct < 2; ++ct) {
+              const int k = 32 * s + 8 * kq + 2 * jw, tp = k / (2 * NARROW), cc = k - tp * 2 * NARROW, ci = ct * 16 + l15;
+              if (tp < K15 && ci < NARROW)
+                idx[base15 + (((long)(s * 2 + ct) * 3 + p) * 64 + lane) * 4 + jw] =
+                    (int)((cc < NARROW ? wl : wr) + ((long)(K15 - 1 - tp) * NARROW + ci) * NARROW + (cc % NARROW)) | simg_mode(p, 1);
+            }
+          for (int ct = 0; ct < nct; ++ct) {
+            const int k = 8 * kq + 2 * jw, co = ct * 16 + l15;
+            if (k < NARROW && co < C) idx[base1 + (((long)ct * 3 + p) * 64 + lane) * 4 + jw] = (int)(w1 + (long)co * NARROW + k) | simg_mode(p, 1);
+          }
+        }
+    }
+    return NSC_OK;
+  }
   const int nk1 = Cin == 1 ? 1 : nk;
   // gate image: row r of the 40 -> tile r / 16, ii = r % 16: channel (r / 16) * 8 + (ii >> 2) * 2 + (ii & 1), branch (ii & 2) ? tanh : lin
   for (int s = 0; s < SPL_KS2; ++s)
@@ -1062,4 +1113,419 @@ int nsc_launch_block_wgrad_split(const BlockWgradBatch& t, int rt9, int nwg, hip
   }
   NSC_CHECK_LAUNCH("gated_block_wgrad_split");
   return NSC_OK;
+}
+
+// =====================================================================================================
+// Data-path backward of the gated block on the bf16 matrix cores (split operands).  Same inputs / outputs as
+// gated_block_dgrad2_kernel (block.hip):
+//   dg   = W9^T * dy                       K = 9 C     (rows of the product = time, columns = the 20 narrow channels)
+//   dlin = dg . th ; dgate = dg . lin . (1 - th^2)                                     -> da [B,40,T]
+//   dz1  = (Wl^T dlin + Wr^T dgate) . lrelu'(h)      K = 15 * 40                        -> dz1 [B,20,T]
+//   dx   = (W1^T dz1 + dy) . act'(x)                 K = 20                             -> dx [B,C,T]
+// The outputs of the two long products are NARROW (20 channels) and their reductions LONG, and the fp32 design's answer stays:
+// split the REDUCTION over the eight waves and add the eight partial sums in the elementwise phase that follows.  What changes:
+//  * k-step = 32 reduction slots of an activation plane in the [time][channels] layout of the forward (row pitch = channel count
+//    rounded to 4: k = tap * pitch + channel is the flat offset from a column's own row); wave w owns k-steps w, w + 8, ...
+//    of both products, for ALL row tiles (time) - so an activation fragment is read from LDS exactly once per tile (the forward,
+//    whose outputs are wide, reads every g fragment seven times: LDS-bound; this kernel is not);
+//  * the WEIGHTS of a wave's k-steps are 16-byte fragments of the split image (which = 1), fetched from L2 into registers at the
+//    start of the phase BEFORE the one that uses them: 3 x bf16 planes of all three kernels are 192 KB, more than the registers or
+//    the LDS left beside the activation planes, and they are the same for every tile - a CU re-reads ~200 KB of L2-resident lines
+//    per tile (3 k cycles of its 64 B/clk fill path, under the MFMA phases);
+//  * every elementwise phase (GLU, lrelu', copy-out) runs while the matrix pipe could work for the other wave of the SIMD.
+// Built for C in {100, 50}, Cin = C, dilation 1 | 2, T % 4 == 0; everything else takes the exact kernels.
+// =====================================================================================================
+template <int C_, int DIL>
+struct DsgGeom {
+  static constexpr int TT = 64, Hh = 7 * DIL, W_a = TT + 2 * Hh, W_dy = W_a + 8;
+  static constexpr int CP = (C_ + 3) & ~3;                       // row pitch of the dy planes (elements)
+  static constexpr int NCT = (C_ + 15) / 16;                     // column tiles of dx
+  static constexpr int NKS9 = (K9 * CP + 31) / 32, NKS15 = (K15 * 2 * NARROW + 31) / 32;
+  static constexpr int NI9 = (NKS9 + 7) / 8, NI15 = (NKS15 + 7) / 8;
+  static constexpr int NRTF = (W_a + 15) / 16;                   // row tiles (time) of a fresh tile: 5 | 6; steady: 4
+  static constexpr int RY = NRTF * 16 + 10;                      // rows of a dy plane: the last row tile's taps + the k-slots past tap 8
+  static constexpr int PLY = RY * CP;
+  static constexpr int RA = DIL == 1 ? ((W_a + 2 + 7) & ~7) : 2 * 48, PLA = RA * 2 * NARROW, AHALF = 48 * 2 * NARROW;
+  static constexpr int RZ = TT + 2, PLZ = RZ * NARROW;
+  static constexpr int PW = NRTF * 16 + 4;                       // row stride (floats) of a partial-sum row: [wave][channel][column]
+  static constexpr size_t smem = (size_t)2 * 3 * (PLY + PLA + PLZ) + (size_t)4 * 8 * NARROW * PW;
+};
+template <int DIL>
+__device__ __forceinline__ int dsg_aoff(int ja) {               // element offset of da column ja in a plane
+  return DIL == 1 ? ja * 2 * NARROW : (ja & 1) * (48 * 2 * NARROW) + (ja >> 1) * 2 * NARROW;
+}
+
+template <int C_, int DIL>
+__global__ __launch_bounds__(512) void gated_block_dgrad3_kernel(BlockDgradArgs a, int ntiles, int tpf) {
+  extern __shared__ __attribute__((aligned(16))) float smf[];
+  using G = DsgGeom<C_, DIL>;
+  constexpr int TT = G::TT, Hh = G::Hh, W_a = G::W_a, CP = G::CP, NCT = G::NCT, NKS9 = G::NKS9, NKS15 = G::NKS15, NI9 = G::NI9, NI15 = G::NI15;
+  constexpr int NRTF = G::NRTF, PLY = G::PLY, PLA = G::PLA, PLZ = G::PLZ, PW = G::PW;
+  u16* dyp = reinterpret_cast<u16*>(smf);                       // [3][RY][CP]      row j <-> step t0 - Hh - 4 + j
+  u16* dap = dyp + 3 * PLY;                                     // [3][RA][40]      column ja <-> step t0 - Hh + ja  (dlin | dgate)
+  u16* dzp = dap + 3 * PLA;                                     // [3][RZ][20]      row tt <-> step t0 + tt
+  float* part = reinterpret_cast<float*>(dzp + 3 * PLZ);        // [8][20][PW]      partial sums of the eight K-slices
+  static_assert((3 * (PLY + PLA + PLZ) * 2) % 16 == 0, "16-byte aligned partial sums");
+  const int T = a.T;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, kq = lane >> 4;
+  const int OOB = 0x7ffffff0;
+  const unsigned nbC = (unsigned)((long)a.B * C_ * T * 4), nbN = (unsigned)((long)a.B * NARROW * T * 4);
+  const __amdgpu_buffer_rsrc_t sdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, nbC, 0x00020000);
+  const __amdgpu_buffer_rsrc_t sxx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, nbC, 0x00020000);
+  const __amdgpu_buffer_rsrc_t slin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.lin), 0, nbN, 0x00020000);
+  const __amdgpu_buffer_rsrc_t sth = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.th), 0, nbN, 0x00020000);
+  const __amdgpu_buffer_rsrc_t sh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.h), 0, nbN, 0x00020000);
+  const unsigned nbDA = (unsigned)(((long)a.B * a.da_rows - (a.da_rows == NARROW ? 0 : NARROW)) * T * 4);
+  const __amdgpu_buffer_rsrc_t sdlin = __builtin_amdgcn_make_buffer_rsrc(a.da, 0, nbDA, 0x00020000);
+  const __amdgpu_buffer_rsrc_t sdgate = __builtin_amdgcn_make_buffer_rsrc(a.dgate, 0, nbDA, 0x00020000);
+  const __amdgpu_buffer_rsrc_t sdz = __builtin_amdgcn_make_buffer_rsrc(a.dz1, 0, nbN, 0x00020000);
+  auto bld = [](const __amdgpu_buffer_rsrc_t& r, int voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, NSC_AUX_STREAM));
+  };
+  // the split image (nsc_gated_block_simage_index, which = 1): fragments [k-step][column tile][plane][lane] of the k9 and the k15
+  // gradient, then [column tile][plane][lane] of the 1x1 gradient
+  const f32x4* img4 = reinterpret_cast<const f32x4*>(a.img) + lane;
+  constexpr int F9 = 0, F15 = NKS9 * 2 * 3 * 64, F1 = F15 + NKS15 * 2 * 3 * 64;
+  // the 1x1 gradient's fragments stay: wave w = column tile w (C = 100), or column tile w & 3 with two of the four row tiles (C = 50)
+  const int ct1 = NCT > 4 ? min(wave, NCT - 1) : (wave & 3);
+  bf16x8 w1f[3];                                                  // (fetched every tile under the lrelu' phase: 12 registers not held)
+  // this wave's weight fragments of the current long product: a ring of two k-steps (the fragments of k-step i + 1 are requested
+  // before the MFMAs of k-step i - one k-step is 48 .. 72 MFMAs, about an L2 round trip; all four at once were 96 registers)
+  bf16x8 wq[2][2][3];
+  auto load_w9 = [&](int i) {
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        wq[i & 1][ct][p] = __builtin_bit_cast(bf16x8, img4[F9 + ((min(wave + 8 * i, NKS9 - 1) * 2 + ct) * 3 + p) * 64]);
+  };
+  auto load_w15 = [&](int i) {
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        wq[i & 1][ct][p] = __builtin_bit_cast(bf16x8, img4[F15 + ((min(wave + 8 * i, NKS15 - 1) * 2 + ct) * 3 + p) * 64]);
+  };
+
+  // zero what no tile writes but fragments read: pad channels of the dy planes, the rows past the staged window, the pad row of dz1
+  for (int e = tid; e < 3 * (PLY + PLA + PLZ) / 2; e += 512) reinterpret_cast<unsigned*>(dyp)[e] = 0u;
+  __syncthreads();
+
+  // ---- prefetch of a tile's inputs: dword loads in the mapping of the phase that consumes them, lanes along time.  Thread =
+  // (column jl = tid & 63, group og = wave); item `it` = channel og + 8 it: the row enters through the SCALAR offset, one vector offset
+  // per column half, no divisions.  "A" items: the 64 columns from j0; "B" items: the columns past them - a fresh tile's 64 + jl
+  // (same mapping), a steady tile's 8 extra dy columns as (column tid & 7, channel (tid >> 3) + 64 it) ----
+  constexpr int NIY = (C_ + 7) / 8, NIA = 3;                     // items per thread and half: dy channels, narrow channels (20 -> 3)
+  constexpr int NCF = NRTF * 16 + 8, NAF = NRTF * 16;            // columns of a fresh tile's dy / da windows
+  float pyA[NIY], pyB[NIY], plA[NIA], plB[NIA], ptA[NIA], ptB[NIA], ph[NIA];
+  const int jl = tid & 63;
+  const int first = (int)((long)blockIdx.x * ntiles / gridDim.x), last = (int)((long)(blockIdx.x + 1) * ntiles / gridDim.x);
+  // (three pieces, each issued right after the phase that consumed the registers it refills: dy after the staging pass, lin / tanh
+  // after the GLU phase, h after the lrelu' phase)
+  auto prefetch_dy = [&](int tile, bool fresh) {
+    const int tl = __builtin_amdgcn_readfirstlane(tile < ntiles ? tile : 0);
+    const int b = tl / tpf, t0 = (tl - b * tpf) * TT;
+    const int j0 = fresh ? 0 : 2 * Hh;
+    {
+      const int tA = t0 - Hh - 4 + j0 + jl;
+      const int vA = (tA >= 0 && tA < T) ? (wave * T + tA) * 4 : OOB;
+#pragma unroll
+      for (int it = 0; it < NIY; ++it)
+        pyA[it] = bld(sdy, (it == NIY - 1 && wave + 8 * it >= C_) ? OOB : vA, (b * C_ + 8 * it) * T * 4);
+      if (fresh) {
+        const int tB = tA + 64;
+        const int vB = (64 + jl < NCF && tB >= 0 && tB < T) ? (wave * T + tB) * 4 : OOB;
+#pragma unroll
+        for (int it = 0; it < NIY; ++it)
+          pyB[it] = bld(sdy, (it == NIY - 1 && wave + 8 * it >= C_) ? OOB : vB, (b * C_ + 8 * it) * T * 4);
+      } else {
+        const int tB = t0 - Hh - 4 + j0 + 64 + (tid & 7);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int o = (tid >> 3) + 64 * it;
+          pyB[it] = bld(sdy, (o < C_ && tB >= 0 && tB < T) ? (o * T + tB) * 4 : OOB, b * C_ * T * 4);
+        }
+      }
+    }
+  };
+  auto prefetch_lt = [&](int tile, bool fresh) {
+    const int tl = __builtin_amdgcn_readfirstlane(tile < ntiles ? tile : 0);
+    const int b = tl / tpf, t0 = (tl - b * tpf) * TT;
+    const int j0 = fresh ? 0 : 2 * Hh;
+    {
+      const int tA = t0 - Hh + j0 + jl, tB = tA + 64;
+      const int vA = (tA >= 0 && tA < T) ? (wave * T + tA) * 4 : OOB;
+      const int vB = (fresh && 64 + jl < W_a && tB >= 0 && tB < T) ? (wave * T + tB) * 4 : OOB;
+#pragma unroll
+      for (int it = 0; it < NIA; ++it) {
+        const bool cok = wave + 8 * it < NARROW;
+        const int so = (b * NARROW + 8 * it) * T * 4;
+        plA[it] = bld(slin, cok ? vA : OOB, so);
+        ptA[it] = bld(sth, cok ? vA : OOB, so);
+        if (fresh) {
+          plB[it] = bld(slin, cok ? vB : OOB, so);
+          ptB[it] = bld(sth, cok ? vB : OOB, so);
+        }
+      }
+    }
+  };
+  auto prefetch_h = [&](int tile) {
+    const int tl = __builtin_amdgcn_readfirstlane(tile < ntiles ? tile : 0);
+    const int b = tl / tpf, t0 = (tl - b * tpf) * TT;
+    const int th_ = t0 + jl;
+#pragma unroll
+    for (int it = 0; it < NIA; ++it)
+      ph[it] = bld(sh, (wave + 8 * it < NARROW && th_ < T) ? (wave * T + th_) * 4 : OOB, (b * NARROW + 8 * it) * T * 4);
+  };
+  prefetch_dy(first, true);
+  prefetch_lt(first, true);
+  prefetch_h(first);
+  load_w9(0);
+  for (int tile = first; tile < last; ++tile) {
+    const int b = tile / tpf, t0 = (tile - b * tpf) * TT;
+    const bool fresh = tile == first || t0 == 0;
+    const bool next_steady = tile + 1 < last && (tile + 1) - ((tile + 1) / tpf) * tpf != 0;
+    const int ja0 = fresh ? 0 : 2 * Hh;                          // first new column of dg / da
+    const int nrt = fresh ? NRTF : TT / 16;                      // row tiles of the k9 gradient
+    // ---- stage: dy -> the three planes (element (row j, channel o)); two items share a split (packed pairs) ----
+    {
+      const int j0 = fresh ? 0 : 2 * Hh;
+      auto put2 = [&](float va, float vb, int ea, int eb, bool oka, bool okb) {
+        unsigned pk[3];
+        nsc_split2(va, vb, pk);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          if (oka) dyp[p * PLY + ea] = (u16)(pk[p] & 0xffffu);
+          if (okb) dyp[p * PLY + eb] = (u16)(pk[p] >> 16);
+        }
+      };
+      const int eA = (j0 + jl) * CP + wave, eB = eA + 64 * CP;
+#pragma unroll
+      for (int it = 0; it < NIY; it += 2)
+        put2(pyA[it], it + 1 < NIY ? pyA[it + 1] : 0.f, eA + 8 * it, eA + 8 * (it + 1), wave + 8 * it < C_, it + 1 < NIY && wave + 8 * (it + 1) < C_);
+      if (fresh) {
+        const bool cokB = 64 + jl < NCF;
+#pragma unroll
+        for (int it = 0; it < NIY; it += 2)
+          put2(pyB[it], it + 1 < NIY ? pyB[it + 1] : 0.f, eB + 8 * it, eB + 8 * (it + 1), cokB && wave + 8 * it < C_,
+               cokB && it + 1 < NIY && wave + 8 * (it + 1) < C_);
+      } else {
+        const int eS = (j0 + 64 + (tid & 7)) * CP + (tid >> 3);
+        put2(pyB[0], pyB[1], eS, eS + 64, (tid >> 3) < C_, (tid >> 3) + 64 < C_);
+      }
+      if (!fresh) {
+        // carried da columns [TT, TT + 2 Hh) -> [0, 2 Hh) (32-bit words; dilation 2: rows [32, 32 + Hh) -> [0, Hh) of either half)
+        constexpr int NW = 2 * Hh * 2 * NARROW / 2 / DIL;
+        for (int e = tid; e < 3 * DIL * NW; e += 512) {
+          const int p = e / (DIL * NW), r = e - p * (DIL * NW), hf = r / NW, i = r - hf * NW;
+          unsigned* q = reinterpret_cast<unsigned*>(dap + p * PLA + hf * G::AHALF) + i;
+          q[0] = q[(TT / DIL) * 2 * NARROW / 2];
+        }
+      }
+    }
+    nsc_lds_barrier();
+    const int ntile = tile + 1 < last ? tile + 1 : tile;
+    prefetch_dy(ntile, !next_steady);                            // (lands during this tile; the staged registers are free again)
+
+    // ---- k9 gradient: this wave's k-steps, all row tiles, both column tiles ----
+    {
+      f32x4 acc[NRTF][2];
+#pragma unroll
+      for (int r = 0; r < NRTF; ++r) acc[r][0] = acc[r][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      nsc_lds_cu16 yb[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) yb[p] = nsc_opaque_lds(dyp + p * PLY + (ja0 + l15) * CP + 8 * kq + 32 * wave);
+#pragma unroll
+      for (int i = 0; i < NI9; ++i) {
+        if (i + 1 < NI9) load_w9(i + 1);
+        if (wave + 8 * i < NKS9) {
+#pragma unroll
+          for (int r = 0; r < NRTF; ++r) {
+            if (r < nrt) {
+              bf16x8 af[3];
+#pragma unroll
+              for (int p = 0; p < 3; ++p) af[p] = ld_frag8(yb[p] + r * 16 * CP + i * 256);
+              acc[r][0] = mfma_split6(af, wq[i & 1][0], acc[r][0]);
+              acc[r][1] = mfma_split6(af, wq[i & 1][1], acc[r][1]);
+            }
+          }
+        }
+      }
+      // partial sums: the lane holds 4 consecutive columns (rows of the product) of channel ct * 16 + l15
+#pragma unroll
+      for (int r = 0; r < NRTF; ++r)
+        if (r < nrt) {
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) {
+            const int c = ct * 16 + l15;
+            if (c < NARROW) *reinterpret_cast<f32x4*>(part + (wave * NARROW + c) * PW + r * 16 + 4 * kq) = acc[r][ct];
+          }
+        }
+    }
+    load_w15(0);
+    nsc_lds_barrier();
+
+    // ---- GLU backward: dg = the eight partial sums; dlin | dgate -> memory (da) and the da planes ----
+    {
+      const int st_lo = fresh ? Hh : 2 * Hh, st_hi = next_steady ? W_a : Hh + TT;
+      const int sda = b * a.da_rows * T * 4;
+      auto glu1 = [&](int c, int i, float l, float tg) {           // channel c, column ja0 + i of this tile's new columns
+        const int ja = ja0 + i;
+        const float* pp = part + c * PW + i;
+        float gg = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) gg += pp[w * NARROW * PW];
+        const float dl_ = gg * tg, dgt = gg * l * (1.f - tg * tg);
+        const int t = t0 - Hh + ja;
+        const int vo = (ja >= st_lo && ja < st_hi && t >= 0 && t < T) ? (c * T + t) * 4 : OOB;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, dl_), sdlin, vo, sda, NSC_AUX_LATE);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, dgt), sdgate, vo, sda, NSC_AUX_LATE);
+        unsigned pk[3];
+        nsc_split2(dl_, dgt, pk);
+        u16* dst = dap + dsg_aoff<DIL>(ja) + c;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          dst[p * PLA] = (u16)(pk[p] & 0xffffu);
+          dst[p * PLA + NARROW] = (u16)(pk[p] >> 16);
+        }
+      };
+#pragma unroll
+      for (int it = 0; it < NIA; ++it) {
+        const int c = wave + 8 * it;
+        if (c < NARROW) {
+          glu1(c, jl, plA[it], ptA[it]);
+          if (fresh && 64 + jl < W_a) glu1(c, 64 + jl, plB[it], ptB[it]);
+        }
+      }
+      prefetch_lt(ntile, !next_steady);
+    }
+    nsc_lds_barrier();
+
+    // ---- k15 gradient: this wave's k-steps, four row tiles, both column tiles ----
+    {
+      f32x4 acc[4][2];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r][0] = acc[r][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < NI15; ++i) {
+        if (i + 1 < NI15) load_w15(i + 1);
+        if (wave + 8 * i < NKS15) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            bf16x8 af[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) af[p] = ld_frag8((nsc_lds_cu16)(dap + p * PLA + dsg_aoff<DIL>(r * 16 + l15) + 8 * kq + 32 * (wave + 8 * i)));
+            acc[r][0] = mfma_split6(af, wq[i & 1][0], acc[r][0]);
+            acc[r][1] = mfma_split6(af, wq[i & 1][1], acc[r][1]);
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          const int c = ct * 16 + l15;
+          if (c < NARROW) *reinterpret_cast<f32x4*>(part + (wave * NARROW + c) * PW + r * 16 + 4 * kq) = acc[r][ct];
+        }
+    }
+    load_w9(0);                                                  // (for the next tile: they arrive under the phases below)
+    nsc_lds_barrier();
+
+    // ---- dz1 = (sum of the partial sums) . lrelu'(h) -> memory and the dz1 planes ----
+    {
+#pragma unroll
+      for (int p = 0; p < 3; ++p) w1f[p] = __builtin_bit_cast(bf16x8, img4[F1 + (ct1 * 3 + p) * 64]);
+#pragma unroll
+      for (int it = 0; it < NIA; ++it) {
+        const int c = wave + 8 * it, tt = jl;
+        if (c < NARROW) {
+          const float* pp = part + c * PW + tt;
+          float s_ = 0.f;
+#pragma unroll
+          for (int w = 0; w < 8; ++w) s_ += pp[w * NARROW * PW];
+          const int t = t0 + tt;
+          const float v = t < T ? s_ * (ph[it] > 0.f ? 1.f : NSC_LRELU_ALPHA) : 0.f;
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), sdz, t < T ? (c * T + t) * 4 : OOB, b * NARROW * T * 4, NSC_AUX_LATE);
+          unsigned pk[3];
+          nsc_split2(v, 0.f, pk);
+#pragma unroll
+          for (int p = 0; p < 3; ++p) dzp[p * PLZ + tt * NARROW + c] = (u16)(pk[p] & 0xffffu);
+        }
+      }
+      prefetch_h(ntile);
+    }
+    nsc_lds_barrier();
+
+    // ---- 1x1 gradient + residual, . act'(x): dx rows leave as 16-byte pieces (4 consecutive steps of one channel per lane) ----
+    {
+      constexpr int NR1 = NCT > 4 ? 4 : 2;                        // row tiles of this wave
+      const int r0 = NCT > 4 ? 0 : 2 * (wave >> 2);
+      const int co = ct1 * 16 + l15;
+      if (NCT <= 4 || wave < NCT) {
+        f32x4 yv[NR1], xv[NR1];
+#pragma unroll
+        for (int r = 0; r < NR1; ++r) {
+          const int t = t0 + (r0 + r) * 16 + 4 * kq;
+          const int vo = (co < C_ && t < T) ? ((b * C_ + co) * T + t) * 4 : OOB;
+          yv[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(sdy, vo, 0, 0));
+          xv[r] = a.in_act == NSC_ACT_LRELU ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(sxx, vo, 0, 0)) : (f32x4){1.f, 1.f, 1.f, 1.f};
+        }
+#pragma unroll
+        for (int r = 0; r < NR1; ++r) {
+          bf16x8 af[3];
+#pragma unroll
+          for (int p = 0; p < 3; ++p) af[p] = ld_frag8((nsc_lds_cu16)(dzp + p * PLZ + ((r0 + r) * 16 + l15) * NARROW + 8 * kq));
+          f32x4 acc = mfma_split6(af, w1f, (f32x4){0.f, 0.f, 0.f, 0.f});
+          const int t = t0 + (r0 + r) * 16 + 4 * kq;
+          if (co < C_ && t < T) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (acc[e] + yv[r][e]) * (xv[r][e] > 0.f ? 1.f : NSC_LRELU_ALPHA);
+            if (a.in_act != NSC_ACT_LRELU) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = acc[e] + yv[r][e];
+            }
+            *reinterpret_cast<f32x4*>(a.dx + ((long)b * C_ + co) * T + t) = v;
+          }
+        }
+      }
+    }
+    nsc_lds_barrier();   // the planes and the partial sums are rewritten by the next tile
+  }
+}
+
+template <int C_, int DIL>
+static int launch_block_dgrad3(const BlockDgradArgs& a, hipStream_t st) {
+  using G = DsgGeom<C_, DIL>;
+  static_assert(G::smem <= 160 * 1024, "LDS of the split data gradient");
+  auto kern = gated_block_dgrad3_kernel<C_, DIL>;
+  const hipError_t e = NSC_SMEM_ATTR(kern, (int)G::smem);
+  NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "gated_block_dgrad3: smem attr: %s", hipGetErrorString(e));
+  const int tpf = nsc_cdiv(a.T, 64);
+  const int ntiles = a.B * tpf;
+  hipLaunchKernelGGL(kern, dim3(std::min(ntiles, 256)), dim3(512), G::smem, st, a, ntiles, tpf);
+  NSC_CHECK_LAUNCH("gated_block_dgrad3");
+  return NSC_OK;
+}
+
+// nsc_gated_block_dgrad_img on a SPLIT image (nsc_gated_block_simage_index, which = 1): same arguments; C in {100, 50}, Cin = C
+extern "C" int nsc_gated_block_dgrad_simg(const float* img, const float* x, const float* h, const float* lin, const float* th,
+                                          const float* dy, float* dx, float* dlin, float* dgate, float* dz1, int B, int C, int Cin,
+                                          int T, int dil, int in_act, int da_rows, void* stream) {
+  NSC_REQUIRE(img && x && h && lin && th && dy && dx && dlin && dgate && dz1, NSC_ERR_BAD_ARG, "nsc_gated_block_dgrad_simg: null pointer");
+  NSC_REQUIRE(B > 0 && T > 0, NSC_ERR_BAD_ARG, "nsc_gated_block_dgrad_simg: bad sizes");
+  NSC_REQUIRE(nsc_gated_block_simage_words(1, C, Cin, dil) > 0, NSC_ERR_UNSUPPORTED,
+              "nsc_gated_block_dgrad_simg: no split kernel for C %d, Cin %d, dil %d", C, Cin, dil);
+  NSC_REQUIRE(((uintptr_t)img & 15) == 0, NSC_ERR_BAD_ARG, "nsc_gated_block_dgrad_simg: image must be 16-byte aligned");
+  NSC_REQUIRE((T & 3) == 0 && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0 && (long)B * C * T * 4 < (1L << 31), NSC_ERR_UNSUPPORTED,
+              "nsc_gated_block_dgrad_simg: needs T %% 4 == 0, 16-byte aligned x / dy / dx and tensors below 2 GB (T %d, B %d): use nsc_gated_block_dgrad_img", T, B);
+  NSC_REQUIRE(in_act == NSC_ACT_NONE || in_act == NSC_ACT_LRELU, NSC_ERR_BAD_ARG, "nsc_gated_block_dgrad_simg: in_act");
+  NSC_REQUIRE(da_rows == NARROW || (da_rows == 2 * NARROW && dgate == dlin + (long)NARROW * T), NSC_ERR_BAD_ARG,
+              "nsc_gated_block_dgrad_simg: da_rows must be 20 (two [B,20,T] tensors) or 40 with dgate = dlin + 20 T");
+  BlockDgradArgs a{B, C, T, dil, in_act, x, h, lin, th, dy, nullptr, nullptr, nullptr, nullptr, dx, dlin, dz1, dgate, da_rows, img};
+  hipStream_t st = (hipStream_t)stream;
+  if (C == 100) return dil == 1 ? launch_block_dgrad3<100, 1>(a, st) : launch_block_dgrad3<100, 2>(a, st);
+  return dil == 1 ? launch_block_dgrad3<50, 1>(a, st) : launch_block_dgrad3<50, 2>(a, st);
 }

@@ -553,13 +553,13 @@ extern "C" int nsc_overlap_add(const float* frames, int nframes, const float* wi
 // dst[e] = src[idx[e]], or 0 where idx[e] < 0  (one launch rebuilds every flipped/transposed dgrad weight from the flat
 // parameter buffer; negative entries are the structural zeros of the polyphase stride-2 data-gradient kernels).
 // Bits 26..29 of an index = m > 0: the word is two bf16 PIECES of the split-operand images (block_split.hip: nsc_gated_block_simage_index):
-// low half from src[i], high half from src[i + stride], plane (m - 1) >> 2 (0 hi, 1 lo, 2 lo2), stride {20, 25, 50, 100}[(m - 1) & 3].
+// low half from src[i], high half from src[i + stride], plane (m - 1) / 5 (0 hi, 1 lo, 2 lo2), stride {20, 25, 50, 100, 1}[(m - 1) % 5].
 __device__ __forceinline__ float gather_word(const float* __restrict__ src, int i) {
   if (i < 0) return 0.f;
   const int m = i >> 26;
   if (m == 0) return src[i];
-  const int base = i & 0x3ffffff, plane = (m - 1) >> 2, sel = (m - 1) & 3;
-  const int stride = sel == 0 ? 20 : (sel == 1 ? 25 : (sel == 2 ? 50 : 100));
+  const int base = i & 0x3ffffff, plane = (m - 1) / 5, sel = (m - 1) - 5 * plane;
+  const int stride = sel == 0 ? 20 : (sel == 1 ? 25 : (sel == 2 ? 50 : (sel == 3 ? 100 : 1)));
   unsigned pk[3];
   nsc_split2(src[base], src[base + stride], pk);
   return __builtin_bit_cast(float, plane == 0 ? pk[0] : (plane == 1 ? pk[1] : pk[2]));

@@ -282,7 +282,13 @@ class _Block:
                 dxf = e.buf(u + ".dx", (B, self.Cin, T))
                 WT = lambda c: e.wt_ptr + 4 * c.w_off
                 tok = e.prof_begin("block_dgrad", self.c1.flops() + self.cl.flops() + self.cr.flops() + self.c9.flops())
-                if e.use_images and self.img_bwd_off is not None:     # (the data-gradient images are rebuilt with wt every step)
+                if e.use_images and e.split_dgrad and self.simg_bwd_off is not None and T % 4 == 0 and self.Cin == self.wide:
+                    check(e.lib.nsc_gated_block_dgrad_simg(e.wt_ptr + 4 * self.simg_bwd_off, self.x.data_ptr(), self.h.data_ptr(),
+                                                           self.lin.data_ptr(), self.th.data_ptr(), dz.data_ptr(), dxf.data_ptr(),
+                                                           da.data_ptr(), da.data_ptr() + 4 * n * T, dh.data_ptr(), B, self.wide,
+                                                           self.Cin, T, self.cl.dil, KIND_ACT[in_kind], 2 * n, e.stream()),
+                          "gated_block_dgrad_simg")
+                elif e.use_images and self.img_bwd_off is not None:     # (the data-gradient images are rebuilt with wt every step)
                     check(e.lib.nsc_gated_block_dgrad_img(e.wt_ptr + 4 * self.img_bwd_off, self.x.data_ptr(), self.h.data_ptr(),
                                                           self.lin.data_ptr(), self.th.data_ptr(), dz.data_ptr(), dxf.data_ptr(),
                                                           da.data_ptr(), da.data_ptr() + 4 * n * T, dh.data_ptr(), B, self.wide,
@@ -490,8 +496,10 @@ class _Codec:
         """Backward through a stack: dz = dL/d(pre-activation of the last block's output).  in_kind_first: what produced the
         first block's input.  Returns dL/d(pre-activation of that producer)."""
         e = self.eng
-        if not (self._pair_ok(blocks) and e.batch_wgrad and e.fused_wgrad and in_kind_first in ("lrelu", "none") and
-                (blocks[0].Cin > 1 or in_kind_first == "none")):
+        # (the split-operand data gradient has no pair form yet: a stack with a block it serves runs block by block)
+        split_any = e.split_dgrad and e.use_images and any(b.simg_bwd_off is not None and b.T % 4 == 0 for b in blocks)
+        if split_any or not (self._pair_ok(blocks) and e.batch_wgrad and e.fused_wgrad and in_kind_first in ("lrelu", "none") and
+                             (blocks[0].Cin > 1 or in_kind_first == "none")):
             for j in range(len(blocks) - 1, -1, -1):
                 dz = blocks[j].bwd(dz, in_kind_rest if j > 0 else in_kind_first)
             return dz
@@ -789,7 +797,7 @@ class CascadeEngine:
         # nsc_gated_block_image_index): one forward and one data-gradient image per block, 16-byte aligned, rebuilt by the
         # same gather launch as the flipped kernels
         for b in blocks:
-            b.img_fwd_off = b.img_bwd_off = b.simg_fwd_off = None
+            b.img_fwd_off = b.img_bwd_off = b.simg_fwd_off = b.simg_bwd_off = None
             if b.narrow == 20 and b.c9.K == 9:
                 for which, attr in ((0, "img_fwd_off"), (1, "img_bwd_off")):
                     nf = int(self.lib.nsc_gated_block_image_floats(which, int(b.wide), int(b.Cin), int(b.cl.dil)))
@@ -798,7 +806,7 @@ class CascadeEngine:
                         setattr(b, attr, n + extra)
                         extra += nf
                 # ... and the SPLIT images of the bf16-matrix-core kernels (csrc/block_split.hip): 32-bit words of packed bf16 pieces
-                for which, attr in ((0, "simg_fwd_off"),):
+                for which, attr in ((0, "simg_fwd_off"), (1, "simg_bwd_off")):
                     nf = int(self.lib.nsc_gated_block_simage_words(which, int(b.wide), int(b.Cin), int(b.cl.dil)))
                     if nf > 0:
                         extra = (n + extra + 3) // 4 * 4 - n
@@ -833,13 +841,15 @@ class CascadeEngine:
                 if which == 1:
                     im = np.where(im >= 0, idx[np.maximum(im, 0)], -1).astype(np.int32)
                 idx[off:off + nf] = im
-            if b.simg_fwd_off is not None:      # split image, straight from the parameters (entries carry a mode in bits 26..29)
-                nf = int(self.lib.nsc_gated_block_simage_words(0, int(b.wide), int(b.Cin), int(b.cl.dil)))
+            for which, off in ((0, b.simg_fwd_off), (1, b.simg_bwd_off)):
+                if off is None:
+                    continue     # split images, straight from the parameters (entries carry a mode in bits 26..29)
+                nf = int(self.lib.nsc_gated_block_simage_words(which, int(b.wide), int(b.Cin), int(b.cl.dil)))
                 offs = [b.c1.w_off, b.c1.b_off, b.cl.w_off, b.cl.b_off, b.cr.w_off, b.cr.b_off, b.c9.w_off, b.c9.b_off]
                 im = np.empty(nf, dtype=np.int32)
-                check(self.lib.nsc_gated_block_simage_index(0, int(b.wide), int(b.Cin), int(b.cl.dil), (C.c_long * len(offs))(*offs),
+                check(self.lib.nsc_gated_block_simage_index(which, int(b.wide), int(b.Cin), int(b.cl.dil), (C.c_long * len(offs))(*offs),
                                                             im.ctypes.data_as(C.c_void_p)), "gated_block_simage_index")
-                idx[b.simg_fwd_off:b.simg_fwd_off + nf] = im
+                idx[off:off + nf] = im
         self.wt_idx = torch.from_numpy(idx).to(self.device)
         # two Adam slot sets (no-quan op / quan op) with independent state (nsc_module:922-926)
         self.adam = [dict(m=torch.zeros(n, **f32), v=torch.zeros(n, **f32), t=0,
@@ -892,6 +902,7 @@ class CascadeEngine:
     # error, the vector ALU left free).  NSC_BLOCK_ARITH=exact|split overrides the default for A/B runs.
     split_fwd = os.environ.get("NSC_BLOCK_ARITH", "exact") == "split"
     split_wgrad_arith = os.environ.get("NSC_BLOCK_ARITH", "exact") == "split"   # (split_wgrad is the two-light-launches switch above)
+    split_dgrad = os.environ.get("NSC_BLOCK_ARITH", "exact") == "split" and os.environ.get("NSC_SPLIT_DGRAD", "1") == "1"
     fused_pairs = True   # the dil-1 / dil-2 blocks of a stack in ONE launch (nsc_gated_block_pair_fwd_img / _dgrad_img: neighbour flags
                          # between workgroups instead of a kernel boundary); False: one launch per block
     fused_chain = True   # the cascade step / output-gradient arithmetic between codecs rides in the epilogue of the Cout = 1 convs

@@ -21,6 +21,9 @@ import torch.nn.functional as F
 from . import nsc_oracle as O
 
 
+LRELU_KINK_SHIFT = 0.0     # see act(): 0 = the reference's leaky_relu
+
+
 def _pad_same(x_bct, K, dil, stride):
     T = x_bct.shape[-1]
     t_out, pl, pr = O.same_pad(T, K, dil, stride)
@@ -33,6 +36,11 @@ def act(x, activation):
     if activation == "tanh":
         return torch.tanh(x)
     if activation == "lrelu":
+        if LRELU_KINK_SHIFT:
+            # test instrument (tests/test_reference_exec_gpu.py::_kink_sensitivity): the kink moved by a fraction of the tensor's rms,
+            # so that every pre-activation within that distance of zero takes the OTHER slope
+            thr = LRELU_KINK_SHIFT * x.detach().pow(2).mean().sqrt()
+            return torch.where(x > thr, x, O.LRELU_ALPHA * x)
         return F.leaky_relu(x, O.LRELU_ALPHA)
     raise ValueError(activation)
 

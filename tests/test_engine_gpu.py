@@ -409,7 +409,12 @@ def test_parameter_write_after_refresh_invalidates_the_block_images():
         assert torch.equal(got, want), how
         eng.refresh_wt()
         assert eng.images_valid
-        assert torch.equal(eng.forward(xd, 1.0, True), want), how + " after refresh"
+        got = eng.forward(xd, 1.0, True)
+        if eng.split_fwd:      # the split-operand kernels (NSC_BLOCK_ARITH=split) agree with the plain entry points to fp32 rounding,
+            # not bit for bit; stale weights would be off by the size of the signal
+            assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max()), how + " after refresh"
+        else:
+            assert torch.equal(got, want), how + " after refresh"
 
 
 def test_bench_line_contract():
