@@ -40,6 +40,8 @@ LR = 2e-4
 RES_SCALAR = 1.0
 MFLOP_PER_FRAME_JOINT = 1428.2           # 2 codecs x 3 x 238.04 MFLOP
 PEAK_F32_MFMA_TFLOPS = 157.3             # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 (exact fp32)
+PEAK_BF16_MFMA_TFLOPS = 2500.0           # MI355X_MICROARCH.md: dense bf16 MFMA; the split-operand kernels spend SIX bf16 products
+PEAK_SPLIT6_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0   # per fp32-class product: their algorithmic FLOPs are priced against 1/6 of it
 
 
 def synth_batch(B, rank, device):
@@ -199,6 +201,9 @@ def main():
                     help="config 3 only: time the FOLLOWER step instead of the joint one (SURVEY 8d: codec 1 frozen and forward-only, "
                          "codec 2 trains on its residual: cmrl.py:137-293; 952.2 MFLOP per frame)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--arith", choices=["split", "exact"], default=None,
+                    help="arithmetic of the gated blocks' forward and weight gradients: split = bf16 matrix cores on fp32 operands split "
+                         "into 3 bf16 pieces, 6 products, fp32 accumulate (the engine's default); exact = the fp32 matrix instruction")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--passes", type=int, default=3, help="timed passes of --steps steps each (value = the median pass)")
     ap.add_argument("--dp-selftest", action="store_true",
@@ -245,6 +250,9 @@ def main():
     eng.batch_wgrad = not args.no_batch_wgrad
     eng.batch_conv_wgrad = not args.no_batch_conv_wgrad
     eng.fused_fwd = not args.unfused_fwd
+    if args.arith is not None:
+        eng.split_fwd = eng.split_wgrad_arith = args.arith == "split"
+    split_on = bool(eng.split_fwd or eng.split_wgrad_arith or eng.split_dgrad)
     xd, lpcd, x_np, lpc_np = synth_batch(B, comm.rank, dev)
     cfg = step_cfg_for(args.config, B, comm.world)
     if args.follower:
@@ -374,6 +382,36 @@ def main():
     dt = ms_step * 1e-3 * args.steps
     fps = comm.world * B * args.steps / dt
 
+    # ---- the SAME step with the gated blocks on the exact fp32 matrix instruction, timed beside the headline (N = 1): what the
+    # split-operand kernels buy, measured in the same run on the same parameters ----
+    ms_exact = None
+    if split_on and comm.world == 1 and dcomm is None and not args.no_graph:
+        keep = (eng.split_fwd, eng.split_wgrad_arith, eng.split_dgrad)
+        eng.split_fwd = eng.split_wgrad_arith = eng.split_dgrad = False
+        try:
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            s2 = torch.cuda.Stream()
+            s2.wait_stream(torch.cuda.current_stream())
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2, stream=s2):
+                step()
+            for _ in range(3):
+                g2.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                g2.replay()
+            torch.cuda.synchronize()
+            ms_exact = 1e3 * (time.perf_counter() - t0) / args.steps
+            del g2
+        except Exception as ex:
+            print(f"[bench] exact-arm timing skipped ({type(ex).__name__}: {ex})", file=sys.stderr)
+        eng.split_fwd, eng.split_wgrad_arith, eng.split_dgrad = keep
+        step()
+        torch.cuda.synchronize()
+
     # ---- roofline of the dominant kernel: per-launch HIP events on extra (eager) steps of the same workload ----
     # Kernels are timed IN ISOLATION: the side-stream overlap of the weight-gradient kernels is switched off for these
     # steps (otherwise a kernel's event bracket also contains whatever shares the CUs with it).
@@ -417,8 +455,12 @@ def main():
         summ = {tag: (n, max(ms - n * brk_us * 1e-3, 0.5 * ms), fl) for tag, (n, ms, fl) in summ.items()}
     # dominant kernel = the instrumented kernel class with the largest share of the step
     KERNELS = {"conv_mfma": "conv1d_fwd_kernel / conv1d_fwd_m32_kernel (convs outside gated blocks: forward + data gradients)",
-               "block_fwd": "gated_block_fwd2_pair_kernel / gated_block_fwd2_kernel (persistent weight-stationary gated block forward; the two blocks of a stack per launch)",
-               "block_wgrad": "gated_block_wgrad_batch_kernel + slab_reduce_batch_kernel (all blocks' weight gradients, one launch per width)",
+               "block_fwd": ("gated_block_fwd3_pair_kernel / gated_block_fwd3_kernel (split operands on the bf16 matrix cores; persistent gated block forward, the two blocks of a stack per launch)"
+                             if eng.split_fwd else
+                             "gated_block_fwd2_pair_kernel / gated_block_fwd2_kernel (persistent weight-stationary gated block forward; the two blocks of a stack per launch)"),
+               "block_wgrad": ("gated_block_wgrad_split_batch_kernel + slab_reduce_batch_kernel (split operands on the bf16 matrix cores; all blocks' weight gradients, one launch per width)"
+                               if eng.split_wgrad_arith else
+                               "gated_block_wgrad_batch_kernel + slab_reduce_batch_kernel (all blocks' weight gradients, one launch per width)"),
                "block_dgrad": "gated_block_dgrad2_pair_kernel / gated_block_dgrad2_kernel (persistent weight-stationary gated block data-path backward; the two blocks of a stack per launch)",
                "wgrad_mfma": "conv1d_wgrad_batch_kernel + conv_slab_reduce_batch_kernel (weight gradients of the convs outside gated blocks)"}
     roof, by_kernel = None, {}
@@ -444,6 +486,20 @@ def main():
                            "kernel-trace average of this command (profiles/)",
                     flop_per_launch_avg=fl / n, peak_measured_on_box=153.7)
     kern_ms = by_kernel
+    # the classes that run on split operands, priced against the bf16 matrix peak / 6 (six bf16 products per fp32-class product)
+    roof_split = None
+    if split_on:
+        roof_split = {"peak": round(PEAK_SPLIT6_TFLOPS, 1), "unit": "TFLOP/s",
+                      "peak_basis": "dense bf16 MFMA peak (2500 TFLOP/s, MI355X_MICROARCH.md) / 6: every fp32-class product is six bf16 products "
+                                    "(three bf16 pieces per operand, fp32 accumulate); algorithmic FLOPs of the class / its time",
+                      "classes": {}}
+        for tag, on in (("block_fwd", eng.split_fwd), ("block_wgrad", eng.split_wgrad_arith), ("block_dgrad", eng.split_dgrad)):
+            if on and tag in summ:
+                n, ms, fl = summ[tag]
+                ach = fl / (ms * 1e-3) / 1e12
+                roof_split["classes"][tag] = dict(kernel=KERNELS[tag], achieved=round(ach, 2), frac=round(ach / PEAK_SPLIT6_TFLOPS, 4),
+                                                  frac_of_f32_mfma_peak=round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                                                  launches_per_step=n // args.prof_steps, avg_launch_us=round(1e3 * ms / n, 2))
 
     # HBM-bound quantizer at the op-surface form (p materialised, 34 816 B/frame fwd): measured at the config-5 batch
     qroof = None
@@ -542,19 +598,26 @@ def main():
             "ms_per_step": round(ms_step, 3), "ms_per_step_passes": [round(v, 3) for v in pass_ms],
             "ms_per_step_min": round(min(pass_ms), 3), "timing": f"median of {len(pass_ms)} passes of {args.steps} steps, each bracketed by barrier + synchronize, max over ranks",
             "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": ("f32 (gated-block " + " + ".join(n_ for n_, on in (("forward", eng.split_fwd), ("weight gradients", eng.split_wgrad_arith),
+                                                                        ("data gradient", eng.split_dgrad)) if on) +
+                      ": fp32 operands split into 3 bf16 pieces, 6 products on the bf16 matrix cores, fp32 accumulate - fp32-class error, "
+                      "gate in profiles/r05_numerics_gate.txt; everything else: exact fp32)") if split_on else "f32",
+            "data": "synthetic",
             "config": {"workload": (wl_name or "BASELINE config 3: 2-codec CMRL (strides [2], 32 bins) on fed LPC residual + 16x256 "
                                     "LSF quantizer, joint finetune step, fwd+loss+bwd+TF1-Adam") +
                                    ("+RCCL grad all-reduce(sum)" if comm.world > 1 else ""),
                        "batch_per_gpu": B, "global_batch": B * comm.world, "frame": 512,
-                       "parallelism": f"dp{comm.world}", "launch": launch, "all_ranks_same_launch": all_same,
+                       "parallelism": f"dp{comm.world}", "block_arithmetic": "split" if split_on else "exact", "launch": launch, "all_ranks_same_launch": all_same,
                        "c_abi_calls_per_step": calls_per_step, "pair_launches": bool(eng.fused_pairs), "pair_launch_timeouts": pair_to, **({"pair_launches_note": pairs_note} if pairs_note else {}),
                        "grad_message": (("one per trainable scope, under the backward pass" if eng.dp_overlap else
                                          "one at the tail of the step") if dcomm is not None else None),
                        "streams": "one (weight gradients batched at the tail of the step)",
                        "roofline_note": "per-kernel numbers: HIP events around each launch on extra eager steps of the same workload"},
             "model_tflops": round(fps * mflop_frame * 1e6 / 1e12, 2), "mflop_per_frame": mflop_frame,
-            "roofline": roof, "roofline_quantizer": qroof, "cpu_baseline": cpu, "codec_forward": infer, "kernels": kern_ms,
+            "ms_per_step_exact_f32": (round(ms_exact, 3) if ms_exact is not None else None),
+            "roofline": roof, "roofline_split_operand_classes": roof_split, "roofline_quantizer": qroof, "cpu_baseline": cpu,
+            "codec_forward": infer, "kernels": kern_ms,
         }
         print(json.dumps(out), flush=True)
     comm.barrier()

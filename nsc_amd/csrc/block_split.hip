@@ -1214,76 +1214,80 @@ __global__ __launch_bounds__(512) void gated_block_dgrad3_kernel(BlockDgradArgs 
   __syncthreads();
 
   // ---- prefetch of a tile's inputs: dword loads in the mapping of the phase that consumes them, lanes along time.  Thread =
-  // (column jl = tid & 63, group og = wave); item `it` = channel og + 8 it: the row enters through the SCALAR offset, one vector offset
-  // per column half, no divisions.  "A" items: the 64 columns from j0; "B" items: the columns past them - a fresh tile's 64 + jl
-  // (same mapping), a steady tile's 8 extra dy columns as (column tid & 7, channel (tid >> 3) + 64 it) ----
-  constexpr int NIY = (C_ + 7) / 8, NIA = 3;                     // items per thread and half: dy channels, narrow channels (20 -> 3)
+  // (column jl = tid & 63, group wave); item `it` = the channel PAIR wave + 8 it (channels 2 pi, 2 pi + 1: one split, one 32-bit LDS
+  // store per plane): the row enters through the SCALAR offset, one vector offset per column half, no divisions.  "A" items: the 64
+  // columns from j0; "B" items: the columns past them - a fresh tile's 64 + jl (same mapping), a steady tile's 8 extra dy columns as
+  // (column tid & 7, pair tid >> 3) ----
+  constexpr int NIP = (C_ / 2 + 7) / 8, NIG = 2;                 // pairs per thread and half: dy channels, narrow channels (10 pairs -> 2)
   constexpr int NCF = NRTF * 16 + 8, NAF = NRTF * 16;            // columns of a fresh tile's dy / da windows
-  float pyA[NIY], pyB[NIY], plA[NIA], plB[NIA], ptA[NIA], ptB[NIA], ph[NIA];
+  static_assert(C_ % 2 == 0, "channel pairs");
+  float pyA[NIP][2], pyB[NIP][2], plA[NIG][2], plB[NIG][2], ptA[NIG][2], ptB[NIG][2], ph[3];
   const int jl = tid & 63;
   const int first = (int)((long)blockIdx.x * ntiles / gridDim.x), last = (int)((long)(blockIdx.x + 1) * ntiles / gridDim.x);
-  // (three pieces, each issued right after the phase that consumed the registers it refills: dy after the staging pass, lin / tanh
-  // after the GLU phase, h after the lrelu' phase)
+  // (three pieces, each issued where the registers it refills are free and there is a phase or more for the data to arrive: dy at
+  // the start of the k15 gradient, lin / tanh after the GLU phase, h after the lrelu' phase)
   auto prefetch_dy = [&](int tile, bool fresh) {
     const int tl = __builtin_amdgcn_readfirstlane(tile < ntiles ? tile : 0);
     const int b = tl / tpf, t0 = (tl - b * tpf) * TT;
     const int j0 = fresh ? 0 : 2 * Hh;
-    {
-      const int tA = t0 - Hh - 4 + j0 + jl;
-      const int vA = (tA >= 0 && tA < T) ? (wave * T + tA) * 4 : OOB;
+    const int tA = t0 - Hh - 4 + j0 + jl;
+    const int vA = (tA >= 0 && tA < T) ? (2 * wave * T + tA) * 4 : OOB;
 #pragma unroll
-      for (int it = 0; it < NIY; ++it)
-        pyA[it] = bld(sdy, (it == NIY - 1 && wave + 8 * it >= C_) ? OOB : vA, (b * C_ + 8 * it) * T * 4);
-      if (fresh) {
-        const int tB = tA + 64;
-        const int vB = (64 + jl < NCF && tB >= 0 && tB < T) ? (wave * T + tB) * 4 : OOB;
+    for (int it = 0; it < NIP; ++it)
 #pragma unroll
-        for (int it = 0; it < NIY; ++it)
-          pyB[it] = bld(sdy, (it == NIY - 1 && wave + 8 * it >= C_) ? OOB : vB, (b * C_ + 8 * it) * T * 4);
-      } else {
-        const int tB = t0 - Hh - 4 + j0 + 64 + (tid & 7);
+      for (int e = 0; e < 2; ++e)
+        pyA[it][e] = bld(sdy, (it == NIP - 1 && 2 * (wave + 8 * it) + e >= C_) ? OOB : vA, (b * C_ + 16 * it + e) * T * 4);
+    if (fresh) {
+      const int tB = tA + 64;
+      const int vB = (64 + jl < NCF && tB >= 0 && tB < T) ? (2 * wave * T + tB) * 4 : OOB;
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-          const int o = (tid >> 3) + 64 * it;
-          pyB[it] = bld(sdy, (o < C_ && tB >= 0 && tB < T) ? (o * T + tB) * 4 : OOB, b * C_ * T * 4);
-        }
-      }
+      for (int it = 0; it < NIP; ++it)
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+          pyB[it][e] = bld(sdy, (it == NIP - 1 && 2 * (wave + 8 * it) + e >= C_) ? OOB : vB, (b * C_ + 16 * it + e) * T * 4);
+    } else {
+      const int tB = t0 - Hh - 4 + j0 + 64 + (tid & 7), o = 2 * (tid >> 3);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) pyB[0][e] = bld(sdy, (o + e < C_ && tB >= 0 && tB < T) ? ((o + e) * T + tB) * 4 : OOB, b * C_ * T * 4);
     }
   };
   auto prefetch_lt = [&](int tile, bool fresh) {
     const int tl = __builtin_amdgcn_readfirstlane(tile < ntiles ? tile : 0);
     const int b = tl / tpf, t0 = (tl - b * tpf) * TT;
     const int j0 = fresh ? 0 : 2 * Hh;
-    {
-      const int tA = t0 - Hh + j0 + jl, tB = tA + 64;
-      const int vA = (tA >= 0 && tA < T) ? (wave * T + tA) * 4 : OOB;
-      const int vB = (fresh && 64 + jl < W_a && tB >= 0 && tB < T) ? (wave * T + tB) * 4 : OOB;
+    const int tA = t0 - Hh + j0 + jl, tB = tA + 64;
+    const int vA = (tA >= 0 && tA < T) ? (2 * wave * T + tA) * 4 : OOB;
+    const int vB = (fresh && 64 + jl < W_a && tB >= 0 && tB < T) ? (2 * wave * T + tB) * 4 : OOB;
 #pragma unroll
-      for (int it = 0; it < NIA; ++it) {
-        const bool cok = wave + 8 * it < NARROW;
-        const int so = (b * NARROW + 8 * it) * T * 4;
-        plA[it] = bld(slin, cok ? vA : OOB, so);
-        ptA[it] = bld(sth, cok ? vA : OOB, so);
+    for (int it = 0; it < NIG; ++it)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const bool cok = 2 * (wave + 8 * it) + e < NARROW;
+        const int so = (b * NARROW + 16 * it + e) * T * 4;
+        plA[it][e] = bld(slin, cok ? vA : OOB, so);
+        ptA[it][e] = bld(sth, cok ? vA : OOB, so);
         if (fresh) {
-          plB[it] = bld(slin, cok ? vB : OOB, so);
-          ptB[it] = bld(sth, cok ? vB : OOB, so);
+          plB[it][e] = bld(slin, cok ? vB : OOB, so);
+          ptB[it][e] = bld(sth, cok ? vB : OOB, so);
         }
       }
-    }
   };
   auto prefetch_h = [&](int tile) {
     const int tl = __builtin_amdgcn_readfirstlane(tile < ntiles ? tile : 0);
     const int b = tl / tpf, t0 = (tl - b * tpf) * TT;
     const int th_ = t0 + jl;
 #pragma unroll
-    for (int it = 0; it < NIA; ++it)
+    for (int it = 0; it < 3; ++it)
       ph[it] = bld(sh, (wave + 8 * it < NARROW && th_ < T) ? (wave * T + th_) * 4 : OOB, (b * NARROW + 8 * it) * T * 4);
   };
+  NSC_STAMP(0);
   prefetch_dy(first, true);
   prefetch_lt(first, true);
   prefetch_h(first);
   load_w9(0);
+  NSC_STAMP(1);
   for (int tile = first; tile < last; ++tile) {
+    NSC_STAMP(2);
     const int b = tile / tpf, t0 = (tile - b * tpf) * TT;
     const bool fresh = tile == first || t0 == 0;
     const bool next_steady = tile + 1 < last && (tile + 1) - ((tile + 1) / tpf) * tpf != 0;
@@ -1292,28 +1296,22 @@ __global__ __launch_bounds__(512) void gated_block_dgrad3_kernel(BlockDgradArgs 
     // ---- stage: dy -> the three planes (element (row j, channel o)); two items share a split (packed pairs) ----
     {
       const int j0 = fresh ? 0 : 2 * Hh;
-      auto put2 = [&](float va, float vb, int ea, int eb, bool oka, bool okb) {
+      auto put2 = [&](float va, float vb, int el, bool ok) {             // channels (2 pi, 2 pi + 1) of one row: a 32-bit word per plane
         unsigned pk[3];
         nsc_split2(va, vb, pk);
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          if (oka) dyp[p * PLY + ea] = (u16)(pk[p] & 0xffffu);
-          if (okb) dyp[p * PLY + eb] = (u16)(pk[p] >> 16);
-        }
+        for (int p = 0; p < 3; ++p)
+          if (ok) *reinterpret_cast<unsigned*>(dyp + p * PLY + el) = pk[p];
       };
-      const int eA = (j0 + jl) * CP + wave, eB = eA + 64 * CP;
+      const int eA = (j0 + jl) * CP + 2 * wave, eB = eA + 64 * CP;
 #pragma unroll
-      for (int it = 0; it < NIY; it += 2)
-        put2(pyA[it], it + 1 < NIY ? pyA[it + 1] : 0.f, eA + 8 * it, eA + 8 * (it + 1), wave + 8 * it < C_, it + 1 < NIY && wave + 8 * (it + 1) < C_);
+      for (int it = 0; it < NIP; ++it) put2(pyA[it][0], pyA[it][1], eA + 16 * it, 2 * (wave + 8 * it) < C_);
       if (fresh) {
         const bool cokB = 64 + jl < NCF;
 #pragma unroll
-        for (int it = 0; it < NIY; it += 2)
-          put2(pyB[it], it + 1 < NIY ? pyB[it + 1] : 0.f, eB + 8 * it, eB + 8 * (it + 1), cokB && wave + 8 * it < C_,
-               cokB && it + 1 < NIY && wave + 8 * (it + 1) < C_);
+        for (int it = 0; it < NIP; ++it) put2(pyB[it][0], pyB[it][1], eB + 16 * it, cokB && 2 * (wave + 8 * it) < C_);
       } else {
-        const int eS = (j0 + 64 + (tid & 7)) * CP + (tid >> 3);
-        put2(pyB[0], pyB[1], eS, eS + 64, (tid >> 3) < C_, (tid >> 3) + 64 < C_);
+        put2(pyB[0][0], pyB[0][1], (j0 + 64 + (tid & 7)) * CP + 2 * (tid >> 3), 2 * (tid >> 3) < C_);
       }
       if (!fresh) {
         // carried da columns [TT, TT + 2 Hh) -> [0, 2 Hh) (32-bit words; dilation 2: rows [32, 32 + Hh) -> [0, Hh) of either half)
@@ -1325,9 +1323,10 @@ __global__ __launch_bounds__(512) void gated_block_dgrad3_kernel(BlockDgradArgs 
         }
       }
     }
+    NSC_STAMP(3);
     nsc_lds_barrier();
+    NSC_STAMP(4);
     const int ntile = tile + 1 < last ? tile + 1 : tile;
-    prefetch_dy(ntile, !next_steady);                            // (lands during this tile; the staged registers are free again)
 
     // ---- k9 gradient: this wave's k-steps, all row tiles, both column tiles ----
     {
@@ -1337,20 +1336,27 @@ __global__ __launch_bounds__(512) void gated_block_dgrad3_kernel(BlockDgradArgs 
       nsc_lds_cu16 yb[3];
 #pragma unroll
       for (int p = 0; p < 3; ++p) yb[p] = nsc_opaque_lds(dyp + p * PLY + (ja0 + l15) * CP + 8 * kq + 32 * wave);
+      // (activation fragments one row tile ahead, scheduling fences as in the forward)
+      bf16x8 af[2][3];
+      auto fetch = [&](int st_, int slot) {                     // step st_ = (k-step i = st_ / NRTF, row tile r = st_ % NRTF)
+        const int i = st_ / NRTF, r = st_ - i * NRTF;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) af[slot][p] = ld_frag8(yb[p] + r * 16 * CP + i * 256);
+      };
+      fetch(0, 0);
 #pragma unroll
       for (int i = 0; i < NI9; ++i) {
         if (i + 1 < NI9) load_w9(i + 1);
-        if (wave + 8 * i < NKS9) {
 #pragma unroll
-          for (int r = 0; r < NRTF; ++r) {
-            if (r < nrt) {
-              bf16x8 af[3];
-#pragma unroll
-              for (int p = 0; p < 3; ++p) af[p] = ld_frag8(yb[p] + r * 16 * CP + i * 256);
-              acc[r][0] = mfma_split6(af, wq[i & 1][0], acc[r][0]);
-              acc[r][1] = mfma_split6(af, wq[i & 1][1], acc[r][1]);
-            }
+        for (int r = 0; r < NRTF; ++r) {
+          const int st_ = i * NRTF + r;
+          if (st_ + 1 < NI9 * NRTF) fetch(st_ + 1, (st_ + 1) & 1);
+          __builtin_amdgcn_sched_barrier(0);
+          if (wave + 8 * i < NKS9 && r < nrt) {
+            acc[r][0] = mfma_split6(af[st_ & 1], wq[i & 1][0], acc[r][0]);
+            acc[r][1] = mfma_split6(af[st_ & 1], wq[i & 1][1], acc[r][1]);
           }
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
       // partial sums: the lane holds 4 consecutive columns (rows of the product) of channel ct * 16 + l15
@@ -1365,61 +1371,95 @@ __global__ __launch_bounds__(512) void gated_block_dgrad3_kernel(BlockDgradArgs 
         }
     }
     load_w15(0);
+    NSC_STAMP(5);
     nsc_lds_barrier();
+    NSC_STAMP(6);
 
     // ---- GLU backward: dg = the eight partial sums; dlin | dgate -> memory (da) and the da planes ----
     {
       const int st_lo = fresh ? Hh : 2 * Hh, st_hi = next_steady ? W_a : Hh + TT;
       const int sda = b * a.da_rows * T * 4;
-      auto glu1 = [&](int c, int i, float l, float tg) {           // channel c, column ja0 + i of this tile's new columns
-        const int ja = ja0 + i;
-        const float* pp = part + c * PW + i;
-        float gg = 0.f;
-#pragma unroll
-        for (int w = 0; w < 8; ++w) gg += pp[w * NARROW * PW];
-        const float dl_ = gg * tg, dgt = gg * l * (1.f - tg * tg);
+      // an item = (channel pair 2 cp, 2 cp + 1; column ja0 + i): dlin of the pair is one 32-bit word of a da plane, dgate another
+      auto glu2 = [&](int cp, int i, const float (&l)[2], const float (&tg)[2]) {
+        const int ja = ja0 + i, c = 2 * cp;
         const int t = t0 - Hh + ja;
         const int vo = (ja >= st_lo && ja < st_hi && t >= 0 && t < T) ? (c * T + t) * 4 : OOB;
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, dl_), sdlin, vo, sda, NSC_AUX_LATE);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, dgt), sdgate, vo, sda, NSC_AUX_LATE);
-        unsigned pk[3];
-        nsc_split2(dl_, dgt, pk);
+        float dl_[2], dgt[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const float* pp = part + (c + e) * PW + i;
+          float gg = 0.f;
+#pragma unroll
+          for (int w = 0; w < 8; ++w) gg += pp[w * NARROW * PW];
+          dl_[e] = gg * tg[e];
+          dgt[e] = gg * l[e] * (1.f - tg[e] * tg[e]);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, dl_[e]), sdlin, vo, sda + e * T * 4, NSC_AUX_LATE);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, dgt[e]), sdgate, vo, sda + e * T * 4, NSC_AUX_LATE);
+        }
+        unsigned pl_[3], pg_[3];
+        nsc_split2(dl_[0], dl_[1], pl_);
+        nsc_split2(dgt[0], dgt[1], pg_);
         u16* dst = dap + dsg_aoff<DIL>(ja) + c;
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
-          dst[p * PLA] = (u16)(pk[p] & 0xffffu);
-          dst[p * PLA + NARROW] = (u16)(pk[p] >> 16);
+          *reinterpret_cast<unsigned*>(dst + p * PLA) = pl_[p];
+          *reinterpret_cast<unsigned*>(dst + p * PLA + NARROW) = pg_[p];
         }
       };
 #pragma unroll
-      for (int it = 0; it < NIA; ++it) {
-        const int c = wave + 8 * it;
-        if (c < NARROW) {
-          glu1(c, jl, plA[it], ptA[it]);
-          if (fresh && 64 + jl < W_a) glu1(c, 64 + jl, plB[it], ptB[it]);
+      for (int it = 0; it < NIG; ++it) {
+        const int cp = wave + 8 * it;
+        if (cp < NARROW / 2) {
+          glu2(cp, jl, plA[it], ptA[it]);
+          if (fresh && 64 + jl < W_a) glu2(cp, 64 + jl, plB[it], ptB[it]);
         }
       }
-      prefetch_lt(ntile, !next_steady);
     }
+    NSC_STAMP(7);
     nsc_lds_barrier();
+    NSC_STAMP(8);
 
     // ---- k15 gradient: this wave's k-steps, four row tiles, both column tiles ----
+    // (first the loads that have this phase and the next to arrive: this tile's residual dy / x pieces of the copy-out - x is touched
+    // here for the first time: from HBM)
+    constexpr int NR1 = NCT > 4 ? 4 : 2;                          // row tiles of this wave in the 1x1 gradient
+    const int r0 = NCT > 4 ? 0 : 2 * (wave >> 2);
+    const int co = ct1 * 16 + l15;
+    f32x4 yv[NR1], xv[NR1];
+#pragma unroll
+    for (int r = 0; r < NR1; ++r) {
+      const int t = t0 + (r0 + r) * 16 + 4 * kq;
+      const int vo = (co < C_ && t < T && (NCT <= 4 || wave < NCT)) ? ((b * C_ + co) * T + t) * 4 : OOB;
+      yv[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(sdy, vo, 0, 0));
+      xv[r] = a.in_act == NSC_ACT_LRELU ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(sxx, vo, 0, 0)) : (f32x4){1.f, 1.f, 1.f, 1.f};
+    }
     {
       f32x4 acc[4][2];
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[r][0] = acc[r][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      nsc_lds_cu16 ab[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) ab[p] = nsc_opaque_lds(dap + p * PLA + 8 * kq + 32 * wave);
+      bf16x8 af[2][3];
+      auto fetch = [&](int st_, int slot) {                     // step st_ = (k-step i = st_ / 4, row tile r = st_ % 4)
+        const int i = st_ >> 2, r = st_ & 3;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) af[slot][p] = ld_frag8(ab[p] + dsg_aoff<DIL>(r * 16 + l15) + i * 256);
+      };
+      fetch(0, 0);
 #pragma unroll
       for (int i = 0; i < NI15; ++i) {
         if (i + 1 < NI15) load_w15(i + 1);
-        if (wave + 8 * i < NKS15) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            bf16x8 af[3];
-#pragma unroll
-            for (int p = 0; p < 3; ++p) af[p] = ld_frag8((nsc_lds_cu16)(dap + p * PLA + dsg_aoff<DIL>(r * 16 + l15) + 8 * kq + 32 * (wave + 8 * i)));
-            acc[r][0] = mfma_split6(af, wq[i & 1][0], acc[r][0]);
-            acc[r][1] = mfma_split6(af, wq[i & 1][1], acc[r][1]);
+        for (int r = 0; r < 4; ++r) {
+          const int st_ = i * 4 + r;
+          if (st_ + 1 < NI15 * 4) fetch(st_ + 1, (st_ + 1) & 1);
+          __builtin_amdgcn_sched_barrier(0);
+          if (wave + 8 * i < NKS15) {
+            acc[r][0] = mfma_split6(af[st_ & 1], wq[i & 1][0], acc[r][0]);
+            acc[r][1] = mfma_split6(af[st_ & 1], wq[i & 1][1], acc[r][1]);
           }
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
 #pragma unroll
@@ -1431,14 +1471,20 @@ __global__ __launch_bounds__(512) void gated_block_dgrad3_kernel(BlockDgradArgs 
         }
     }
     load_w9(0);                                                  // (for the next tile: they arrive under the phases below)
+    NSC_STAMP(9);
     nsc_lds_barrier();
+    NSC_STAMP(10);
 
     // ---- dz1 = (sum of the partial sums) . lrelu'(h) -> memory and the dz1 planes ----
+    // (the next tile's dy, lin and tanh go out here: their registers are free from now on, and two phases plus the next tile's
+    // staging / k9 gradient are time enough)
+    prefetch_dy(ntile, !next_steady);
+    prefetch_lt(ntile, !next_steady);
     {
 #pragma unroll
       for (int p = 0; p < 3; ++p) w1f[p] = __builtin_bit_cast(bf16x8, img4[F1 + (ct1 * 3 + p) * 64]);
 #pragma unroll
-      for (int it = 0; it < NIA; ++it) {
+      for (int it = 0; it < 3; ++it) {
         const int c = wave + 8 * it, tt = jl;
         if (c < NARROW) {
           const float* pp = part + c * PW + tt;
@@ -1456,22 +1502,13 @@ __global__ __launch_bounds__(512) void gated_block_dgrad3_kernel(BlockDgradArgs 
       }
       prefetch_h(ntile);
     }
+    NSC_STAMP(11);
     nsc_lds_barrier();
+    NSC_STAMP(12);
 
     // ---- 1x1 gradient + residual, . act'(x): dx rows leave as 16-byte pieces (4 consecutive steps of one channel per lane) ----
     {
-      constexpr int NR1 = NCT > 4 ? 4 : 2;                        // row tiles of this wave
-      const int r0 = NCT > 4 ? 0 : 2 * (wave >> 2);
-      const int co = ct1 * 16 + l15;
       if (NCT <= 4 || wave < NCT) {
-        f32x4 yv[NR1], xv[NR1];
-#pragma unroll
-        for (int r = 0; r < NR1; ++r) {
-          const int t = t0 + (r0 + r) * 16 + 4 * kq;
-          const int vo = (co < C_ && t < T) ? ((b * C_ + co) * T + t) * 4 : OOB;
-          yv[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(sdy, vo, 0, 0));
-          xv[r] = a.in_act == NSC_ACT_LRELU ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(sxx, vo, 0, 0)) : (f32x4){1.f, 1.f, 1.f, 1.f};
-        }
 #pragma unroll
         for (int r = 0; r < NR1; ++r) {
           bf16x8 af[3];
@@ -1492,8 +1529,11 @@ __global__ __launch_bounds__(512) void gated_block_dgrad3_kernel(BlockDgradArgs 
         }
       }
     }
+    NSC_STAMP(13);
     nsc_lds_barrier();   // the planes and the partial sums are rewritten by the next tile
+    NSC_STAMP(14);
   }
+  NSC_STAMP(15);
 }
 
 template <int C_, int DIL>

@@ -899,10 +899,13 @@ class CascadeEngine:
     fused_quant = True   # the training-shape quantizer forward in the launch of the encoder's output conv (nsc_conv1d_cout1_fwd_quant)
     # Arithmetic of the gated blocks' long contractions: False = the exact fp32 matrix instruction (csrc/block.hip); True = the bf16
     # matrix cores on operands split into three bf16 pieces, six products, fp32 accumulation (csrc/block_split.hip: fp32-class
-    # error, the vector ALU left free).  NSC_BLOCK_ARITH=exact|split overrides the default for A/B runs.
-    split_fwd = os.environ.get("NSC_BLOCK_ARITH", "exact") == "split"
-    split_wgrad_arith = os.environ.get("NSC_BLOCK_ARITH", "exact") == "split"   # (split_wgrad is the two-light-launches switch above)
-    split_dgrad = os.environ.get("NSC_BLOCK_ARITH", "exact") == "split" and os.environ.get("NSC_SPLIT_DGRAD", "1") == "1"
+    # error, the vector ALU left free: the default since round 5 - numerics gate in profiles/r05_numerics_gate.txt).
+    # NSC_BLOCK_ARITH=exact|split overrides the default for A/B runs.
+    split_fwd = os.environ.get("NSC_BLOCK_ARITH", "split") == "split"
+    split_wgrad_arith = os.environ.get("NSC_BLOCK_ARITH", "split") == "split"   # (split_wgrad is the two-light-launches switch above)
+    # the split-operand DATA gradient (gated_block_dgrad3_kernel) is correct and tested but no faster than the exact pair launches
+    # yet (profiles/r05h_dgrad_split_time.txt: 0.8-0.98x): off unless asked for
+    split_dgrad = os.environ.get("NSC_SPLIT_DGRAD", "0") == "1"
     fused_pairs = True   # the dil-1 / dil-2 blocks of a stack in ONE launch (nsc_gated_block_pair_fwd_img / _dgrad_img: neighbour flags
                          # between workgroups instead of a kernel boundary); False: one launch per block
     fused_chain = True   # the cascade step / output-gradient arithmetic between codecs rides in the epilogue of the Cout = 1 convs

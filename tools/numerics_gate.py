@@ -1,0 +1,46 @@
+"""Numerics gate of the split-operand arithmetic: the B = 128 value tests and the reference-executed fixtures run
+under BOTH arms of the gated-block kernels (NSC_BLOCK_ARITH=exact | split); the achieved error of every gradient class against the
+float64 oracle is recorded for both, and the split arm must stay within 1.5x of the exact arm (+ the floor the tests themselves use).
+Writes gpurun_out/r05_numerics_gate.txt and the per-arm records next to it.   python tools/numerics_gate.py"""
+import json, os, shutil, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "gpurun_out")
+os.makedirs(OUT, exist_ok=True)
+FILES = ["grad_ratios_joint.json", "grad_ratios_follower.json", "refexec_grad_margins_td.json", "refexec_grad_margins_lp.json"]
+lines, rec = [], {}
+for arm in ("exact", "split"):
+    env = dict(os.environ, NSC_BLOCK_ARITH=arm)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "tests/test_fullsize_gpu.py", "tests/test_reference_exec_gpu.py",
+                        "tests/test_block_split_gpu.py"], cwd=ROOT, env=env, capture_output=True, text=True)
+    tail = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-300:]
+    lines.append(f"arm {arm}: pytest tests/test_fullsize_gpu.py tests/test_reference_exec_gpu.py tests/test_block_split_gpu.py -> rc {r.returncode}: {tail}")
+    rec[arm] = {}
+    for f in FILES:
+        src = os.path.join(OUT, f)
+        if os.path.exists(src):
+            dst = os.path.join(OUT, "r05_" + f.replace(".json", f"_{arm}.json"))
+            shutil.copy(src, dst)
+            rec[arm][f] = json.load(open(src))
+ok = True
+for f in FILES[:2]:
+    if f not in rec.get("exact", {}) or f not in rec.get("split", {}):
+        lines.append(f"{f}: missing")
+        ok = False
+        continue
+    lines.append(f"--- {f}: max |grad - float64| / tensor scale per gradient class at B = 128 (hip = the product, fp32_cpu = the PyTorch-CPU float32 oracle)")
+    for k, ve in rec["exact"][f].items():
+        vs = rec["split"][f].get(k)
+        if vs is None:
+            continue
+        e, s_ = ve["hip"], vs["hip"]
+        flag = "" if s_ <= 1.5 * e + 1e-6 else "   <-- above 1.5x exact + 1e-6"
+        ok = ok and not flag
+        lines.append(f"   {k:34s} exact {e:.3e}   split {s_:.3e}   ratio {s_ / max(e, 1e-30):5.2f}   (fp32 CPU oracle {ve['fp32_cpu']:.3e}){flag}")
+for f in FILES[2:]:
+    for arm in ("exact", "split"):
+        if f in rec.get(arm, {}):
+            used = {k: v["used"] for k, v in rec[arm][f].items()}
+            lines.append(f"{f} [{arm}]: largest share of a gradient bound used, per phase / optimizer: {used}")
+lines.append("GATE: " + ("green" if ok and all("rc 0" in l for l in lines[:1] + [l for l in lines if l.startswith("arm split")]) else "see above"))
+open(os.path.join(OUT, "r05_numerics_gate.txt"), "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
