@@ -11,8 +11,9 @@ synthetic 16 kHz frames.  A "step" = one optimizer step over one bat
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
 `python bench.py --gpus N` with N > 1 and no launcher environment starts the N ranks ITSELF: the parent (which never touches
-a GPU) runs `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child process, relays rank 0's JSON line
-and exits with the child's return code.
+a GPU: the device count comes from sysfs) runs `python -m torch.distributed.run --standalone --nproc-per-node N bench.py ...` as a
+child process, relays rank 0's JSON line and exits with the child's return code; if the first set of ranks dies before printing,
+one more set of fresh ranks runs without HSA_ENABLE_IPC_MODE_LEGACY (spawn_ranks).
 
 Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel class of the step (the persistent gated-block
 data-gradient kernel, gated_block_dgrad2_kernel, unless another class takes a larger share), timed live with HIP events on
@@ -155,32 +156,63 @@ class _NullComm:
         pass
 
 
+def _count_gpus_sysfs():
+    """GPUs of this node WITHOUT touching HIP / HSA (torch.cuda.device_count() initialises the runtime on ROCm builds without amdsmi):
+    KFD topology nodes with a non-zero simd_count.  None when the topology is not readable (the children then report what they see)."""
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    if not os.path.isdir("/sys/class/kfd"):
+        return 0                               # no amdgpu compute driver on this machine
+    try:
+        n = 0
+        for d in os.listdir(root):
+            with open(os.path.join(root, d, "properties")) as f:
+                for line in f:
+                    if line.startswith("simd_count"):
+                        n += int(line.split()[1]) > 0
+                        break
+        return n
+    except OSError:
+        return None
+
+
 def spawn_ranks(n, argv):
-    """--gpus N > 1 without a launcher: start N fresh ranks under torch.distributed.run as a CHILD process (this parent has not
-    initialised a GPU and never does; nothing is exec'ed), relay the child's output and return its exit code."""
+    """--gpus N > 1 without a launcher: start N fresh ranks under torch.distributed.run as a CHILD process and relay rank 0's JSON
+    line.  This parent never initialises a GPU (the device count comes from sysfs), nothing is exec'ed, and the rendezvous port is
+    picked by the launcher itself (--standalone: a c10d store on a free loopback port - no bind / close / reuse race).
+    First contact with RCCL: the children run with HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC, what this driver supports; already
+    exported on the pool's boxes).  If they exit non-zero BEFORE rank 0 printed its line, ONE more set of fresh children is started
+    with the variable unset - a new child process, not a restart of a process that touched a GPU - and the line says so."""
     backend = os.environ.get("NSC_DIST_BACKEND") or "nccl"
-    ndev = torch.cuda.device_count()          # (counting devices does not initialise the GPU on this stack)
-    if backend == "nccl" and ndev < n:
+    ndev = _count_gpus_sysfs()
+    if backend == "nccl" and ndev is not None and ndev < n:
         print(f"[bench] --gpus {n} needs {n} GPUs for RCCL (one rank per GPU) but this node shows {ndev}; nothing was launched.  "
               f"(NSC_DIST_BACKEND=gloo shares the visible GPU(s) between ranks: control-flow test only.)", file=sys.stderr)
         return 2
-    with socket.socket() as so:               # a free rendezvous port on the loopback interface
-        so.bind(("127.0.0.1", 0))
-        port = so.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={n}", os.path.abspath(__file__)] + list(argv)
+
+    def attempt(env, note):
+        print(f"[bench] launching {n} ranks{note}: {' '.join(cmd)}", file=sys.stderr, flush=True)
+        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True)
+        line_json = None
+        for line in proc.stdout:              # rank 0 prints the ONE JSON line; anything else goes to stderr untouched
+            if line.lstrip().startswith("{") and '"metric"' in line:
+                line_json = line.strip()
+            else:
+                sys.stderr.write(line)
+        return proc.wait(), line_json
+
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL's intra-node transport on this driver
     env.setdefault("OMP_NUM_THREADS", "8")
-    print(f"[bench] launching {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
-    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True)
-    line_json = None
-    for line in proc.stdout:                  # rank 0 prints the ONE JSON line; anything else goes to stderr untouched
-        if line.lstrip().startswith("{") and '"metric"' in line:
-            line_json = line.strip()
-        else:
-            sys.stderr.write(line)
-    rc = proc.wait()
+    rc, line_json = attempt(env, "")
+    if rc != 0 and line_json is None and backend == "nccl" and os.environ.get("NSC_BENCH_NO_IPC_RETRY") is None:
+        env2 = dict(env)
+        env2.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)
+        env2["NSC_BENCH_LAUNCH_NOTE"] = "second set of ranks, HSA_ENABLE_IPC_MODE_LEGACY unset (the first set exited with %d before printing)" % rc
+        print(f"[bench] the ranks exited with {rc} before printing a line; ONE more set of fresh ranks without HSA_ENABLE_IPC_MODE_LEGACY",
+              file=sys.stderr, flush=True)
+        rc, line_json = attempt(env2, " (retry)")
     if line_json is not None:
         print(line_json, flush=True)
     elif rc == 0:
@@ -608,6 +640,7 @@ def main():
                                     "LSF quantizer, joint finetune step, fwd+loss+bwd+TF1-Adam") +
                                    ("+RCCL grad all-reduce(sum)" if comm.world > 1 else ""),
                        "batch_per_gpu": B, "global_batch": B * comm.world, "frame": 512,
+                       **({"launch_note": os.environ["NSC_BENCH_LAUNCH_NOTE"]} if os.environ.get("NSC_BENCH_LAUNCH_NOTE") else {}),
                        "parallelism": f"dp{comm.world}", "block_arithmetic": "split" if split_on else "exact", "launch": launch, "all_ranks_same_launch": all_same,
                        "c_abi_calls_per_step": calls_per_step, "pair_launches": bool(eng.fused_pairs), "pair_launch_timeouts": pair_to, **({"pair_launches_note": pairs_note} if pairs_note else {}),
                        "grad_message": (("one per trainable scope, under the backward pass" if eng.dp_overlap else

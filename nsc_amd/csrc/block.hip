@@ -2491,10 +2491,10 @@ __device__ __forceinline__ void gated_block_dgrad2_role(const BlockDgradArgs& a,
     }
     NSC_STAMP(5);
     if (dma15 && tile == first) {
-      // the k15 table's LDS-DMA has had the whole k9-gradient phase to land.  Vector-memory operations retire in order: the only
-      // younger ones are the NQY dy prefetch loads of the hooks above (spread form), so vmcnt(NQY) = "the DMA is in LDS".
-      if (spread) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQY) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // the k15 table's LDS-DMA has had the whole k9-gradient phase to land.
+      // (vmcnt(0), not a count of the younger prefetch loads - ADVICE r4: a counted wait breaks silently when a load or store is added
+      // between the DMA and this point; first tile of a launch only, and the dy prefetch it also waits for went out a phase ago)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     nsc_lds_barrier();
     NSC_STAMP(6);

@@ -453,6 +453,11 @@ class _Codec:
         e = self.eng
         if not (e.fused_pairs and e.fused_fwd and e.fused_dgrad and e.use_images and len(blocks) == 2):
             return False
+        # A pair launch needs every one of its workgroups resident at once.  With per-scope gradient messages under the backward
+        # pass (dp_overlap) a collective's kernel can hold compute units while a 256-workgroup pair launch waits for them: its
+        # neighbour waits would spin into the time-out.  The default tail message overlaps nothing and keeps the pairs.
+        if e.dp_overlap and e._dp_comm_attached:
+            return False
         b0, b1 = blocks
         return ((b0.Cin == b0.wide or (b0.Cin == 1 and e.batch_cin1_wgrad)) and b0.wide == b1.Cin == b1.wide and
                 b0.wide in (100, 50, 25) and b0.cl.dil == 1 and b1.cl.dil == 2 and
@@ -806,7 +811,10 @@ class CascadeEngine:
                         setattr(b, attr, n + extra)
                         extra += nf
                 # ... and the SPLIT images of the bf16-matrix-core kernels (csrc/block_split.hip): 32-bit words of packed bf16 pieces
+                # (the data-gradient images only when that kernel is switched on: they are re-gathered every step)
                 for which, attr in ((0, "simg_fwd_off"), (1, "simg_bwd_off")):
+                    if which == 1 and not self.split_dgrad:
+                        continue
                     nf = int(self.lib.nsc_gated_block_simage_words(which, int(b.wide), int(b.Cin), int(b.cl.dil)))
                     if nf > 0:
                         extra = (n + extra + 3) // 4 * 4 - n
@@ -928,6 +936,7 @@ class CascadeEngine:
                          # flushes, 3.360 at the tail, 3.352 for the single-GPU graph - splitting the batched launches costs
                          # 0.14 ms, more than the ~0.05 ms an exposed 2.8 MB all-reduce takes
     _rec = None          # segment recorder while a step is being captured (capture_train_step)
+    _dp_comm_attached = False   # a communicator is attached to the step being run / captured (train_step, capture_train_step)
 
     def _collective(self, kind, fn):
         """Every collective of a step goes through here.  Eager: run it.  While a step is being captured as hipGraph
@@ -1483,6 +1492,7 @@ class CascadeEngine:
             self._leave()
 
     def _train_step(self, x, target, cfg, lpc_x, comm):
+        self._dp_comm_attached = comm is not None
         # ONE launch opens the step: zero gradients + histograms, rebuild the data-gradient kernels / parameter images (refresh_wt),
         # advance the optimizer's device step counter (read by the Adam launch at the end of this step)
         slot = cfg.get("slot", 1)

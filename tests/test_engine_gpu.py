@@ -417,6 +417,23 @@ def test_parameter_write_after_refresh_invalidates_the_block_images():
             assert torch.equal(got, want), how + " after refresh"
 
 
+def test_pair_launches_are_off_under_per_scope_gradient_messages():
+    """with dp_overlap (a collective's kernel may hold compute units under the backward pass) and a communicator
+    attached, the stacks must not use the pair launches (all their workgroups have to be resident at once); the default tail
+    message keeps them."""
+    ps = make_store(1, [[2]], [32], seed=1)
+    eng = _engine(2, 1, [[2]], [32], ps)
+    c = eng.codecs[0]
+    stack = c.enc_stages[0][0]
+    if not eng.fused_pairs:
+        pytest.skip("pair launches are off in this process (ranks share a device)")
+    assert c._pair_ok(stack)
+    eng.dp_overlap, eng._dp_comm_attached = True, True
+    assert not c._pair_ok(stack)
+    eng.dp_overlap = False
+    assert c._pair_ok(stack)
+
+
 def test_bench_line_contract():
     """`python bench.py` (the command the driver runs) prints ONE JSON line with the contract's keys; the live roofline record carries
     the kernel's average launch time corrected by the event bracket's own overhead (measured in the same run) and stays below the peak."""
