@@ -290,31 +290,34 @@ def mse_loss(decoded, original):
     return np.sqrt(np.mean((decoded - original) ** 2, axis=-1) + 1e-7)
 
 
-def hertz_to_mel(f):
-    return 1127.0 * np.log1p(np.asarray(f, np.float64) / 700.0)
+def hertz_to_mel(f, dtype=np.float64):
+    return (dtype(1127.0) * np.log1p(np.asarray(f, dtype) / dtype(700.0))).astype(dtype)
 
 
 def linear_to_mel_weight_matrix(num_mel_bins, num_spectrogram_bins=257, sample_rate=16000,
-                                lower_edge_hertz=0.0, upper_edge_hertz=8000.0):
+                                lower_edge_hertz=0.0, upper_edge_hertz=8000.0, dtype=np.float64):
     """tf.signal.linear_to_mel_weight_matrix [TF-semantics] (loss_terms_and_measures.py:138):
-    HTK mel scale, DC bin zeroed, triangles built in the mel domain, computed in float64."""
-    nyquist = sample_rate / 2.0
-    lin = np.linspace(0.0, nyquist, num_spectrogram_bins)[1:]
-    spec_mel = hertz_to_mel(lin)[:, None]
-    edges = np.linspace(hertz_to_mel(lower_edge_hertz), hertz_to_mel(upper_edge_hertz), num_mel_bins + 2)
+    HTK mel scale, DC bin zeroed, triangles built in the mel domain.
+    dtype: the precision of the whole computation.  The shim / oracle / product take float64 then cast the result to float32
+    (TensorFlow >= 2.1 computes in float64 internally); TensorFlow 2.0 - the README badge of the reference - computes every step in
+    the requested dtype, float32.  tests/test_mel_precision.py bounds what that choice does to mfcc_loss and its gradient."""
+    nyquist = dtype(sample_rate / 2.0)
+    lin = np.linspace(dtype(0.0), nyquist, num_spectrogram_bins, dtype=dtype)[1:]
+    spec_mel = hertz_to_mel(lin, dtype)[:, None]
+    edges = np.linspace(hertz_to_mel(lower_edge_hertz, dtype), hertz_to_mel(upper_edge_hertz, dtype), num_mel_bins + 2, dtype=dtype)
     lower, center, upper = edges[:-2][None, :], edges[1:-1][None, :], edges[2:][None, :]
     lower_slopes = (spec_mel - lower) / (center - lower)
     upper_slopes = (upper - spec_mel) / (upper - center)
-    w = np.maximum(0.0, np.minimum(lower_slopes, upper_slopes))
-    return np.pad(w, [[1, 0], [0, 0]])
+    w = np.maximum(dtype(0.0), np.minimum(lower_slopes, upper_slopes))
+    return np.pad(w, [[1, 0], [0, 0]]).astype(dtype)
 
 
 MEL_BANKS = (8, 16, 32, 128)  # loss_terms_and_measures.py:133
 
 
-def mel_matrix_cat():
-    """The 4 banks concatenated to [257, 184]; cast through float32 like TF's returned matrix."""
-    return np.concatenate([linear_to_mel_weight_matrix(n) for n in MEL_BANKS], axis=1) \
+def mel_matrix_cat(dtype=np.float64):
+    """The 4 banks concatenated to [257, 184]; cast through float32 like TF's returned matrix (dtype: see above)."""
+    return np.concatenate([linear_to_mel_weight_matrix(n, dtype=dtype) for n in MEL_BANKS], axis=1) \
         .astype(np.float32).astype(np.float64)
 
 
