@@ -83,6 +83,75 @@ def step_cfg():
                 trainable=[True, True], lr=LR, slot=1, c_quan_lpc=COEFF[2], c_ent_lpc=0.0, train_lpc=True, quan_op=True, global_entropy=False)
 
 
+def op_surface_leg(B, x_np, dev, steps=20, warmup=3):
+    """The SAME codec step built from the drop-in op surface (nsc_amd.nn_core_operator / loss_terms_and_measures under torch autograd:
+    what a user of the reference's nn_core_operator.py gets) beside the engine's figure for BASELINE config 2 (1 codec, strides [2],
+    32 bins, quan + entropy terms), both timed here at the same batch.  The surface leg is forward + loss + backward (gradients of
+    every variable); the engine's step also applies TF1-Adam."""
+    from nsc_amd import loss_terms_and_measures as L
+    from nsc_amd.engine import CascadeEngine
+    from nsc_amd.neural_speech_coding_module import neuralSpeechCodingModule
+    from nsc_amd.scope import VariableStore, set_store
+    xe = torch.from_numpy(x_np[:B].copy()).to(dev)          # [B,1,512] (the engine's layout)
+    xd = xe.reshape(B, 512, 1)                              # channels_last, like the reference's placeholder
+    tgt = xd[:, :, 0].contiguous()
+    st = VariableStore(device=str(dev))
+    set_store(st)
+    try:
+        m = neuralSpeechCodingModule.__new__(neuralSpeechCodingModule)
+        m._bottleneck_kernel_and_dilation = list(BKD)
+
+        def surface_step():
+            st.begin_pass()
+            for v in st.vars.values():
+                v.grad = None
+            p, _, _, _, decoded, _, _, _ = m.computational_graph_end2end_quan_on(xd, True, 1.0, 32, "scope_1", [2])
+            loss = (COEFF[0] * L.mse_loss(decoded, tgt) + COEFF[1] * L.mfcc_loss(decoded, tgt) + COEFF[2] * L.quan_loss(p)).sum() + \
+                B * 0.3 * L.entropy_coding_loss(p)
+            loss.backward()
+
+        def timed(fn, n):
+            fn(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n
+
+        for _ in range(warmup):
+            surface_step()
+        torch.cuda.synchronize()
+        t_surface = timed(surface_step, steps)
+    finally:
+        set_store(None)
+    eng = CascadeEngine(B, 1, BKD, [[2]], [32], res_scalar=RES_SCALAR, scale_first=False, lpc=False, device=dev)
+    cfg = step_cfg_for(2, B, 1)
+    for _ in range(warmup):
+        eng.train_step(xe, xe, cfg)
+    torch.cuda.synchronize()
+    t_eager = timed(lambda: eng.train_step(xe, xe, cfg), steps)
+    t_graph = None
+    try:
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            eng.train_step(xe, xe, cfg)
+        torch.cuda.current_stream().wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            eng.train_step(xe, xe, cfg)
+        t_graph = timed(g.replay, steps)
+    except Exception as e:                                  # the eager figure stands
+        print(f"[bench] op_surface: engine graph capture failed ({e})", file=sys.stderr)
+    t_eng = t_graph if t_graph is not None else t_eager
+    return dict(frames_per_s=round(B / t_surface, 1), ms_per_step=round(1e3 * t_surface, 3), launch="eager (torch autograd tape)",
+                work="forward + loss + backward of one codec through nn_core_operator / loss_terms_and_measures (no optimizer)",
+                engine_config2_frames_per_s=round(B / t_eng, 1), engine_config2_ms_per_step=round(1e3 * t_eng, 3),
+                engine_config2_launch="hipGraph" if t_graph is not None else "eager",
+                engine_config2_eager_ms_per_step=round(1e3 * t_eager, 3),
+                engine_work="the same codec step + TF1-Adam", batch=B, steps=steps, frac_of_engine=round(t_eng / t_surface, 3))
+
+
 def cpu_baseline(B, x_np, lpc_np, budget_s=24.0):
     """float32 PyTorch-CPU port of the same joint step (oracle/nsc_oracle_torch.py).  BASELINE.md section 3 protocol inside
     a bounded budget: warm-up steps, then up to 10 timed steps on all host cores (median step time), plus a 1-thread
@@ -245,6 +314,7 @@ def main():
                          "launches: measured slower) instead of one message at the tail of the step")
     ap.add_argument("--prof-steps", type=int, default=3)
     ap.add_argument("--no-infer", action="store_true", help="skip the codec-forward us/frame measurement")
+    ap.add_argument("--no-op-surface", action="store_true", help="skip the op-surface leg (a codec step built from nn_core_operator ops)")
     ap.add_argument("--no-overlap", action="store_true", help="weight-gradient kernels on the main stream (profiling)")
     ap.add_argument("--wgrad-waves", type=int, default=8)
     ap.add_argument("--no-split-wgrad", action="store_true")
@@ -619,6 +689,10 @@ def main():
                      batch1_latency_us=round(1e6 * t1f, 1), hard_codes=True,
                      tflops=round(4096 / tb * 476.1e6 / 1e12, 2))
 
+    surface = None
+    if comm.rank == 0 and comm.world == 1 and not args.no_op_surface and not args.no_infer:
+        surface = op_surface_leg(B, x_np, dev)
+
     cpu = None
     if comm.rank == 0 and comm.world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(B, x_np, lpc_np)
@@ -650,7 +724,7 @@ def main():
             "model_tflops": round(fps * mflop_frame * 1e6 / 1e12, 2), "mflop_per_frame": mflop_frame,
             "ms_per_step_exact_f32": (round(ms_exact, 3) if ms_exact is not None else None),
             "roofline": roof, "roofline_split_operand_classes": roof_split, "roofline_quantizer": qroof, "cpu_baseline": cpu,
-            "codec_forward": infer, "kernels": kern_ms,
+            "codec_forward": infer, "op_surface": surface, "kernels": kern_ms,
         }
         print(json.dumps(out), flush=True)
     comm.barrier()

@@ -114,6 +114,10 @@ int nsc_conv1d_wgrad_batch(const nsc_conv_wgrad_job* jobs, int njobs, float* wor
                            void* stream);
 /* wt[K-1-k, o, i] = w[k, i, o] : weights of the data-gradient conv (dgrad == nsc_conv1d_fwd on wt). */
 int nsc_weight_flip_transpose(const float* w, float* wt, int K, int Cin, int Cout, void* stream);
+/* The four flipped / transposed kernels nsc_gated_block_dgrad[_cin1] reads, in ONE launch: wt = wt1 [1][narrow][Cin] | wtl [15][narrow][narrow]
+ * | wtr | wt9 [k9][C][narrow], contiguous (Cin*narrow + 2*15*narrow*narrow + k9*narrow*C floats). */
+int nsc_gated_block_flip_weights(const float* w1, const float* wl, const float* wr, const float* w9, float* wt, int C, int Cin,
+                                 int narrow, int k9, void* stream);
 
 /* ---- fused gated bottleneck block (replaces the whole of nn_core_operator.py:82-112 `gated_bottleneck` for
  *      Cin == wide_layer > 1, narrow_layer == 20, non_dilated_neck_kernel_size == 9, "gln" blocks) ----
@@ -290,6 +294,8 @@ int nsc_gather(const float* src, const int* idx, float* dst, long n, void* strea
 int nsc_axpby(const float* x, const float* y, float* out, float a, float b, long n, void* stream); /* out = a*x + b*y (y nullable) */
 int nsc_channel_sum(const float* x, float* out, int B, int C, int T, int accumulate, void* stream); /* out[b,0,t] (+)= sum_c x[b,c,t] */
 int nsc_unshuffle2(const float* ys /*[B,C/2,2T]*/, float* y /*[B,C,T]*/, int B, int C, int T, void* stream);
+/* the sub-pixel shuffle itself (neural_speech_coding_module.py:158-167) on [B,C,T] tensors: ys[b, c>>1, 2t + (c&1)] = y[b,c,t] */
+int nsc_shuffle2(const float* y /*[B,C,T]*/, float* ys /*[B,C/2,2T]*/, int B, int C, int T, void* stream);
 int nsc_transpose_last2(const float* x /*[B,R,Cc]*/, float* y /*[B,Cc,R]*/, int B, int R, int Cc, void* stream);
 /* cascade step between two codecs (cmrl.py:49-94): decoded = sc*dec (+ decoded if accumulate); xin (nullable: last codec)
  * = rs*x - rs*decoded, i.e. the next codec's input res_scalar * (x - sum of the outputs so far) */

@@ -35,6 +35,7 @@ PROTOTYPES = {
     "nsc_frame_entropy": [_P, _I, _I, _I, _P, _P],
     "nsc_conv1d_wgrad_ws": [C.POINTER(ConvDesc), _P, _P, _P, _P, _I, _P, _L, _P],
     "nsc_weight_flip_transpose": [_P, _P, _I, _I, _I, _P],
+    "nsc_gated_block_flip_weights": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "nsc_gated_block_fwd": [_P] * 14 + [_I] * 7 + [_P],
     "nsc_gated_block_fwd_cin1": [_P] * 14 + [_I] * 7 + [_P],
     "nsc_gated_block_wgrad": [_P] * 16 + [_I] * 9 + [_P, _P],
@@ -62,6 +63,7 @@ PROTOTYPES = {
     "nsc_axpby": [_P, _P, _P, _F, _F, _L, _P],
     "nsc_channel_sum": [_P, _P, _I, _I, _I, _I, _P],
     "nsc_unshuffle2": [_P, _P, _I, _I, _I, _P],
+    "nsc_shuffle2": [_P, _P, _I, _I, _I, _P],
     "nsc_transpose_last2": [_P, _P, _I, _I, _I, _P],
     "nsc_sum_all": [_P, _P, _L, _P],
     "nsc_cascade_step": [_P, _P, _I, _P, _P, _F, _F, _L, _P],

@@ -1296,6 +1296,37 @@ __global__ void slab_reduce_batch_kernel(SlabReduceBatch t) {
   }
 }
 
+// The same for a launch with FEW jobs (a caller that flushes block by block: the op surface's BlockFn): the kernel above would run 64
+// workgroups per half, each thread walking all 256 slabs - latency-bound (40 us for one C = 100 job).  Here a workgroup owns 64
+// elements; its four waves take every fourth slab (four loads in flight each), partial sums meet in LDS, still one adder per element.
+__global__ __launch_bounds__(256) void slab_reduce_batch_wide_kernel(SlabReduceBatch t) {
+  __shared__ float part[4][64];
+  const int j = blockIdx.y >> 1, half = blockIdx.y & 1;
+  const int i0 = half ? t.off9[j] : 0, i1 = half ? t.range[j] : t.off9[j];
+  const int w0 = t.w0[j], w1 = t.w1[j];
+  const float* __restrict__ slab = t.slab[j];
+  const long stride = t.stride[j];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int base = i0 + blockIdx.x * 64; base < i1; base += gridDim.x * 64) {   // uniform per workgroup
+    const int i = base + lane;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < i1) {
+      int w = w0 + wave;
+      for (; w + 12 < w1; w += 16) {
+        s0 += slab[(long)w * stride + i];
+        s1 += slab[(long)(w + 4) * stride + i];
+        s2 += slab[(long)(w + 8) * stride + i];
+        s3 += slab[(long)(w + 12) * stride + i];
+      }
+      for (; w < w1; w += 4) s0 += slab[(long)w * stride + i];
+    }
+    part[wave][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (wave == 0 && i < i1) t.grads[j][i] += (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    __syncthreads();
+  }
+}
+
 // grads[i] += sum_w slab[w * stride + i]; blockIdx.y splits the slabs (8 groups) so enough loads are in flight
 __global__ void slab_reduce_kernel(const float* __restrict__ slab, long stride, int nslabs, float* __restrict__ grads, int n) {
   const int per = (nslabs + gridDim.y - 1) / gridDim.y;
@@ -1470,6 +1501,12 @@ static int launch_wgrad_batch(const nsc_block_wgrad_job* jobs, const int* idx, i
 }
 static int launch_slab_reduce(SlabReduceBatch& r, int& nr, hipStream_t st) {
   if (nr == 0) return NSC_OK;
+  if (nr <= 2) {
+    hipLaunchKernelGGL(slab_reduce_batch_wide_kernel, dim3(512, 2 * nr), dim3(256), 0, st, r);
+    NSC_CHECK_LAUNCH("slab_reduce_batch_wide");
+    nr = 0;
+    return NSC_OK;
+  }
   hipLaunchKernelGGL(slab_reduce_batch_kernel, dim3(64, 2 * nr), dim3(256), 0, st, r);
   NSC_CHECK_LAUNCH("slab_reduce_batch");
   nr = 0;

@@ -1800,6 +1800,31 @@ __global__ void weight_flip_transpose_kernel(const float* __restrict__ w, float*
     wt[e] = w[((long)(K - 1 - kt) * Cin + i) * Cout + o];
   }
 }
+// the four kernels of a gated block in ONE launch: wt = wt1 [1][20][Cin] | wtl [15][20][20] | wtr [15][20][20] | wt9 [9][C][20]
+struct Flip4 { const float* w[4]; int K[4], ci[4], co[4], end[4]; };
+__global__ void weight_flip_transpose4_kernel(Flip4 f, float* __restrict__ wt) {
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < f.end[3]; e += gridDim.x * blockDim.x) {
+    const int q = e < f.end[0] ? 0 : (e < f.end[1] ? 1 : (e < f.end[2] ? 2 : 3));
+    const int l = e - (q ? f.end[q - 1] : 0);
+    const int Cin = f.ci[q], Cout = f.co[q];
+    const int i = l % Cin, o = (l / Cin) % Cout, kt = l / (Cin * Cout);
+    wt[e] = f.w[q][((long)(f.K[q] - 1 - kt) * Cin + i) * Cout + o];
+  }
+}
+extern "C" int nsc_gated_block_flip_weights(const float* w1, const float* wl, const float* wr, const float* w9, float* wt, int C,
+                                            int Cin, int narrow, int k9, void* stream) {
+  NSC_REQUIRE(w1 && wl && wr && w9 && wt && C > 0 && Cin > 0 && narrow > 0 && k9 > 0, NSC_ERR_BAD_ARG, "nsc_gated_block_flip_weights: bad args");
+  Flip4 f;
+  f.w[0] = w1; f.K[0] = 1; f.ci[0] = Cin; f.co[0] = narrow;
+  f.w[1] = wl; f.K[1] = 15; f.ci[1] = narrow; f.co[1] = narrow;
+  f.w[2] = wr; f.K[2] = 15; f.ci[2] = narrow; f.co[2] = narrow;
+  f.w[3] = w9; f.K[3] = k9; f.ci[3] = narrow; f.co[3] = C;
+  int end = 0;
+  for (int q = 0; q < 4; ++q) { end += f.K[q] * f.ci[q] * f.co[q]; f.end[q] = end; }
+  hipLaunchKernelGGL(weight_flip_transpose4_kernel, dim3(std::min(1024, nsc_cdiv(end, 256))), dim3(256), 0, (hipStream_t)stream, f, wt);
+  NSC_CHECK_LAUNCH("weight_flip_transpose4");
+  return NSC_OK;
+}
 extern "C" int nsc_weight_flip_transpose(const float* w, float* wt, int K, int Cin, int Cout, void* stream) {
   NSC_REQUIRE(w && wt && K > 0 && Cin > 0 && Cout > 0, NSC_ERR_BAD_ARG, "nsc_weight_flip_transpose: bad args");
   const int n = K * Cin * Cout;

@@ -370,6 +370,24 @@ __global__ void unshuffle2_kernel(const float* __restrict__ ys, float* __restric
     y[e] = ys[(b * (C >> 1) + (c >> 1)) * (2L * T) + 2 * t + (c & 1)];
   }
 }
+// ys[b, c>>1, 2t + (c&1)] = y[b,c,t]   (the sub-pixel shuffle itself, nsc_module:158-167, on [B,C,T] tensors: used by the op surface;
+// the engine's up-sampling kernel shuffles in its epilogue)
+__global__ void shuffle2_kernel(const float* __restrict__ y, float* __restrict__ ys, int C, int T, long n) {
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    const long row = e / (2 * T);                 // (b, c2)
+    const int u = (int)(e - row * 2 * T);         // 2t + j
+    const long b = row / (C / 2);
+    const int c2 = (int)(row - b * (C / 2));
+    ys[e] = y[(b * C + 2 * c2 + (u & 1)) * T + (u >> 1)];
+  }
+}
+extern "C" int nsc_shuffle2(const float* y, float* ys, int B, int C, int T, void* stream) {
+  NSC_REQUIRE(ys && y && B > 0 && C > 0 && !(C & 1) && T > 0, NSC_ERR_BAD_ARG, "nsc_shuffle2: bad args");
+  const long n = (long)B * C * T;
+  hipLaunchKernelGGL(shuffle2_kernel, dim3(std::min<long>(4096, nsc_cdiv(n, 256))), dim3(256), 0, (hipStream_t)stream, y, ys, C, T, n);
+  NSC_CHECK_LAUNCH("shuffle2");
+  return NSC_OK;
+}
 extern "C" int nsc_unshuffle2(const float* ys, float* y, int B, int C, int T, void* stream) {
   NSC_REQUIRE(ys && y && B > 0 && C > 0 && !(C & 1) && T > 0, NSC_ERR_BAD_ARG, "nsc_unshuffle2: bad args");
   const long n = (long)B * C * T;

@@ -14,6 +14,7 @@ from . import ops
 from .scope import current_store
 
 tanh = "tanh"   # stands in for tf.nn.tanh in `activation=` arguments
+FUSED_BLOCKS = True   # gated_bottleneck as one fused kernel per direction where the shape allows (False: composed op by op)
 
 
 def _act_name(activation):
@@ -24,15 +25,20 @@ def _act_name(activation):
     raise ValueError(f"unsupported activation {activation!r} (None, 'tanh' or 'lrelu')")
 
 
+def _conv1d_variables(cin, num_filters, filter_size):
+    """The kernel / bias pair tf.compat.v1.layers.conv1d creates (glorot-uniform kernel, zero bias), under the next free 'conv1d_N'."""
+    st = current_store()
+    name = st.uniq("conv1d")
+    w = st.get(name + "/kernel", (filter_size, cin, num_filters), st.glorot(filter_size * cin, filter_size * num_filters))
+    b = st.get(name + "/bias", (num_filters,), lambda s: torch.zeros(s).numpy())
+    return w, b
+
+
 def conv1d(inputs, num_filters, filter_size, padding='SAME', dilation_rate=1, strides=1, activation=tanh):
     """nn_core_operator.py:6-14 (tf.compat.v1.layers.conv1d, channels_last, glorot-uniform kernel, zero bias)."""
     if padding != 'SAME':
         raise ValueError("only padding='SAME' is used by the reference and implemented")
-    st = current_store()
-    name = st.uniq("conv1d")
-    cin = int(inputs.shape[-1])
-    w = st.get(name + "/kernel", (filter_size, cin, num_filters), st.glorot(filter_size * cin, filter_size * num_filters))
-    b = st.get(name + "/bias", (num_filters,), lambda s: torch.zeros(s).numpy())
+    w, b = _conv1d_variables(int(inputs.shape[-1]), num_filters, filter_size)
     return ops.Conv1dFn.apply(inputs, w, b, int(dilation_rate), int(strides), _act_name(activation))
 
 
@@ -81,7 +87,21 @@ def the_bottleneck(the_input, wide_layer=30, narrow_layer=10, non_dilated_neck_k
 def gated_bottleneck(the_input, wide_layer=30, narrow_layer=10, non_dilated_neck_kernel_size=9, dilated_neck_kernel_size=9,
                      dilation_rate=1, is_last_flat=False, the_share=False):
     """nn_core_operator.py:82-112.  dilated kernel size is the hard-coded 15 of :92/:97 (dilated_neck_kernel_size is
-    ignored there too); `the_share` is unused in the reference."""
+    ignored there too); `the_share` is unused in the reference.
+
+    The shipped shapes (narrow 20, 9-tap output conv, dilation 1 | 2, wide <= 112 with wide input channels, or one input channel into
+    wide in {100, 50, 25}) run as ONE fused call per direction (ops.BlockFn: the persistent block kernels the engine uses); the four
+    convs' variables are created in the same order and under the same names either way.  FUSED_BLOCKS = False, or any other shape:
+    the composed form below, op by op."""
+    cin = int(the_input.shape[-1])
+    fusable = (FUSED_BLOCKS and narrow_layer == 20 and non_dilated_neck_kernel_size == 9 and int(dilation_rate) in (1, 2) and
+               ((cin == wide_layer and 1 < wide_layer <= 112) or (cin == 1 and wide_layer in (100, 50, 25))))
+    if fusable:
+        w1, b1 = _conv1d_variables(cin, narrow_layer, 1)
+        wl, bl = _conv1d_variables(narrow_layer, narrow_layer, 15)
+        wr, br = _conv1d_variables(narrow_layer, narrow_layer, 15)
+        w9, b9 = _conv1d_variables(narrow_layer, wide_layer, non_dilated_neck_kernel_size)
+        return ops.BlockFn.apply(the_input, w1, b1, wl, bl, wr, br, w9, b9, int(dilation_rate), bool(is_last_flat))
     c2 = conv1d(the_input, narrow_layer, filter_size=1, padding='SAME', dilation_rate=1, activation=None)
     c2 = activation_func(c2)
     left = conv1d(c2, narrow_layer, filter_size=15, padding='SAME', dilation_rate=dilation_rate, activation=None)

@@ -7,13 +7,17 @@ and the autograd tape only.  No CPU path: a CPU tensor raises.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
+import numpy as np
 import torch
 
 from . import _lib
 from ._lib import ConvDesc, check
 
 ACT = {None: 0, "none": 0, "tanh": 1, "lrelu": 2}
+# arithmetic of the gated block's weight gradients behind BlockFn: the engine's switch (engine.py: split_wgrad_arith)
+SPLIT_ARITH = os.environ.get("NSC_BLOCK_ARITH", "split") == "split"
 
 
 def _lib_():
@@ -21,13 +25,53 @@ def _lib_():
 
 
 def _st():
-    return torch.cuda.current_stream().cuda_stream
+    """Raw handle of the current HIP stream (torch.cuda.current_stream() builds a Stream object: ~8 us of host time per launch)."""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def _req(t, name="tensor"):
+    """Type check only.  LAYOUT: the kernels work on time-contiguous [B,C,T] memory, the surface speaks channels_last [B,T,C].  An op
+    hands its [B,C,T] result back as the TRANSPOSED VIEW `y.transpose(1, 2)` - shape and values of the [B,T,C] tensor the reference
+    would return, no copy - and the next op recognises such a view (`to_bct`) and uses the memory as it lies: a chain of surface ops
+    transposes nothing.  A tensor that really is channels_last in memory (user data, a torch op in between) is transposed once on
+    the way in (nsc_transpose_last2)."""
     if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32):
         raise _lib.NscError(f"{name}: nsc_amd ops need float32 CUDA tensors (there is no CPU fallback)")
-    return t.contiguous()
+    return t
+
+
+def _is_lazy_bct(x):
+    return x.dim() == 3 and x.shape[-1] > 1 and x.shape[1] > 1 and not x.is_contiguous() and x.transpose(1, 2).is_contiguous()
+
+
+def _mem(x):
+    """The tensor as contiguous memory + whether that memory is [B,C,T] behind a [B,T,C] view (elementwise ops keep the layout)."""
+    if _is_lazy_bct(x):
+        return x.transpose(1, 2), True
+    return x.contiguous(), False
+
+
+def _same_mem(a, b):
+    """Two same-shaped operands of an elementwise op in ONE memory order: [B,C,T] if either already lies that way."""
+    ma, la = _mem(a)
+    mb, lb = _mem(b)
+    if la == lb:
+        return ma, mb, la
+    if la:
+        return ma, to_bct(b), True
+    return to_bct(a), mb, True
+
+
+def _workspace(floats, dev):
+    """Caller-owned scratch of the slab-flush weight-gradient kernels: one buffer per device, grown on demand (launches on one stream
+    are ordered, so they can share it; the old buffer of a grow stays alive until the kernels using it have run - torch's
+    stream-ordered allocator)."""
+    key = ("ws", str(dev))
+    ws = _CACHE.get(key)
+    if ws is None or ws.numel() < floats:
+        ws = torch.empty(max(floats, 1), dtype=torch.float32, device=dev)
+        _CACHE[key] = ws
+    return ws
 
 
 def same_pad(T, k, dil=1, stride=1):
@@ -37,23 +81,24 @@ def same_pad(T, k, dil=1, stride=1):
 
 
 def to_bct(x):
-    """[B,T,C] -> [B,C,T] (free when C == 1)."""
+    """[B,T,C] -> contiguous [B,C,T]: free when C == 1 or when x is the transposed view an op returned; else one transpose launch."""
     B, T, Cc = x.shape
-    if Cc == 1:
-        return x.reshape(B, 1, T)
+    if Cc == 1 or T == 1:
+        return x.contiguous().reshape(B, Cc, T)
+    if _is_lazy_bct(x):
+        return x.transpose(1, 2)
+    x = x.contiguous()
     y = torch.empty((B, Cc, T), dtype=x.dtype, device=x.device)
     check(_lib_().nsc_transpose_last2(x.data_ptr(), y.data_ptr(), B, T, Cc, _st()), "transpose")
     return y
 
 
 def to_btc(x):
-    """[B,C,T] -> [B,T,C]."""
+    """contiguous [B,C,T] -> the [B,T,C] tensor of the surface, as a VIEW of the same memory (see _req)."""
     B, Cc, T = x.shape
     if Cc == 1:
         return x.reshape(B, T, 1)
-    y = torch.empty((B, T, Cc), dtype=x.dtype, device=x.device)
-    check(_lib_().nsc_transpose_last2(x.data_ptr(), y.data_ptr(), B, Cc, T, _st()), "transpose")
-    return y
+    return x.transpose(1, 2)
 
 
 def _desc(B, Cin, Cout, Tin, Tout, K, dil, stride, padL, **kw):
@@ -70,7 +115,7 @@ class Conv1dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, dil, stride, act):
         lib = _lib_()
-        x, w, b = _req(x, "inputs"), _req(w, "kernel"), _req(b, "bias")
+        x, w, b = _req(x, "inputs"), _req(w, "kernel").contiguous(), _req(b, "bias").contiguous()
         B, T, Cin = x.shape
         K, Cin2, Cout = w.shape
         if Cin != Cin2:
@@ -97,15 +142,20 @@ class Conv1dFn(torch.autograd.Function):
             dz2 = torch.empty_like(dz)
             check(lib.nsc_act_bwd(dz.data_ptr(), y.data_ptr(), dz2.data_ptr(), dz.numel(), ACT[act], _st()), "act_bwd")
             dz = dz2
-        dw = torch.zeros_like(w)
-        db = torch.zeros(Cout, dtype=torch.float32, device=w.device)
+        dwb = torch.zeros(w.numel() + Cout, dtype=torch.float32, device=w.device)      # dw | db
+        dw, db = dwb[:w.numel()].view(w.shape), dwb[w.numel():]
+        # partial sums of the (b,t) splits go to private slabs + one reduce launch (nsc_conv1d_wgrad_ws) instead of same-address atomics
         if Cout == 1:
             d = _desc(B, 1, Cin, Tout, T, K, dil, 1, (K - 1) * dil - padL)
-            check(lib.nsc_conv1d_wgrad(C.byref(d), dz.data_ptr(), xb.data_ptr(), dw.data_ptr(), None, 1, _st()), "wgrad")
+            ws = _workspace(int(lib.nsc_conv1d_wgrad_workspace(C.byref(d))), w.device)
+            check(lib.nsc_conv1d_wgrad_ws(C.byref(d), dz.data_ptr(), xb.data_ptr(), dw.data_ptr(), None, 1, ws.data_ptr(), ws.numel(), _st()),
+                  "wgrad")
             check(lib.nsc_sum_all(dz.data_ptr(), db.data_ptr(), dz.numel(), _st()), "bias grad")
         else:
             d = _desc(B, Cin, Cout, T, Tout, K, dil, stride, padL)
-            check(lib.nsc_conv1d_wgrad(C.byref(d), xb.data_ptr(), dz.data_ptr(), dw.data_ptr(), db.data_ptr(), 0, _st()), "wgrad")
+            ws = _workspace(int(lib.nsc_conv1d_wgrad_workspace(C.byref(d))), w.device)
+            check(lib.nsc_conv1d_wgrad_ws(C.byref(d), xb.data_ptr(), dz.data_ptr(), dw.data_ptr(), db.data_ptr(), 0, ws.data_ptr(),
+                                          ws.numel(), _st()), "wgrad")
         dx = None
         if ctx.needs_input_grad[0]:
             wt = torch.empty((K, Cout, Cin), dtype=torch.float32, device=w.device)
@@ -123,7 +173,7 @@ class DepthwiseFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, wd):
-        x, wd = _req(x), _req(wd)
+        x, wd = _req(x), _req(wd).contiguous()
         B, T, Cc = x.shape
         K = wd.shape[0]
         xb = to_bct(x)
@@ -148,20 +198,20 @@ class DepthwiseFn(torch.autograd.Function):
 class ActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, act):
-        x = _req(x)
-        y = torch.empty_like(x)
-        check(_lib_().nsc_act_fwd(x.data_ptr(), y.data_ptr(), x.numel(), ACT[act], _st()), "act")
+        xm, lazy = _mem(_req(x))
+        y = torch.empty_like(xm)
+        check(_lib_().nsc_act_fwd(xm.data_ptr(), y.data_ptr(), xm.numel(), ACT[act], _st()), "act")
         ctx.save_for_backward(y)
-        ctx.act = act
-        return y
+        ctx.act, ctx.lazy = act, lazy
+        return y.transpose(1, 2) if lazy else y
 
     @staticmethod
     def backward(ctx, dy):
         (y,) = ctx.saved_tensors
-        dy = _req(dy)
-        dx = torch.empty_like(dy)
-        check(_lib_().nsc_act_bwd(dy.data_ptr(), y.data_ptr(), dx.data_ptr(), dy.numel(), ACT[ctx.act], _st()), "act_bwd")
-        return dx, None
+        dym = to_bct(_req(dy)) if ctx.lazy else _req(dy).contiguous()
+        dx = torch.empty_like(dym)
+        check(_lib_().nsc_act_bwd(dym.data_ptr(), y.data_ptr(), dx.data_ptr(), dym.numel(), ACT[ctx.act], _st()), "act_bwd")
+        return (dx.transpose(1, 2) if ctx.lazy else dx), None
 
 
 class MulFn(torch.autograd.Function):
@@ -169,21 +219,22 @@ class MulFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, a, b):
-        a, b = _req(a), _req(b)
+        a, b, lazy = _same_mem(_req(a), _req(b))
         out = torch.empty_like(a)
         check(_lib_().nsc_mul(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _st()), "mul")
         ctx.save_for_backward(a, b)
-        return out
+        ctx.lazy = lazy
+        return out.transpose(1, 2) if lazy else out
 
     @staticmethod
     def backward(ctx, dg):
         a, b = ctx.saved_tensors
-        dg = _req(dg)
+        dg = to_bct(_req(dg)) if ctx.lazy else _req(dg).contiguous()
         da, db = torch.empty_like(a), torch.empty_like(b)
         lib = _lib_()
         check(lib.nsc_mul(dg.data_ptr(), b.data_ptr(), da.data_ptr(), a.numel(), _st()), "mul")
         check(lib.nsc_mul(dg.data_ptr(), a.data_ptr(), db.data_ptr(), a.numel(), _st()), "mul")
-        return da, db
+        return (da.transpose(1, 2), db.transpose(1, 2)) if ctx.lazy else (da, db)
 
 
 class AddFn(torch.autograd.Function):
@@ -194,12 +245,16 @@ class AddFn(torch.autograd.Function):
         a, b = _req(a), _req(b)
         ctx.bshape = tuple(b.shape)
         lib = _lib_()
-        out = torch.empty_like(a)
         if a.shape == b.shape:
-            check(lib.nsc_axpby(a.data_ptr(), b.data_ptr(), out.data_ptr(), 1.0, 1.0, a.numel(), _st()), "add")
+            am, bm, lazy = _same_mem(a, b)
+            out = torch.empty_like(am)
+            check(lib.nsc_axpby(am.data_ptr(), bm.data_ptr(), out.data_ptr(), 1.0, 1.0, am.numel(), _st()), "add")
+            if lazy:
+                out = out.transpose(1, 2)
         else:  # broadcast over channels: run the add in [B,C,T] through a 1-tap identity-free path
             assert b.shape[-1] == 1 and a.shape[:2] == b.shape[:2]
             B, T, Cc = a.shape
+            b = b.contiguous()
             ab = to_bct(a)
             ob = torch.empty_like(ab)
             # one launch: an identity 1x1 conv whose epilogue adds the broadcast residual (res_mode 2)
@@ -223,18 +278,90 @@ class AddFn(torch.autograd.Function):
 
 
 class ShuffleFn(torch.autograd.Function):
-    """Sub-pixel shuffle (nsc_module:158-167): out[b, 2t+j, c] = in[b, t, 2c+j]."""
+    """Sub-pixel shuffle (nsc_module:158-167): out[b, 2t+j, c] = in[b, t, 2c+j] - in [B,C,T] memory: out[b, c, 2t+j] = in[b, 2c+j, t]
+    (nsc_shuffle2 / nsc_unshuffle2)."""
 
     @staticmethod
     def forward(ctx, x):
-        x = _req(x)
-        B, T, Cc = x.shape
-        return x.reshape(B, T, Cc // 2, 2).permute(0, 1, 3, 2).reshape(B, 2 * T, Cc // 2).contiguous()
+        xb = to_bct(_req(x))
+        B, Cc, T = xb.shape
+        y = torch.empty((B, Cc // 2, 2 * T), dtype=torch.float32, device=x.device)
+        check(_lib_().nsc_shuffle2(xb.data_ptr(), y.data_ptr(), B, Cc, T, _st()), "shuffle2")
+        return to_btc(y)
 
     @staticmethod
     def backward(ctx, dy):
-        B, T2, C2 = dy.shape
-        return dy.reshape(B, T2 // 2, 2, C2).permute(0, 1, 3, 2).reshape(B, T2 // 2, 2 * C2).contiguous()
+        dyb = to_bct(_req(dy))
+        B, C2, T2 = dyb.shape
+        dx = torch.empty((B, 2 * C2, T2 // 2), dtype=torch.float32, device=dy.device)
+        check(_lib_().nsc_unshuffle2(dyb.data_ptr(), dx.data_ptr(), B, 2 * C2, T2 // 2, _st()), "unshuffle2")
+        return to_btc(dx)
+
+
+class BlockFn(torch.autograd.Function):
+    """gated_bottleneck (nn_core_operator.py:82-112) as ONE function call, like the reference's: the fused persistent kernels
+    nsc_gated_block_fwd[_cin1] / nsc_gated_block_dgrad[_cin1] / nsc_gated_block_wgrad instead of four convs + multiply + add +
+    activations.  narrow 20, k9 9, dilation 1 | 2, wide <= 112 (one input channel: wide in {100, 50, 25}); other shapes keep the
+    composed form (nn_core_operator.gated_bottleneck decides)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, wl, bl, wr, br, w9, b9, dil, flat):
+        lib = _lib_()
+        xb = to_bct(_req(x, "the_input"))
+        ws = [_req(t).contiguous() for t in (w1, b1, wl, bl, wr, br, w9, b9)]
+        B, Cin, T = xb.shape
+        C_ = ws[6].shape[2]
+        out = torch.empty((B, C_, T), dtype=torch.float32, device=x.device)
+        h, lin, th, g = torch.empty((4, B, 20, T), dtype=torch.float32, device=x.device).unbind(0)
+        fn = lib.nsc_gated_block_fwd_cin1 if Cin == 1 else lib.nsc_gated_block_fwd
+        check(fn(xb.data_ptr(), *[t.data_ptr() for t in ws], out.data_ptr(), h.data_ptr(), lin.data_ptr(), th.data_ptr(), g.data_ptr(),
+                 B, C_, T, 20, 9, int(dil), int(bool(flat)), _st()), "gated_block_fwd")
+        ctx.save_for_backward(xb, h, lin, th, g, out, *ws)
+        ctx.cfg = (int(dil), bool(flat))
+        return to_btc(out)
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib_()
+        xb, h, lin, th, g, out, w1, b1, wl, bl, wr, br, w9, b9 = ctx.saved_tensors
+        dil, flat = ctx.cfg
+        B, Cin, T = xb.shape
+        C_ = w9.shape[2]
+        dev = xb.device
+        dz = to_bct(_req(dy, "grad"))
+        if not flat:                                   # through the block's output leaky-relu
+            dz2 = torch.empty_like(dz)
+            check(lib.nsc_act_bwd(dz.data_ptr(), out.data_ptr(), dz2.data_ptr(), dz.numel(), ACT["lrelu"], _st()), "act_bwd")
+            dz = dz2
+        # flipped / transposed kernels of the four convs (what tf.gradients' conv backprop reads): one launch, one buffer
+        n1, n15, n9 = Cin * 20, 15 * 20 * 20, 9 * 20 * C_
+        wt = torch.empty(n1 + 2 * n15 + n9, dtype=torch.float32, device=dev)
+        check(lib.nsc_gated_block_flip_weights(w1.data_ptr(), wl.data_ptr(), wr.data_ptr(), w9.data_ptr(), wt.data_ptr(), C_, Cin, 20, 9,
+                                               _st()), "flip")
+        p0 = wt.data_ptr()
+        wts = [p0, p0 + 4 * n1, p0 + 4 * (n1 + n15), p0 + 4 * (n1 + 2 * n15)]
+        dx = torch.empty((B, Cin, T), dtype=torch.float32, device=dev)
+        da = torch.empty((B, 40, T), dtype=torch.float32, device=dev)
+        dz1 = torch.empty((B, 20, T), dtype=torch.float32, device=dev)
+        if Cin == 1:
+            check(lib.nsc_gated_block_dgrad_cin1(h.data_ptr(), lin.data_ptr(), th.data_ptr(), dz.data_ptr(), *wts,
+                                                 dx.data_ptr(), da.data_ptr(), da.data_ptr() + 4 * 20 * T, dz1.data_ptr(), B, C_, T, 20, 9,
+                                                 dil, 40, _st()), "gated_block_dgrad_cin1")
+        else:
+            check(lib.nsc_gated_block_dgrad(xb.data_ptr(), h.data_ptr(), lin.data_ptr(), th.data_ptr(), dz.data_ptr(),
+                                            *wts, dx.data_ptr(), da.data_ptr(), dz1.data_ptr(), B, C_, T, 20, 9,
+                                            dil, ACT[None], _st()), "gated_block_dgrad")
+        # parameter gradients: the batched launch with one job (it serves both block forms); the eight gradients are one contiguous
+        # range in creation order, handed back as views of it
+        sizes = [Cin * 20, 20, n15, 20, n15, 20, n9, C_]
+        flat_g = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        job = _lib.BlockWgradJob(xb.data_ptr(), h.data_ptr(), g.data_ptr(), dz.data_ptr(), da.data_ptr(), dz1.data_ptr(),
+                                 flat_g.data_ptr(), C_, T, dil, Cin)
+        ws_ = _workspace(int(lib.nsc_gated_block_wgrad_batch_workspace(112)), dev)
+        fn = lib.nsc_gated_block_wgrad_batch_split if SPLIT_ARITH else lib.nsc_gated_block_wgrad_batch
+        check(fn((_lib.BlockWgradJob * 1)(job), 1, B, 20, 9, ws_.data_ptr(), ws_.numel(), _st()), "gated_block_wgrad_batch")
+        grads = [gr.view(t.shape) for gr, t in zip(flat_g.split(sizes), (w1, b1, wl, bl, wr, br, w9, b9))]
+        return (to_btc(dx), *grads, None, None)
 
 
 class QuantizeFn(torch.autograd.Function):
@@ -242,8 +369,8 @@ class QuantizeFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, code, alpha, bins, is_quan_on, soft):
-        code, bins = _req(code, "floating_code"), _req(bins, "bins")
-        alpha = _req(alpha.reshape(1), "alpha")
+        code, bins = _req(code, "floating_code").contiguous(), _req(bins, "bins").contiguous()
+        alpha = _req(alpha.reshape(1), "alpha").contiguous()
         B, L, _ = code.shape
         nb = bins.numel()
         p = torch.empty((B, L, nb), dtype=torch.float32, device=code.device)
@@ -263,8 +390,8 @@ class QuantizeFn(torch.autograd.Function):
         dcode = torch.empty_like(code)
         dalpha = torch.zeros(1, dtype=torch.float32, device=code.device)
         dbins = torch.zeros_like(bins)
-        dp = _req(dp) if dp is not None else None
-        dout = _req(dout) if dout is not None else None
+        dp = _req(dp).contiguous() if dp is not None else None
+        dout = _req(dout).contiguous() if dout is not None else None
         check(_lib_().nsc_quantize_bwd(code.data_ptr(), alpha.data_ptr(), bins.data_ptr(), on, soft, B, L, nb,
                                        _lib.ptr(dout), _lib.ptr(dp), 0.0, None, 0.0, 0, dcode.data_ptr(), dalpha.data_ptr(),
                                        dbins.data_ptr(), _st()), "quantize_bwd")
@@ -277,7 +404,7 @@ class ReconLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, decoded, original):
         from .loss_terms_and_measures import mel_matrix_cat
-        decoded, original = _req(decoded), _req(original)
+        decoded, original = _req(decoded).contiguous(), _req(original).contiguous()
         B = decoded.shape[0]
         dev = decoded.device
         key = ("mel", str(dev))
@@ -298,8 +425,8 @@ class ReconLossFn(torch.autograd.Function):
         B = decoded.shape[0]
         dev = decoded.device
         mel, melT = _CACHE[("mel", str(dev))]
-        gt = _req(gt) if gt is not None else torch.zeros(B, device=dev)
-        gf = _req(gf) if gf is not None else torch.zeros(B, device=dev)
+        gt = _req(gt).contiguous() if gt is not None else torch.zeros(B, device=dev)
+        gf = _req(gf).contiguous() if gf is not None else torch.zeros(B, device=dev)
         g = torch.empty_like(decoded)
         t, f = torch.empty(B, device=dev), torch.empty(B, device=dev)
         check(_lib_().nsc_recon_loss(decoded.data_ptr(), original.data_ptr(), B, 0.0, 0.0, gt.data_ptr(), gf.data_ptr(),
@@ -314,7 +441,7 @@ _CACHE = {}
 class QuanLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, p):
-        p = _req(p)
+        p = _req(p).contiguous()
         B, L, nb = p.shape
         q = torch.empty(B, device=p.device)
         check(_lib_().nsc_p_stats(p.data_ptr(), B, L, nb, q.data_ptr(), None, _st()), "p_stats")
@@ -326,14 +453,14 @@ class QuanLossFn(torch.autograd.Function):
         (p,) = ctx.saved_tensors
         B, L, nb = p.shape
         dp = torch.empty_like(p)
-        check(_lib_().nsc_p_stats_bwd(p.data_ptr(), _req(gq).data_ptr(), None, dp.data_ptr(), B, L, nb, _st()), "p_stats_bwd")
+        check(_lib_().nsc_p_stats_bwd(p.data_ptr(), _req(gq).contiguous().data_ptr(), None, dp.data_ptr(), B, L, nb, _st()), "p_stats_bwd")
         return dp
 
 
 class EntropyFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, p):
-        p = _req(p)
+        p = _req(p).contiguous()
         B, L, nb = p.shape
         hist = torch.zeros(nb, device=p.device)
         ent = torch.empty(1, device=p.device)
@@ -362,7 +489,7 @@ def recon_losses(decoded, original):
 
 
 def rfft512(sig):
-    sig = _req(sig).reshape(-1, 512)
+    sig = _req(sig).contiguous().reshape(-1, 512)
     B = sig.shape[0]
     re, im, mag = (torch.empty((B, 257), device=sig.device) for _ in range(3))
     check(_lib_().nsc_rfft512(sig.data_ptr(), B, re.data_ptr(), im.data_ptr(), mag.data_ptr(), _st()), "rfft512")
