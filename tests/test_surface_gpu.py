@@ -66,6 +66,111 @@ def test_op_surface_codec_matches_oracle_forward_and_gradients():
         set_store(None)
 
 
+@pytest.mark.parametrize("cin,wide,dil,flat,T", [(100, 100, 1, False, 96), (100, 100, 2, True, 130), (50, 50, 2, False, 64),
+                                                (1, 100, 1, False, 77), (1, 50, 2, True, 64), (24, 24, 1, False, 40)])
+def test_fused_gated_bottleneck_matches_the_composed_ops_and_the_oracle(cin, wide, dil, flat, T):
+    """nn_core_operator.gated_bottleneck as ONE fused call per direction (ops.BlockFn) against the same function composed op by op
+    (FUSED_BLOCKS False) and against the float64 oracle: output, input gradient, all eight parameter gradients; same variable names
+    in the same creation order."""
+    from nsc_amd import nn_core_operator as nn
+    from nsc_amd.scope import VariableStore, set_store, variable_scope
+    rng = np.random.default_rng(cin + 7 * dil + T)
+    B = 3
+    x_np = rng.standard_normal((B, T, cin)).astype(np.float32)
+    w_np = rng.standard_normal((B, T, wide)).astype(np.float32)      # weights of the scalar the gradients are taken of
+    res = {}
+    try:
+        for fused in (True, False):
+            nn.FUSED_BLOCKS = fused
+            st = VariableStore(device="cuda", seed=5)
+            set_store(st)
+            x = dev(x_np).requires_grad_(True)
+            with variable_scope("s"):
+                y = nn.gated_bottleneck(x, wide, 20, 9, 9, dil, flat)
+            (y * dev(w_np)).sum().backward()
+            res[fused] = (y.detach().cpu().numpy(), x.grad.cpu().numpy(), {k: v.grad.cpu().numpy().copy() for k, v in st.vars.items()},
+                          {k: v.detach().cpu().numpy().copy() for k, v in st.vars.items()})
+    finally:
+        nn.FUSED_BLOCKS = True
+        set_store(None)
+    assert list(res[True][2].keys()) == list(res[False][2].keys()) == [
+        f"s/conv1d{sfx}/{n}" for sfx in ("", "_1", "_2", "_3") for n in ("kernel", "bias")]
+    for k in res[True][3]:
+        assert np.array_equal(res[True][3][k], res[False][3][k]), k        # same initial values either way
+    # float64 oracle on the same parameters
+    tp_t = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in res[True][3].items()}
+
+    class _TP:
+        t = tp_t
+        n = 0
+
+        def conv(self, scope):
+            nm = "s/conv1d" + ("" if self.n == 0 else f"_{self.n}")
+            self.n += 1
+            return self.t[nm + "/kernel"], self.t[nm + "/bias"]
+    xo = torch.tensor(x_np, dtype=torch.float64, requires_grad=True)
+    yo = OT.gated_bottleneck(xo, _TP(), "s", dil, flat)
+    (yo * torch.tensor(w_np, dtype=torch.float64)).sum().backward()
+    for fused in (True, False):
+        yv, dxv, gr, _ = res[fused]
+        assert_close(yv, yo.detach().numpy(), what=f"block out fused={fused}")
+        assert_close(dxv, xo.grad.numpy(), what=f"block dx fused={fused}")
+        for k, g in gr.items():
+            assert relerr(g.reshape(-1), tp_t[k].grad.numpy().reshape(-1)) < 2e-5, (fused, k)
+
+
+def test_surface_ops_chain_without_transposes_and_accept_channels_last_memory(monkeypatch):
+    """Between surface ops a tensor is [B,C,T] memory behind a [B,T,C] view: a chain conv -> lrelu -> block -> shuffle -> multiply
+    launches nsc_transpose_last2 once for the channels_last input and once for the channels_last gradient torch hands to the last op,
+    and nowhere in between; a real
+    channels_last tensor produced by torch in the middle of the chain is still taken (transposed on the way in)."""
+    from nsc_amd import _lib, nn_core_operator as nn, ops
+    from nsc_amd.scope import VariableStore, set_store, variable_scope
+    lib = _lib.load()
+    calls = [0]
+    real = lib.nsc_transpose_last2
+
+    class _Counting:
+        def __getattr__(self, name):
+            f = getattr(lib, name)
+            if name != "nsc_transpose_last2":
+                return f
+
+            def g(*a):
+                calls[0] += 1
+                return real(*a)
+            return g
+    monkeypatch.setattr(ops, "_lib_", lambda: _Counting())
+    rng = np.random.default_rng(3)
+    x_np = rng.standard_normal((2, 64, 6)).astype(np.float32)
+    set_store(VariableStore(device="cuda", seed=1))
+    try:
+        x = dev(x_np).requires_grad_(True)
+        with variable_scope("s"):
+            h = nn.activation_func(nn.conv1d(x, 100, 9, activation=None))
+            h = nn.gated_bottleneck(h, 100, 20, 9, 9, 2, False)
+            up = ops.ShuffleFn.apply(h)                                   # [2,128,50]
+            out = ops.MulFn.apply(up, up)
+        assert out.shape == (2, 128, 50) and not out.is_contiguous() and out.transpose(1, 2).is_contiguous()
+        assert calls[0] == 1
+        out.sum().backward()
+        assert calls[0] == 2 and x.grad.shape == x.shape
+        # the shuffle itself against the reference's reshape / transpose (neural_speech_coding_module.py:158-167)
+        assert np.array_equal(up.detach().cpu().numpy(), OT.subpixel_shuffle(h.detach().cpu(), 2).numpy())
+        # channels_last memory in the middle (a torch op materialises [B,T,C]): same values as the lazy route
+        with variable_scope("t"):
+            a = nn.conv1d(h, 10, 3)
+        set_store(VariableStore(device="cuda", seed=1))
+        with variable_scope("s"):
+            h2 = nn.activation_func(nn.conv1d(x, 100, 9, activation=None))
+            h2 = nn.gated_bottleneck(h2, 100, 20, 9, 9, 2, False)
+        with variable_scope("t"):
+            b = nn.conv1d(h2.contiguous() * 1.0, 10, 3)
+        assert b.is_contiguous() is False and np.array_equal(a.detach().cpu().numpy(), b.detach().cpu().numpy())
+    finally:
+        set_store(None)
+
+
 def test_surface_rejects_cpu_tensors_and_bad_shapes():
     from nsc_amd import _lib, nn_core_operator as nn
     from nsc_amd.scope import VariableStore, set_store
