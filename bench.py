@@ -354,7 +354,8 @@ def main():
     eng.fused_fwd = not args.unfused_fwd
     if args.arith is not None:
         eng.split_fwd = eng.split_wgrad_arith = args.arith == "split"
-    split_on = bool(eng.split_fwd or eng.split_wgrad_arith or eng.split_dgrad)
+        eng.split_conv = eng.split_conv and args.arith == "split"      # (laid out at construction: can only be switched off)
+    split_on = bool(eng.split_fwd or eng.split_wgrad_arith or eng.split_dgrad or eng.split_conv)
     xd, lpcd, x_np, lpc_np = synth_batch(B, comm.rank, dev)
     cfg = step_cfg_for(args.config, B, comm.world)
     if args.follower:
@@ -488,8 +489,8 @@ def main():
     # split-operand kernels buy, measured in the same run on the same parameters ----
     ms_exact = None
     if split_on and comm.world == 1 and dcomm is None and not args.no_graph:
-        keep = (eng.split_fwd, eng.split_wgrad_arith, eng.split_dgrad)
-        eng.split_fwd = eng.split_wgrad_arith = eng.split_dgrad = False
+        keep = (eng.split_fwd, eng.split_wgrad_arith, eng.split_dgrad, eng.split_conv)
+        eng.split_fwd = eng.split_wgrad_arith = eng.split_dgrad = eng.split_conv = False
         try:
             for _ in range(2):
                 step()
@@ -510,7 +511,7 @@ def main():
             del g2
         except Exception as ex:
             print(f"[bench] exact-arm timing skipped ({type(ex).__name__}: {ex})", file=sys.stderr)
-        eng.split_fwd, eng.split_wgrad_arith, eng.split_dgrad = keep
+        eng.split_fwd, eng.split_wgrad_arith, eng.split_dgrad, eng.split_conv = keep
         step()
         torch.cuda.synchronize()
 
@@ -564,6 +565,7 @@ def main():
                                if eng.split_wgrad_arith else
                                "gated_block_wgrad_batch_kernel + slab_reduce_batch_kernel (all blocks' weight gradients, one launch per width)"),
                "block_dgrad": "gated_block_dgrad2_pair_kernel / gated_block_dgrad2_kernel (persistent weight-stationary gated block data-path backward; the two blocks of a stack per launch)",
+               "conv_split": "conv_split_kernel (the stride-2 down-sampling convs, forward + polyphase data gradient, split operands on the bf16 matrix cores)",
                "wgrad_mfma": "conv1d_wgrad_batch_kernel + conv_slab_reduce_batch_kernel (weight gradients of the convs outside gated blocks)"}
     roof, by_kernel = None, {}
     traffic = {}
@@ -574,7 +576,7 @@ def main():
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         by_kernel[tag] = dict(ms_per_step=round(ms / args.prof_steps, 3), launches_per_step=n // args.prof_steps,
                               achieved_tflops=round(ach, 2))
-    mf = {k: v for k, v in summ.items() if k in KERNELS}
+    mf = {k: v for k, v in summ.items() if k in KERNELS and k != "conv_split"}
     if mf:
         tag = max(mf, key=lambda k: mf[k][1])
         n, ms, fl = mf[tag]
@@ -595,7 +597,8 @@ def main():
                       "peak_basis": "dense bf16 MFMA peak (2500 TFLOP/s, MI355X_MICROARCH.md) / 6: every fp32-class product is six bf16 products "
                                     "(three bf16 pieces per operand, fp32 accumulate); algorithmic FLOPs of the class / its time",
                       "classes": {}}
-        for tag, on in (("block_fwd", eng.split_fwd), ("block_wgrad", eng.split_wgrad_arith), ("block_dgrad", eng.split_dgrad)):
+        for tag, on in (("block_fwd", eng.split_fwd), ("block_wgrad", eng.split_wgrad_arith), ("block_dgrad", eng.split_dgrad),
+                        ("conv_split", eng.split_conv)):
             if on and tag in summ:
                 n, ms, fl = summ[tag]
                 ach = fl / (ms * 1e-3) / 1e12
@@ -705,8 +708,9 @@ def main():
             "ms_per_step_min": round(min(pass_ms), 3), "timing": f"median of {len(pass_ms)} passes of {args.steps} steps, each bracketed by barrier + synchronize, max over ranks",
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": ("f32 (gated-block " + " + ".join(n_ for n_, on in (("forward", eng.split_fwd), ("weight gradients", eng.split_wgrad_arith),
-                                                                        ("data gradient", eng.split_dgrad)) if on) +
+            "dtype": ("f32 (" + " + ".join(n_ for n_, on in (("gated-block forward", eng.split_fwd), ("gated-block weight gradients", eng.split_wgrad_arith),
+                                                             ("gated-block data gradient", eng.split_dgrad),
+                                                             ("stride-2 convs forward + data gradient", eng.split_conv)) if on) +
                       ": fp32 operands split into 3 bf16 pieces, 6 products on the bf16 matrix cores, fp32 accumulate - fp32-class error, "
                       "gate in profiles/r05_numerics_gate.txt; everything else: exact fp32)") if split_on else "f32",
             "data": "synthetic",

@@ -112,6 +112,19 @@ typedef struct nsc_conv_wgrad_job {
 long nsc_conv1d_wgrad_batch_workspace(const nsc_conv_wgrad_job* jobs, int njobs);
 int nsc_conv1d_wgrad_batch(const nsc_conv_wgrad_job* jobs, int njobs, float* workspace, long workspace_floats,
                            void* stream);
+/* The stride-2 down-sampling conv of the encoder (conv1d(h, 100, 9, strides=2) + leaky-relu, neural_speech_coding_module.py:229-233)
+ * and its data gradient (tf.gradients through it) with the contraction on the bf16 matrix cores: every fp32 operand split into three
+ * bf16 pieces, six products, fp32 accumulation - fp32-class results (see nsc_gated_block_fwd_simg).  d = the FORWARD conv's
+ * descriptor in both calls; served: Cin = Cout = 100, K 9, stride 2, dilation 1, padL 3, Tout % 64 == 0, 16-byte aligned tensors,
+ * no residual / multiply / shuffle epilogue (NSC_ERR_UNSUPPORTED otherwise: nsc_conv1d_fwd serves every shape).
+ *   nsc_conv1d_simage_words(which, d)              words (4 bytes) of the kernel-ready weight image; which 0 forward, 1 data gradient; 0 = not served
+ *   nsc_conv1d_simage_index(which, d, w_off, idx)  nsc_gather index of the image from a buffer that holds the kernel [9][100][100] at w_off
+ *   nsc_conv1d_fwd_simg:    y [B,100,Tout] = act(conv(x [B,100,Tin]) + bias)
+ *   nsc_conv1d_dgrad_simg:  dx [B,100,Tin] = conv^T(dy [B,100,Tout])   (polyphase form: no zero-upsampled input) */
+long nsc_conv1d_simage_words(int which, const nsc_conv_desc* d);
+int nsc_conv1d_simage_index(int which, const nsc_conv_desc* d, long w_off, int* idx);
+int nsc_conv1d_fwd_simg(const nsc_conv_desc* d, const float* x, const void* image, const float* bias, float* y, void* stream);
+int nsc_conv1d_dgrad_simg(const nsc_conv_desc* d, const float* dy, const void* image, float* dx, void* stream);
 /* wt[K-1-k, o, i] = w[k, i, o] : weights of the data-gradient conv (dgrad == nsc_conv1d_fwd on wt). */
 int nsc_weight_flip_transpose(const float* w, float* wt, int K, int Cin, int Cout, void* stream);
 /* The four flipped / transposed kernels nsc_gated_block_dgrad[_cin1] reads, in ONE launch: wt = wt1 [1][narrow][Cin] | wtl [15][narrow][narrow]

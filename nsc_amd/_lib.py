@@ -35,6 +35,9 @@ PROTOTYPES = {
     "nsc_frame_entropy": [_P, _I, _I, _I, _P, _P],
     "nsc_conv1d_wgrad_ws": [C.POINTER(ConvDesc), _P, _P, _P, _P, _I, _P, _L, _P],
     "nsc_weight_flip_transpose": [_P, _P, _I, _I, _I, _P],
+    "nsc_conv1d_simage_index": [_I, C.POINTER(ConvDesc), _L, _P],
+    "nsc_conv1d_fwd_simg": [C.POINTER(ConvDesc), _P, _P, _P, _P, _P],
+    "nsc_conv1d_dgrad_simg": [C.POINTER(ConvDesc), _P, _P, _P, _P],
     "nsc_gated_block_flip_weights": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "nsc_gated_block_fwd": [_P] * 14 + [_I] * 7 + [_P],
     "nsc_gated_block_fwd_cin1": [_P] * 14 + [_I] * 7 + [_P],
@@ -129,7 +132,7 @@ PROTOTYPES["nsc_gated_block_wgrad_batch"] = [C.POINTER(BlockWgradJob), _I, _I, _
 PROTOTYPES["nsc_gated_block_wgrad_batch_split"] = [C.POINTER(BlockWgradJob), _I, _I, _I, _I, _P, _L, _P]
 PROTOTYPES["nsc_conv1d_wgrad_batch"] = [C.POINTER(ConvWgradJob), _I, _P, _L, _P]
 EXPORTS = sorted(list(PROTOTYPES) + ["nsc_version", "nsc_last_error", "nsc_gated_block_wgrad_workspace", "nsc_gated_block_image_floats",
-                  "nsc_gated_block_simage_words",
+                  "nsc_gated_block_simage_words", "nsc_conv1d_simage_words",
                   "nsc_gated_block_pair_flag_ints",
                   "nsc_conv1d_wgrad_workspace", "nsc_gated_block_wgrad_batch_workspace",
                   "nsc_conv1d_wgrad_batch_workspace"])
@@ -165,6 +168,8 @@ def load():
     lib.nsc_conv1d_wgrad_batch_workspace.restype = C.c_long
     lib.nsc_gated_block_image_floats.argtypes = [C.c_int] * 4
     lib.nsc_gated_block_image_floats.restype = C.c_long
+    lib.nsc_conv1d_simage_words.argtypes = [C.c_int, C.POINTER(ConvDesc)]
+    lib.nsc_conv1d_simage_words.restype = C.c_long
     lib.nsc_gated_block_simage_words.argtypes = [C.c_int] * 4
     lib.nsc_gated_block_simage_words.restype = C.c_long
     lib.nsc_version.restype = C.c_int

@@ -103,11 +103,18 @@ class _Conv:
         """chain (Cout = 1 only): a _lib.Cout1Chain applied elementwise to the [B,1,T] result in the conv's own epilogue."""
         e = self.eng
         d = self.desc(act=KIND_ACT[act], res_mode=res_mode, out_mode=out_mode)
-        tok = e.prof_begin("conv_cout1" if self.Cout == 1 else "conv_mfma", self.flops())
+        split = (e.split_conv and getattr(self, "simg_off", None) is not None and res is None and out_mode == 0 and e.use_images and
+                 e.images_valid)
+        tok = e.prof_begin("conv_cout1" if self.Cout == 1 else ("conv_split" if split else "conv_mfma"), self.flops())
         if self.Cout == 1:
             check(e.lib.nsc_conv1d_cout1_fwd_chain(C.byref(d), x.data_ptr(), self._p(e.p_ptr, self.w_off), self._p(e.p_ptr, self.b_off),
                                                    _lib.ptr(res), None, y.data_ptr(), C.byref(chain) if chain is not None else None,
                                                    e.stream()), f"conv fwd {self.name}")
+        elif split:
+            # the stride-2 down-sampling conv on split operands (bf16 matrix cores, csrc/conv_split.hip)
+            assert chain is None
+            check(e.lib.nsc_conv1d_fwd_simg(C.byref(d), x.data_ptr(), e.wt_ptr + 4 * self.simg_off[0], self._p(e.p_ptr, self.b_off),
+                                            y.data_ptr(), e.stream()), f"conv fwd (split) {self.name}")
         else:
             assert chain is None
             check(e.lib.nsc_conv1d_fwd(C.byref(d), x.data_ptr(), self._p(e.p_ptr, self.w_off), self._p(e.p_ptr, self.b_off),
@@ -137,6 +144,12 @@ class _Conv:
         """dx = conv^T(dz) (+res) (* act'(aux)); runs the forward kernel on the flipped/transposed weights.
         chain (Cin = 1 only): a _lib.Cout1Chain applied to the [B,1,T] result in the kernel's epilogue."""
         e = self.eng
+        if e.split_conv and getattr(self, "simg_off", None) is not None and res is None and mul_kind == "none":
+            tok = e.prof_begin("conv_split", self.flops())
+            check(e.lib.nsc_conv1d_dgrad_simg(C.byref(self.desc()), dz.data_ptr(), e.wt_ptr + 4 * self.simg_off[1], dx.data_ptr(), e.stream()),
+                  f"conv dgrad (split) {self.name}")
+            e.prof_end(tok)
+            return
         if self.poly_ok() and e.poly_dgrad:
             d = ConvDesc(B=e.B, Cin=self.Cout, Cout=2 * self.Cin, Tin=self.Tout, Tout=self.Tout, K=5, dil=1, stride=1, padL=2,
                          act=0, res_mode=res_mode, mul_mode=KIND_MUL[mul_kind], out_mode=1, in_up=0, accumulate=0)
@@ -794,9 +807,17 @@ class CascadeEngine:
             b.wtlr_off = n + extra
             extra += b.cl.K * 2 * b.narrow * b.narrow
         # polyphase data-gradient kernels of the stride-2 k9 convs: W'[t', o, 2 ci + p] (5 taps, structural zero at p=0, t'=4)
+        # ... or, on split operands (csrc/conv_split.hip), kernel-ready images of the forward and the data-gradient GEMM instead
         poly = [c for c in self.convs if c.poly_ok()]
         for c in poly:
-            c.wtpoly_off = n + extra
+            c.simg_off = None
+            nw = [int(self.lib.nsc_conv1d_simage_words(which, C.byref(c.desc()))) for which in (0, 1)] if self.split_conv else [0, 0]
+            if nw[0] > 0 and nw[1] > 0:
+                extra = (n + extra + 3) // 4 * 4 - n
+                c.simg_off = (n + extra, n + extra + nw[0])
+                c.simg_words = tuple(nw)
+                extra += nw[0] + nw[1]
+            c.wtpoly_off = n + extra            # (kept beside the images: split_conv can be switched off at run time for A/B)
             extra += 5 * c.Cout * 2 * c.Cin
         # kernel-ready parameter images of the gated blocks the persistent kernels serve (fast prologue: include/nsc_hip.h,
         # nsc_gated_block_image_index): one forward and one data-gradient image per block, 16-byte aligned, rebuilt by the
@@ -833,6 +854,12 @@ class CascadeEngine:
             ir = b.cr.wt_index().reshape(K, nn, nn)
             idx[b.wtlr_off:b.wtlr_off + K * 2 * nn * nn] = np.concatenate([il, ir], axis=1).reshape(-1)
         for c in poly:
+            if c.simg_off is not None:
+                for which in (0, 1):
+                    im = np.empty(c.simg_words[which], dtype=np.int32)
+                    check(self.lib.nsc_conv1d_simage_index(which, C.byref(c.desc()), int(c.w_off), im.ctypes.data_as(C.c_void_p)),
+                          "conv1d_simage_index")
+                    idx[c.simg_off[which]:c.simg_off[which] + c.simg_words[which]] = im
             idx[c.wtpoly_off:c.wtpoly_off + 5 * c.Cout * 2 * c.Cin] = c.wtpoly_index()
         for b in blocks:
             for which, off in ((0, b.img_fwd_off), (1, b.img_bwd_off)):
@@ -914,6 +941,9 @@ class CascadeEngine:
     # the split-operand DATA gradient (gated_block_dgrad3_kernel) is correct and tested but no faster than the exact pair launches
     # yet (profiles/r05h_dgrad_split_time.txt: 0.8-0.98x): off unless asked for
     split_dgrad = os.environ.get("NSC_SPLIT_DGRAD", "0") == "1"
+    # the stride-2 down-sampling convs (forward + data gradient) on split operands too (csrc/conv_split.hip); the images are laid out
+    # at construction if this is on then - later it can only be switched OFF (A/B runs)
+    split_conv = os.environ.get("NSC_BLOCK_ARITH", "split") == "split"
     fused_pairs = True   # the dil-1 / dil-2 blocks of a stack in ONE launch (nsc_gated_block_pair_fwd_img / _dgrad_img: neighbour flags
                          # between workgroups instead of a kernel boundary); False: one launch per block
     fused_chain = True   # the cascade step / output-gradient arithmetic between codecs rides in the epilogue of the Cout = 1 convs

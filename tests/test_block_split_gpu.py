@@ -273,3 +273,72 @@ def test_split_gated_block_dgrad_matches_the_float64_oracle(lib, case):
         re_, rs = float(np.sqrt(np.mean((e_ - r_) ** 2))) / rms, float(np.sqrt(np.mean((s_ - r_) ** 2))) / rms
         print(f"  {nm}: rms err / rms  exact {re_:.2e}  split {rs:.2e}")
         assert rs <= 1.5 * re_ + 1e-7, (nm, re_, rs)
+
+
+# ---- the stride-2 down-sampling conv and its data gradient on split operands (csrc/conv_split.hip) ----
+def _conv_image(lib, which, d, src, w_off):
+    n = int(lib.nsc_conv1d_simage_words(which, C.byref(d)))
+    assert n > 0
+    idx = np.empty(n, np.int32)
+    assert lib.nsc_conv1d_simage_index(which, C.byref(d), int(w_off), idx.ctypes.data_as(C.c_void_p)) == 0, lib.nsc_last_error()
+    img = torch.empty(n, device="cuda")
+    assert lib.nsc_gather(src.data_ptr(), torch.tensor(idx, device="cuda").data_ptr(), img.data_ptr(), n, _st()) == 0
+    return img
+
+
+def _down_desc(B, Tin, act=0):
+    from nsc_amd._lib import ConvDesc
+    return ConvDesc(B=B, Cin=100, Cout=100, Tin=Tin, Tout=Tin // 2, K=9, dil=1, stride=2, padL=3, act=act, res_mode=0, mul_mode=0,
+                    out_mode=0, in_up=0, accumulate=0)
+
+
+@pytest.mark.parametrize("B,Tin,act", [(2, 512, 2), (3, 128, 0), (1, 256, 2), (130, 512, 2)])
+def test_split_stride2_conv_forward_and_data_gradient_match_float64_and_the_exact_kernels(lib, B, Tin, act):
+    """nsc_conv1d_fwd_simg / nsc_conv1d_dgrad_simg (bf16 matrix cores, split operands) against float64 (same bounds as the exact
+    kernels) and against nsc_conv1d_fwd (forward; polyphase data gradient on the gathered W' kernel)."""
+    rng = np.random.default_rng(B + Tin)
+    Tout = Tin // 2
+    w = (0.05 * rng.standard_normal((9, 100, 100))).astype(np.float32)
+    bias = (0.1 * rng.standard_normal(100)).astype(np.float32)
+    x = rng.standard_normal((B, 100, Tin)).astype(np.float32)
+    dy = rng.standard_normal((B, 100, Tout)).astype(np.float32)
+    pad = 7                                                   # offset of the kernel in the gathered buffer (not 0: exercises w_off)
+    src = dev(np.concatenate([np.zeros(pad, np.float32), w.reshape(-1)]))
+    d = _down_desc(B, Tin, act)
+    xd, dyd, bd = dev(x), dev(dy), dev(bias)
+    # float64 reference
+    xp = np.pad(x.astype(np.float64), ((0, 0), (0, 0), (3, 4)))
+    yr = sum(np.einsum("bit,io->bot", xp[:, :, k:k + 2 * Tout:2], w[k].astype(np.float64)) for k in range(9)) + bias[None, :, None]
+    if act == 2:
+        yr = np.where(yr > 0, yr, 0.2 * yr)
+    dxr = np.zeros((B, 100, Tin + 7))
+    for k in range(9):
+        dxr[:, :, k:k + 2 * Tout:2] += np.einsum("bot,io->bit", dy.astype(np.float64), w[k].astype(np.float64))
+    dxr = dxr[:, :, 3:3 + Tin]
+    # split kernels
+    y = torch.full((B, 100, Tout), float("nan"), device="cuda")
+    img0 = _conv_image(lib, 0, d, src, pad)
+    assert lib.nsc_conv1d_fwd_simg(C.byref(d), P(xd), P(img0), P(bd), P(y), _st()) == 0, lib.nsc_last_error()
+    dx = torch.full((B, 100, Tin), float("nan"), device="cuda")
+    img1 = _conv_image(lib, 1, d, src, pad)
+    assert lib.nsc_conv1d_dgrad_simg(C.byref(d), P(dyd), P(img1), P(dx), _st()) == 0, lib.nsc_last_error()
+    # exact forward
+    ye = torch.empty_like(y)
+    assert lib.nsc_conv1d_fwd(C.byref(d), P(xd), src.data_ptr() + 4 * pad, P(bd), None, None, P(ye), _st()) == 0
+    torch.cuda.synchronize()
+    assert_close(y.cpu().numpy(), yr, what="split stride-2 conv forward")
+    assert_close(dx.cpu().numpy(), dxr, what="split stride-2 conv data gradient")
+    es = np.sqrt(np.mean((y.cpu().numpy() - yr) ** 2)), np.sqrt(np.mean((ye.cpu().numpy() - yr) ** 2))
+    print(f"stride-2 conv forward rms error vs float64: split {es[0]:.3e}, exact {es[1]:.3e}")
+    assert es[0] <= 1.5 * es[1] + 1e-7 * np.sqrt(np.mean(yr ** 2))
+
+
+def test_split_stride2_conv_refuses_other_shapes(lib):
+    from nsc_amd._lib import ConvDesc
+    d = ConvDesc(B=1, Cin=50, Cout=50, Tin=128, Tout=64, K=9, dil=1, stride=2, padL=3, act=0, res_mode=0, mul_mode=0, out_mode=0, in_up=0,
+                 accumulate=0)
+    assert int(lib.nsc_conv1d_simage_words(0, C.byref(d))) == 0
+    d2 = _down_desc(1, 96)                                    # Tout = 48: not a multiple of the 64-column tile
+    assert int(lib.nsc_conv1d_simage_words(0, C.byref(d2))) == 0
+    t = torch.zeros(16, device="cuda")
+    assert lib.nsc_conv1d_fwd_simg(C.byref(d2), P(t), P(t), None, P(t), _st()) == -2
