@@ -21,8 +21,18 @@
 #include <algorithm>
 #include <type_traits>
 
+#include "block_common.h"
+#ifdef NSC_PROBES
+extern "C" int nsc_probe_read_conv_split(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(nsc_dbg_stamps), sizeof(unsigned long long) * 128) == hipSuccess ? 0 : -3;
+}
+#endif
+
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
+#ifndef NSC_EXP
+#define NSC_EXP 0
+#endif
 
 namespace {
 constexpr int CS_C = 100, CS_TT = 64;
@@ -77,29 +87,37 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvSplitArgs a) {
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const int b = tile / a.tpf, t0 = (tile - b * a.tpf) * CS_TT;
     const float* xb = a.x + (long)b * CS_C * a.Tin;
+    NSC_STAMP(0);
     // ---- stage: rows u = STRIDE t0 - PADL + r (r = 0 .. ROWS-1) of all 100 channels -> three bf16 planes [r][ch] ----
     // a unit = (channel pair, 16-byte group of 4 samples); a wave takes 8 pairs x 8 groups: 128 contiguous bytes per channel row from
     // memory, and LDS words that are at most 2-way bank conflicts
     {
       const int u_al = G::STRIDE * t0 - G::PADL - G::SHIFT;               // multiple of 4
       constexpr int NCPB = (CS_C / 2 + 7) / 8, NGB = (G::NG + 7) / 8;     // blocks of 8 pairs / 8 groups
+      constexpr int NIT = (NCPB * NGB + 7) / 8;                           // units per wave
       const int gl = lane & 7, cl = lane >> 3;
-      for (int ub = wave; ub < NCPB * NGB; ub += 8) {
-        const int cpb = ub / NGB, gb = ub - cpb * NGB;
+      f32x4 v0[NIT], v1[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {                                  // all loads of the tile in flight at once
+        const int ub = wave + 8 * it, cpb = ub / NGB, gb = ub - cpb * NGB;
+        const int cp = cpb * 8 + cl, g = gb * 8 + gl, u = u_al + 4 * g;
+        v0[it] = v1[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (ub < NCPB * NGB && cp < CS_C / 2 && g < G::NG && u >= 0 && u < a.Tin) {
+          v0[it] = *reinterpret_cast<const f32x4*>(xb + (long)(2 * cp) * a.Tin + u);
+          v1[it] = *reinterpret_cast<const f32x4*>(xb + (long)(2 * cp + 1) * a.Tin + u);
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int ub = wave + 8 * it, cpb = ub / NGB, gb = ub - cpb * NGB;
         const int cp = cpb * 8 + cl, g = gb * 8 + gl;
-        if (cp < CS_C / 2 && g < G::NG) {
-          const int u = u_al + 4 * g;
-          f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
-          if (u >= 0 && u < a.Tin) {
-            v0 = *reinterpret_cast<const f32x4*>(xb + (long)(2 * cp) * a.Tin + u);
-            v1 = *reinterpret_cast<const f32x4*>(xb + (long)(2 * cp + 1) * a.Tin + u);
-          }
+        if (ub < NCPB * NGB && cp < CS_C / 2 && g < G::NG && !((NSC_EXP & 256) && tile != (int)blockIdx.x)) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int r = 4 * g + j - G::SHIFT;
             if (r >= 0) {
               unsigned pk[3];
-              nsc_split2(v0[j], v1[j], pk);
+              nsc_split2(v0[it][j], v1[it][j], pk);
               unsigned* w = reinterpret_cast<unsigned*>(plane + r * CS_C + 2 * cp);
 #pragma unroll
               for (int p = 0; p < 3; ++p) w[p * (PLS / 2)] = pk[p];
@@ -108,7 +126,9 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvSplitArgs a) {
         }
       }
     }
+    NSC_STAMP(1);
     __syncthreads();
+    NSC_STAMP(2);
 
     // ---- the GEMM: wave (cp2, qd): column tiles 2 cp2 + {0, 1}, row tiles [rt0, rt0 + NR) ----
     const u16* bcol = plane + (G::STRIDE * (cp2 * 32 + l15)) * CS_C + 8 * q;      // second column tile: + STRIDE * 16 rows
@@ -140,25 +160,50 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvSplitArgs a) {
           }
         }
       };
-      auto step = [&](int s, bf16x8 (&cur)[NR][3], bf16x8 (&nxt)[NR][3]) {
-        bf16x8 bf[2][3];
-        load_b(s, 0, bf[0]);
-        load_b(s, 1, bf[1]);
-        if (s + 1 < G::KS) load_a(s + 1, nxt);
+      // timing experiments (make exp EXP=64|128|256, WRONG RESULTS): 64 = the A fragments are loop-invariant (no image stream),
+      // 128 = the B fragments are (no LDS operand reads), 256 = no staging
+      // One k-step: the NEXT step's fragments are requested first (A from the image: an L2 round trip; B from the planes), a scheduling
+      // fence keeps the requests up there (left alone, hipcc re-used the idle A buffer's registers for this step's B fragments and sank
+      // the image loads to the END of the step: every other step waited out a full L2 latency), then the 12 NR products - product-major,
+      // so that consecutive MFMAs go to different accumulators (a dependent bf16 MFMA issues ~12 cycles late).
+      bf16x8 bbuf[2][2][3];
+      auto step = [&](int s, bf16x8 (&cur)[NR][3], bf16x8 (&nxt)[NR][3], bf16x8 (&bc)[2][3], bf16x8 (&bn)[2][3]) {
+        {   // unconditional (the last step re-requests its own fragments): a branch here makes hipcc's vmcnt bookkeeping assume the
+            // shorter path and wait for the NEW requests before the first MFMA
+          const int sn = s + 1 < G::KS ? s + 1 : G::KS - 1;
+          if (!(NSC_EXP & 64)) load_a(sn, nxt);
+          load_b((NSC_EXP & 128) ? 0 : sn, 0, bn[0]);
+          load_b((NSC_EXP & 128) ? 0 : sn, 1, bn[1]);
+        }
+        if (NSC_EXP & 64) {
 #pragma unroll
-        for (int r = 0; r < NR; ++r)
+          for (int r = 0; r < NR; ++r)
 #pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            if (MODE == 0) acc[e][r] = cs_split6(bf[e], cur[r], acc[e][r]);   // transposed product: a lane's 4 values = 4 consecutive steps of one o
-            else acc[e][r] = cs_split6(cur[r], bf[e], acc[e][r]);
-          }
+            for (int p = 0; p < 3; ++p) nxt[r][p] = cur[r][p];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int PW[6] = {1, 0, 2, 0, 1, 0}, PX[6] = {1, 2, 0, 1, 0, 0};      // (weight piece, activation piece), smallest first
+#pragma unroll
+        for (int pi = 0; pi < 6; ++pi)
+#pragma unroll
+          for (int r = 0; r < NR; ++r)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              if (MODE == 0) acc[e][r] = cs_mfma(bc[e][PX[pi]], cur[r][PW[pi]], acc[e][r]);   // transposed product: a lane's 4 values = 4 consecutive steps of one o
+              else acc[e][r] = cs_mfma(cur[r][PW[pi]], bc[e][PX[pi]], acc[e][r]);
+            }
+        __builtin_amdgcn_sched_barrier(0);
       };
       load_a(0, abuf[0]);
+      load_b(0, 0, bbuf[0][0]);
+      load_b(0, 1, bbuf[0][1]);
 #pragma unroll 1
-      for (int s = 0; s < G::KS; s += 2) {
-        step(s, abuf[0], abuf[1]);
-        if (s + 1 < G::KS) step(s + 1, abuf[1], abuf[0]);
+      for (int s = 0; s + 1 < G::KS; s += 2) {
+        step(s, abuf[0], abuf[1], bbuf[0], bbuf[1]);
+        step(s + 1, abuf[1], abuf[0], bbuf[1], bbuf[0]);
       }
+      if (G::KS & 1) step(G::KS - 1, abuf[0], abuf[1], bbuf[0], bbuf[1]);
+      NSC_STAMP(3);
       // ---- epilogue ----
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
@@ -197,7 +242,9 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvSplitArgs a) {
       if (qd < G::NRREM) run(std::integral_constant<int, G::NRB + 1>{}, rt0);
       else run(std::integral_constant<int, G::NRB>{}, rt0);
     }
+    NSC_STAMP(4);
     __syncthreads();                                      // the planes are rewritten by the next tile
+    NSC_STAMP(5);
   }
 }
 
