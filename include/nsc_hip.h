@@ -125,6 +125,12 @@ long nsc_conv1d_simage_words(int which, const nsc_conv_desc* d);
 int nsc_conv1d_simage_index(int which, const nsc_conv_desc* d, long w_off, int* idx);
 int nsc_conv1d_fwd_simg(const nsc_conv_desc* d, const float* x, const void* image, const float* bias, float* y, void* stream);
 int nsc_conv1d_dgrad_simg(const nsc_conv_desc* d, const float* dy, const void* image, float* dx, void* stream);
+/* ... and its WEIGHT gradient (tf.gradients w.r.t. the conv's kernel and bias) on split operands: the jobs of nsc_conv1d_wgrad_batch
+ * that have this shape (x = the conv's input [B,100,Tin], dz = dy [B,100,Tout], flip_taps 0), up to 8 per call, one persistent launch
+ * + one slab reduction; dw [9][100][100] / db [100] (nullable) are ACCUMULATED into.  workspace: nsc_conv1d_wgrad_split_workspace()
+ * floats, caller-owned, 16-byte aligned.  Other shapes: NSC_ERR_UNSUPPORTED (nsc_conv1d_wgrad_batch serves them). */
+long nsc_conv1d_wgrad_split_workspace(void);
+int nsc_conv1d_wgrad_split(const nsc_conv_wgrad_job* jobs, int njobs, float* workspace, long workspace_floats, void* stream);
 /* wt[K-1-k, o, i] = w[k, i, o] : weights of the data-gradient conv (dgrad == nsc_conv1d_fwd on wt). */
 int nsc_weight_flip_transpose(const float* w, float* wt, int K, int Cin, int Cout, void* stream);
 /* The four flipped / transposed kernels nsc_gated_block_dgrad[_cin1] reads, in ONE launch: wt = wt1 [1][narrow][Cin] | wtl [15][narrow][narrow]

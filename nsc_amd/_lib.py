@@ -131,8 +131,9 @@ PROTOTYPES["nsc_entropy_from_hist_batch"] = [C.POINTER(EntropyJob), _I, _P]
 PROTOTYPES["nsc_gated_block_wgrad_batch"] = [C.POINTER(BlockWgradJob), _I, _I, _I, _I, _P, _L, _P]
 PROTOTYPES["nsc_gated_block_wgrad_batch_split"] = [C.POINTER(BlockWgradJob), _I, _I, _I, _I, _P, _L, _P]
 PROTOTYPES["nsc_conv1d_wgrad_batch"] = [C.POINTER(ConvWgradJob), _I, _P, _L, _P]
+PROTOTYPES["nsc_conv1d_wgrad_split"] = [C.POINTER(ConvWgradJob), _I, _P, _L, _P]
 EXPORTS = sorted(list(PROTOTYPES) + ["nsc_version", "nsc_last_error", "nsc_gated_block_wgrad_workspace", "nsc_gated_block_image_floats",
-                  "nsc_gated_block_simage_words", "nsc_conv1d_simage_words",
+                  "nsc_gated_block_simage_words", "nsc_conv1d_simage_words", "nsc_conv1d_wgrad_split_workspace",
                   "nsc_gated_block_pair_flag_ints",
                   "nsc_conv1d_wgrad_workspace", "nsc_gated_block_wgrad_batch_workspace",
                   "nsc_conv1d_wgrad_batch_workspace"])
@@ -168,6 +169,8 @@ def load():
     lib.nsc_conv1d_wgrad_batch_workspace.restype = C.c_long
     lib.nsc_gated_block_image_floats.argtypes = [C.c_int] * 4
     lib.nsc_gated_block_image_floats.restype = C.c_long
+    lib.nsc_conv1d_wgrad_split_workspace.argtypes = []
+    lib.nsc_conv1d_wgrad_split_workspace.restype = C.c_long
     lib.nsc_conv1d_simage_words.argtypes = [C.c_int, C.POINTER(ConvDesc)]
     lib.nsc_conv1d_simage_words.restype = C.c_long
     lib.nsc_gated_block_simage_words.argtypes = [C.c_int] * 4

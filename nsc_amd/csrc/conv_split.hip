@@ -324,3 +324,254 @@ extern "C" int nsc_conv1d_dgrad_simg(const nsc_conv_desc* d, const float* dy, co
   ConvSplitArgs a{dy, (const uint4*)image, nullptr, dx, d->B, d->Tout, d->Tout, 0, d->B * (d->Tout / CS_TT), d->Tout / CS_TT};
   return cs_launch<1>(a, (hipStream_t)stream);
 }
+
+// =====================================================================================================
+// WEIGHT GRADIENT of the same conv on split operands:  dW[k][ci][o] += sum_{b,t} x[b][ci][2 t + k - 3] dy[b][o][t],  db[o] += sum dy.
+// GEMM rows m = (k, ci) (900 -> 57 row tiles), columns o (100 -> 7 column tiles), reduction over (b, t).  The 399 accumulator tiles are
+// 408 KB - most of a CU's register file - so a job is split into two PARTS (row tiles 0..28 | 29..56), each served by its own
+// persistent workgroups: wave w keeps row tiles w, w + 8, w + 16, w + 24 of its part x all 7 column tiles (112 registers) and walks
+// 64-step tiles of (frame, time).  Per tile: x is staged exactly as in the forward kernel (three bf16 planes [2 t0 - 3 + r][100], row
+// pitch exactly 100, so row m of the virtual im2col matrix at output step tl is element 2 tl * 100 + m); the A fragment wants 8
+// consecutive STEPS of one row - the transpose of what is contiguous - and comes from two ds_read_b64_tr_b16 (block_split.hip, weight
+// gradients); dy is staged as [o][t] planes (row pitch 72) and read as 16-byte fragments.  Both operands come from LDS, so the NEXT
+// tile's x and dy travel in registers during the MFMAs.  A workgroup ends by storing its accumulators to a private slab; one reduce
+// launch sums the slabs into dW / db (accumulating).
+// =====================================================================================================
+namespace {
+constexpr int CW_LDT = 72, CW_NRT = 57, CW_NRT0 = 29, CW_NCT = 7, CW_MAXJ = 8;
+constexpr int CW_ROWS0 = CW_NRT0 * 16;                      // 464 rows of (k, ci) in part 0
+constexpr int CW_DB_OFF = CW_ROWS0 * CS_C;                  // db behind part 0's rows in its slabs
+constexpr long CW_SLAB = ((long)CW_DB_OFF + CS_C + 63) & ~63L;
+struct ConvWgradSplitJob { const float* x; const float* dy; float* dw; float* db; int Tin, Tout, ntiles, tpf, wg0, nwg; };
+struct ConvWgradSplitBatch { ConvWgradSplitJob j[CW_MAXJ]; int njobs, B; float* slabs; };
+
+typedef short s16x4_ __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 cw_frag_tr(const u16* p0, const u16* p1) {
+  typedef __attribute__((address_space(3))) s16x4_* lds_p;
+  const s16x4_ v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p0));
+  const s16x4_ v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p1));
+  return (bf16x8){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+}
+
+__global__ __launch_bounds__(512) void conv_wgrad_split_kernel(ConvWgradSplitBatch t) {
+  using G = CsGeom<0>;
+  extern __shared__ __attribute__((aligned(16))) u16 cs_sm[];
+  constexpr int PLS = (G::PL + 8 + 7) & ~7;
+  constexpr int PLD = CW_NCT * 16 * CW_LDT;
+  u16* const xpl = cs_sm;
+  u16* const dpl = cs_sm + 3 * PLS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, kq = lane >> 4, tq = l15 >> 2, tp = l15 & 3;
+  int ji = 0;
+  for (int q = 1; q < t.njobs; ++q)
+    if ((int)blockIdx.x >= t.j[q].wg0) ji = q;
+  const ConvWgradSplitJob& jb = t.j[ji];
+  const int wl = blockIdx.x - jb.wg0, part = wl / jb.nwg, slot = wl - part * jb.nwg;
+  const int rt0 = (part ? CW_NRT0 : 0) + wave;                          // this wave's row tiles: rt0 + 8 r
+  const bool has4 = rt0 + 24 < (part ? CW_NRT : CW_NRT0);
+
+  f32x4 acc[4][CW_NCT];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < CW_NCT; ++c) acc[r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // ---- staging: units of the x tile as in conv_split_kernel<0>; units (o, 16-byte group) of the dy tile ----
+  constexpr int NCPB = (CS_C / 2 + 7) / 8, NGB = (G::NG + 7) / 8, NITX = (NCPB * NGB + 7) / 8;
+  constexpr int NITD = (CS_C * (CS_TT / 4) + 511) / 512;
+  const int gl = lane & 7, cl = lane >> 3;
+  f32x4 xv0[NITX], xv1[NITX], dv[NITD];
+  float bs[NITD];
+#pragma unroll
+  for (int it = 0; it < NITD; ++it) bs[it] = 0.f;
+  auto load_tile = [&](int tile) {
+    const int b = tile / jb.tpf, t0 = (tile - b * jb.tpf) * CS_TT;
+    const float* xb = jb.x + (long)b * CS_C * jb.Tin;
+    const int u_al = 2 * t0 - G::PADL - G::SHIFT;
+#pragma unroll
+    for (int it = 0; it < NITX; ++it) {
+      const int ub = wave + 8 * it, cpb = ub / NGB, gb = ub - cpb * NGB;
+      const int cp = cpb * 8 + cl, g = gb * 8 + gl, u = u_al + 4 * g;
+      xv0[it] = xv1[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (ub < NCPB * NGB && cp < CS_C / 2 && g < G::NG && u >= 0 && u < jb.Tin) {
+        xv0[it] = *reinterpret_cast<const f32x4*>(xb + (long)(2 * cp) * jb.Tin + u);
+        xv1[it] = *reinterpret_cast<const f32x4*>(xb + (long)(2 * cp + 1) * jb.Tin + u);
+      }
+    }
+    const float* db_ = jb.dy + (long)b * CS_C * jb.Tout + t0;
+#pragma unroll
+    for (int it = 0; it < NITD; ++it) {
+      const int id = it * 512 + tid, o = id >> 4, g = id & 15;
+      dv[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (o < CS_C) dv[it] = *reinterpret_cast<const f32x4*>(db_ + (long)o * jb.Tout + 4 * g);
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int it = 0; it < NITX; ++it) {
+      const int ub = wave + 8 * it, cpb = ub / NGB, gb = ub - cpb * NGB;
+      const int cp = cpb * 8 + cl, g = gb * 8 + gl;
+      if (ub < NCPB * NGB && cp < CS_C / 2 && g < G::NG) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = 4 * g + j - G::SHIFT;
+          if (r >= 0) {
+            unsigned pk[3];
+            nsc_split2(xv0[it][j], xv1[it][j], pk);
+            unsigned* w = reinterpret_cast<unsigned*>(xpl + r * CS_C + 2 * cp);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) w[p * (PLS / 2)] = pk[p];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NITD; ++it) {
+      const int id = it * 512 + tid, o = id >> 4, g = id & 15;
+      if (o < CS_C) {
+        unsigned pa[3], pb[3];
+        nsc_split2(dv[it][0], dv[it][1], pa);
+        nsc_split2(dv[it][2], dv[it][3], pb);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(dpl + p * PLD + o * CW_LDT + 4 * g) = make_uint2(pa[p], pb[p]);
+        bs[it] += (dv[it][0] + dv[it][1]) + (dv[it][2] + dv[it][3]);
+      }
+    }
+  };
+
+  // fragment addresses: A = transposed reads of the x planes (block row tq = step 32 s + 8 kq + tq (+ 4), columns 16 rt + 4 tp ..),
+  // B = [o][t] planes, row 16 ct + l15, k = 32 s + 8 kq ..
+  const u16* const atr = xpl + (2 * (8 * kq + tq)) * CS_C + 16 * rt0 + 4 * tp;
+  const u16* const bfr = dpl + l15 * CW_LDT + 8 * kq;
+
+  if (slot < jb.ntiles) load_tile(slot);
+  for (int tile = slot; tile < jb.ntiles; tile += jb.nwg) {
+    __syncthreads();                                   // everyone is done reading the previous tile
+    store_tile();
+    __syncthreads();
+    if (tile + jb.nwg < jb.ntiles) load_tile(tile + jb.nwg);       // in flight during the MFMAs below
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int rp = 0; rp < 2; ++rp) {
+        if (rp == 1 && !has4) {
+          // (waves with three row tiles: the pair's second tile is skipped below)
+        }
+        bf16x8 af[2][3];
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+            const u16* q0 = atr + p * PLS + s * (64 * CS_C) + (2 * rp + r2) * 128;
+            af[r2][p] = cw_frag_tr(q0, q0 + 8 * CS_C);
+          }
+#pragma unroll
+        for (int c = 0; c < CW_NCT; ++c) {
+          bf16x8 bf[3];
+#pragma unroll
+          for (int p = 0; p < 3; ++p) bf[p] = *reinterpret_cast<const bf16x8*>(bfr + p * PLD + c * 16 * CW_LDT + 32 * s);
+          acc[2 * rp][c] = cs_split6(af[0], bf, acc[2 * rp][c]);
+          if (rp == 0 || has4) acc[2 * rp + 1][c] = cs_split6(af[1], bf, acc[2 * rp + 1][c]);
+          if (c & 1) __builtin_amdgcn_sched_barrier(0);       // (keeps hipcc from hoisting all 21 B fragments: registers)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+
+  // ---- flush to this workgroup's slab ----
+  float* slab = t.slabs + (long)blockIdx.x * CW_SLAB;
+  const int m_base = part ? CW_ROWS0 : 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (r == 3 && !has4) break;
+#pragma unroll
+    for (int c = 0; c < CW_NCT; ++c) {
+      const int o = 16 * c + l15;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = 16 * (rt0 + 8 * r) + 4 * kq + i;
+        if (o < CS_C && m < 9 * CS_C) slab[(long)(m - m_base) * CS_C + o] = acc[r][c][i];
+      }
+    }
+  }
+  if (part == 0) {
+#pragma unroll
+    for (int it = 0; it < NITD; ++it) {
+      float v = bs[it];
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) v += __shfl_xor(v, off);
+      const int o = (it * 512 + tid) >> 4;
+      if ((tid & 15) == 0 && o < CS_C) slab[CW_DB_OFF + o] = v;
+    }
+  }
+}
+
+// dw / db += sum of the part's slabs; blockIdx.y = job * 2 + part; a workgroup owns 64 elements, its four waves take every fourth slab
+__global__ __launch_bounds__(256) void conv_wgrad_split_reduce_kernel(ConvWgradSplitBatch t) {
+  __shared__ float part_[4][64];
+  const int ji = blockIdx.y >> 1, part = blockIdx.y & 1;
+  const ConvWgradSplitJob& jb = t.j[ji];
+  const int n = part ? (9 * CS_C - CW_ROWS0) * CS_C : CW_DB_OFF + CS_C;
+  const float* s0 = t.slabs + (long)(jb.wg0 + part * jb.nwg) * CW_SLAB;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int base = blockIdx.x * 64; base < n; base += gridDim.x * 64) {
+    const int i = base + lane;
+    float a0 = 0.f, a1 = 0.f;
+    if (i < n) {
+      int w = wave;
+      for (; w + 4 < jb.nwg; w += 8) {
+        a0 += s0[(long)w * CW_SLAB + i];
+        a1 += s0[(long)(w + 4) * CW_SLAB + i];
+      }
+      for (; w < jb.nwg; w += 4) a0 += s0[(long)w * CW_SLAB + i];
+    }
+    part_[wave][lane] = a0 + a1;
+    __syncthreads();
+    if (wave == 0 && i < n) {
+      const float v = (part_[0][lane] + part_[1][lane]) + (part_[2][lane] + part_[3][lane]);
+      if (part == 0 && i >= CW_DB_OFF) { if (jb.db) jb.db[i - CW_DB_OFF] += v; }
+      else jb.dw[(long)(part ? CW_ROWS0 : 0) * CS_C + i] += v;
+    }
+    __syncthreads();
+  }
+}
+}  // namespace
+
+extern "C" long nsc_conv1d_wgrad_split_workspace() { return 256L * CW_SLAB; }
+
+// jobs: nsc_conv_wgrad_job (x = the conv's input, dz = dy, dw / db accumulated into, flip_taps 0) of stride-2 k9 100 -> 100 convs
+extern "C" int nsc_conv1d_wgrad_split(const nsc_conv_wgrad_job* jobs, int njobs, float* workspace, long workspace_floats, void* stream) {
+  NSC_REQUIRE(jobs && njobs > 0 && workspace, NSC_ERR_BAD_ARG, "nsc_conv1d_wgrad_split: bad arguments");
+  NSC_REQUIRE(njobs <= CW_MAXJ, NSC_ERR_UNSUPPORTED, "nsc_conv1d_wgrad_split: more than %d jobs", CW_MAXJ);
+  NSC_REQUIRE(workspace_floats >= 256L * CW_SLAB && ((uintptr_t)workspace & 15) == 0, NSC_ERR_BAD_ARG,
+              "nsc_conv1d_wgrad_split: workspace %ld floats < %ld", workspace_floats, 256L * CW_SLAB);
+  ConvWgradSplitBatch t;
+  memset(&t, 0, sizeof(t));
+  t.njobs = njobs;
+  t.slabs = workspace;
+  const int per = 256 / (2 * njobs);                       // workgroups per (job, part)
+  int wg = 0;
+  for (int q = 0; q < njobs; ++q) {
+    const nsc_conv_wgrad_job& jb = jobs[q];
+    NSC_REQUIRE(jb.x && jb.dz && jb.dw, NSC_ERR_BAD_ARG, "nsc_conv1d_wgrad_split: job %d: null x/dz/dw", q);
+    NSC_REQUIRE(cs_shape_ok(&jb.d) && !jb.flip_taps, NSC_ERR_UNSUPPORTED, "nsc_conv1d_wgrad_split: job %d: the stride-2 k9 100 -> 100 conv only", q);
+    NSC_REQUIRE((((uintptr_t)jb.x | (uintptr_t)jb.dz) & 15) == 0, NSC_ERR_UNSUPPORTED, "nsc_conv1d_wgrad_split: 16-byte aligned tensors");
+    ConvWgradSplitJob& j = t.j[q];
+    j.x = jb.x; j.dy = jb.dz; j.dw = jb.dw; j.db = jb.db; j.Tin = jb.d.Tin; j.Tout = jb.d.Tout;
+    j.tpf = jb.d.Tout / CS_TT; j.ntiles = jb.d.B * j.tpf;
+    j.nwg = std::max(1, std::min(per, j.ntiles)); j.wg0 = wg;
+    wg += 2 * j.nwg;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  auto kern = conv_wgrad_split_kernel;
+  using G = CsGeom<0>;
+  const size_t smem = (size_t)(3 * ((G::PL + 8 + 7) & ~7) + 3 * CW_NCT * 16 * CW_LDT) * sizeof(u16);
+  const hipError_t e = NSC_SMEM_ATTR(kern, 160 * 1024);
+  NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "conv_wgrad_split: smem attr: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL(kern, dim3(wg), dim3(512), smem, st, t);
+  NSC_CHECK_LAUNCH("conv_wgrad_split");
+  hipLaunchKernelGGL(conv_wgrad_split_reduce_kernel, dim3(256, 2 * njobs), dim3(256), 0, st, t);
+  NSC_CHECK_LAUNCH("conv_wgrad_split_reduce");
+  return NSC_OK;
+}

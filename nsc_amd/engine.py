@@ -1024,6 +1024,25 @@ class CascadeEngine:
         self._sum_jobs = []
         if not self._cw_jobs:
             return
+        tok = self.prof_begin("wgrad_mfma", self._cw_flops)
+        if self.split_conv:
+            # the stride-2 down-sampling convs: their own launch on split operands (csrc/conv_split.hip), up to 8 jobs per call
+            sp = [j for j in self._cw_jobs if not j.flip_taps and int(self.lib.nsc_conv1d_simage_words(0, C.byref(j.d))) > 0]
+            if sp:
+                self._cw_jobs = [j for j in self._cw_jobs if not any(j is q for q in sp)]
+                need = int(self.lib.nsc_conv1d_wgrad_split_workspace())
+                ws = self._bufs.get("cwgrad.split.ws")
+                if ws is None:
+                    ws = torch.empty(need, dtype=torch.float32, device=self.device)
+                    self._bufs["cwgrad.split.ws"] = ws
+                for lo in range(0, len(sp), 8):
+                    chunk = sp[lo:lo + 8]
+                    check(self.lib.nsc_conv1d_wgrad_split((_lib.ConvWgradJob * len(chunk))(*chunk), len(chunk), ws.data_ptr(), ws.numel(),
+                                                          self.stream()), "conv1d_wgrad_split")
+        if not self._cw_jobs:
+            self.prof_end(tok)
+            self._cw_flops = 0.0
+            return
         n = len(self._cw_jobs)
         jobs = (_lib.ConvWgradJob * n)(*self._cw_jobs)
         need = int(self.lib.nsc_conv1d_wgrad_batch_workspace(jobs, n))
@@ -1031,7 +1050,6 @@ class CascadeEngine:
         if ws is None or ws.numel() < need:
             ws = torch.empty(need, dtype=torch.float32, device=self.device)
             self._bufs["cwgrad.ws"] = ws
-        tok = self.prof_begin("wgrad_mfma", self._cw_flops)
         check(self.lib.nsc_conv1d_wgrad_batch(jobs, n, ws.data_ptr(), ws.numel(), self.stream()), "conv1d_wgrad_batch")
         self.prof_end(tok)
         self._cw_jobs, self._cw_flops = [], 0.0

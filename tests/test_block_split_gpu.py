@@ -342,3 +342,42 @@ def test_split_stride2_conv_refuses_other_shapes(lib):
     assert int(lib.nsc_conv1d_simage_words(0, C.byref(d2))) == 0
     t = torch.zeros(16, device="cuda")
     assert lib.nsc_conv1d_fwd_simg(C.byref(d2), P(t), P(t), None, P(t), _st()) == -2
+
+
+@pytest.mark.parametrize("B,Tin,njobs", [(2, 128, 1), (5, 256, 2), (130, 512, 2), (3, 128, 3)])
+def test_split_stride2_conv_weight_gradient_matches_float64_and_the_exact_kernel(lib, B, Tin, njobs):
+    """nsc_conv1d_wgrad_split (bf16 matrix cores, split operands; several jobs per launch, accumulating) against float64 and against
+    nsc_conv1d_wgrad_ws."""
+    from nsc_amd._lib import ConvWgradJob
+    rng = np.random.default_rng(B * 7 + Tin + njobs)
+    Tout = Tin // 2
+    d = _down_desc(B, Tin)
+    ws = torch.empty(int(lib.nsc_conv1d_wgrad_split_workspace()), device="cuda")
+    keep, jobs, refs = [], [], []
+    for q in range(njobs):
+        x = rng.standard_normal((B, 100, Tin)).astype(np.float32)
+        dy = rng.standard_normal((B, 100, Tout)).astype(np.float32)
+        dw0 = (0.5 * rng.standard_normal((9, 100, 100))).astype(np.float32)       # the launch ACCUMULATES into dw / db
+        db0 = (0.5 * rng.standard_normal(100)).astype(np.float32)
+        xd, dyd, dwd, dbd = dev(x), dev(dy), dev(dw0), dev(db0)
+        keep += [xd, dyd, dwd, dbd]
+        jobs.append(ConvWgradJob(d, P(xd), P(dyd), P(dwd), P(dbd) if q != 1 else None, 0))      # (job 1: no bias gradient wanted)
+        xp = np.pad(x.astype(np.float64), ((0, 0), (0, 0), (3, 4)))
+        dwr = np.stack([np.einsum("bit,bot->io", xp[:, :, k:k + 2 * Tout:2], dy.astype(np.float64)) for k in range(9)])
+        refs.append((dwd, dbd, dw0, db0, dwr, dy.astype(np.float64).sum((0, 2)), xd, dyd))
+    assert lib.nsc_conv1d_wgrad_split((ConvWgradJob * njobs)(*jobs), njobs, P(ws), ws.numel(), _st()) == 0, lib.nsc_last_error()
+    torch.cuda.synchronize()
+    for q, (dwd, dbd, dw0, db0, dwr, dbr, xd, dyd) in enumerate(refs):
+        assert_close(dwd.cpu().numpy() - dw0, dwr, what=f"split stride-2 conv dW (job {q})")
+        if q != 1:
+            assert_close(dbd.cpu().numpy() - db0, dbr, what=f"split stride-2 conv db (job {q})")
+        else:
+            assert np.array_equal(dbd.cpu().numpy(), db0)
+    # against the exact kernel (job 0)
+    dwd, dbd, dw0, db0, dwr, dbr, xd, dyd = refs[0]
+    dwe, dbe = torch.zeros(9, 100, 100, device="cuda"), torch.zeros(100, device="cuda")
+    assert lib.nsc_conv1d_wgrad_ws(C.byref(d), P(xd), P(dyd), P(dwe), P(dbe), 0, None, 0, _st()) == 0
+    torch.cuda.synchronize()
+    es = np.sqrt(np.mean((dwd.cpu().numpy() - dw0 - dwr) ** 2)), np.sqrt(np.mean((dwe.cpu().numpy() - dwr) ** 2))
+    print(f"stride-2 conv dW rms error vs float64: split {es[0]:.3e}, exact {es[1]:.3e}")
+    assert es[0] <= 1.5 * es[1] + 3e-7 * np.sqrt(np.mean(dwr ** 2))

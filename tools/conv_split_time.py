@@ -63,5 +63,15 @@ for B, Tin in [(128, 512), (256, 512), (1024, 512), (128, 256)]:
     dxe = dx.clone()
     t_ds = timeit(lambda: _lib.check(lib.nsc_conv1d_dgrad_simg(C.byref(d), P(dy), P(imgs[1]), P(dx), st), "dgrad simg"))
     err = float((dx - dxe).abs().max() / dxe.abs().max())
+    # weight gradient: two jobs per launch, as in the 2-codec step
+    from nsc_amd._lib import ConvWgradJob
+    dw = [torch.zeros(9, 100, 100, device="cuda") for _ in range(2)]
+    db = [torch.zeros(100, device="cuda") for _ in range(2)]
+    jobs = (ConvWgradJob * 2)(*[ConvWgradJob(d, P(x), P(dy), P(dw[q]), P(db[q]), 0) for q in range(2)])
+    wsb = torch.empty(int(lib.nsc_conv1d_wgrad_batch_workspace(jobs, 2)), device="cuda")
+    wss = torch.empty(int(lib.nsc_conv1d_wgrad_split_workspace()), device="cuda")
+    t_we = timeit(lambda: _lib.check(lib.nsc_conv1d_wgrad_batch(jobs, 2, P(wsb), wsb.numel(), st), "wgrad batch"), n=20)
+    t_ws = timeit(lambda: _lib.check(lib.nsc_conv1d_wgrad_split(jobs, 2, P(wss), wss.numel(), st), "wgrad split"), n=20)
     print(f"B={B:5d} Tin={Tin}: forward exact {t_fe:6.1f} us {fl / t_fe / 1e6:6.1f} TF | split {t_fs:6.1f} us {fl / t_fs / 1e6:6.1f} TF | x{t_fe / t_fs:.2f}    "
-          f"data gradient exact {t_de:6.1f} us | split {t_ds:6.1f} us {fl / t_ds / 1e6:6.1f} TF | x{t_de / t_ds:.2f}  (split vs exact dx: {err:.1e})")
+          f"data gradient exact {t_de:6.1f} us | split {t_ds:6.1f} us {fl / t_ds / 1e6:6.1f} TF | x{t_de / t_ds:.2f}  (split vs exact dx: {err:.1e})    "
+          f"weight gradient, 2 jobs: exact {t_we:6.1f} us | split {t_ws:6.1f} us {2 * fl / t_ws / 1e6:6.1f} TF | x{t_we / t_ws:.2f}")
