@@ -602,7 +602,16 @@ extern "C" int nsc_gather(const float* src, const int* idx, float* dst, long n, 
 __global__ void step_begin_kernel(const float* __restrict__ src, const int* __restrict__ idx, float* __restrict__ dst, long n,
                                   float* __restrict__ zero, long zn4, int* __restrict__ counter, int gather_blocks) {
   if ((int)blockIdx.x < gather_blocks) {
-    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gather_blocks * blockDim.x)
+    // four words per thread: one 16-byte index load, four gathers in flight, one 16-byte store (round 5: the images of the split-operand
+    // kernels tripled the gathered words; a word per thread was latency-bound at 29 us)
+    const long n4 = n >> 2;
+    const i32x4_t* idx4 = reinterpret_cast<const i32x4_t*>(idx);
+    f32x4* dst4 = reinterpret_cast<f32x4*>(dst);
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n4; e += (long)gather_blocks * blockDim.x) {
+      const i32x4_t i = idx4[e];
+      dst4[e] = (f32x4){gather_word(src, i[0]), gather_word(src, i[1]), gather_word(src, i[2]), gather_word(src, i[3])};
+    }
+    for (long e = 4 * n4 + blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gather_blocks * blockDim.x)
       dst[e] = gather_word(src, idx[e]);
     if (counter && blockIdx.x == 0 && threadIdx.x == 0) counter[0] += 1;
   } else {
@@ -616,7 +625,8 @@ extern "C" int nsc_step_begin(const float* src, const int* idx, float* dst, long
                               void* stream) {
   NSC_REQUIRE(src && idx && dst && n > 0 && zero && zero_n > 0, NSC_ERR_BAD_ARG, "nsc_step_begin: bad args");
   NSC_REQUIRE((zero_n & 3) == 0 && ((uintptr_t)zero & 15) == 0, NSC_ERR_BAD_ARG, "nsc_step_begin: the zeroed range must be 16-byte aligned and a multiple of 4 floats");
-  const int gb = (int)std::min<long>(2048, nsc_cdiv(n, 256)), zb = (int)std::min<long>(512, nsc_cdiv(zero_n / 4, 256));
+  NSC_REQUIRE((((uintptr_t)idx | (uintptr_t)dst) & 15) == 0, NSC_ERR_BAD_ARG, "nsc_step_begin: idx and dst must be 16-byte aligned");
+  const int gb = (int)std::min<long>(2048, nsc_cdiv(nsc_cdiv(n, 4), 256)), zb = (int)std::min<long>(512, nsc_cdiv(zero_n / 4, 256));
   hipLaunchKernelGGL(step_begin_kernel, dim3(gb + zb), dim3(256), 0, (hipStream_t)stream, src, idx, dst, n, zero, zero_n / 4, counter, gb);
   NSC_CHECK_LAUNCH("step_begin");
   return NSC_OK;

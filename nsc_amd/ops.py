@@ -109,8 +109,27 @@ def _desc(B, Cin, Cout, Tin, Tout, K, dil, stride, padL, **kw):
     return d
 
 
+def _split_conv_image(lib, which, d, w):
+    """Kernel-ready image of a stride-2 k9 100 -> 100 kernel for the split-operand conv kernels (csrc/conv_split.hip): one gather launch
+    from the kernel tensor itself; the index map is cached per device.  None: this shape is not served (or NSC_BLOCK_ARITH=exact)."""
+    if not SPLIT_ARITH:
+        return None
+    n = int(lib.nsc_conv1d_simage_words(which, C.byref(d)))
+    if n <= 0 or w.data_ptr() % 16:
+        return None
+    key = ("cs_idx", which, str(w.device))
+    if key not in _CACHE:
+        idx = np.empty(n, np.int32)
+        check(lib.nsc_conv1d_simage_index(which, C.byref(d), 0, idx.ctypes.data_as(C.c_void_p)), "conv1d_simage_index")
+        _CACHE[key] = torch.from_numpy(idx).to(w.device)
+    img = torch.empty(n, dtype=torch.float32, device=w.device)
+    check(lib.nsc_gather(w.data_ptr(), _CACHE[key].data_ptr(), img.data_ptr(), n, _st()), "gather")
+    return img
+
+
 class Conv1dFn(torch.autograd.Function):
-    """tf.compat.v1.layers.conv1d(padding='SAME', channels_last) + bias + activation."""
+    """tf.compat.v1.layers.conv1d(padding='SAME', channels_last) + bias + activation.  The stride-2 down-sampling conv takes the
+    split-operand kernels of the engine (forward, data gradient, weight gradient) like the gated blocks do."""
 
     @staticmethod
     def forward(ctx, x, w, b, dil, stride, act):
@@ -124,8 +143,12 @@ class Conv1dFn(torch.autograd.Function):
         xb = to_bct(x)
         y = torch.empty((B, Cout, Tout), dtype=torch.float32, device=x.device)
         d = _desc(B, Cin, Cout, T, Tout, K, dil, stride, padL, act=ACT[act])
-        fn = lib.nsc_conv1d_cout1_fwd if Cout == 1 else lib.nsc_conv1d_fwd
-        check(fn(C.byref(d), xb.data_ptr(), w.data_ptr(), b.data_ptr(), None, None, y.data_ptr(), _st()), "conv1d")
+        img = _split_conv_image(lib, 0, d, w) if stride == 2 else None
+        if img is not None and xb.data_ptr() % 16 == 0:
+            check(lib.nsc_conv1d_fwd_simg(C.byref(d), xb.data_ptr(), img.data_ptr(), b.data_ptr(), y.data_ptr(), _st()), "conv1d (split)")
+        else:
+            fn = lib.nsc_conv1d_cout1_fwd if Cout == 1 else lib.nsc_conv1d_fwd
+            check(fn(C.byref(d), xb.data_ptr(), w.data_ptr(), b.data_ptr(), None, None, y.data_ptr(), _st()), "conv1d")
         ctx.save_for_backward(xb, w, y)
         ctx.cfg = (dil, stride, act, padL, T, Tout)
         return to_btc(y)
@@ -145,7 +168,14 @@ class Conv1dFn(torch.autograd.Function):
         dwb = torch.zeros(w.numel() + Cout, dtype=torch.float32, device=w.device)      # dw | db
         dw, db = dwb[:w.numel()].view(w.shape), dwb[w.numel():]
         # partial sums of the (b,t) splits go to private slabs + one reduce launch (nsc_conv1d_wgrad_ws) instead of same-address atomics
-        if Cout == 1:
+        dfw = _desc(B, Cin, Cout, T, Tout, K, dil, stride, padL)
+        split = (stride == 2 and SPLIT_ARITH and int(lib.nsc_conv1d_simage_words(0, C.byref(dfw))) > 0 and
+                 (xb.data_ptr() | dz.data_ptr() | w.data_ptr()) % 16 == 0)
+        if split:
+            ws = _workspace(int(lib.nsc_conv1d_wgrad_split_workspace()), w.device)
+            job = _lib.ConvWgradJob(dfw, xb.data_ptr(), dz.data_ptr(), dw.data_ptr(), db.data_ptr(), 0)
+            check(lib.nsc_conv1d_wgrad_split((_lib.ConvWgradJob * 1)(job), 1, ws.data_ptr(), ws.numel(), _st()), "wgrad (split)")
+        elif Cout == 1:
             d = _desc(B, 1, Cin, Tout, T, K, dil, 1, (K - 1) * dil - padL)
             ws = _workspace(int(lib.nsc_conv1d_wgrad_workspace(C.byref(d))), w.device)
             check(lib.nsc_conv1d_wgrad_ws(C.byref(d), dz.data_ptr(), xb.data_ptr(), dw.data_ptr(), None, 1, ws.data_ptr(), ws.numel(), _st()),
@@ -157,7 +187,12 @@ class Conv1dFn(torch.autograd.Function):
             check(lib.nsc_conv1d_wgrad_ws(C.byref(d), xb.data_ptr(), dz.data_ptr(), dw.data_ptr(), db.data_ptr(), 0, ws.data_ptr(),
                                           ws.numel(), _st()), "wgrad")
         dx = None
-        if ctx.needs_input_grad[0]:
+        img = _split_conv_image(lib, 1, dfw, w) if (split and ctx.needs_input_grad[0]) else None
+        if img is not None:
+            dxb = torch.empty((B, Cin, T), dtype=torch.float32, device=w.device)
+            check(lib.nsc_conv1d_dgrad_simg(C.byref(dfw), dz.data_ptr(), img.data_ptr(), dxb.data_ptr(), _st()), "dgrad (split)")
+            dx = to_btc(dxb)
+        elif ctx.needs_input_grad[0]:
             wt = torch.empty((K, Cout, Cin), dtype=torch.float32, device=w.device)
             check(lib.nsc_weight_flip_transpose(w.data_ptr(), wt.data_ptr(), K, Cin, Cout, _st()), "flip")
             dxb = torch.empty((B, Cin, T), dtype=torch.float32, device=w.device)
