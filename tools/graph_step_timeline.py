@@ -2,7 +2,7 @@
 and the gap to the previous kernel's end.  usage: python tools/graph_step_timeline.py <kernel_trace.csv>  (picks a step of typical span)"""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-ks = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0][:70]) for r in rows)
+ks = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0][:70]) for r in rows)
 adam = [i for i, k in enumerate(ks) if 'adam' in k[2]]
 spans = [(ks[adam[i]][1] - ks[adam[i - 1]][1]) / 1e3 for i in range(1, len(adam))]
 med = sorted(spans)[len(spans) // 2]

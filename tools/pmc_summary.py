@@ -5,7 +5,7 @@ d = sys.argv[1]; steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); calls = collections.Counter()
 for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        name = r["Kernel_Name"].split("(")[0].replace("void ", "")[-40:]
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")[-40:]
         agg[name][r["Counter_Name"]] += float(r["Counter_Value"])
         calls[(name, r["Counter_Name"])] += 1
 names = sorted(agg, key=lambda n: -agg[n].get("SQ_WAVE_CYCLES", agg[n].get("FETCH_SIZE", agg[n].get("WRITE_SIZE", 0))))

@@ -8,7 +8,7 @@ import collections, csv, glob, json, sys
 d = sys.argv[1]
 CLASSES = [("conv1d_fwd_kernel", "conv_mfma"), ("gated_block_fwd", "block_fwd"), ("gated_block_dgrad", "block_dgrad"),
            ("gated_block_wgrad", "block_wgrad"), ("conv1d_wgrad_kernel", "wgrad_mfma"), ("quantize_fwd_kernel", "quantize_fwd"),
-           ("conv1d_cout1_kernel", "conv_cout1")]
+           ("conv1d_cout1_kernel", "conv_cout1"), ("conv_split_kernel", "conv_split"), ("conv_wgrad_split_kernel", "conv_wgrad_split")]
 
 
 def read(sub, counter, by_grid=False):

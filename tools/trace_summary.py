@@ -8,7 +8,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
 agg = collections.defaultdict(list)
 for r in rows:
-    name = r['Kernel_Name'].split('(')[0].replace('void ', '')[-44:]
+    name = r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0].replace('void ', '')[-44:]
     key = (name, int(r['Grid_Size_X']) // max(1, int(r['Workgroup_Size_X'])), r['Grid_Size_Y'], r['Grid_Size_Z'],
            r['LDS_Block_Size'], r['VGPR_Count'], r['Accum_VGPR_Count'])
     agg[key].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
