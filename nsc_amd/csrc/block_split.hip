@@ -80,10 +80,21 @@ __device__ __forceinline__ nsc_lds_cu16 nsc_opaque_lds(const u16* p) {
   asm volatile("" : "+v"(a));
   return (nsc_lds_cu16)(unsigned long long)a;
 }
+// NSC_FRAG8_SPLIT (A/B build switch): the second half through an address hipcc cannot see next to the first, so the two 8-byte reads
+// stay two ds_read_b64 (2 cycles each per wave) instead of one ds_read2_b64 (8 cycles)
+#ifndef NSC_FRAG8_SPLIT
+#define NSC_FRAG8_SPLIT 0
+#endif
 __device__ __forceinline__ bf16x8 ld_frag8(nsc_lds_cu16 p) {
   typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
   typedef __attribute__((address_space(3))) const u32x2_* lds_u2;
+#if NSC_FRAG8_SPLIT
+  unsigned a2 = (unsigned)(unsigned long long)(p + 4);
+  asm volatile("" : "+v"(a2));
+  const u32x2_ a = *(lds_u2)(p), b = *(lds_u2)(unsigned long long)a2;
+#else
   const u32x2_ a = *(lds_u2)(p), b = *(lds_u2)(p + 4);
+#endif
   const i32x4_t v = {(int)a[0], (int)a[1], (int)b[0], (int)b[1]};
   return __builtin_bit_cast(bf16x8, v);
 }

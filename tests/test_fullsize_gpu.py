@@ -157,7 +157,9 @@ def _tensor_class(name, shapes):
 
 def _grad_report(mine, g64, g32, what, only=None):
     """Worst max|hip - f64| / max|f64| per tensor class, next to what the same graph delivers in float32 on the CPU.  Printed
-    (pytest -s / -rA), written to gpurun_out/grad_ratios_<what>.json, returned as {class: (hip ratio, fp32-CPU ratio, worst name)}."""
+    (pytest -s / -rA), written to gpurun_out/grad_ratios_<what>.json, returned as {class: (hip ratio, fp32-CPU ratio, worst name)}.
+    The record also carries the RMS error of the class's worst tensor (rms|hip - f64| / rms|f64|): a leaky-relu kink that flips against
+    float64 moves a handful of elements by a whole contribution (the max norm sees only that), the rms norm sees the arithmetic."""
     import json, os
     rep = {}
     shapes = {n: tuple(g.shape) for n, g in g64.items()}
@@ -168,16 +170,19 @@ def _grad_report(mine, g64, g32, what, only=None):
         scale = max(float(np.max(np.abs(b))), 1e-6)
         err = float(np.max(np.abs(a - b))) / scale
         e32 = float(np.max(np.abs(g32[name].reshape(-1) - b))) / scale
+        rb = max(float(np.sqrt(np.mean(b * b))), 1e-12)
+        rms = float(np.sqrt(np.mean((a - b) ** 2))) / rb
+        rms32 = float(np.sqrt(np.mean((g32[name].reshape(-1) - b) ** 2))) / rb
         k = _tensor_class(name, shapes)
         if k not in rep or err > rep[k][0]:
-            rep[k] = (err, e32, name)
+            rep[k] = (err, e32, name, rms, rms32)
     print(f"\nachieved gradient error ({what}; max|hip - f64| / max|f64| per tensor class | the float32 CPU oracle on the same step):")
     for k in sorted(rep):
         print(f"  {k:32s} {rep[k][0]:.3e} | {rep[k][1]:.3e}   worst: {rep[k][2]}")
     try:
         d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
         os.makedirs(d, exist_ok=True)
-        json.dump({k: dict(hip=v[0], fp32_cpu=v[1], worst=v[2]) for k, v in rep.items()},
+        json.dump({k: dict(hip=v[0], fp32_cpu=v[1], worst=v[2], hip_rms=v[3], fp32_cpu_rms=v[4]) for k, v in rep.items()},
                   open(os.path.join(d, f"grad_ratios_{what}.json"), "w"), indent=1)
     except OSError:
         pass

@@ -28,17 +28,25 @@ for f in FILES[:2]:
         lines.append(f"{f}: missing")
         ok = False
         continue
-    lines.append(f"--- {f}: max |grad - float64| / tensor scale per gradient class at B = 128 (hip = the product, fp32_cpu = the PyTorch-CPU float32 oracle)")
+    lines.append(f"--- {f}: error of the worst gradient tensor of each class against float64 at B = 128: rms|g - f64| / rms|f64| and max|g - f64| / max|f64| "
+                 f"(fp32 CPU oracle = the PyTorch-CPU float32 restatement of the same step)")
     for k, ve in rec["exact"][f].items():
         vs = rec["split"][f].get(k)
         if vs is None:
             continue
         e, s_ = ve["hip"], vs["hip"]
-        # (floor 3e-6: where the exact arm sits at 2e-7 .. 7e-7 - twenty times below the float32 CPU oracle's own error - the split arm's
-        # 1e-6 .. 2.5e-6 is a ratio above 1.5 of two numbers that are both rounding noise)
-        flag = "" if s_ <= 1.5 * e + 3e-6 else "   <-- above 1.5x exact + 3e-6"
+        er, sr = ve.get("hip_rms"), vs.get("hip_rms")
+        # The criterion (split <= 1.5x exact + 3e-6) is applied to the RMS error of the class's worst tensor.  The max-norm figures are
+        # shown beside it: in the joint step they move in quanta of ~5e-5 in BOTH arms - one leaky-relu activation within rounding of zero
+        # taking the other slope than float64 (tests/test_fullsize_gpu.py: GRAD_CEILING comment; profiles/r05_kink_flips.txt) - and say
+        # which arm happened to flip more elements, not how well it multiplies.  (Floor 3e-6: where the exact arm sits at 2e-7 .. 7e-7,
+        # twenty times below the float32 CPU oracle's own error, a ratio above 1.5 compares two numbers that are both rounding noise.)
+        if er is None or sr is None:
+            er, sr = e, s_
+        flag = "" if sr <= 1.5 * er + 3e-6 else "   <-- rms above 1.5x exact + 3e-6"
         ok = ok and not flag
-        lines.append(f"   {k:34s} exact {e:.3e}   split {s_:.3e}   ratio {s_ / max(e, 1e-30):5.2f}   (fp32 CPU oracle {ve['fp32_cpu']:.3e}){flag}")
+        lines.append(f"   {k:34s} rms: exact {er:.3e} split {sr:.3e} ratio {sr / max(er, 1e-30):5.2f} | max: exact {e:.3e} split {s_:.3e} ratio "
+                     f"{s_ / max(e, 1e-30):5.2f} (fp32 CPU oracle: rms {ve.get('fp32_cpu_rms', float('nan')):.3e}, max {ve['fp32_cpu']:.3e}){flag}")
 for f in FILES[2:4]:
     for arm in ("exact", "split"):
         if f in rec.get(arm, {}):
