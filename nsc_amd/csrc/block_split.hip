@@ -38,6 +38,9 @@ extern "C" int nsc_probe_read_split(unsigned long long* out) {
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
+#ifndef NSC_EXP
+#define NSC_EXP 0   // timing experiments (make exp EXP=n, WRONG RESULTS): 512 = phase-2 B fragments loop-invariant, 1024 = phase-2 A fragments, 2048 = phase-3 B fragments
+#endif
 
 __device__ __forceinline__ f32x4 mfma_bf(const bf16x8& a, const bf16x8& b, const f32x4& c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
@@ -80,8 +83,9 @@ __device__ __forceinline__ nsc_lds_cu16 nsc_opaque_lds(const u16* p) {
   asm volatile("" : "+v"(a));
   return (nsc_lds_cu16)(unsigned long long)a;
 }
-// NSC_FRAG8_SPLIT (A/B build switch): the second half through an address hipcc cannot see next to the first, so the two 8-byte reads
-// stay two ds_read_b64 (2 cycles each per wave) instead of one ds_read2_b64 (8 cycles)
+// NSC_FRAG8_SPLIT (A/B build switch, `make EXTRA=-DNSC_FRAG8_SPLIT=1`): the second half through an address hipcc cannot see next to
+// the first, so the two 8-byte reads stay two ds_read_b64 instead of one ds_read2_b64.  Measured: no gain (forward launches +0..2 %).
+// Also measured and not kept: fragments three sub-steps ahead instead of one (rings of 4; 256 VGPRs + 8-32 B scratch): +14 %.
 #ifndef NSC_FRAG8_SPLIT
 #define NSC_FRAG8_SPLIT 0
 #endif
@@ -366,11 +370,11 @@ __device__ __forceinline__ void gated_block_fwd3_body(const BlockArgs& a, int nt
         auto fetch_a = [&](int u, int slot) {
           const int s_ = u >> 1, r = u & 1;
 #pragma unroll
-          for (int p = 0; p < 3; ++p) aa[slot][p] = ld_frag16(wl_ + (s_ * 3 + p) * (4 * SPL_W2ROWS * 8) + r * 16 * 8);
+          for (int p = 0; p < 3; ++p) aa[slot][p] = ld_frag16(wl_ + (((NSC_EXP & 1024) ? 0 : s_) * 3 + p) * (4 * SPL_W2ROWS * 8) + r * 16 * 8);
         };
         auto fetch_b = [&](int s_, int slot) {
 #pragma unroll
-          for (int p = 0; p < 3; ++p) bb[slot][p] = ld_frag8(hb[p] + 32 * s_);
+          for (int p = 0; p < 3; ++p) bb[slot][p] = ld_frag8(hb[p] + 32 * ((NSC_EXP & 512) ? 0 : s_));
         };
         fetch_b(0, 0);
         fetch_a(0, 0);
@@ -401,8 +405,8 @@ __device__ __forceinline__ void gated_block_fwd3_body(const BlockArgs& a, int nt
             const int s_ = u >> 1, e = u & 1;
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
-              bb[slot][p] = ld_frag8(hbe[e][p] + 32 * s_);
-              aa[slot][p] = ld_frag16((e ? wa1 : wl_ + 32 * 8) + (s_ * 3 + p) * (4 * SPL_W2ROWS * 8));
+              bb[slot][p] = ld_frag8(hbe[e][p] + 32 * ((NSC_EXP & 512) ? 0 : s_));
+              aa[slot][p] = ld_frag16((e ? wa1 : wl_ + 32 * 8) + (((NSC_EXP & 1024) ? 0 : s_) * 3 + p) * (4 * SPL_W2ROWS * 8));
             }
           };
           fetch(0, 0);
@@ -417,8 +421,8 @@ __device__ __forceinline__ void gated_block_fwd3_body(const BlockArgs& a, int nt
           auto fetch = [&](int s_, int slot) {
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
-              bb[slot][p] = ld_frag8(hbe[0][p] + 32 * s_);
-              aa[slot][p] = ld_frag16(wl_ + 32 * 8 + (s_ * 3 + p) * (4 * SPL_W2ROWS * 8));
+              bb[slot][p] = ld_frag8(hbe[0][p] + 32 * ((NSC_EXP & 512) ? 0 : s_));
+              aa[slot][p] = ld_frag16(wl_ + 32 * 8 + (((NSC_EXP & 1024) ? 0 : s_) * 3 + p) * (4 * SPL_W2ROWS * 8));
             }
           };
           fetch(0, 0);
@@ -506,7 +510,7 @@ __device__ __forceinline__ void gated_block_fwd3_body(const BlockArgs& a, int nt
       auto fetch = [&](int i, int slot) {
         const int s = i / NC, c = i - s * NC;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) gf[slot][p] = ld_frag8(gb[p][c >> 1] + (c & 1) * 16 * NARROW + 32 * s);
+        for (int p = 0; p < 3; ++p) gf[slot][p] = ld_frag8(gb[p][(NSC_EXP & 2048) ? 0 : (c >> 1)] + ((NSC_EXP & 2048) ? 0 : ((c & 1) * 16 * NARROW + 32 * s)));
       };
       fetch(0, 0);
 #pragma unroll
