@@ -602,8 +602,10 @@ extern "C" int nsc_gather(const float* src, const int* idx, float* dst, long n, 
 __global__ void step_begin_kernel(const float* __restrict__ src, const int* __restrict__ idx, float* __restrict__ dst, long n,
                                   float* __restrict__ zero, long zn4, int* __restrict__ counter, int gather_blocks) {
   if ((int)blockIdx.x < gather_blocks) {
-    // four words per thread: one 16-byte index load, four gathers in flight, one 16-byte store (round 5: the images of the split-operand
-    // kernels tripled the gathered words; a word per thread was latency-bound at 29 us)
+#ifndef NSC_SB_VEC
+#define NSC_SB_VEC 0     // A/B (make EXTRA=-DNSC_SB_VEC=1): four words per thread (16-byte index loads / stores) - measured SLOWER (45 vs 29 us)
+#endif
+#if NSC_SB_VEC
     const long n4 = n >> 2;
     const i32x4_t* idx4 = reinterpret_cast<const i32x4_t*>(idx);
     f32x4* dst4 = reinterpret_cast<f32x4*>(dst);
@@ -613,6 +615,10 @@ __global__ void step_begin_kernel(const float* __restrict__ src, const int* __re
     }
     for (long e = 4 * n4 + blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gather_blocks * blockDim.x)
       dst[e] = gather_word(src, idx[e]);
+#else
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gather_blocks * blockDim.x)
+      dst[e] = gather_word(src, idx[e]);
+#endif
     if (counter && blockIdx.x == 0 && threadIdx.x == 0) counter[0] += 1;
   } else {
     const int zb = gridDim.x - gather_blocks;
@@ -626,7 +632,10 @@ extern "C" int nsc_step_begin(const float* src, const int* idx, float* dst, long
   NSC_REQUIRE(src && idx && dst && n > 0 && zero && zero_n > 0, NSC_ERR_BAD_ARG, "nsc_step_begin: bad args");
   NSC_REQUIRE((zero_n & 3) == 0 && ((uintptr_t)zero & 15) == 0, NSC_ERR_BAD_ARG, "nsc_step_begin: the zeroed range must be 16-byte aligned and a multiple of 4 floats");
   NSC_REQUIRE((((uintptr_t)idx | (uintptr_t)dst) & 15) == 0, NSC_ERR_BAD_ARG, "nsc_step_begin: idx and dst must be 16-byte aligned");
-  const int gb = (int)std::min<long>(2048, nsc_cdiv(nsc_cdiv(n, 4), 256)), zb = (int)std::min<long>(512, nsc_cdiv(zero_n / 4, 256));
+#ifndef NSC_SB_BLOCKS
+#define NSC_SB_BLOCKS 2048
+#endif
+  const int gb = (int)std::min<long>(NSC_SB_BLOCKS, nsc_cdiv(NSC_SB_VEC ? nsc_cdiv(n, 4) : n, 256)), zb = (int)std::min<long>(512, nsc_cdiv(zero_n / 4, 256));
   hipLaunchKernelGGL(step_begin_kernel, dim3(gb + zb), dim3(256), 0, (hipStream_t)stream, src, idx, dst, n, zero, zero_n / 4, counter, gb);
   NSC_CHECK_LAUNCH("step_begin");
   return NSC_OK;
