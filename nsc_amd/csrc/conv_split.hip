@@ -130,14 +130,14 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvSplitArgs a) {
     __syncthreads();
     NSC_STAMP(2);
 
-    // ---- the GEMM: wave (cp2, qd): column tiles 2 cp2 + {0, 1}, row tiles [rt0, rt0 + NR) ----
-    const u16* bcol = plane + (G::STRIDE * (cp2 * 32 + l15)) * CS_C + 8 * q;      // second column tile: + STRIDE * 16 rows
+    // ---- the GEMM: a wave computes row tiles [rt0, rt0 + NR) x column tiles [ct0, ct0 + NC) ----
     const uint4* imgl = a.img + lane;
-    auto run = [&](auto nr_c, int rt0) {
-      constexpr int NR = decltype(nr_c)::value;
-      f32x4 acc[2][NR];
+    auto run = [&](auto nr_c, auto nc_c, int rt0, int ct0) {
+      constexpr int NR = decltype(nr_c)::value, NC = decltype(nc_c)::value;
+      const u16* bcol = plane + (G::STRIDE * (ct0 * 16 + l15)) * CS_C + 8 * q;      // next column tile: + STRIDE * 16 rows
+      f32x4 acc[NC][NR];
 #pragma unroll
-      for (int e = 0; e < 2; ++e)
+      for (int e = 0; e < NC; ++e)
 #pragma unroll
         for (int r = 0; r < NR; ++r) acc[e][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
       bf16x8 abuf[2][NR][3];
@@ -166,14 +166,14 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvSplitArgs a) {
       // fence keeps the requests up there (left alone, hipcc re-used the idle A buffer's registers for this step's B fragments and sank
       // the image loads to the END of the step: every other step waited out a full L2 latency), then the 12 NR products - product-major,
       // so that consecutive MFMAs go to different accumulators (a dependent bf16 MFMA issues ~12 cycles late).
-      bf16x8 bbuf[2][2][3];
-      auto step = [&](int s, bf16x8 (&cur)[NR][3], bf16x8 (&nxt)[NR][3], bf16x8 (&bc)[2][3], bf16x8 (&bn)[2][3]) {
+      bf16x8 bbuf[2][NC][3];
+      auto step = [&](int s, bf16x8 (&cur)[NR][3], bf16x8 (&nxt)[NR][3], bf16x8 (&bc)[NC][3], bf16x8 (&bn)[NC][3]) {
         {   // unconditional (the last step re-requests its own fragments): a branch here makes hipcc's vmcnt bookkeeping assume the
             // shorter path and wait for the NEW requests before the first MFMA
           const int sn = s + 1 < G::KS ? s + 1 : G::KS - 1;
           if (!(NSC_EXP & 64)) load_a(sn, nxt);
-          load_b((NSC_EXP & 128) ? 0 : sn, 0, bn[0]);
-          load_b((NSC_EXP & 128) ? 0 : sn, 1, bn[1]);
+#pragma unroll
+          for (int e = 0; e < NC; ++e) load_b((NSC_EXP & 128) ? 0 : sn, e, bn[e]);
         }
         if (NSC_EXP & 64) {
 #pragma unroll
@@ -188,15 +188,15 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvSplitArgs a) {
 #pragma unroll
           for (int r = 0; r < NR; ++r)
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
+            for (int e = 0; e < NC; ++e) {
               if (MODE == 0) acc[e][r] = cs_mfma(bc[e][PX[pi]], cur[r][PW[pi]], acc[e][r]);   // transposed product: a lane's 4 values = 4 consecutive steps of one o
               else acc[e][r] = cs_mfma(cur[r][PW[pi]], bc[e][PX[pi]], acc[e][r]);
             }
         __builtin_amdgcn_sched_barrier(0);
       };
       load_a(0, abuf[0]);
-      load_b(0, 0, bbuf[0][0]);
-      load_b(0, 1, bbuf[0][1]);
+#pragma unroll
+      for (int e = 0; e < NC; ++e) load_b(0, e, bbuf[0][e]);
 #pragma unroll 1
       for (int s = 0; s + 1 < G::KS; s += 2) {
         step(s, abuf[0], abuf[1], bbuf[0], bbuf[1]);
@@ -206,8 +206,8 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvSplitArgs a) {
       NSC_STAMP(3);
       // ---- epilogue ----
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int ct = 2 * cp2 + e;
+      for (int e = 0; e < NC; ++e) {
+        const int ct = ct0 + e;
         if (MODE == 0) {
           // D^T: acc[r][i] = y[o = (rt0 + r) 16 + l15][t0 + 16 ct + 4 q + i]
           float* yb = a.y + (long)b * CS_C * a.Tn + t0 + 16 * ct + 4 * q;
@@ -237,10 +237,19 @@ __global__ __launch_bounds__(512) void conv_split_kernel(ConvSplitArgs a) {
         }
       }
     };
-    {
+#ifndef NSC_CS_MAP
+#define NSC_CS_MAP 0
+#endif
+    if (NSC_CS_MAP == 1 && MODE == 0) {
+      // A/B: one row tile x all four column tiles per wave (wave 7 idle): every image fragment fetched once per workgroup
+      if (wave < 7) run(std::integral_constant<int, 1>{}, std::integral_constant<int, 4>{}, wave, 0);
+    } else if (NSC_CS_MAP == 1 && MODE == 1) {
+      if (wave < 5) run(std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{}, 2 * wave, 0);
+      else run(std::integral_constant<int, 1>{}, std::integral_constant<int, 4>{}, 10 + (wave - 5), 0);
+    } else {
       const int rt0 = qd * G::NRB + (qd < G::NRREM ? qd : G::NRREM);
-      if (qd < G::NRREM) run(std::integral_constant<int, G::NRB + 1>{}, rt0);
-      else run(std::integral_constant<int, G::NRB>{}, rt0);
+      if (qd < G::NRREM) run(std::integral_constant<int, G::NRB + 1>{}, std::integral_constant<int, 2>{}, rt0, 2 * cp2);
+      else run(std::integral_constant<int, G::NRB>{}, std::integral_constant<int, 2>{}, rt0, 2 * cp2);
     }
     NSC_STAMP(4);
     __syncthreads();                                      // the planes are rewritten by the next tile
