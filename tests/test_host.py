@@ -356,3 +356,73 @@ def test_comm_refuses_rccl_with_fewer_gpus_than_local_ranks(monkeypatch):
     monkeypatch.setattr(D.torch.cuda, "device_count", lambda: 1)
     with pytest.raises(RuntimeError, match="one GPU per local rank"):
         D.Comm(backend="nccl")
+
+
+def _bf16_split3(a):
+    """x = hi + lo + lo2 with round-to-nearest-even bf16 pieces (csrc/nsc_common.h: nsc_split2), in numpy."""
+    def rne(v):
+        u = v.astype(np.float32).view(np.uint32).astype(np.uint64)
+        u = (u + 0x7fff + ((u >> 16) & 1)) >> 16 << 16
+        return (u & 0xffffffff).astype(np.uint32).view(np.float32)
+    hi = rne(a)
+    lo = rne(a - hi)
+    lo2 = rne(a - hi - lo)
+    return hi, lo, lo2
+
+
+@pytest.mark.parametrize("which", [0, 1])
+def test_split_conv_image_index_rebuilds_the_gemm_operand_on_the_host(which):
+    """nsc_conv1d_simage_index is host code: emulate nsc_gather's word rule (bits 26..29 = piece plane and source stride, csrc/misc.hip:
+    gather_word) in numpy and check that the image IS the GEMM's A operand in fragment order - forward: Wmat[o][tap * 100 + ci] =
+    W[tap][ci][o]; data gradient (polyphase): Wmat[2 ci + p][t' * 100 + o] = W[7 - 2 t' + p][ci][o], zero where that tap does not exist -
+    as three bf16 pieces that sum back to the float32 weight to 2^-24."""
+    import ctypes as C
+    from nsc_amd import _lib
+    from nsc_amd._lib import ConvDesc
+    lib = _lib.load()
+    d = ConvDesc(B=4, Cin=100, Cout=100, Tin=512, Tout=256, K=9, dil=1, stride=2, padL=3, act=0, res_mode=0, mul_mode=0, out_mode=0, in_up=0,
+                 accumulate=0)
+    n = int(lib.nsc_conv1d_simage_words(which, C.byref(d)))
+    assert n > 0 and n % 256 == 0
+    off = 12
+    idx = np.empty(n, np.int32)
+    assert lib.nsc_conv1d_simage_index(which, C.byref(d), off, idx.ctypes.data_as(C.c_void_p)) == 0
+    rng = np.random.default_rng(which)
+    w = rng.standard_normal((9, 100, 100)).astype(np.float32)
+    src = np.concatenate([np.zeros(off, np.float32), w.reshape(-1), np.zeros(128, np.float32)])
+    pieces = _bf16_split3(src)
+    strides = [20, 25, 50, 100, 1]
+    M, KT, nrt = (100, 9, 7) if which == 0 else (200, 5, 13)
+    ks = n // (nrt * 3 * 256)
+    got = np.zeros((3, nrt * 16, ks * 32), np.float32)              # piece, row m, k
+    im = idx.reshape(ks, nrt, 3, 64, 4)
+    for s in range(ks):
+        for rt in range(nrt):
+            for p in range(3):
+                e = im[s, rt, p]                                     # [lane][word]
+                m_ = (e >> 26) & 15
+                base = e & 0x3ffffff
+                valid = e >= 0
+                assert np.all(~valid | (m_ > 0))                    # every entry of these images is a packed pair of pieces
+                plane = np.where(valid, (m_ - 1) // 5, 0)
+                assert np.all(~valid | (plane == p))
+                stride = np.array(strides)[np.where(valid, (m_ - 1) % 5, 0)]
+                for lane in range(64):
+                    row = rt * 16 + (lane & 15)
+                    for jw in range(4):
+                        k = 32 * s + 8 * (lane >> 4) + 2 * jw
+                        if valid[lane, jw]:
+                            got[p, row, k] = pieces[p][base[lane, jw]]
+                            got[p, row, k + 1] = pieces[p][base[lane, jw] + stride[lane, jw]]
+    want = np.zeros((nrt * 16, ks * 32), np.float32)
+    for tp in range(KT):
+        if which == 0:
+            want[:100, tp * 100:(tp + 1) * 100] = w[tp].T             # [o][ci]
+        else:
+            for par in range(2):
+                kk = 7 - 2 * tp + par
+                if 0 <= kk < 9:
+                    want[par:200:2, tp * 100:(tp + 1) * 100] = w[kk]  # [ci][o] -> rows 2 ci + par
+    rebuilt = got.astype(np.float64).sum(0)
+    assert np.max(np.abs(rebuilt - want)) <= 2.0 ** -23 * np.max(np.abs(want))
+    assert np.array_equal(got[0], _bf16_split3(want)[0])              # the leading piece is the bf16 rounding of the weight itself
