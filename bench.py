@@ -744,7 +744,8 @@ def main():
                        "c_abi_calls_per_step": calls_per_step, "pair_launches": bool(eng.fused_pairs), "pair_launch_timeouts": pair_to, **({"pair_launches_note": pairs_note} if pairs_note else {}),
                        "grad_message": (("one per trainable scope, under the backward pass" if eng.dp_overlap else
                                          "one at the tail of the step") if dcomm is not None else None),
-                       "streams": "one (weight gradients batched at the tail of the step)",
+                       "streams": ("one; at the tail of the step the convs' batched weight gradients run on a second stream beside the gated blocks'"
+                                   if eng.tail_overlap else "one (weight gradients batched at the tail of the step)"),
                        "roofline_note": "per-kernel numbers: HIP events around each launch on extra eager steps of the same workload"},
             "model_tflops": round(fps * mflop_frame * 1e6 / 1e12, 2), "mflop_per_frame": mflop_frame,
             "ms_per_step_exact_f32": (round(ms_exact, 3) if ms_exact is not None else None),
