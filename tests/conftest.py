@@ -12,7 +12,24 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# Collection order of the GPU suite: kernel parity first, then the reference-executed fixtures, the full-size properties, the other
+# BASELINE configs, the op surface and LAST the whole-engine tests - within that file the ones that spawn subprocesses
+# (torch.distributed.run ranks, bench.py, main.py) at the very end.  Under `-x` one red integration test then cannot hide the
+# per-shape kernel parity behind it (round 5: 208 of 289 tests never ran).
+_FILE_ORDER = ["test_kernels_gpu", "test_block_split_gpu", "test_reference_exec_gpu", "test_fullsize_gpu", "test_configs_gpu",
+               "test_surface_gpu", "test_engine_gpu"]
+_LATE_WORDS = ("data_parallel", "bench", "cli", "subprocess", "torchrun", "main_py", "dp_")
+
+
+def _order_key(item):
+    mod = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+    rank = _FILE_ORDER.index(mod) if mod in _FILE_ORDER else -1          # CPU files keep their place in front
+    late = int(rank >= 0 and any(w in item.name.lower() for w in _LATE_WORDS))
+    return (late, rank)
+
+
 def pytest_collection_modifyitems(config, items):
+    items.sort(key=_order_key)          # stable: the order inside a file is kept
     import torch
     if torch.cuda.is_available():
         return

@@ -1,0 +1,86 @@
+"""Stress test behind the intermittent red of test_data_parallel_engine_two_ranks_equals_one_process[True] (round 5 driver run,
+reproduced once in 24 steps in round 6): repeat the config-3 data-parallel step many times per (tail stream, message layout) pair
+and compare every repetition with the first - gradients AND every engine buffer (checksums), so that a glitch names the first
+tensor that differs.
+
+    python tools/dp_race_stress.py [reps]                                        (one process, collectives are no-ops)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node=2 --master-addr 127.0.0.1 --master-port 29661 tools/dp_race_stress.py [reps]
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from nsc_amd.dist import Comm
+from nsc_amd.engine import CascadeEngine
+from tests._util import BKD, make_store, synth_frames, dev
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+comm = Comm(backend="gloo")
+B = 4
+Bl = B // comm.world
+LPC = os.environ.get("NSC_DEBUG_LPC", "1") == "1"
+ps = make_store(2, [[2], [2]], [32, 32], lpc=LPC)
+x = synth_frames(B)
+cfg = dict(is_quan_on=1.0, c_time=60.0, c_freq=10.0, c_quan=[10.0, 10.0], c_ent=[0.3, 0.5], trainable=[True, True], lr=2e-4, slot=1)
+kw = {}
+lpc_all = None
+if LPC:
+    ps.params["lpc_quan/alpha"] = np.array(-40.0)
+    cfg.update(c_quan_lpc=10.0, train_lpc=True, quan_op=True)
+    kw = dict(res_scalar=2.0, scale_first=True, lpc=True)
+    lpc_all = np.sort(np.random.default_rng(3).uniform(0.03, 3.1, (B, 16, 1)), axis=1).astype(np.float32)
+lo, hi = comm.shard(B)
+eng = CascadeEngine(Bl, 2, BKD, [[2], [2]], [32, 32], **kw)
+if os.environ.get("NSC_STRESS_PAIRS", "") == "0":
+    eng.fused_pairs = False
+xd = dev(x[lo:hi].transpose(0, 2, 1))
+lx = dev(lpc_all[lo:hi]) if LPC else None
+
+
+def snapshot():
+    torch.cuda.synchronize()
+    g = eng.grads.detach().cpu().numpy().copy()
+    sums = {k: float(v.double().sum().item()) for k, v in eng._bufs.items() if v.dtype == torch.float32}
+    return g, sums
+
+
+def name_of(i):
+    for name, (off, shape) in eng.layout.entries.items():
+        n = int(np.prod(shape)) if len(shape) else 1
+        if off <= i < off + n:
+            return f"{name}[{i - off}]"
+    return str(i)
+
+
+for tail in (True, False):
+    for overlap in (True, False):
+        eng.tail_overlap = tail
+        eng.dp_overlap = overlap
+        base = None
+        bad = 0
+        worst = 0.0
+        for r in range(reps):
+            eng.load_named(ps.params); eng.reset_adam()
+            eng.train_step(xd, xd, cfg, lpc_x=lx, comm=comm)
+            g, sums = snapshot()
+            if base is None:
+                base = (g, sums)
+                continue
+            d = np.abs(g - base[0])
+            rel = float(d.max() / np.abs(base[0]).max())
+            worst = max(worst, rel)
+            if rel > 1e-6:
+                bad += 1
+                if bad <= 3 and comm.rank == 0:
+                    i = int(d.argmax())
+                    diff = [(abs(sums[k] - base[1][k]) / (abs(base[1][k]) + 1e-30), k) for k in sums if k in base[1]]
+                    diff = [t for t in diff if t[0] > 1e-6]
+                    print(f"  glitch at rep {r}: rel {rel:.3e} at {name_of(i)}; {int((d > 1e-6 * np.abs(base[0]).max()).sum())} gradient "
+                          f"entries off; buffers whose checksum moved (> 1e-6): {sorted(diff, reverse=True)[:12]}")
+        if comm.rank == 0:
+            print(f"tail_overlap={tail} dp_overlap={overlap} world={comm.world} fused_pairs={eng.fused_pairs}: {bad} glitches in "
+                  f"{reps - 1} repetitions, worst rel diff {worst:.3e}", flush=True)
+comm.barrier()
+comm.close()
