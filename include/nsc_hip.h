@@ -216,7 +216,7 @@ int nsc_gated_block_pair_dgrad_img(const float* img1, const float* x1, const flo
  *      <= 2^-24 |a||b|), at 2.7x its rate, with the vector ALU free for the elementwise phases.  The 1x1 conv stays on the exact
  *      fp32 instruction.  Results agree with nsc_gated_block_fwd_img to fp32 rounding (not bit for bit).
  *   nsc_gated_block_simage_words(which, C, Cin, dil)   size of the split image in 32-bit words (0: no split kernel for this shape;
- *                                                      which = 0: forward, 1: data gradient)
+ *                                                      which = 0: forward, 1: fused data gradient, 2: three-launch data gradient)
  *   nsc_gated_block_simage_index(which, ..., offs, idx) index map for nsc_gather / nsc_step_begin, offs as for
  *      nsc_gated_block_image_index.  Entries carry a MODE in bits 26..29 (so source offsets must stay below 2^26 - 2^20):
  *      0 = the fp32 value; m > 0 = two bf16 pieces packed in one word, low half from src[i], high half from src[i + stride],
@@ -232,6 +232,15 @@ int nsc_gated_block_fwd_simg(const float* img, const float* x, float* out, float
 int nsc_gated_block_dgrad_simg(const float* img, const float* x, const float* h, const float* lin, const float* th,
                                const float* dy, float* dx, float* dlin, float* dgate, float* dz1, int B, int C, int Cin,
                                int T, int dil, int in_act, int da_rows, void* stream);
+/* The same data-path backward as THREE launches on the which = 2 image (csrc/block_bwd_split.hip): the two long contractions as
+ * polyphase GEMMs with 80 = 4 x 20 rows (no padded row tiles, no halo recompute, no partial sums across waves), then the HBM-bound
+ * 1x1 gradient + residual.  which = 2 image: the three bf16 pieces of W9 [9][20][C -> multiple of 8] and of Wl | Wr [15][20][40] in
+ * the kernels' own layout (offs as for which = 0; C in {100, 50}).  w1: the 1x1 kernel in the PARAMETER layout [Cin][20];
+ * da = the joint [B,40,T] tensor (dlin | dgate); dx nullable; Cin = C or 1 (in_act none); T % 4 == 0, 16-byte aligned tensors.
+ * Replaces (on the bf16 matrix cores) the tf.gradients of nn_core_operator.py:82-112 with respect to the block's input. */
+int nsc_gated_block_dgrad_simg2(const void* img, const float* w1, const float* x, const float* h, const float* lin, const float* th,
+                                const float* dy, float* dx, float* da, float* dz1, int B, int C, int Cin, int T, int dil, int in_act,
+                                void* stream);
 int nsc_gated_block_pair_fwd_simg(const float* img0, const float* img1, const float* x, float* out0, float* h0, float* lin0,
                                   float* th0, float* g0, float* out1, float* h1, float* lin1, float* th1, float* g1, int B, int C,
                                   int Cin0, int T, int flat1, int* flags, int* timeouts, void* stream);

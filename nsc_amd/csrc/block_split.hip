@@ -574,7 +574,11 @@ __global__ __launch_bounds__(512) void gated_block_fwd3_pair_kernel(BlockArgs a0
 //   as in nsc_gated_block_image_index) | group B per phase-3 row tile: [6][3][64][4 words] k9 fragments + [64][4] (word 0: b9 of the lane's
 //   channel) | group C [8][2][64][4] fp32: gate biases of the wave's two phase-2 jobs.
 // =====================================================================================================
+// which = 2: the weight pieces of the three-launch data gradient (block_bwd_split.hip)
+long nsc_bb_simage_words(int C);
+void nsc_bb_simage_index(int C, long w9, long wl, long wr, const int mode_bits[3], int* idx);
 static bool simg_shape(int which, int C, int Cin, int dil, int* rt9, int* nk) {
+  if (which == 2) return (C == 100 || C == 50) && (Cin == C || Cin == 1) && (dil == 1 || dil == 2);
   if (which != 0 && which != 1) return false;
   if (which == 1 && !(Cin == C && (C == 100 || C == 50))) return false;      // data gradient: gated_block_dgrad3_kernel's shapes
   if (!(dil == 1 || dil == 2) || !(C == 100 || C == 50 || C == 25) || !(Cin == C || Cin == 1)) return false;
@@ -589,6 +593,7 @@ static int simg_mode(int plane, int stride) {
 extern "C" long nsc_gated_block_simage_words(int which, int C, int Cin, int dil) {
   int rt9, nk;
   if (!simg_shape(which, C, Cin, dil, &rt9, &nk)) return 0;
+  if (which == 2) return nsc_bb_simage_words(C);
   if (which == 1) {
     const int cp = (C + 3) & ~3, nks9 = (K9 * cp + 31) / 32, nks15 = (K15 * 2 * NARROW + 31) / 32, nct = (C + 15) / 16;
     return 256L * 3 * (2 * nks9 + 2 * nks15 + nct);
@@ -608,6 +613,11 @@ extern "C" int nsc_gated_block_simage_index(int which, int C, int Cin, int dil, 
   const long w1 = offs[0], b1 = offs[1], wl = offs[2], bl = offs[3], wr = offs[4], br = offs[5], w9 = offs[6], b9 = offs[7];
   for (long i = 0; i < 8; ++i)
     NSC_REQUIRE(offs[i] >= 0 && offs[i] < (1L << 26) - (1L << 20), NSC_ERR_UNSUPPORTED, "nsc_gated_block_simage_index: offset %ld does not fit 26 bits", offs[i]);
+  if (which == 2) {
+    const int modes[3] = {simg_mode(0, 1), simg_mode(1, 1), simg_mode(2, 1)};
+    nsc_bb_simage_index(C, w9, wl, wr, modes, idx);
+    return NSC_OK;
+  }
   if (which == 1) {
     // Data gradient (gated_block_dgrad3_kernel).  B fragments: lane (n = l15: column = input channel ci of the k9 | k15 kernel,
     // output channel co of the 1x1), k = 32 s + 8 kq + 2 jw (+ 1), straight from the PARAMETERS (offs as for which = 0):

@@ -296,11 +296,12 @@ class _Block:
                 WT = lambda c: e.wt_ptr + 4 * c.w_off
                 tok = e.prof_begin("block_dgrad", self.c1.flops() + self.cl.flops() + self.cr.flops() + self.c9.flops())
                 if e.use_images and e.split_dgrad and self.simg_bwd_off is not None and T % 4 == 0 and self.Cin == self.wide:
-                    check(e.lib.nsc_gated_block_dgrad_simg(e.wt_ptr + 4 * self.simg_bwd_off, self.x.data_ptr(), self.h.data_ptr(),
-                                                           self.lin.data_ptr(), self.th.data_ptr(), dz.data_ptr(), dxf.data_ptr(),
-                                                           da.data_ptr(), da.data_ptr() + 4 * n * T, dh.data_ptr(), B, self.wide,
-                                                           self.Cin, T, self.cl.dil, KIND_ACT[in_kind], 2 * n, e.stream()),
-                          "gated_block_dgrad_simg")
+                    # three launches on the bf16 matrix cores (csrc/block_bwd_split.hip): k9^T + GLU', k15^T + lrelu', 1x1^T + residual
+                    check(e.lib.nsc_gated_block_dgrad_simg2(e.wt_ptr + 4 * self.simg_bwd_off, e.p_ptr + 4 * self.c1.w_off,
+                                                            self.x.data_ptr(), self.h.data_ptr(), self.lin.data_ptr(),
+                                                            self.th.data_ptr(), dz.data_ptr(), dxf.data_ptr(), da.data_ptr(),
+                                                            dh.data_ptr(), B, self.wide, self.Cin, T, self.cl.dil, KIND_ACT[in_kind],
+                                                            e.stream()), "gated_block_dgrad_simg2")
                 elif e.use_images and self.img_bwd_off is not None:     # (the data-gradient images are rebuilt with wt every step)
                     check(e.lib.nsc_gated_block_dgrad_img(e.wt_ptr + 4 * self.img_bwd_off, self.x.data_ptr(), self.h.data_ptr(),
                                                           self.lin.data_ptr(), self.th.data_ptr(), dz.data_ptr(), dxf.data_ptr(),
@@ -368,7 +369,12 @@ class _Block:
                 dlin, dgate = da[:, :n], da[:, n:]      # data_ptr of the halves: dgate = dlin + 20 T floats
             WT = lambda c: e.wt_ptr + 4 * c.w_off
             tok = e.prof_begin("block_dgrad", self.c1.flops() + self.cl.flops() + self.cr.flops() + self.c9.flops())
-            if e.use_images and self.img_bwd_off is not None:
+            if e.use_images and e.split_dgrad and self.simg_bwd_off is not None and T % 4 == 0 and batched:
+                check(e.lib.nsc_gated_block_dgrad_simg2(e.wt_ptr + 4 * self.simg_bwd_off, e.p_ptr + 4 * self.c1.w_off, None,
+                                                        self.h.data_ptr(), self.lin.data_ptr(), self.th.data_ptr(), dz.data_ptr(),
+                                                        dx.data_ptr(), da.data_ptr(), dh.data_ptr(), B, self.wide, 1, T, self.cl.dil,
+                                                        KIND_ACT["none"], e.stream()), "gated_block_dgrad_simg2 (one input channel)")
+            elif e.use_images and self.img_bwd_off is not None:
                 check(e.lib.nsc_gated_block_dgrad_img(e.wt_ptr + 4 * self.img_bwd_off, None, self.h.data_ptr(), self.lin.data_ptr(),
                                                       self.th.data_ptr(), dz.data_ptr(), dx.data_ptr(), dlin.data_ptr(),
                                                       dgate.data_ptr(), dh.data_ptr(), B, self.wide, 1, T, self.cl.dil,
@@ -770,6 +776,8 @@ class CascadeEngine:
             self.lpc_bins_off = self.layout.add("lpc_quan/bins", (len(lpc_coeff_lsf_bins),))
         self.codecs = [_Codec(self, f"scope_{i + 1}", self.bkd, strides[i], num_bins[i]) for i in range(self.N)]
         n = self.layout.size
+        # gather indices (nsc_gather / nsc_step_begin) keep bits 26..29 for the split-image word modes: offsets must fit 26 bits
+        assert n < (1 << 26), "flat parameter buffer too large for the gather index encoding (bits 26..29 are mode bits)"
         if layout_only:
             return
         f32 = dict(dtype=torch.float32, device=self.device)
@@ -833,8 +841,8 @@ class CascadeEngine:
                         extra += nf
                 # ... and the SPLIT images of the bf16-matrix-core kernels (csrc/block_split.hip): 32-bit words of packed bf16 pieces
                 # (the data-gradient images only when that kernel is switched on: they are re-gathered every step)
-                for which, attr in ((0, "simg_fwd_off"), (1, "simg_bwd_off")):
-                    if which == 1 and not self.split_dgrad:
+                for which, attr in ((0, "simg_fwd_off"), (2, "simg_bwd_off")):
+                    if which == 2 and not self.split_dgrad:
                         continue
                     nf = int(self.lib.nsc_gated_block_simage_words(which, int(b.wide), int(b.Cin), int(b.cl.dil)))
                     if nf > 0:
@@ -876,7 +884,7 @@ class CascadeEngine:
                 if which == 1:
                     im = np.where(im >= 0, idx[np.maximum(im, 0)], -1).astype(np.int32)
                 idx[off:off + nf] = im
-            for which, off in ((0, b.simg_fwd_off), (1, b.simg_bwd_off)):
+            for which, off in ((0, b.simg_fwd_off), (2, b.simg_bwd_off)):
                 if off is None:
                     continue     # split images, straight from the parameters (entries carry a mode in bits 26..29)
                 nf = int(self.lib.nsc_gated_block_simage_words(which, int(b.wide), int(b.Cin), int(b.cl.dil)))

@@ -267,22 +267,41 @@ eng = CascadeEngine(Bl, 2, BKD, [[2], [2]], [32, 32], **kw)
 eng.load_named(ps.params)
 xd = dev(x[lo:hi].transpose(0, 2, 1))
 lx = dev(lpc_all[lo:hi]) if LPC else None
-eng.train_step(xd, xd, cfg, lpc_x=lx, comm=comm)   # per-scope grad all-reduces + histograms (eager launches)
-torch.cuda.synchronize()
-g_eager, p_eager = eng.grads.cpu().numpy(), eng.params.cpu().numpy()
-ent_eager = [float(c.ent.item()) for c in eng.codecs]
+# Two ranks SHARE the one GPU of the test box here (gloo), and a GPU shared between processes is not bit-stable on this stack: alone,
+# 2 400 consecutive steps of this engine reproduce to float-atomics noise (2e-7) in every message layout; with a second process on
+# the device - these two ranks, or two unrelated single-GPU runs - 1-2 %% of the steps come out different in a few entries (up to
+# 1e-2 of a tensor; tools/dp_race_stress.py, profiles/r06_gpu_sharing_*.txt).  One process per GPU - the deployment model, and what
+# the RCCL variant of this test runs - does not share.  So every quantity below is the elementwise MEDIAN of three repetitions: a
+# transient glitch of one repetition drops out, a systematic difference stays.
+def med3(run):
+    outs = [run() for _ in range(3)]
+    return tuple(np.median(np.stack([o[k] for o in outs]), axis=0) for k in range(len(outs[0])))
+
+
+def eager_step():
+    eng.load_named(ps.params); eng.reset_adam()
+    eng.train_step(xd, xd, cfg, lpc_x=lx, comm=comm)   # gradient all-reduce(s) + histograms (eager launches)
+    torch.cuda.synchronize()
+    return eng.grads.cpu().numpy(), eng.params.cpu().numpy(), np.array([float(c.ent.item()) for c in eng.codecs])
+
+
+g_eager, p_eager, ent_eager = med3(eager_step)          # the default layout: one message at the tail of the step
+ent_eager = [float(v) for v in ent_eager]
 # the same step replayed as hipGraph SEGMENTS cut at the collectives (what bench.py does at N > 1), in both message layouts
 seg = {}
 for overlap in (True, False):
     eng.dp_overlap = overlap
-    eng.load_named(ps.params); eng.reset_adam()
-    eng.train_step(xd, xd, cfg, lpc_x=lx, comm=comm)          # eager warm-up of this layout
+    g_lay = med3(eager_step)[0]                                # eager step of THIS layout
     eng.load_named(ps.params); eng.reset_adam()
     st = eng.capture_train_step(xd, xd, cfg, lpc_x=lx, comm=comm)
-    eng.load_named(ps.params); eng.reset_adam()
-    st.replay()
-    torch.cuda.synchronize()
-    seg[overlap] = (eng.grads.cpu().numpy(), eng.params.cpu().numpy(), st.nseg, st.ncoll)
+
+    def replay_step():
+        eng.load_named(ps.params); eng.reset_adam()
+        st.replay()
+        torch.cuda.synchronize()
+        return eng.grads.cpu().numpy(), eng.params.cpu().numpy()
+    g_rep, p_rep = med3(replay_step)
+    seg[overlap] = (g_rep, p_rep, st.nseg, st.ncoll, float(np.abs(g_rep - g_lay).max() / np.abs(g_lay).max()))
     st.replay(); st.replay()                                  # replays keep working (Adam's device step counter advances)
     torch.cuda.synchronize()
 if comm.rank == 0:
@@ -296,9 +315,9 @@ if comm.rank == 0:
     pe = lambda p_: float(np.mean(np.abs(p_ - p2) > 1e-6))
     print(json.dumps({"gerr": ge(g_eager), "perr": pe(p_eager), "ent": ent_eager,
                       "ent_ref": [float(e.item()) for e in (c.ent for c in ref.codecs)],
-                      "seg_overlap": [ge(seg[True][0]), pe(seg[True][1]), seg[True][2], seg[True][3],
-                                      float(np.abs(seg[True][0] - g_eager).max() / np.abs(g_eager).max())],
-                      "seg_tail": [ge(seg[False][0]), pe(seg[False][1]), seg[False][2], seg[False][3]]}))
+                      # [4]: the replay against the EAGER step of the same message layout (same kernels, same messages)
+                      "seg_overlap": [ge(seg[True][0]), pe(seg[True][1]), seg[True][2], seg[True][3], seg[True][4]],
+                      "seg_tail": [ge(seg[False][0]), pe(seg[False][1]), seg[False][2], seg[False][3], seg[False][4]]}))
 comm.barrier()
 comm.close()
 '''
@@ -334,7 +353,7 @@ def test_data_parallel_engine_two_ranks_equals_one_process(tmp_path, lpc, backen
     # segmented hipGraph replay == the eager data-parallel step (same kernels, same messages; a few gradients are float
     # atomics, so not bit for bit) == one process
     assert res["seg_overlap"][0] < 2e-4 and res["seg_overlap"][1] < 2e-3 and res["seg_overlap"][4] < 1e-5, res
-    assert res["seg_tail"][0] < 2e-4 and res["seg_tail"][1] < 2e-3, res
+    assert res["seg_tail"][0] < 2e-4 and res["seg_tail"][1] < 2e-3 and res["seg_tail"][4] < 1e-5, res
     # forward + loss | histograms | codec 2 | codec 1 (+ LSF quantizer) | wait | Adam   vs  one gradient message at the tail
     assert res["seg_overlap"][3] == 3 and res["seg_tail"][3] == 2, res        # histograms + two scopes | histograms + one
     assert res["seg_overlap"][2] == 4 and res["seg_tail"][2] == 3, res        # no empty segment between message and wait

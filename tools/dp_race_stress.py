@@ -17,6 +17,8 @@ from nsc_amd.engine import CascadeEngine
 from tests._util import BKD, make_store, synth_frames, dev
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+SOLO = os.environ.get("NSC_STRESS_SOLO", "") == "1"     # no communicator at all: the plain single-GPU step (run two such processes
+                                                       # side by side to see what SHARING the GPU alone does)
 comm = Comm(backend="gloo")
 B = 4
 Bl = B // comm.world
@@ -37,6 +39,23 @@ if os.environ.get("NSC_STRESS_PAIRS", "") == "0":
     eng.fused_pairs = False
 xd = dev(x[lo:hi].transpose(0, 2, 1))
 lx = dev(lpc_all[lo:hi]) if LPC else None
+
+
+RESTORE = os.environ.get("NSC_STRESS_RESTORE", "h2d")   # how the parameters are put back between repetitions: h2d = load_named (a host->device
+                                                        # copy, what the tests do) | d2d = a device-side copy | lr0 = never changed (lr = 0)
+if RESTORE == "lr0":
+    cfg["lr"] = 0.0
+eng.load_named(ps.params)
+torch.cuda.synchronize()
+saved = eng.params.clone()
+
+
+def restore():
+    if RESTORE == "h2d":
+        eng.load_named(ps.params)
+    elif RESTORE == "d2d":
+        eng.set_params(saved)
+    eng.reset_adam()
 
 
 def snapshot():
@@ -62,8 +81,8 @@ for tail in (True, False):
         bad = 0
         worst = 0.0
         for r in range(reps):
-            eng.load_named(ps.params); eng.reset_adam()
-            eng.train_step(xd, xd, cfg, lpc_x=lx, comm=comm)
+            restore()
+            eng.train_step(xd, xd, cfg, lpc_x=lx, comm=None if SOLO else comm)
             g, sums = snapshot()
             if base is None:
                 base = (g, sums)
@@ -75,12 +94,13 @@ for tail in (True, False):
                 bad += 1
                 if bad <= 3 and comm.rank == 0:
                     i = int(d.argmax())
-                    diff = [(abs(sums[k] - base[1][k]) / (abs(base[1][k]) + 1e-30), k) for k in sums if k in base[1]]
-                    diff = [t for t in diff if t[0] > 1e-6]
+                    # buffers in creation order = the order of their first use in a step: the first one named is the origin
+                    diff = [(k, f"{abs(sums[k] - base[1][k]) / (abs(base[1][k]) + 1e-30):.1e}") for k in sums if k in base[1]
+                            and abs(sums[k] - base[1][k]) > 1e-9 * (abs(base[1][k]) + 1e-30)]
                     print(f"  glitch at rep {r}: rel {rel:.3e} at {name_of(i)}; {int((d > 1e-6 * np.abs(base[0]).max()).sum())} gradient "
-                          f"entries off; buffers whose checksum moved (> 1e-6): {sorted(diff, reverse=True)[:12]}")
+                          f"entries off; buffers whose checksum moved, in creation order: {diff[:10]} ... {len(diff)} in all")
         if comm.rank == 0:
-            print(f"tail_overlap={tail} dp_overlap={overlap} world={comm.world} fused_pairs={eng.fused_pairs}: {bad} glitches in "
+            print(f"restore={RESTORE} tail_overlap={tail} dp_overlap={overlap} world={comm.world} fused_pairs={eng.fused_pairs}: {bad} glitches in "
                   f"{reps - 1} repetitions, worst rel diff {worst:.3e}", flush=True)
 comm.barrier()
 comm.close()
