@@ -522,7 +522,7 @@ class _Codec:
         e = self.eng
         # (the split-operand data gradient has no pair form yet: a stack with a block it serves runs block by block)
         split_any = e.split_dgrad and e.use_images and any(b.simg_bwd_off is not None and b.T % 4 == 0 for b in blocks)
-        if split_any or not (self._pair_ok(blocks) and e.batch_wgrad and e.fused_wgrad and in_kind_first in ("lrelu", "none") and
+        if split_any or not (self._pair_ok(blocks) and e.pair_bwd and e.batch_wgrad and e.fused_wgrad and in_kind_first in ("lrelu", "none") and
                              (blocks[0].Cin > 1 or in_kind_first == "none")):
             for j in range(len(blocks) - 1, -1, -1):
                 dz = blocks[j].bwd(dz, in_kind_rest if j > 0 else in_kind_first)
@@ -954,6 +954,7 @@ class CascadeEngine:
     split_conv = os.environ.get("NSC_BLOCK_ARITH", "split") == "split"
     fused_pairs = True   # the dil-1 / dil-2 blocks of a stack in ONE launch (nsc_gated_block_pair_fwd_img / _dgrad_img: neighbour flags
                          # between workgroups instead of a kernel boundary); False: one launch per block
+    pair_bwd = os.environ.get("NSC_PAIR_BWD", "1") == "1"   # A/B: the data gradients of a stack as one pair launch (False: block by block)
     fused_chain = True   # the cascade step / output-gradient arithmetic between codecs rides in the epilogue of the Cout = 1 convs
                          # (nsc_conv1d_cout1_fwd_chain) instead of nsc_cascade_step / nsc_axpby launches
     poly_dgrad = True    # stride-2 data gradients in polyphase form (half the MFMAs of the zero-upsampled form)
