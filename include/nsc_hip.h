@@ -402,6 +402,9 @@ int nsc_spin(float* sink, int iters, void* stream);
  * the data-gradient kernels and parameter images); zero[0, zero_n) = 0 (gradients + histograms; 16-byte aligned, zero_n % 4 == 0);
  * counter[0] += 1 when non-null (the Adam step counter nsc_adam_tf1_step reads at the end of the step). */
 int nsc_step_begin(const float* src, const int* idx, float* dst, long n, float* zero, long zero_n, int* counter, void* stream);
+/* ... gathering only the chunks[c] = {first word, words (<= 1024)} of dst / idx that the step's kernels read (int pairs, device memory) */
+int nsc_step_begin_chunks(const float* src, const int* idx, float* dst, const int* chunks, int nchunks, float* zero, long zero_n,
+                          int* counter, void* stream);
 
 /* ---- LPC front / back end of the collaborative-quantisation path (replaces the tf.py_func bodies of
  *      lpc_utilities.py: `lsf2poly_after_quan` :28-33, `lpc_analysis_get_residual` :37-77, `lpc_synthesizer_tr` :137-156;

@@ -85,6 +85,7 @@ PROTOTYPES = {
     "nsc_gated_block_pair_fwd_img": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
     "nsc_gated_block_pair_dgrad_img": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
     "nsc_step_begin": [_P, _P, _P, _L, _P, _L, _P, _P],
+    "nsc_step_begin_chunks": [_P, _P, _P, _P, _I, _P, _L, _P, _P],
     "nsc_frame_utterance": [_P, _L, _P, _P, _I, _P],
     "nsc_overlap_add": [_P, _I, _P, _P, _P],
     "nsc_lsf2poly": [_P, _P, _I, _I, _P],

@@ -641,6 +641,70 @@ extern "C" int nsc_step_begin(const float* src, const int* idx, float* dst, long
   return NSC_OK;
 }
 
+// nsc_step_begin over the LIVE regions of dst only: chunks[c] = (first word, words <= 1024) of dst / idx that this step's kernels read
+// (the engine records them in a step's first run: most of the index map serves the OTHER arithmetic arm and the unfused paths - 1.7 M of
+// the headline step's 3.8 M words).  Everything else as nsc_step_begin.
+__global__ void step_begin_chunks_kernel(const float* __restrict__ src, const int* __restrict__ idx, float* __restrict__ dst,
+                                         const int2* __restrict__ chunks, int nchunks, float* __restrict__ zero, long zn4,
+                                         int* __restrict__ counter) {
+  if ((int)blockIdx.x < nchunks) {
+    const int2 c = chunks[blockIdx.x];
+    // four words per thread with every level of the dependent chain (index -> one or two source words -> store) issued for all four
+    // at once: the plain loop was four serial chains of three memory round trips each (the gather is latency, not bandwidth)
+    int ix[4];
+    float a[4], b[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = threadIdx.x + 256 * j;
+      ix[j] = e < c.y ? idx[c.x + e] : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = ix[j], m = i < 0 ? 0 : (i >> 26), base = i < 0 ? 0 : (i & 0x3ffffff);
+      const int sel = m > 0 ? (m - 1) % 5 : 4;
+      const int stride = m == 0 ? 0 : (sel == 0 ? 20 : (sel == 1 ? 25 : (sel == 2 ? 50 : (sel == 3 ? 100 : 1))));
+      a[j] = src[base];
+      b[j] = src[base + stride];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = threadIdx.x + 256 * j, i = ix[j];
+      if (e < c.y) {
+        float v = 0.f;
+        if (i >= 0) {
+          const int m = i >> 26;
+          if (m == 0) {
+            v = a[j];
+          } else {
+            unsigned pk[3];
+            nsc_split2(a[j], b[j], pk);
+            const int plane = (m - 1) / 5;
+            v = __builtin_bit_cast(float, plane == 0 ? pk[0] : (plane == 1 ? pk[1] : pk[2]));
+          }
+        }
+        dst[c.x + e] = v;
+      }
+    }
+    if (counter && blockIdx.x == 0 && threadIdx.x == 0) counter[0] += 1;
+  } else {
+    const int zb = gridDim.x - nchunks;
+    f32x4* z4 = reinterpret_cast<f32x4*>(zero);
+    for (long e = (blockIdx.x - nchunks) * (long)blockDim.x + threadIdx.x; e < zn4; e += (long)zb * blockDim.x)
+      z4[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+}
+extern "C" int nsc_step_begin_chunks(const float* src, const int* idx, float* dst, const int* chunks, int nchunks, float* zero, long zero_n,
+                                     int* counter, void* stream) {
+  NSC_REQUIRE(src && idx && dst && chunks && nchunks > 0 && zero && zero_n > 0, NSC_ERR_BAD_ARG, "nsc_step_begin_chunks: bad args");
+  NSC_REQUIRE((zero_n & 3) == 0 && ((uintptr_t)zero & 15) == 0 && ((uintptr_t)chunks & 7) == 0, NSC_ERR_BAD_ARG,
+              "nsc_step_begin_chunks: the zeroed range must be 16-byte aligned and a multiple of 4 floats, chunks 8-byte aligned");
+  const int zb = (int)std::min<long>(512, nsc_cdiv(zero_n / 4, 256));
+  hipLaunchKernelGGL(step_begin_chunks_kernel, dim3(nchunks + zb), dim3(256), 0, (hipStream_t)stream, src, idx, dst,
+                     reinterpret_cast<const int2*>(chunks), nchunks, zero, zero_n / 4, counter);
+  NSC_CHECK_LAUNCH("step_begin_chunks");
+  return NSC_OK;
+}
+
 // elementwise product (tf.multiply of the two gate branches) and its backward given lin, th = tanh(gate)
 __global__ void mul_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long n) {
   for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x)

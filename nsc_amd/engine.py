@@ -113,7 +113,7 @@ class _Conv:
         elif split:
             # the stride-2 down-sampling conv on split operands (bf16 matrix cores, csrc/conv_split.hip)
             assert chain is None
-            check(e.lib.nsc_conv1d_fwd_simg(C.byref(d), x.data_ptr(), e.wt_ptr + 4 * self.simg_off[0], self._p(e.p_ptr, self.b_off),
+            check(e.lib.nsc_conv1d_fwd_simg(C.byref(d), x.data_ptr(), e.wtp(self.simg_off[0]), self._p(e.p_ptr, self.b_off),
                                             y.data_ptr(), e.stream()), f"conv fwd (split) {self.name}")
         else:
             assert chain is None
@@ -146,7 +146,7 @@ class _Conv:
         e = self.eng
         if e.split_conv and getattr(self, "simg_off", None) is not None and res is None and mul_kind == "none":
             tok = e.prof_begin("conv_split", self.flops())
-            check(e.lib.nsc_conv1d_dgrad_simg(C.byref(self.desc()), dz.data_ptr(), e.wt_ptr + 4 * self.simg_off[1], dx.data_ptr(), e.stream()),
+            check(e.lib.nsc_conv1d_dgrad_simg(C.byref(self.desc()), dz.data_ptr(), e.wtp(self.simg_off[1]), dx.data_ptr(), e.stream()),
                   f"conv dgrad (split) {self.name}")
             e.prof_end(tok)
             return
@@ -154,7 +154,7 @@ class _Conv:
             d = ConvDesc(B=e.B, Cin=self.Cout, Cout=2 * self.Cin, Tin=self.Tout, Tout=self.Tout, K=5, dil=1, stride=1, padL=2,
                          act=0, res_mode=res_mode, mul_mode=KIND_MUL[mul_kind], out_mode=1, in_up=0, accumulate=0)
             tok = e.prof_begin("conv_mfma", self.flops())
-            check(e.lib.nsc_conv1d_fwd(C.byref(d), dz.data_ptr(), e.wt_ptr + 4 * self.wtpoly_off, None, _lib.ptr(res),
+            check(e.lib.nsc_conv1d_fwd(C.byref(d), dz.data_ptr(), e.wtp(self.wtpoly_off), None, _lib.ptr(res),
                                        _lib.ptr(aux) if mul_kind != "none" else None, dx.data_ptr(), e.stream()),
                   f"conv dgrad (polyphase) {self.name}")
             e.prof_end(tok)
@@ -165,12 +165,12 @@ class _Conv:
                      in_up=1 if self.stride == 2 else 0, accumulate=0)
         tok = e.prof_begin("conv_cout1" if self.Cin == 1 else "conv_mfma", self.flops())
         if self.Cin == 1:
-            check(e.lib.nsc_conv1d_cout1_fwd_chain(C.byref(d), dz.data_ptr(), self._p(e.wt_ptr, self.w_off), None, _lib.ptr(res),
+            check(e.lib.nsc_conv1d_cout1_fwd_chain(C.byref(d), dz.data_ptr(), e.wtp(self.w_off), None, _lib.ptr(res),
                                                    _lib.ptr(aux) if mul_kind != "none" else None, dx.data_ptr(),
                                                    C.byref(chain) if chain is not None else None, e.stream()), f"conv dgrad {self.name}")
         else:
             assert chain is None
-            check(e.lib.nsc_conv1d_fwd(C.byref(d), dz.data_ptr(), self._p(e.wt_ptr, self.w_off), None, _lib.ptr(res),
+            check(e.lib.nsc_conv1d_fwd(C.byref(d), dz.data_ptr(), e.wtp(self.w_off), None, _lib.ptr(res),
                                        _lib.ptr(aux) if mul_kind != "none" else None, dx.data_ptr(), e.stream()), f"conv dgrad {self.name}")
         e.prof_end(tok)
 
@@ -254,11 +254,11 @@ class _Block:
             save = e.keep_activations
             sv = [t.data_ptr() if save else None for t in (self.h, self.lin, self.th, self.g)]
             if e.use_images and e.images_valid and e.split_fwd and self.simg_fwd_off is not None and T % 4 == 0:
-                check(e.lib.nsc_gated_block_fwd_simg(e.wt_ptr + 4 * self.simg_fwd_off, x.data_ptr(), self.out.data_ptr(), *sv, B,
+                check(e.lib.nsc_gated_block_fwd_simg(e.wtp(self.simg_fwd_off), x.data_ptr(), self.out.data_ptr(), *sv, B,
                                                      self.wide, self.Cin, T, self.cl.dil, int(self.flat), e.stream()),
                       "gated_block_fwd_simg")
             elif e.use_images and e.images_valid and self.img_fwd_off is not None:
-                check(e.lib.nsc_gated_block_fwd_img(e.wt_ptr + 4 * self.img_fwd_off, x.data_ptr(), self.out.data_ptr(), *sv, B,
+                check(e.lib.nsc_gated_block_fwd_img(e.wtp(self.img_fwd_off), x.data_ptr(), self.out.data_ptr(), *sv, B,
                                                     self.wide, self.Cin, T, self.cl.dil, int(self.flat), e.stream()),
                       "gated_block_fwd_img")
             else:
@@ -293,17 +293,17 @@ class _Block:
             if fused_dgrad:
                 # one 8-wave kernel for the whole data path of the block: dx, da (dlin | dgate) and dz1
                 dxf = e.buf(u + ".dx", (B, self.Cin, T))
-                WT = lambda c: e.wt_ptr + 4 * c.w_off
+                WT = lambda c: e.wtp(c.w_off)
                 tok = e.prof_begin("block_dgrad", self.c1.flops() + self.cl.flops() + self.cr.flops() + self.c9.flops())
                 if e.use_images and e.split_dgrad and self.simg_bwd_off is not None and T % 4 == 0 and self.Cin == self.wide:
                     # three launches on the bf16 matrix cores (csrc/block_bwd_split.hip): k9^T + GLU', k15^T + lrelu', 1x1^T + residual
-                    check(e.lib.nsc_gated_block_dgrad_simg2(e.wt_ptr + 4 * self.simg_bwd_off, e.p_ptr + 4 * self.c1.w_off,
+                    check(e.lib.nsc_gated_block_dgrad_simg2(e.wtp(self.simg_bwd_off), e.p_ptr + 4 * self.c1.w_off,
                                                             self.x.data_ptr(), self.h.data_ptr(), self.lin.data_ptr(),
                                                             self.th.data_ptr(), dz.data_ptr(), dxf.data_ptr(), da.data_ptr(),
                                                             dh.data_ptr(), B, self.wide, self.Cin, T, self.cl.dil, KIND_ACT[in_kind],
                                                             e.stream()), "gated_block_dgrad_simg2")
                 elif e.use_images and self.img_bwd_off is not None:     # (the data-gradient images are rebuilt with wt every step)
-                    check(e.lib.nsc_gated_block_dgrad_img(e.wt_ptr + 4 * self.img_bwd_off, self.x.data_ptr(), self.h.data_ptr(),
+                    check(e.lib.nsc_gated_block_dgrad_img(e.wtp(self.img_bwd_off), self.x.data_ptr(), self.h.data_ptr(),
                                                           self.lin.data_ptr(), self.th.data_ptr(), dz.data_ptr(), dxf.data_ptr(),
                                                           da.data_ptr(), da.data_ptr() + 4 * n * T, dh.data_ptr(), B, self.wide,
                                                           self.Cin, T, self.cl.dil, KIND_ACT[in_kind], 2 * n, e.stream()),
@@ -323,7 +323,7 @@ class _Block:
                              padL=(cl.K - 1) * cl.dil - cl.padL, act=0, res_mode=0, mul_mode=KIND_MUL["lrelu"], out_mode=0,
                              in_up=0, accumulate=0)
                 tok = e.prof_begin("conv_mfma", self.cl.flops() + self.cr.flops())
-                check(e.lib.nsc_conv1d_fwd(C.byref(d), da.data_ptr(), e.wt_ptr + 4 * self.wtlr_off, None, None,
+                check(e.lib.nsc_conv1d_fwd(C.byref(d), da.data_ptr(), e.wtp(self.wtlr_off), None, None,
                                            self.h.data_ptr(), dh.data_ptr(), e.stream()), "gate dgrad (fused lin|gate)")
                 e.prof_end(tok)
             dx = e.buf(u + ".dx", (B, self.Cin, T)) if need_dx else None
@@ -338,7 +338,7 @@ class _Block:
             tok = e.prof_begin("block_wgrad", fl)
             st = e.side_fork()
             args = (self.x.data_ptr(), self.h.data_ptr(), self.g.data_ptr(), dz.data_ptr(), da.data_ptr(), dh.data_ptr(),
-                    dw1, db1, dwl, dbl, dwr, dbr, dw9, db9, e.wt_ptr + 4 * self.c1.w_off)
+                    dw1, db1, dwl, dbl, dwr, dbr, dw9, db9, e.wtp(self.c1.w_off))
             tail = (KIND_ACT[in_kind], B, self.Cin, T, n, 9, self.cl.dil)
             if e.overlap_wgrad and e.split_wgrad:
                 # two light persistent launches (dW9 | dWl, dWr, dW1) that can share CUs with the main-stream kernels
@@ -367,15 +367,15 @@ class _Block:
             if batched:
                 da = e.buf(u + ".da", (B, 2 * n, T))
                 dlin, dgate = da[:, :n], da[:, n:]      # data_ptr of the halves: dgate = dlin + 20 T floats
-            WT = lambda c: e.wt_ptr + 4 * c.w_off
+            WT = lambda c: e.wtp(c.w_off)
             tok = e.prof_begin("block_dgrad", self.c1.flops() + self.cl.flops() + self.cr.flops() + self.c9.flops())
             if e.use_images and e.split_dgrad and self.simg_bwd_off is not None and T % 4 == 0 and batched:
-                check(e.lib.nsc_gated_block_dgrad_simg2(e.wt_ptr + 4 * self.simg_bwd_off, e.p_ptr + 4 * self.c1.w_off, None,
+                check(e.lib.nsc_gated_block_dgrad_simg2(e.wtp(self.simg_bwd_off), e.p_ptr + 4 * self.c1.w_off, None,
                                                         self.h.data_ptr(), self.lin.data_ptr(), self.th.data_ptr(), dz.data_ptr(),
                                                         dx.data_ptr(), da.data_ptr(), dh.data_ptr(), B, self.wide, 1, T, self.cl.dil,
                                                         KIND_ACT["none"], e.stream()), "gated_block_dgrad_simg2 (one input channel)")
             elif e.use_images and self.img_bwd_off is not None:
-                check(e.lib.nsc_gated_block_dgrad_img(e.wt_ptr + 4 * self.img_bwd_off, None, self.h.data_ptr(), self.lin.data_ptr(),
+                check(e.lib.nsc_gated_block_dgrad_img(e.wtp(self.img_bwd_off), None, self.h.data_ptr(), self.lin.data_ptr(),
                                                       self.th.data_ptr(), dz.data_ptr(), dx.data_ptr(), dlin.data_ptr(),
                                                       dgate.data_ptr(), dh.data_ptr(), B, self.wide, 1, T, self.cl.dil,
                                                       KIND_ACT["none"], 2 * n if batched else n, e.stream()), "gated_block_dgrad_img")
@@ -505,12 +505,12 @@ class _Codec:
         fl = sum(c.flops() for blk in blocks for c in (blk.c1, blk.cl, blk.cr, blk.c9))
         tok = e.prof_begin("block_fwd", fl)
         if e.split_fwd and b0.simg_fwd_off is not None and b1.simg_fwd_off is not None:
-            check(e.lib.nsc_gated_block_pair_fwd_simg(e.wt_ptr + 4 * b0.simg_fwd_off, e.wt_ptr + 4 * b1.simg_fwd_off, h.data_ptr(),
+            check(e.lib.nsc_gated_block_pair_fwd_simg(e.wtp(b0.simg_fwd_off), e.wtp(b1.simg_fwd_off), h.data_ptr(),
                                                       b0.out.data_ptr(), *sv(b0), b1.out.data_ptr(), *sv(b1), B, b0.wide, b0.Cin, T,
                                                       int(b1.flat), e.pair_flags(), e.pair_timeouts_ptr(), e.stream()),
                   "gated_block_pair_fwd_simg")
         else:
-            check(e.lib.nsc_gated_block_pair_fwd_img(e.wt_ptr + 4 * b0.img_fwd_off, e.wt_ptr + 4 * b1.img_fwd_off, h.data_ptr(),
+            check(e.lib.nsc_gated_block_pair_fwd_img(e.wtp(b0.img_fwd_off), e.wtp(b1.img_fwd_off), h.data_ptr(),
                                                      b0.out.data_ptr(), *sv(b0), b1.out.data_ptr(), *sv(b1), B, b0.wide, b0.Cin, T,
                                                      int(b1.flat), e.pair_flags(), e.pair_timeouts_ptr(), e.stream()), "gated_block_pair_fwd_img")
         e.prof_end(tok)
@@ -537,8 +537,8 @@ class _Codec:
         fl = sum(c.flops() for blk in blocks for c in (blk.c1, blk.cl, blk.cr, blk.c9))
         tok = e.prof_begin("block_dgrad", fl)
         P = lambda t: t.data_ptr()
-        check(e.lib.nsc_gated_block_pair_dgrad_img(e.wt_ptr + 4 * b1.img_bwd_off, P(b1.x), P(b1.h), P(b1.lin), P(b1.th), P(dz), P(dx1),
-                                                   P(da1), P(dh1), e.wt_ptr + 4 * b0.img_bwd_off, P(b0.x), P(b0.h), P(b0.lin),
+        check(e.lib.nsc_gated_block_pair_dgrad_img(e.wtp(b1.img_bwd_off), P(b1.x), P(b1.h), P(b1.lin), P(b1.th), P(dz), P(dx1),
+                                                   P(da1), P(dh1), e.wtp(b0.img_bwd_off), P(b0.x), P(b0.h), P(b0.lin),
                                                    P(b0.th), P(dx0), P(da0), P(dh0), B, b0.wide, b0.Cin, T, KIND_ACT[in_kind_first],
                                                    e.pair_flags(), e.pair_timeouts_ptr(), e.stream()), "gated_block_pair_dgrad_img")
         e.prof_end(tok)
@@ -771,6 +771,7 @@ class CascadeEngine:
         self._wg_jobs, self._wg_keep, self._wg_flops = [], [], 0.0
         self._cw_jobs, self._cw_flops = [], 0.0
         self._sum_jobs = []
+        self._live_tables = {}
         if self.lpc:  # 'lpc_quan' scope is created before scope_1 (nsc_module:993-996)
             self.lpc_alpha_off = self.layout.add("lpc_quan/alpha", ())
             self.lpc_bins_off = self.layout.add("lpc_quan/bins", (len(lpc_coeff_lsf_bins),))
@@ -811,8 +812,12 @@ class CascadeEngine:
         # (wt_lr[tap', c' in 0..39, ci]) so that both gate data-gradients run as a single 40-channel conv.
         blocks = [b for c in self.codecs for b in c.all_blocks()]
         extra = 0
+        self._wt_regions = {}                                   # first word -> words, of every region a kernel may be pointed at
+        for c in self.convs:
+            self._wt_regions[c.w_off] = c.K * c.Cin * c.Cout      # (the flipped / transposed copy of each conv kernel, at its own offset)
         for b in blocks:
             b.wtlr_off = n + extra
+            self._wt_regions[b.wtlr_off] = b.cl.K * 2 * b.narrow * b.narrow
             extra += b.cl.K * 2 * b.narrow * b.narrow
         # polyphase data-gradient kernels of the stride-2 k9 convs: W'[t', o, 2 ci + p] (5 taps, structural zero at p=0, t'=4)
         # ... or, on split operands (csrc/conv_split.hip), kernel-ready images of the forward and the data-gradient GEMM instead
@@ -824,8 +829,10 @@ class CascadeEngine:
                 extra = (n + extra + 3) // 4 * 4 - n
                 c.simg_off = (n + extra, n + extra + nw[0])
                 c.simg_words = tuple(nw)
+                self._wt_regions[c.simg_off[0]], self._wt_regions[c.simg_off[1]] = nw[0], nw[1]
                 extra += nw[0] + nw[1]
             c.wtpoly_off = n + extra            # (kept beside the images: split_conv can be switched off at run time for A/B)
+            self._wt_regions[c.wtpoly_off] = 5 * c.Cout * 2 * c.Cin
             extra += 5 * c.Cout * 2 * c.Cin
         # kernel-ready parameter images of the gated blocks the persistent kernels serve (fast prologue: include/nsc_hip.h,
         # nsc_gated_block_image_index): one forward and one data-gradient image per block, 16-byte aligned, rebuilt by the
@@ -838,6 +845,7 @@ class CascadeEngine:
                     if nf > 0:
                         extra = (n + extra + 3) // 4 * 4 - n
                         setattr(b, attr, n + extra)
+                        self._wt_regions[n + extra] = nf
                         extra += nf
                 # ... and the SPLIT images of the bf16-matrix-core kernels (csrc/block_split.hip): 32-bit words of packed bf16 pieces
                 # (the data-gradient images only when that kernel is switched on: they are re-gathered every step)
@@ -848,6 +856,7 @@ class CascadeEngine:
                     if nf > 0:
                         extra = (n + extra + 3) // 4 * 4 - n
                         setattr(b, attr, n + extra)
+                        self._wt_regions[n + extra] = nf
                         extra += nf
         self.wt = torch.zeros(n + extra, **f32)
         self.p_ptr, self.g_ptr, self.wt_ptr = self.params.data_ptr(), self.grads.data_ptr(), self.wt.data_ptr()
@@ -1069,8 +1078,14 @@ class CascadeEngine:
     # (same box, two runs each).  Safe here and only here: no pair launch (all workgroups resident, neighbour flags) runs at the tail.
     tail_overlap = os.environ.get("NSC_TAIL_OVERLAP", "1") == "1"
 
+    def _tail_two_streams(self):
+        """The second stream at the tail is for the step that overlaps nothing else: with per-scope gradient messages under the backward
+        pass (dp_overlap + a communicator) a collective's kernel may already hold compute units, and two persistent launches beside it
+        are the residency squeeze _pair_ok avoids - one stream then."""
+        return self.tail_overlap and self.prof is None and not (self.dp_overlap and self._dp_comm_attached)
+
     def flush_block_wgrads(self):
-        if self.tail_overlap and self.prof is None and self._cw_jobs and self._wg_jobs:
+        if self._tail_two_streams() and self._cw_jobs and self._wg_jobs:
             if self._tail_stream is None:
                 self._tail_stream = torch.cuda.Stream(device=self.device)
             side, cur = self._tail_stream, torch.cuda.current_stream()
@@ -1292,7 +1307,8 @@ class CascadeEngine:
 
     @property
     def images_valid(self):
-        return self._img_ok and self.params._version == self._img_version
+        return (self._img_ok and self.params._version == self._img_version and
+                (self._img_live_flags is None or self._img_live_flags == self._flags_key()))
 
     @images_valid.setter
     def images_valid(self, v):
@@ -1304,6 +1320,34 @@ class CascadeEngine:
         self.params.copy_(flat)
         self.images_valid = False
 
+    # ---- which words of wt a step reads: most of the index map serves the OTHER arithmetic arm and the unfused paths (exact forward
+    # images, the k15 gate concatenation, the polyphase kernels, the flipped copies of the block convs: 1.7 M of the headline step's 3.8 M
+    # words).  Every pointer into wt goes through wtp(); a step's FIRST run with a given (flags, trainable pattern) gathers everything and
+    # records the regions it was pointed at, later runs gather those only (nsc_step_begin_chunks).  A forward outside a training step sees
+    # images_valid only while the flags are the ones the last gather was recorded for. ----
+    live_gather = os.environ.get("NSC_LIVE_GATHER", "1") == "1"
+    _wt_rec = None
+    _img_live_flags = None
+
+    def wtp(self, off):
+        if self._wt_rec is not None:
+            self._wt_rec.add(int(off))
+        return self.wt_ptr + 4 * off
+
+    def _flags_key(self):
+        return (self.split_fwd, self.split_wgrad_arith, self.split_conv, self.split_dgrad, self.fused_fwd, self.fused_dgrad, self.fused_wgrad,
+                self.fused_pairs, self.pair_bwd, self.use_images, self.poly_dgrad, self.fused_up, self.batch_wgrad, self.batch_cin1_wgrad,
+                self.batch_conv_wgrad, self.overlap_wgrad, self.fused_chain, self.fused_quant,
+                self.dp_overlap and self._dp_comm_attached)
+
+    def _chunk_table(self, offs):
+        rows = []
+        for off in sorted(offs):
+            nw = self._wt_regions[off]
+            for lo in range(0, nw, 1024):
+                rows.append((off + lo, min(1024, nw - lo)))
+        return torch.tensor(np.asarray(rows, dtype=np.int32).reshape(-1, 2), device=self.device), len(rows)
+
     def refresh_wt(self):
         """Rebuild everything derived from the parameters: the flipped / transposed data-gradient kernels and the kernel-ready
         block images.  train_step does it every step; an inference user calls it once after loading weights (without it the
@@ -1311,6 +1355,7 @@ class CascadeEngine:
         check(self.lib.nsc_gather(self.p_ptr, self.wt_idx.data_ptr(), self.wt_ptr, self.wt.numel(), self.stream()),
               "gather wt")
         self.images_valid = True
+        self._img_live_flags = None
 
     # ---- forward ----
     def forward(self, x, is_quan_on=1.0, soft=True, lpc_x=None, want_p=False, hists_clean=False, first_needed=0):
@@ -1578,8 +1623,19 @@ class CascadeEngine:
         # ONE launch opens the step: zero gradients + histograms, rebuild the data-gradient kernels / parameter images (refresh_wt),
         # advance the optimizer's device step counter (read by the Adam launch at the end of this step)
         slot = cfg.get("slot", 1)
-        check(self.lib.nsc_step_begin(self.p_ptr, self.wt_idx.data_ptr(), self.wt_ptr, self.wt.numel(), self.g_ptr, self._gh_floats,
-                                      self.adam[slot]["t_dev"].data_ptr(), self.stream()), "step_begin")
+        flags = self._flags_key()
+        key = (flags, tuple(bool(t) for t in cfg["trainable"]), lpc_x is not None)
+        live = self._live_tables.get(key) if self.live_gather else None
+        if live is not None:
+            check(self.lib.nsc_step_begin_chunks(self.p_ptr, self.wt_idx.data_ptr(), self.wt_ptr, live[0].data_ptr(), live[1], self.g_ptr,
+                                                 self._gh_floats, self.adam[slot]["t_dev"].data_ptr(), self.stream()), "step_begin_chunks")
+            self._img_live_flags = flags
+        else:
+            check(self.lib.nsc_step_begin(self.p_ptr, self.wt_idx.data_ptr(), self.wt_ptr, self.wt.numel(), self.g_ptr, self._gh_floats,
+                                          self.adam[slot]["t_dev"].data_ptr(), self.stream()), "step_begin")
+            self._img_live_flags = None
+            if self.live_gather and self._rec is None and not torch.cuda.is_current_stream_capturing():
+                self._wt_rec = set()                         # this run records what it is pointed at
         self.images_valid = True
         self.forward(x, cfg["is_quan_on"], True, lpc_x=lpc_x, hists_clean=True,
                      first_needed=min([i for i, t in enumerate(cfg["trainable"]) if t], default=self.N))
@@ -1600,4 +1656,7 @@ class CascadeEngine:
         if self.lpc and train_lpc:
             scopes = ["lpc_quan"] + scopes
         self.adam_step(scopes, cfg["lr"], slot, counted=True)
+        if self._wt_rec is not None:
+            self._live_tables[key] = self._chunk_table(self._wt_rec)
+            self._wt_rec = None
         return terms

@@ -453,6 +453,75 @@ def test_pair_launches_are_off_under_per_scope_gradient_messages():
     assert c._pair_ok(stack)
 
 
+def test_live_gather_covers_every_word_a_step_reads():
+    """The step's opening launch gathers only the regions of the kernel-ready images that the step's kernels are pointed at (recorded
+    in the first run of a (flags, trainable pattern) pair: engine.wtp).  Proof that nothing else is read: everything the gather does not
+    rewrite is NaN in the second run, and the gradients come out the same.  A new pattern / new flags gather everything again."""
+    ps = make_store(2, [[2], [2]], [32, 32], lpc=True)
+    eng = _engine(2, 2, [[2], [2]], [32, 32], ps, res_scalar=2.0, scale_first=True, lpc=True)
+    if not eng.live_gather:
+        pytest.skip("NSC_LIVE_GATHER=0")
+    x = dev(synth_frames(2).transpose(0, 2, 1))
+    lx = dev(np.sort(np.random.default_rng(3).uniform(0.03, 3.1, (2, 16, 1)), axis=1).astype(np.float32))
+    joint = dict(is_quan_on=1.0, c_time=60.0, c_freq=10.0, c_quan=[10.0, 10.0], c_ent=[0.0, 0.0], trainable=[True, True], lr=0.0, slot=1,
+                 c_quan_lpc=10.0, train_lpc=True, quan_op=True)
+    foll = dict(joint, c_quan=[0.0, 10.0], c_ent=[0.0, 0.3], trainable=[False, True], c_quan_lpc=0.0, train_lpc=False)
+    for cfg in (joint, foll):
+        eng.train_step(x, x, cfg, lpc_x=lx)                      # full gather, records
+        torch.cuda.synchronize()
+        g1 = eng.grads.cpu().numpy().copy()
+        key = [k for k in eng._live_tables if k[1] == tuple(cfg["trainable"])]
+        assert len(key) == 1
+        words = int(eng._live_tables[key[0]][0][:, 1].sum().item())
+        assert 0 < words < eng.wt.numel()
+        eng.wt.fill_(float("nan"))
+        eng.train_step(x, x, cfg, lpc_x=lx)                      # gathers the recorded regions only
+        torch.cuda.synchronize()
+        g2 = eng.grads.cpu().numpy()
+        assert np.all(np.isfinite(g2)) and np.abs(g2 - g1).max() <= 1e-6 * np.abs(g1).max(), (words, eng.wt.numel())
+        print(f"live gather, trainable {cfg['trainable']}: {words} of {eng.wt.numel()} words")
+        if cfg is joint:
+            g_joint = g1
+    assert words < int(eng._live_tables[[k for k in eng._live_tables if k[1] == (True, True)][0]][0][:, 1].sum().item())   # a frozen codec needs no backward images
+    # a forward outside a step, on flags the last gather was not recorded for, must not trust the images (they are partly NaN here)
+    eng.train_step(x, x, joint, lpc_x=lx)
+    eng.images_valid = True            # (lr = 0: the parameters are the ones the step's gather read; Adam's launch had cleared the flag)
+    assert eng.images_valid
+    eng.split_fwd = False
+    assert not eng.images_valid
+    d = eng.forward(x, 1.0, True, lpc_x=lx)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(d).all())
+    # ... and a step on the new flags gathers everything again (and records its own table)
+    eng.wt.fill_(float("nan"))
+    eng.train_step(x, x, joint, lpc_x=lx)
+    torch.cuda.synchronize()
+    g3 = eng.grads.cpu().numpy()
+    assert np.all(np.isfinite(g3)) and np.abs(g3 - g_joint).max() <= 1e-3 * np.abs(g_joint).max()      # (exact against split forward)
+    assert len(eng._live_tables) == 3
+
+
+def test_tail_stream_is_off_under_per_scope_gradient_messages():
+    """the second stream at the tail of the step (the convs' deferred weight gradients beside the blocks') is for the
+    step that overlaps nothing else; with per-scope messages under the backward pass and a communicator attached the flushes stay on
+    one stream.  And the two-stream tail gives the one-stream gradients (same kernels, same order per tensor)."""
+    ps = make_store(1, [[2]], [32], seed=1)
+    eng = _engine(2, 1, [[2]], [32], ps)
+    assert eng._tail_two_streams() == eng.tail_overlap
+    eng.dp_overlap, eng._dp_comm_attached = True, True
+    assert not eng._tail_two_streams()
+    eng.dp_overlap = eng._dp_comm_attached = False
+    x = dev(synth_frames(2).transpose(0, 2, 1))
+    cfg = dict(is_quan_on=1.0, c_time=60.0, c_freq=10.0, c_quan=[10.0], c_ent=[0.3], trainable=[True], lr=0.0, slot=1)
+    got = {}
+    for two in (True, False):
+        eng.tail_overlap = two
+        eng.train_step(x, x, cfg)
+        torch.cuda.synchronize()
+        got[two] = eng.grads.cpu().numpy().copy()
+    assert np.abs(got[True] - got[False]).max() <= 1e-6 * np.abs(got[False]).max()
+
+
 def test_bench_line_contract():
     """`python bench.py` (the command the driver runs) prints ONE JSON line with the contract's keys; the live roofline record carries
     the kernel's average launch time corrected by the event bracket's own overhead (measured in the same run) and stays below the peak."""
