@@ -265,6 +265,18 @@ def _count_gpus_sysfs():
         return None
 
 
+def _count_gpus_visible():
+    """GPUs a child process of this one would SEE: the sysfs count ignores HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES and cgroup
+    device limits, so ask a throw-away child (device_count() only - this parent still never touches a GPU).  None when the
+    probe itself fails."""
+    try:
+        out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True,
+                             timeout=300)
+        return int(out.stdout.strip().splitlines()[-1]) if out.returncode == 0 else None
+    except (OSError, ValueError, IndexError, subprocess.TimeoutExpired):
+        return None
+
+
 def spawn_ranks(n, argv):
     """--gpus N > 1 without a launcher: start N fresh ranks under torch.distributed.run as a CHILD process and relay rank 0's JSON
     line.  This parent never initialises a GPU (the device count comes from sysfs), nothing is exec'ed, and the rendezvous port is
@@ -274,8 +286,12 @@ def spawn_ranks(n, argv):
     with the variable unset - a new child process, not a restart of a process that touched a GPU - and the line says so."""
     backend = os.environ.get("NSC_DIST_BACKEND") or "nccl"
     ndev = _count_gpus_sysfs()
+    if backend == "nccl" and (ndev is None or ndev >= n):
+        nvis = _count_gpus_visible()           # (only when sysfs says there could be enough)
+        if nvis is not None:
+            ndev = nvis if ndev is None else min(ndev, nvis)
     if backend == "nccl" and ndev is not None and ndev < n:
-        print(f"[bench] --gpus {n} needs {n} GPUs for RCCL (one rank per GPU) but this node shows {ndev}; nothing was launched.  "
+        print(f"[bench] --gpus {n} needs {n} GPUs for RCCL (one rank per GPU) but this process can see {ndev}; nothing was launched.  "
               f"(NSC_DIST_BACKEND=gloo shares the visible GPU(s) between ranks: control-flow test only.)", file=sys.stderr)
         return 2
     cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",

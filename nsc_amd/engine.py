@@ -805,6 +805,7 @@ class CascadeEngine:
         self._hist_flat = self._gh[n:n + nh]
         self._flags = self._gh[n + nh:n + nh + nfl].view(torch.int32)
         self._flag_next = 0
+        self._pair_to = torch.zeros(4, dtype=torch.int32, device=self.device)
         self._quan_acc = self._gh[n + nh + nfl:n + nh + nfl + nquan].view(self.N, self.B)     # quan_loss per frame, accumulated by tiles
         self._hist_slots, self._hist_used = {}, 0
         # wt = flipped/transposed kernels of every conv at the same offsets as the parameters, followed by one extra
@@ -1206,17 +1207,14 @@ class CascadeEngine:
         return self._flags.data_ptr() + 4 * stride * k
 
     def pair_timeouts_ptr(self):
-        """The STICKY time-out counter of the pair launches: one int outside everything a step zeroes; the kernels only add to it."""
-        if self._pair_to is None:
-            self._pair_to = torch.zeros(4, dtype=torch.int32, device=self.device)
+        """The STICKY time-out counter of the pair launches: one int outside everything a step zeroes; the kernels only add to it
+        (allocated with the engine - ADVICE r5: a lazy allocation inside a graph capture would have captured its zero-fill)."""
         return self._pair_to.data_ptr()
 
     def pair_timeouts(self):
         """Neighbour waits of pair launches that timed out since this engine was created (must be 0: the launch that counted one
         read unpublished data).  Synchronises the device."""
-        return 0 if self._pair_to is None else int(self._pair_to[0].item())
-
-    _pair_to = None
+        return int(self._pair_to[0].item())
 
     def hist_view(self, key, nb):
         """[nb] slice of the flat histogram buffer (codecs' 32-bin and the LSF quantizer's 256-bin histograms side by side)."""

@@ -66,9 +66,15 @@ def _workspace(floats, dev):
     """Caller-owned scratch of the slab-flush weight-gradient kernels: one buffer per device, grown on demand (launches on one stream
     are ordered, so they can share it; the old buffer of a grow stays alive until the kernels using it have run - torch's
     stream-ordered allocator)."""
-    key = ("ws", str(dev))
+    # (ADVICE r5) one buffer per (device, STREAM): two backward passes on two streams would race on a shared slab; and never allocated
+    # or grown while a hipGraph is being captured - the buffer would belong to the graph's private pool and be handed out again after
+    # the graph is freed: the first eager use sizes it, a capture that needs more says so
+    key = ("ws", str(dev), int(_st()))
     ws = _CACHE.get(key)
     if ws is None or ws.numel() < floats:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError(f"nsc_amd.ops: the weight-gradient workspace ({floats} floats) must exist before graph capture: run the "
+                               f"step once eagerly on this stream first")
         ws = torch.empty(max(floats, 1), dtype=torch.float32, device=dev)
         _CACHE[key] = ws
     return ws
@@ -117,7 +123,7 @@ def _split_conv_image(lib, which, d, w):
     n = int(lib.nsc_conv1d_simage_words(which, C.byref(d)))
     if n <= 0 or w.data_ptr() % 16:
         return None
-    key = ("cs_idx", which, str(w.device))
+    key = ("cs_idx", which, str(w.device), tuple(w.shape))
     if key not in _CACHE:
         idx = np.empty(n, np.int32)
         check(lib.nsc_conv1d_simage_index(which, C.byref(d), 0, idx.ctypes.data_as(C.c_void_p)), "conv1d_simage_index")
