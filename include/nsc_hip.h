@@ -216,22 +216,17 @@ int nsc_gated_block_pair_dgrad_img(const float* img1, const float* x1, const flo
  *      <= 2^-24 |a||b|), at 2.7x its rate, with the vector ALU free for the elementwise phases.  The 1x1 conv stays on the exact
  *      fp32 instruction.  Results agree with nsc_gated_block_fwd_img to fp32 rounding (not bit for bit).
  *   nsc_gated_block_simage_words(which, C, Cin, dil)   size of the split image in 32-bit words (0: no split kernel for this shape;
- *                                                      which = 0: forward, 1: fused data gradient, 2: three-launch data gradient)
+ *                                                      which = 0: forward, 2: the three-launch data gradient below)
  *   nsc_gated_block_simage_index(which, ..., offs, idx) index map for nsc_gather / nsc_step_begin, offs as for
  *      nsc_gated_block_image_index.  Entries carry a MODE in bits 26..29 (so source offsets must stay below 2^26 - 2^20):
  *      0 = the fp32 value; m > 0 = two bf16 pieces packed in one word, low half from src[i], high half from src[i + stride],
  *      plane (m - 1) / 5 (0 hi, 1 lo, 2 lo2), stride {20, 25, 50, 100, 1}[(m - 1) % 5].  nsc_gather understands them.
- *      which = 1 (data gradient; C in {100, 50}, Cin = C): offs as for which = 0 - the fragments are taken straight from the
- *      parameters, flipped and transposed by the index map.
- *   nsc_gated_block_fwd_simg / nsc_gated_block_pair_fwd_simg / nsc_gated_block_dgrad_simg: arguments of nsc_gated_block_fwd_img /
- *      _pair_fwd_img / _dgrad_img; T % 4 == 0 and 16-byte aligned tensors (NSC_ERR_UNSUPPORTED otherwise: use the exact kernels). */
+ *   nsc_gated_block_fwd_simg / nsc_gated_block_pair_fwd_simg: arguments of nsc_gated_block_fwd_img / _pair_fwd_img; T % 4 == 0 and
+ *      16-byte aligned tensors (NSC_ERR_UNSUPPORTED otherwise: use the exact kernels). */
 long nsc_gated_block_simage_words(int which, int C, int Cin, int dil);
 int nsc_gated_block_simage_index(int which, int C, int Cin, int dil, const long* offs, int* idx);
 int nsc_gated_block_fwd_simg(const float* img, const float* x, float* out, float* h_out, float* lin_out, float* th_out,
                              float* g_out, int B, int C, int Cin, int T, int dil, int flat, void* stream);
-int nsc_gated_block_dgrad_simg(const float* img, const float* x, const float* h, const float* lin, const float* th,
-                               const float* dy, float* dx, float* dlin, float* dgate, float* dz1, int B, int C, int Cin,
-                               int T, int dil, int in_act, int da_rows, void* stream);
 /* The same data-path backward as THREE launches on the which = 2 image (csrc/block_bwd_split.hip): the two long contractions as
  * polyphase GEMMs with 80 = 4 x 20 rows (no padded row tiles, no halo recompute, no partial sums across waves), then the HBM-bound
  * 1x1 gradient + residual.  which = 2 image: the three bf16 pieces of W9 [9][20][C -> multiple of 8] and of Wl | Wr [15][20][40] in

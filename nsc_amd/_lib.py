@@ -50,7 +50,6 @@ PROTOTYPES = {
     "nsc_gated_block_image_index": [_I, _I, _I, _I, _P, _P],
     "nsc_gated_block_simage_index": [_I, _I, _I, _I, _P, _P],
     "nsc_gated_block_fwd_simg": [_P] * 7 + [_I] * 6 + [_P],
-    "nsc_gated_block_dgrad_simg": [_P] * 10 + [_I] * 7 + [_P],
     "nsc_gated_block_dgrad_simg2": [_P] * 10 + [_I] * 6 + [_P],
     "nsc_gated_block_pair_fwd_simg": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
     "nsc_depthwise_fwd": [_P, _P, _P, _I, _I, _I, _I, _P],

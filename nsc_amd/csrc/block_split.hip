@@ -579,8 +579,7 @@ long nsc_bb_simage_words(int C);
 void nsc_bb_simage_index(int C, long w9, long wl, long wr, const int mode_bits[3], int* idx);
 static bool simg_shape(int which, int C, int Cin, int dil, int* rt9, int* nk) {
   if (which == 2) return (C == 100 || C == 50) && (Cin == C || Cin == 1) && (dil == 1 || dil == 2);
-  if (which != 0 && which != 1) return false;
-  if (which == 1 && !(Cin == C && (C == 100 || C == 50))) return false;      // data gradient: gated_block_dgrad3_kernel's shapes
+  if (which != 0) return false;                                              // (which = 1, the fused split data gradient of round 5, is gone)
   if (!(dil == 1 || dil == 2) || !(C == 100 || C == 50 || C == 25) || !(Cin == C || Cin == 1)) return false;
   *rt9 = C == 100 ? 7 : 4;
   *nk = C == 100 ? 25 : (C == 50 ? 13 : 7);
@@ -594,10 +593,6 @@ extern "C" long nsc_gated_block_simage_words(int which, int C, int Cin, int dil)
   int rt9, nk;
   if (!simg_shape(which, C, Cin, dil, &rt9, &nk)) return 0;
   if (which == 2) return nsc_bb_simage_words(C);
-  if (which == 1) {
-    const int cp = (C + 3) & ~3, nks9 = (K9 * cp + 31) / 32, nks15 = (K15 * 2 * NARROW + 31) / 32, nct = (C + 15) / 16;
-    return 256L * 3 * (2 * nks9 + 2 * nks15 + nct);
-  }
   const int nk1 = Cin == 1 ? 1 : nk;
   const long n2 = (SPL_W2U16 + SPL_W2SLACK) / 2;
   return n2 + 256L * (2 * ((nk1 + 4 + 3) / 4) + (rt9 == 7 ? 7 : 4) * (SPL_KS3 * 3 + 1) + 8 * 2);
@@ -616,39 +611,6 @@ extern "C" int nsc_gated_block_simage_index(int which, int C, int Cin, int dil, 
   if (which == 2) {
     const int modes[3] = {simg_mode(0, 1), simg_mode(1, 1), simg_mode(2, 1)};
     nsc_bb_simage_index(C, w9, wl, wr, modes, idx);
-    return NSC_OK;
-  }
-  if (which == 1) {
-    // Data gradient (gated_block_dgrad3_kernel).  B fragments: lane (n = l15: column = input channel ci of the k9 | k15 kernel,
-    // output channel co of the 1x1), k = 32 s + 8 kq + 2 jw (+ 1), straight from the PARAMETERS (offs as for which = 0):
-    //   k9:  k = tap' * CP + o   -> w9[8 - tap'][ci][o]           (CP = C rounded to 4: the pad slots are zeros)
-    //   k15: k = tap' * 40 + c'  -> (c' < 20 ? wl : wr)[14 - tap'][ci][c' % 20]
-    //   1x1: k = c (< 20)        -> w1[co][c]
-    const int cp = (C + 3) & ~3, nks9 = (K9 * cp + 31) / 32, nks15 = (K15 * 2 * NARROW + 31) / 32, nct = (C + 15) / 16;
-    const long base15 = 256L * 3 * 2 * nks9, base1 = base15 + 256L * 3 * 2 * nks15;
-    for (int lane = 0; lane < 64; ++lane) {
-      const int l15 = lane & 15, kq = lane >> 4;
-      for (int p = 0; p < 3; ++p)
-        for (int jw = 0; jw < 4; ++jw) {
-          for (int s = 0; s < nks9; ++s)
-            for (int ct = 0; ct < 2; ++ct) {
-              const int k = 32 * s + 8 * kq + 2 * jw, tp = k / cp, o = k - tp * cp, ci = ct * 16 + l15;
-              if (tp < K9 && o < C && ci < NARROW)
-                idx[(((long)(s * 2 + ct) * 3 + p) * 64 + lane) * 4 + jw] = (int)(w9 + ((long)(K9 - 1 - tp) * NARROW + ci) * C + o) | simg_mode(p, 1);
-            }
-          for (int s = 0; s < nks15; ++s)
-            for (int ct = 0; ct < 2; ++ct) {
-              const int k = 32 * s + 8 * kq + 2 * jw, tp = k / (2 * NARROW), cc = k - tp * 2 * NARROW, ci = ct * 16 + l15;
-              if (tp < K15 && ci < NARROW)
-                idx[base15 + (((long)(s * 2 + ct) * 3 + p) * 64 + lane) * 4 + jw] =
-                    (int)((cc < NARROW ? wl : wr) + ((long)(K15 - 1 - tp) * NARROW + ci) * NARROW + (cc % NARROW)) | simg_mode(p, 1);
-            }
-          for (int ct = 0; ct < nct; ++ct) {
-            const int k = 8 * kq + 2 * jw, co = ct * 16 + l15;
-            if (k < NARROW && co < C) idx[base1 + (((long)ct * 3 + p) * 64 + lane) * 4 + jw] = (int)(w1 + (long)co * NARROW + k) | simg_mode(p, 1);
-          }
-        }
-    }
     return NSC_OK;
   }
   const int nk1 = Cin == 1 ? 1 : nk;
@@ -1138,459 +1100,4 @@ int nsc_launch_block_wgrad_split(const BlockWgradBatch& t, int rt9, int nwg, hip
   }
   NSC_CHECK_LAUNCH("gated_block_wgrad_split");
   return NSC_OK;
-}
-
-// =====================================================================================================
-// Data-path backward of the gated block on the bf16 matrix cores (split operands).  Same inputs / outputs as
-// gated_block_dgrad2_kernel (block.hip):
-//   dg   = W9^T * dy                       K = 9 C     (rows of the product = time, columns = the 20 narrow channels)
-//   dlin = dg . th ; dgate = dg . lin . (1 - th^2)                                     -> da [B,40,T]
-//   dz1  = (Wl^T dlin + Wr^T dgate) . lrelu'(h)      K = 15 * 40                        -> dz1 [B,20,T]
-//   dx   = (W1^T dz1 + dy) . act'(x)                 K = 20                             -> dx [B,C,T]
-// The outputs of the two long products are NARROW (20 channels) and their reductions LONG, and the fp32 design's answer stays:
-// split the REDUCTION over the eight waves and add the eight partial sums in the elementwise phase that follows.  What changes:
-//  * k-step = 32 reduction slots of an activation plane in the [time][channels] layout of the forward (row pitch = channel count
-//    rounded to 4: k = tap * pitch + channel is the flat offset from a column's own row); wave w owns k-steps w, w + 8, ...
-//    of both products, for ALL row tiles (time) - so an activation fragment is read from LDS exactly once per tile (the forward,
-//    whose outputs are wide, reads every g fragment seven times: LDS-bound; this kernel is not);
-//  * the WEIGHTS of a wave's k-steps are 16-byte fragments of the split image (which = 1), fetched from L2 into registers at the
-//    start of the phase BEFORE the one that uses them: 3 x bf16 planes of all three kernels are 192 KB, more than the registers or
-//    the LDS left beside the activation planes, and they are the same for every tile - a CU re-reads ~200 KB of L2-resident lines
-//    per tile (3 k cycles of its 64 B/clk fill path, under the MFMA phases);
-//  * every elementwise phase (GLU, lrelu', copy-out) runs while the matrix pipe could work for the other wave of the SIMD.
-// Built for C in {100, 50}, Cin = C, dilation 1 | 2, T % 4 == 0; everything else takes the exact kernels.
-// =====================================================================================================
-template <int C_, int DIL>
-struct DsgGeom {
-  static constexpr int TT = 64, Hh = 7 * DIL, W_a = TT + 2 * Hh, W_dy = W_a + 8;
-  static constexpr int CP = (C_ + 3) & ~3;                       // row pitch of the dy planes (elements)
-  static constexpr int NCT = (C_ + 15) / 16;                     // column tiles of dx
-  static constexpr int NKS9 = (K9 * CP + 31) / 32, NKS15 = (K15 * 2 * NARROW + 31) / 32;
-  static constexpr int NI9 = (NKS9 + 7) / 8, NI15 = (NKS15 + 7) / 8;
-  static constexpr int NRTF = (W_a + 15) / 16;                   // row tiles (time) of a fresh tile: 5 | 6; steady: 4
-  static constexpr int RY = NRTF * 16 + 10;                      // rows of a dy plane: the last row tile's taps + the k-slots past tap 8
-  static constexpr int PLY = RY * CP;
-  static constexpr int RA = DIL == 1 ? ((W_a + 2 + 7) & ~7) : 2 * 48, PLA = RA * 2 * NARROW, AHALF = 48 * 2 * NARROW;
-  static constexpr int RZ = TT + 2, PLZ = RZ * NARROW;
-  static constexpr int PW = NRTF * 16 + 4;                       // row stride (floats) of a partial-sum row: [wave][channel][column]
-  static constexpr size_t smem = (size_t)2 * 3 * (PLY + PLA + PLZ) + (size_t)4 * 8 * NARROW * PW;
-};
-template <int DIL>
-__device__ __forceinline__ int dsg_aoff(int ja) {               // element offset of da column ja in a plane
-  return DIL == 1 ? ja * 2 * NARROW : (ja & 1) * (48 * 2 * NARROW) + (ja >> 1) * 2 * NARROW;
-}
-
-template <int C_, int DIL>
-__global__ __launch_bounds__(512) void gated_block_dgrad3_kernel(BlockDgradArgs a, int ntiles, int tpf) {
-  extern __shared__ __attribute__((aligned(16))) float smf[];
-  using G = DsgGeom<C_, DIL>;
-  constexpr int TT = G::TT, Hh = G::Hh, W_a = G::W_a, CP = G::CP, NCT = G::NCT, NKS9 = G::NKS9, NKS15 = G::NKS15, NI9 = G::NI9, NI15 = G::NI15;
-  constexpr int NRTF = G::NRTF, PLY = G::PLY, PLA = G::PLA, PLZ = G::PLZ, PW = G::PW;
-  u16* dyp = reinterpret_cast<u16*>(smf);                       // [3][RY][CP]      row j <-> step t0 - Hh - 4 + j
-  u16* dap = dyp + 3 * PLY;                                     // [3][RA][40]      column ja <-> step t0 - Hh + ja  (dlin | dgate)
-  u16* dzp = dap + 3 * PLA;                                     // [3][RZ][20]      row tt <-> step t0 + tt
-  float* part = reinterpret_cast<float*>(dzp + 3 * PLZ);        // [8][20][PW]      partial sums of the eight K-slices
-  static_assert((3 * (PLY + PLA + PLZ) * 2) % 16 == 0, "16-byte aligned partial sums");
-  const int T = a.T;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l15 = lane & 15, kq = lane >> 4;
-  const int OOB = 0x7ffffff0;
-  const unsigned nbC = (unsigned)((long)a.B * C_ * T * 4), nbN = (unsigned)((long)a.B * NARROW * T * 4);
-  const __amdgpu_buffer_rsrc_t sdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, nbC, 0x00020000);
-  const __amdgpu_buffer_rsrc_t sxx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, nbC, 0x00020000);
-  const __amdgpu_buffer_rsrc_t slin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.lin), 0, nbN, 0x00020000);
-  const __amdgpu_buffer_rsrc_t sth = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.th), 0, nbN, 0x00020000);
-  const __amdgpu_buffer_rsrc_t sh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.h), 0, nbN, 0x00020000);
-  const unsigned nbDA = (unsigned)(((long)a.B * a.da_rows - (a.da_rows == NARROW ? 0 : NARROW)) * T * 4);
-  const __amdgpu_buffer_rsrc_t sdlin = __builtin_amdgcn_make_buffer_rsrc(a.da, 0, nbDA, 0x00020000);
-  const __amdgpu_buffer_rsrc_t sdgate = __builtin_amdgcn_make_buffer_rsrc(a.dgate, 0, nbDA, 0x00020000);
-  const __amdgpu_buffer_rsrc_t sdz = __builtin_amdgcn_make_buffer_rsrc(a.dz1, 0, nbN, 0x00020000);
-  auto bld = [](const __amdgpu_buffer_rsrc_t& r, int voff, int soff) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, NSC_AUX_STREAM));
-  };
-  // the split image (nsc_gated_block_simage_index, which = 1): fragments [k-step][column tile][plane][lane] of the k9 and the k15
-  // gradient, then [column tile][plane][lane] of the 1x1 gradient
-  const f32x4* img4 = reinterpret_cast<const f32x4*>(a.img) + lane;
-  constexpr int F9 = 0, F15 = NKS9 * 2 * 3 * 64, F1 = F15 + NKS15 * 2 * 3 * 64;
-  // the 1x1 gradient's fragments stay: wave w = column tile w (C = 100), or column tile w & 3 with two of the four row tiles (C = 50)
-  const int ct1 = NCT > 4 ? min(wave, NCT - 1) : (wave & 3);
-  bf16x8 w1f[3];                                                  // (fetched every tile under the lrelu' phase: 12 registers not held)
-  // this wave's weight fragments of the current long product: a ring of two k-steps (the fragments of k-step i + 1 are requested
-  // before the MFMAs of k-step i - one k-step is 48 .. 72 MFMAs, about an L2 round trip; all four at once were 96 registers)
-  bf16x8 wq[2][2][3];
-  auto load_w9 = [&](int i) {
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-      for (int p = 0; p < 3; ++p)
-        wq[i & 1][ct][p] = __builtin_bit_cast(bf16x8, img4[F9 + ((min(wave + 8 * i, NKS9 - 1) * 2 + ct) * 3 + p) * 64]);
-  };
-  auto load_w15 = [&](int i) {
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-      for (int p = 0; p < 3; ++p)
-        wq[i & 1][ct][p] = __builtin_bit_cast(bf16x8, img4[F15 + ((min(wave + 8 * i, NKS15 - 1) * 2 + ct) * 3 + p) * 64]);
-  };
-
-  // zero what no tile writes but fragments read: pad channels of the dy planes, the rows past the staged window, the pad row of dz1
-  for (int e = tid; e < 3 * (PLY + PLA + PLZ) / 2; e += 512) reinterpret_cast<unsigned*>(dyp)[e] = 0u;
-  __syncthreads();
-
-  // ---- prefetch of a tile's inputs: dword loads in the mapping of the phase that consumes them, lanes along time.  Thread =
-  // (column jl = tid & 63, group wave); item `it` = the channel PAIR wave + 8 it (channels 2 pi, 2 pi + 1: one split, one 32-bit LDS
-  // store per plane): the row enters through the SCALAR offset, one vector offset per column half, no divisions.  "A" items: the 64
-  // columns from j0; "B" items: the columns past them - a fresh tile's 64 + jl (same mapping), a steady tile's 8 extra dy columns as
-  // (column tid & 7, pair tid >> 3) ----
-  constexpr int NIP = (C_ / 2 + 7) / 8, NIG = 2;                 // pairs per thread and half: dy channels, narrow channels (10 pairs -> 2)
-  constexpr int NCF = NRTF * 16 + 8, NAF = NRTF * 16;            // columns of a fresh tile's dy / da windows
-  static_assert(C_ % 2 == 0, "channel pairs");
-  float pyA[NIP][2], pyB[NIP][2], plA[NIG][2], plB[NIG][2], ptA[NIG][2], ptB[NIG][2], ph[3];
-  const int jl = tid & 63;
-  const int first = (int)((long)blockIdx.x * ntiles / gridDim.x), last = (int)((long)(blockIdx.x + 1) * ntiles / gridDim.x);
-  // (three pieces, each issued where the registers it refills are free and there is a phase or more for the data to arrive: dy at
-  // the start of the k15 gradient, lin / tanh after the GLU phase, h after the lrelu' phase)
-  auto prefetch_dy = [&](int tile, bool fresh) {
-    const int tl = __builtin_amdgcn_readfirstlane(tile < ntiles ? tile : 0);
-    const int b = tl / tpf, t0 = (tl - b * tpf) * TT;
-    const int j0 = fresh ? 0 : 2 * Hh;
-    const int tA = t0 - Hh - 4 + j0 + jl;
-    const int vA = (tA >= 0 && tA < T) ? (2 * wave * T + tA) * 4 : OOB;
-#pragma unroll
-    for (int it = 0; it < NIP; ++it)
-#pragma unroll
-      for (int e = 0; e < 2; ++e)
-        pyA[it][e] = bld(sdy, (it == NIP - 1 && 2 * (wave + 8 * it) + e >= C_) ? OOB : vA, (b * C_ + 16 * it + e) * T * 4);
-    if (fresh) {
-      const int tB = tA + 64;
-      const int vB = (64 + jl < NCF && tB >= 0 && tB < T) ? (2 * wave * T + tB) * 4 : OOB;
-#pragma unroll
-      for (int it = 0; it < NIP; ++it)
-#pragma unroll
-        for (int e = 0; e < 2; ++e)
-          pyB[it][e] = bld(sdy, (it == NIP - 1 && 2 * (wave + 8 * it) + e >= C_) ? OOB : vB, (b * C_ + 16 * it + e) * T * 4);
-    } else {
-      const int tB = t0 - Hh - 4 + j0 + 64 + (tid & 7), o = 2 * (tid >> 3);
-#pragma unroll
-      for (int e = 0; e < 2; ++e) pyB[0][e] = bld(sdy, (o + e < C_ && tB >= 0 && tB < T) ? ((o + e) * T + tB) * 4 : OOB, b * C_ * T * 4);
-    }
-  };
-  auto prefetch_lt = [&](int tile, bool fresh) {
-    const int tl = __builtin_amdgcn_readfirstlane(tile < ntiles ? tile : 0);
-    const int b = tl / tpf, t0 = (tl - b * tpf) * TT;
-    const int j0 = fresh ? 0 : 2 * Hh;
-    const int tA = t0 - Hh + j0 + jl, tB = tA + 64;
-    const int vA = (tA >= 0 && tA < T) ? (2 * wave * T + tA) * 4 : OOB;
-    const int vB = (fresh && 64 + jl < W_a && tB >= 0 && tB < T) ? (2 * wave * T + tB) * 4 : OOB;
-#pragma unroll
-    for (int it = 0; it < NIG; ++it)
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const bool cok = 2 * (wave + 8 * it) + e < NARROW;
-        const int so = (b * NARROW + 16 * it + e) * T * 4;
-        plA[it][e] = bld(slin, cok ? vA : OOB, so);
-        ptA[it][e] = bld(sth, cok ? vA : OOB, so);
-        if (fresh) {
-          plB[it][e] = bld(slin, cok ? vB : OOB, so);
-          ptB[it][e] = bld(sth, cok ? vB : OOB, so);
-        }
-      }
-  };
-  auto prefetch_h = [&](int tile) {
-    const int tl = __builtin_amdgcn_readfirstlane(tile < ntiles ? tile : 0);
-    const int b = tl / tpf, t0 = (tl - b * tpf) * TT;
-    const int th_ = t0 + jl;
-#pragma unroll
-    for (int it = 0; it < 3; ++it)
-      ph[it] = bld(sh, (wave + 8 * it < NARROW && th_ < T) ? (wave * T + th_) * 4 : OOB, (b * NARROW + 8 * it) * T * 4);
-  };
-  NSC_STAMP(0);
-  prefetch_dy(first, true);
-  prefetch_lt(first, true);
-  prefetch_h(first);
-  load_w9(0);
-  NSC_STAMP(1);
-  for (int tile = first; tile < last; ++tile) {
-    NSC_STAMP(2);
-    const int b = tile / tpf, t0 = (tile - b * tpf) * TT;
-    const bool fresh = tile == first || t0 == 0;
-    const bool next_steady = tile + 1 < last && (tile + 1) - ((tile + 1) / tpf) * tpf != 0;
-    const int ja0 = fresh ? 0 : 2 * Hh;                          // first new column of dg / da
-    const int nrt = fresh ? NRTF : TT / 16;                      // row tiles of the k9 gradient
-    // ---- stage: dy -> the three planes (element (row j, channel o)); two items share a split (packed pairs) ----
-    {
-      const int j0 = fresh ? 0 : 2 * Hh;
-      auto put2 = [&](float va, float vb, int el, bool ok) {             // channels (2 pi, 2 pi + 1) of one row: a 32-bit word per plane
-        unsigned pk[3];
-        nsc_split2(va, vb, pk);
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-          if (ok) *reinterpret_cast<unsigned*>(dyp + p * PLY + el) = pk[p];
-      };
-      const int eA = (j0 + jl) * CP + 2 * wave, eB = eA + 64 * CP;
-#pragma unroll
-      for (int it = 0; it < NIP; ++it) put2(pyA[it][0], pyA[it][1], eA + 16 * it, 2 * (wave + 8 * it) < C_);
-      if (fresh) {
-        const bool cokB = 64 + jl < NCF;
-#pragma unroll
-        for (int it = 0; it < NIP; ++it) put2(pyB[it][0], pyB[it][1], eB + 16 * it, cokB && 2 * (wave + 8 * it) < C_);
-      } else {
-        put2(pyB[0][0], pyB[0][1], (j0 + 64 + (tid & 7)) * CP + 2 * (tid >> 3), 2 * (tid >> 3) < C_);
-      }
-      if (!fresh) {
-        // carried da columns [TT, TT + 2 Hh) -> [0, 2 Hh) (32-bit words; dilation 2: rows [32, 32 + Hh) -> [0, Hh) of either half)
-        constexpr int NW = 2 * Hh * 2 * NARROW / 2 / DIL;
-        for (int e = tid; e < 3 * DIL * NW; e += 512) {
-          const int p = e / (DIL * NW), r = e - p * (DIL * NW), hf = r / NW, i = r - hf * NW;
-          unsigned* q = reinterpret_cast<unsigned*>(dap + p * PLA + hf * G::AHALF) + i;
-          q[0] = q[(TT / DIL) * 2 * NARROW / 2];
-        }
-      }
-    }
-    NSC_STAMP(3);
-    nsc_lds_barrier();
-    NSC_STAMP(4);
-    const int ntile = tile + 1 < last ? tile + 1 : tile;
-
-    // ---- k9 gradient: this wave's k-steps, all row tiles, both column tiles ----
-    {
-      f32x4 acc[NRTF][2];
-#pragma unroll
-      for (int r = 0; r < NRTF; ++r) acc[r][0] = acc[r][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      nsc_lds_cu16 yb[3];
-#pragma unroll
-      for (int p = 0; p < 3; ++p) yb[p] = nsc_opaque_lds(dyp + p * PLY + (ja0 + l15) * CP + 8 * kq + 32 * wave);
-      // (activation fragments one row tile ahead, scheduling fences as in the forward)
-      bf16x8 af[2][3];
-      auto fetch = [&](int st_, int slot) {                     // step st_ = (k-step i = st_ / NRTF, row tile r = st_ % NRTF)
-        const int i = st_ / NRTF, r = st_ - i * NRTF;
-#pragma unroll
-        for (int p = 0; p < 3; ++p) af[slot][p] = ld_frag8(yb[p] + r * 16 * CP + i * 256);
-      };
-      fetch(0, 0);
-#pragma unroll
-      for (int i = 0; i < NI9; ++i) {
-        if (i + 1 < NI9) load_w9(i + 1);
-#pragma unroll
-        for (int r = 0; r < NRTF; ++r) {
-          const int st_ = i * NRTF + r;
-          if (st_ + 1 < NI9 * NRTF) fetch(st_ + 1, (st_ + 1) & 1);
-          __builtin_amdgcn_sched_barrier(0);
-          if (wave + 8 * i < NKS9 && r < nrt) {
-            acc[r][0] = mfma_split6(af[st_ & 1], wq[i & 1][0], acc[r][0]);
-            acc[r][1] = mfma_split6(af[st_ & 1], wq[i & 1][1], acc[r][1]);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      // partial sums: the lane holds 4 consecutive columns (rows of the product) of channel ct * 16 + l15
-#pragma unroll
-      for (int r = 0; r < NRTF; ++r)
-        if (r < nrt) {
-#pragma unroll
-          for (int ct = 0; ct < 2; ++ct) {
-            const int c = ct * 16 + l15;
-            if (c < NARROW) *reinterpret_cast<f32x4*>(part + (wave * NARROW + c) * PW + r * 16 + 4 * kq) = acc[r][ct];
-          }
-        }
-    }
-    load_w15(0);
-    NSC_STAMP(5);
-    nsc_lds_barrier();
-    NSC_STAMP(6);
-
-    // ---- GLU backward: dg = the eight partial sums; dlin | dgate -> memory (da) and the da planes ----
-    {
-      const int st_lo = fresh ? Hh : 2 * Hh, st_hi = next_steady ? W_a : Hh + TT;
-      const int sda = b * a.da_rows * T * 4;
-      // an item = (channel pair 2 cp, 2 cp + 1; column ja0 + i): dlin of the pair is one 32-bit word of a da plane, dgate another
-      auto glu2 = [&](int cp, int i, const float (&l)[2], const float (&tg)[2]) {
-        const int ja = ja0 + i, c = 2 * cp;
-        const int t = t0 - Hh + ja;
-        const int vo = (ja >= st_lo && ja < st_hi && t >= 0 && t < T) ? (c * T + t) * 4 : OOB;
-        float dl_[2], dgt[2];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const float* pp = part + (c + e) * PW + i;
-          float gg = 0.f;
-#pragma unroll
-          for (int w = 0; w < 8; ++w) gg += pp[w * NARROW * PW];
-          dl_[e] = gg * tg[e];
-          dgt[e] = gg * l[e] * (1.f - tg[e] * tg[e]);
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, dl_[e]), sdlin, vo, sda + e * T * 4, NSC_AUX_LATE);
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, dgt[e]), sdgate, vo, sda + e * T * 4, NSC_AUX_LATE);
-        }
-        unsigned pl_[3], pg_[3];
-        nsc_split2(dl_[0], dl_[1], pl_);
-        nsc_split2(dgt[0], dgt[1], pg_);
-        u16* dst = dap + dsg_aoff<DIL>(ja) + c;
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          *reinterpret_cast<unsigned*>(dst + p * PLA) = pl_[p];
-          *reinterpret_cast<unsigned*>(dst + p * PLA + NARROW) = pg_[p];
-        }
-      };
-#pragma unroll
-      for (int it = 0; it < NIG; ++it) {
-        const int cp = wave + 8 * it;
-        if (cp < NARROW / 2) {
-          glu2(cp, jl, plA[it], ptA[it]);
-          if (fresh && 64 + jl < W_a) glu2(cp, 64 + jl, plB[it], ptB[it]);
-        }
-      }
-    }
-    NSC_STAMP(7);
-    nsc_lds_barrier();
-    NSC_STAMP(8);
-
-    // ---- k15 gradient: this wave's k-steps, four row tiles, both column tiles ----
-    // (first the loads that have this phase and the next to arrive: this tile's residual dy / x pieces of the copy-out - x is touched
-    // here for the first time: from HBM)
-    constexpr int NR1 = NCT > 4 ? 4 : 2;                          // row tiles of this wave in the 1x1 gradient
-    const int r0 = NCT > 4 ? 0 : 2 * (wave >> 2);
-    const int co = ct1 * 16 + l15;
-    f32x4 yv[NR1], xv[NR1];
-#pragma unroll
-    for (int r = 0; r < NR1; ++r) {
-      const int t = t0 + (r0 + r) * 16 + 4 * kq;
-      const int vo = (co < C_ && t < T && (NCT <= 4 || wave < NCT)) ? ((b * C_ + co) * T + t) * 4 : OOB;
-      yv[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(sdy, vo, 0, 0));
-      xv[r] = a.in_act == NSC_ACT_LRELU ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(sxx, vo, 0, 0)) : (f32x4){1.f, 1.f, 1.f, 1.f};
-    }
-    {
-      f32x4 acc[4][2];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r][0] = acc[r][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      nsc_lds_cu16 ab[3];
-#pragma unroll
-      for (int p = 0; p < 3; ++p) ab[p] = nsc_opaque_lds(dap + p * PLA + 8 * kq + 32 * wave);
-      bf16x8 af[2][3];
-      auto fetch = [&](int st_, int slot) {                     // step st_ = (k-step i = st_ / 4, row tile r = st_ % 4)
-        const int i = st_ >> 2, r = st_ & 3;
-#pragma unroll
-        for (int p = 0; p < 3; ++p) af[slot][p] = ld_frag8(ab[p] + dsg_aoff<DIL>(r * 16 + l15) + i * 256);
-      };
-      fetch(0, 0);
-#pragma unroll
-      for (int i = 0; i < NI15; ++i) {
-        if (i + 1 < NI15) load_w15(i + 1);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int st_ = i * 4 + r;
-          if (st_ + 1 < NI15 * 4) fetch(st_ + 1, (st_ + 1) & 1);
-          __builtin_amdgcn_sched_barrier(0);
-          if (wave + 8 * i < NKS15) {
-            acc[r][0] = mfma_split6(af[st_ & 1], wq[i & 1][0], acc[r][0]);
-            acc[r][1] = mfma_split6(af[st_ & 1], wq[i & 1][1], acc[r][1]);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-          const int c = ct * 16 + l15;
-          if (c < NARROW) *reinterpret_cast<f32x4*>(part + (wave * NARROW + c) * PW + r * 16 + 4 * kq) = acc[r][ct];
-        }
-    }
-    load_w9(0);                                                  // (for the next tile: they arrive under the phases below)
-    NSC_STAMP(9);
-    nsc_lds_barrier();
-    NSC_STAMP(10);
-
-    // ---- dz1 = (sum of the partial sums) . lrelu'(h) -> memory and the dz1 planes ----
-    // (the next tile's dy, lin and tanh go out here: their registers are free from now on, and two phases plus the next tile's
-    // staging / k9 gradient are time enough)
-    prefetch_dy(ntile, !next_steady);
-    prefetch_lt(ntile, !next_steady);
-    {
-#pragma unroll
-      for (int p = 0; p < 3; ++p) w1f[p] = __builtin_bit_cast(bf16x8, img4[F1 + (ct1 * 3 + p) * 64]);
-#pragma unroll
-      for (int it = 0; it < 3; ++it) {
-        const int c = wave + 8 * it, tt = jl;
-        if (c < NARROW) {
-          const float* pp = part + c * PW + tt;
-          float s_ = 0.f;
-#pragma unroll
-          for (int w = 0; w < 8; ++w) s_ += pp[w * NARROW * PW];
-          const int t = t0 + tt;
-          const float v = t < T ? s_ * (ph[it] > 0.f ? 1.f : NSC_LRELU_ALPHA) : 0.f;
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), sdz, t < T ? (c * T + t) * 4 : OOB, b * NARROW * T * 4, NSC_AUX_LATE);
-          unsigned pk[3];
-          nsc_split2(v, 0.f, pk);
-#pragma unroll
-          for (int p = 0; p < 3; ++p) dzp[p * PLZ + tt * NARROW + c] = (u16)(pk[p] & 0xffffu);
-        }
-      }
-      prefetch_h(ntile);
-    }
-    NSC_STAMP(11);
-    nsc_lds_barrier();
-    NSC_STAMP(12);
-
-    // ---- 1x1 gradient + residual, . act'(x): dx rows leave as 16-byte pieces (4 consecutive steps of one channel per lane) ----
-    {
-      if (NCT <= 4 || wave < NCT) {
-#pragma unroll
-        for (int r = 0; r < NR1; ++r) {
-          bf16x8 af[3];
-#pragma unroll
-          for (int p = 0; p < 3; ++p) af[p] = ld_frag8((nsc_lds_cu16)(dzp + p * PLZ + ((r0 + r) * 16 + l15) * NARROW + 8 * kq));
-          f32x4 acc = mfma_split6(af, w1f, (f32x4){0.f, 0.f, 0.f, 0.f});
-          const int t = t0 + (r0 + r) * 16 + 4 * kq;
-          if (co < C_ && t < T) {
-            f32x4 v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (acc[e] + yv[r][e]) * (xv[r][e] > 0.f ? 1.f : NSC_LRELU_ALPHA);
-            if (a.in_act != NSC_ACT_LRELU) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = acc[e] + yv[r][e];
-            }
-            *reinterpret_cast<f32x4*>(a.dx + ((long)b * C_ + co) * T + t) = v;
-          }
-        }
-      }
-    }
-    NSC_STAMP(13);
-    nsc_lds_barrier();   // the planes and the partial sums are rewritten by the next tile
-    NSC_STAMP(14);
-  }
-  NSC_STAMP(15);
-}
-
-template <int C_, int DIL>
-static int launch_block_dgrad3(const BlockDgradArgs& a, hipStream_t st) {
-  using G = DsgGeom<C_, DIL>;
-  static_assert(G::smem <= 160 * 1024, "LDS of the split data gradient");
-  auto kern = gated_block_dgrad3_kernel<C_, DIL>;
-  const hipError_t e = NSC_SMEM_ATTR(kern, (int)G::smem);
-  NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "gated_block_dgrad3: smem attr: %s", hipGetErrorString(e));
-  const int tpf = nsc_cdiv(a.T, 64);
-  const int ntiles = a.B * tpf;
-  hipLaunchKernelGGL(kern, dim3(std::min(ntiles, 256)), dim3(512), G::smem, st, a, ntiles, tpf);
-  NSC_CHECK_LAUNCH("gated_block_dgrad3");
-  return NSC_OK;
-}
-
-// nsc_gated_block_dgrad_img on a SPLIT image (nsc_gated_block_simage_index, which = 1): same arguments; C in {100, 50}, Cin = C
-extern "C" int nsc_gated_block_dgrad_simg(const float* img, const float* x, const float* h, const float* lin, const float* th,
-                                          const float* dy, float* dx, float* dlin, float* dgate, float* dz1, int B, int C, int Cin,
-                                          int T, int dil, int in_act, int da_rows, void* stream) {
-  NSC_REQUIRE(img && x && h && lin && th && dy && dx && dlin && dgate && dz1, NSC_ERR_BAD_ARG, "nsc_gated_block_dgrad_simg: null pointer");
-  NSC_REQUIRE(B > 0 && T > 0, NSC_ERR_BAD_ARG, "nsc_gated_block_dgrad_simg: bad sizes");
-  NSC_REQUIRE(nsc_gated_block_simage_words(1, C, Cin, dil) > 0, NSC_ERR_UNSUPPORTED,
-              "nsc_gated_block_dgrad_simg: no split kernel for C %d, Cin %d, dil %d", C, Cin, dil);
-  NSC_REQUIRE(((uintptr_t)img & 15) == 0, NSC_ERR_BAD_ARG, "nsc_gated_block_dgrad_simg: image must be 16-byte aligned");
-  NSC_REQUIRE((T & 3) == 0 && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0 && (long)B * C * T * 4 < (1L << 31), NSC_ERR_UNSUPPORTED,
-              "nsc_gated_block_dgrad_simg: needs T %% 4 == 0, 16-byte aligned x / dy / dx and tensors below 2 GB (T %d, B %d): use nsc_gated_block_dgrad_img", T, B);
-  NSC_REQUIRE(in_act == NSC_ACT_NONE || in_act == NSC_ACT_LRELU, NSC_ERR_BAD_ARG, "nsc_gated_block_dgrad_simg: in_act");
-  NSC_REQUIRE(da_rows == NARROW || (da_rows == 2 * NARROW && dgate == dlin + (long)NARROW * T), NSC_ERR_BAD_ARG,
-              "nsc_gated_block_dgrad_simg: da_rows must be 20 (two [B,20,T] tensors) or 40 with dgate = dlin + 20 T");
-  BlockDgradArgs a{B, C, T, dil, in_act, x, h, lin, th, dy, nullptr, nullptr, nullptr, nullptr, dx, dlin, dz1, dgate, da_rows, img};
-  hipStream_t st = (hipStream_t)stream;
-  if (C == 100) return dil == 1 ? launch_block_dgrad3<100, 1>(a, st) : launch_block_dgrad3<100, 2>(a, st);
-  return dil == 1 ? launch_block_dgrad3<50, 1>(a, st) : launch_block_dgrad3<50, 2>(a, st);
 }

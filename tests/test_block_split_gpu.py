@@ -236,45 +236,6 @@ def _dgrad_ref(w, x, h, lin, th, dy, dil, in_act):
     return dx, np.concatenate([dlin, dgate], 1), dz1
 
 
-@pytest.mark.parametrize("case", [(2, 100, 512, 2, 2), (2, 100, 256, 1, 0), (3, 50, 512, 2, 2), (2, 50, 512, 1, 2), (1, 100, 200, 2, 2),
-                                  (70, 100, 300, 2, 2), (40, 50, 512, 1, 0), (150, 100, 512, 1, 2), (150, 50, 512, 2, 2), (72, 100, 256, 2, 2),
-                                  (3, 100, 132, 2, 2), (40, 100, 204, 1, 2), (5, 50, 68, 2, 0), (128, 100, 256, 2, 2)])
-def test_split_gated_block_dgrad_matches_the_float64_oracle(lib, case):
-    """nsc_gated_block_dgrad_simg (bf16 matrix cores, split operands, weights streamed from the split image) against float64 and
-    against the exact kernel on its image: the exact kernel's bounds; rms error within 1.5x of the exact arm."""
-    B, C_, T, dil, act = case
-    rng = np.random.default_rng(7 + C_ + T + dil + B)
-    w, pflat, offs = _params(rng, C_, C_)
-    r = lambda *sh: rng.standard_normal(sh).astype(np.float32)
-    x, h, lin, dy = r(B, C_, T), r(B, 20, T), r(B, 20, T), r(B, C_, T)
-    th = np.tanh(r(B, 20, T)).astype(np.float32)
-    ref = _dgrad_ref(w, x, h, lin, th, dy, dil, act == 2)
-    xd, hd, ld, td, dyd = [dev(v) for v in (x, h, lin, th, dy)]
-    pd = dev(pflat)
-    # the exact image is built from the flipped / transposed kernels
-    wt = [np.ascontiguousarray(w[i][::-1].transpose(0, 2, 1)) for i in (0, 2, 4, 6)]
-    tflat = np.concatenate([a.reshape(-1) for a in wt])
-    toffs = np.concatenate([[0], np.cumsum([a.size for a in wt])[:-1]]).astype(np.int64)
-    res = {}
-    for split in (False, True):
-        img = _image(lib, True, 1, C_, C_, dil, pd, offs) if split else _image(lib, False, 1, C_, C_, dil, dev(tflat), toffs)
-        dx = torch.full((B, C_, T), float("nan"), device="cuda")
-        da = torch.full((B, 40, T), float("nan"), device="cuda")
-        dz1 = torch.full((B, 20, T), float("nan"), device="cuda")
-        fn = lib.nsc_gated_block_dgrad_simg if split else lib.nsc_gated_block_dgrad_img
-        assert fn(img.data_ptr(), xd.data_ptr(), hd.data_ptr(), ld.data_ptr(), td.data_ptr(), dyd.data_ptr(), dx.data_ptr(), da.data_ptr(),
-                  da.data_ptr() + 4 * 20 * T, dz1.data_ptr(), B, C_, C_, T, dil, act, 40, _st()) == 0, lib.nsc_last_error()
-        torch.cuda.synchronize()
-        res[split] = [t.cpu().numpy() for t in (dx, da, dz1)]
-    for nm, a, r_ in zip(["dx", "da", "dz1"], res[True], ref):
-        assert_close(a, r_, what=f"split dgrad {nm} {case}")
-    for nm, e_, s_, r_ in zip(["dx", "da", "dz1"], res[False], res[True], ref):
-        rms = float(np.sqrt(np.mean(r_ ** 2)))
-        re_, rs = float(np.sqrt(np.mean((e_ - r_) ** 2))) / rms, float(np.sqrt(np.mean((s_ - r_) ** 2))) / rms
-        print(f"  {nm}: rms err / rms  exact {re_:.2e}  split {rs:.2e}")
-        assert rs <= 1.5 * re_ + 1e-7, (nm, re_, rs)
-
-
 @pytest.mark.parametrize("case", [(2, 100, 100, 512, 2, 2), (2, 100, 100, 256, 1, 0), (3, 50, 50, 512, 2, 2), (2, 50, 50, 512, 1, 2),
                                   (1, 100, 100, 200, 2, 2), (70, 100, 100, 300, 2, 2), (40, 50, 50, 512, 1, 0), (150, 100, 100, 512, 1, 2),
                                   (150, 50, 50, 512, 2, 2), (72, 100, 100, 256, 2, 2), (3, 100, 100, 132, 2, 2), (40, 100, 100, 204, 1, 2),

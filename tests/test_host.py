@@ -426,3 +426,51 @@ def test_split_conv_image_index_rebuilds_the_gemm_operand_on_the_host(which):
     rebuilt = got.astype(np.float64).sum(0)
     assert np.max(np.abs(rebuilt - want)) <= 2.0 ** -23 * np.max(np.abs(want))
     assert np.array_equal(got[0], _bf16_split3(want)[0])              # the leading piece is the bf16 rounding of the weight itself
+
+
+@pytest.mark.parametrize("C_", [100, 50])
+def test_three_launch_dgrad_image_is_the_weight_pieces_in_kernel_layout(C_):
+    """nsc_gated_block_simage_index(which = 2) is host code: with nsc_gather's word rule emulated in numpy the image must be, per half
+    of 50 output channels, the three bf16 pieces of W9 as [tap][ci][56] (+ 8 zeros), then those of Wl | Wr as [tap][ci][40] (+ 8 zeros) -
+    pieces that sum back to the float32 weight to 2^-24, pad columns and tails structural zeros (csrc/block_bwd_split.hip)."""
+    import ctypes as C
+    from nsc_amd import _lib
+    lib = _lib.load()
+    n = int(lib.nsc_gated_block_simage_words(2, C_, C_, 1))
+    assert n > 0 and n == int(lib.nsc_gated_block_simage_words(2, C_, 1, 2))         # the image does not depend on Cin / dilation
+    rng = np.random.default_rng(C_)
+    shapes = [(1, C_, 20), (20,), (15, 20, 20), (20,), (15, 20, 20), (20,), (9, 20, C_), (C_,)]
+    w = [rng.standard_normal(sh).astype(np.float32) for sh in shapes]
+    offs = np.concatenate([[0], np.cumsum([a.size for a in w])[:-1]]).astype(np.int64) + 12
+    src = np.concatenate([np.zeros(12, np.float32)] + [a.reshape(-1) for a in w] + [np.zeros(64, np.float32)])
+    idx = np.empty(n, np.int32)
+    assert lib.nsc_gated_block_simage_index(2, C_, C_, 1, (C.c_long * 8)(*[int(o) for o in offs]), idx.ctypes.data_as(C.c_void_p)) == 0
+    pieces = _bf16_split3(src)
+    valid = idx >= 0
+    m_ = np.where(valid, (idx >> 26) & 15, 0)
+    base = np.where(valid, idx & 0x3ffffff, 0)
+    assert np.all(~valid | ((m_ - 1) % 5 == 4))                                     # every pair is (o, o + 1): gather stride 1
+    plane = np.where(valid, (m_ - 1) // 5, 0)
+    lo = np.where(valid, np.choose(plane, [p[base] for p in pieces]), 0.0)          # low half of the word = first element of the pair
+    hi = np.where(valid, np.choose(plane, [p[base + 1] for p in pieces]), 0.0)
+    el = np.stack([lo, hi], -1).reshape(-1)                                          # the image as bf16-valued elements
+    plw9, plw15 = 9 * 20 * 56 + 8, 15 * 20 * 40 + 8
+    nh = C_ // 50
+    assert el.size == nh * 3 * plw9 + 3 * plw15
+    pl_of = np.stack([np.where(valid, plane, -1)] * 2, -1).reshape(-1)
+    for hf in range(nh):
+        got = el[hf * 3 * plw9:(hf + 1) * 3 * plw9].reshape(3, plw9)
+        pls = pl_of[hf * 3 * plw9:(hf + 1) * 3 * plw9].reshape(3, plw9)
+        for p in range(3):
+            assert np.all((pls[p] == p) | (pls[p] == -1))
+        body = got[:, :9 * 20 * 56].reshape(3, 9, 20, 56)
+        assert np.all(got[:, 9 * 20 * 56:] == 0) and np.all(body[..., 50:] == 0)
+        want = w[6][:, :, 50 * hf:50 * hf + 50]
+        assert np.max(np.abs(body[..., :50].astype(np.float64).sum(0) - want)) <= 2.0 ** -23 * np.max(np.abs(want))
+        assert np.array_equal(body[0, ..., :50], _bf16_split3(want)[0])
+    got = el[nh * 3 * plw9:].reshape(3, plw15)
+    body = got[:, :15 * 20 * 40].reshape(3, 15, 20, 40)
+    assert np.all(got[:, 15 * 20 * 40:] == 0)
+    want = np.concatenate([w[2], w[4]], axis=2)                                      # [tap][ci][lin 0..19 | gate 20..39]
+    assert np.max(np.abs(body.astype(np.float64).sum(0) - want)) <= 2.0 ** -23 * np.max(np.abs(want))
+
