@@ -749,7 +749,7 @@ def main():
                                                              ("gated-block data gradient", eng.split_dgrad),
                                                              ("stride-2 convs forward + data gradient", eng.split_conv)) if on) +
                       ": fp32 operands split into 3 bf16 pieces, 6 products on the bf16 matrix cores, fp32 accumulate - fp32-class error, "
-                      "gate in profiles/r05_numerics_gate.txt; everything else: exact fp32)") if split_on else "f32",
+                      "gate: tests/test_fullsize_gpu.py::_numerics_gate, profiles/r06_numerics_gate_*.txt; everything else: exact fp32)") if split_on else "f32",
             "data": "synthetic",
             "config": {"workload": (wl_name or "BASELINE config 3: 2-codec CMRL (strides [2], 32 bins) on fed LPC residual + 16x256 "
                                     "LSF quantizer, joint finetune step, fwd+loss+bwd+TF1-Adam") +

@@ -952,7 +952,7 @@ class CascadeEngine:
     fused_quant = True   # the training-shape quantizer forward in the launch of the encoder's output conv (nsc_conv1d_cout1_fwd_quant)
     # Arithmetic of the gated blocks' long contractions: False = the exact fp32 matrix instruction (csrc/block.hip); True = the bf16
     # matrix cores on operands split into three bf16 pieces, six products, fp32 accumulation (csrc/block_split.hip: fp32-class
-    # error, the vector ALU left free: the default since round 5 - numerics gate in profiles/r05_numerics_gate.txt).
+    # error, the vector ALU left free: the default since round 5 - numerics gate: tests/test_fullsize_gpu.py::_numerics_gate, profiles/r06_numerics_gate_*.txt).
     # NSC_BLOCK_ARITH=exact|split overrides the default for A/B runs.
     split_fwd = os.environ.get("NSC_BLOCK_ARITH", "split") == "split"
     split_wgrad_arith = os.environ.get("NSC_BLOCK_ARITH", "split") == "split"   # (split_wgrad is the two-light-launches switch above)

@@ -453,6 +453,33 @@ def test_pair_launches_are_off_under_per_scope_gradient_messages():
     assert c._pair_ok(stack)
 
 
+def test_engine_step_on_nan_poisoned_lds_equals_the_plain_step():
+    """Every launch of a whole train step (the config-3 joint step and a follower step: fused quantizer / chain epilogues, pair launches,
+    batched weight gradients - the call patterns the per-kernel tests do not all reach) preceded by a launch that leaves NaN in the LDS
+    of every CU (tests/test_kernels_gpu.py::_PoisonedLib): a kernel that reads LDS it never wrote would turn its output into NaN.  The
+    gradients must equal the unpoisoned step's.  (Round 6: one of the things ruled out for the steps that differ when two processes
+    share a GPU.)"""
+    from tests.test_kernels_gpu import _PoisonedLib
+    ps = make_store(2, [[2], [2]], [32, 32], lpc=True)
+    x = dev(synth_frames(3).transpose(0, 2, 1))
+    lx = dev(np.sort(np.random.default_rng(3).uniform(0.03, 3.1, (3, 16, 1)), axis=1).astype(np.float32))
+    joint = dict(is_quan_on=1.0, c_time=60.0, c_freq=10.0, c_quan=[10.0, 10.0], c_ent=[0.3, 0.5], trainable=[True, True], lr=0.0, slot=1,
+                 c_quan_lpc=10.0, train_lpc=True, quan_op=True)
+    foll = dict(joint, c_quan=[0.0, 10.0], c_ent=[0.0, 0.3], trainable=[False, True], c_quan_lpc=0.0, train_lpc=False)
+    for cfg in (joint, foll):
+        got = {}
+        for poisoned in (False, True):
+            eng = _engine(3, 2, [[2], [2]], [32, 32], ps, res_scalar=2.0, scale_first=True, lpc=True)
+            if poisoned:
+                eng.lib = _PoisonedLib(eng.lib)
+            eng.train_step(x, x, cfg, lpc_x=lx)
+            torch.cuda.synchronize()
+            got[poisoned] = (eng.grads.cpu().numpy().copy(), eng.decoded.cpu().numpy().copy())
+        for a, b, what in zip(got[True], got[False], ("gradients", "decoded frames")):
+            assert np.all(np.isfinite(a)), what
+            assert np.abs(a - b).max() <= 1e-6 * np.abs(b).max(), (what, float(np.abs(a - b).max()), float(np.abs(b).max()))
+
+
 def test_live_gather_covers_every_word_a_step_reads():
     """The step's opening launch gathers only the regions of the kernel-ready images that the step's kernels are pointed at (recorded
     in the first run of a (flags, trainable pattern) pair: engine.wtp).  Proof that nothing else is read: everything the gather does not
