@@ -86,7 +86,7 @@ def test_single_codec_forward_matches_golden_and_oracle():
     terms = eng.loss_backward(dev(x.transpose(0, 2, 1)), 60.0, 10.0, [10.0], [0.3], [True])
     torch.cuda.synchronize()
     assert_close(terms["time"].cpu().numpy(), gold["time_loss"], what="time loss vs golden")
-    assert_close(terms["freq"].cpu().numpy(), gold["freq_loss"], tol=3e-4, what="freq loss vs golden")
+    assert_close(terms["freq"].cpu().numpy(), gold["freq_loss"], what="freq loss vs golden")     # (the standard 1e-4 bound: round 6)
     assert abs(float(terms["ent"][0]) - float(gold["ent_loss"])) < 1e-4 * float(gold["ent_loss"])
     flat = eng.grads.cpu().numpy()
     assert_close(flat, gold["flat_grad"], tol=5e-4, what="flat gradient vs golden")

@@ -345,7 +345,7 @@ def test_headline_step_values_match_the_float64_oracle():
     _, _, g32 = _oracle_joint_step(x_np, lpc_np, ps, torch.float32)
     _term("joint", "decoded", dec.cpu().numpy()[:, 0], d64)
     _term("joint", "time loss per frame", terms["time"].cpu().numpy(), t64["time"].detach().numpy())
-    _term("joint", "mel loss per frame", terms["freq"].cpu().numpy(), t64["freq"].detach().numpy(), tol=3e-4)
+    _term("joint", "mel loss per frame", terms["freq"].cpu().numpy(), t64["freq"].detach().numpy())
     for i in range(2):
         _term("joint", f"quan loss of codec {i + 1} per frame", terms["quan"][i].cpu().numpy(), t64["quan"][i].detach().numpy())
     _term("joint", "LSF quan loss per frame", terms["quan_lpc"].cpu().numpy(), t64["quan_lpc"].detach().numpy())
@@ -414,7 +414,7 @@ def test_headline_forward_at_alpha_minus_300_matches_the_float64_oracle():
             assert float(np.max(np.abs(cd.qcode.cpu().numpy()[:, 0] - o["code"].numpy()[:, :, 0]))) <= 2e-3 * 2 * half_bin
             _term("alpha300", f"quan loss of codec {i + 1}", terms["quan"][i].cpu().numpy(), OT.quan_loss(o["p"]).numpy(), tol=2e-3)
         _term("alpha300", "time loss per frame", terms["time"].cpu().numpy(), OT.mse_loss(d64, tgt).numpy())
-        _term("alpha300", "mel loss per frame", terms["freq"].cpu().numpy(), OT.mfcc_loss(d64, tgt).numpy(), tol=3e-4)
+        _term("alpha300", "mel loss per frame", terms["freq"].cpu().numpy(), OT.mfcc_loss(d64, tgt).numpy())
         _term("alpha300", "LSF quan loss per frame", terms["quan_lpc"].cpu().numpy(), OT.quan_loss(pl).numpy(), tol=2e-3)
         # ---- hard forward: nearest-bin codes, bit exact away from the midpoints ----
         dech = eng.forward(x, 1.0, False, lpc_x=lpc)
