@@ -990,7 +990,8 @@ static int cout1_fwd_impl(const nsc_conv_desc* d, const float* x, const float* w
     // R outputs per lane: 4 when that still gives every CU a workgroup, else 2
     // (R = 4 already at half a chip's worth of workgroups: the launch is latency, not throughput - B = 128, T = 256: 128 workgroups of
     // 256 steps take 22.2 us, 256 workgroups of 128 steps 24.5)
-    const bool r4 = (long)d->B * nsc_cdiv(d->Tout, 256) >= 128;
+    static const int force_r = NSC_PROBE_INT("NSC_COUT1_R", 0);      // (probes build: 2 | 4 forces the outputs per lane - round 6, GPU-sharing study)
+    const bool r4 = force_r ? force_r == 4 : (long)d->B * nsc_cdiv(d->Tout, 256) >= 128;
     const int rc2 = r4 ? launch_cout1_v2<55, 4>(d, x, w, bias, res, aux, y, (hipStream_t)stream, ch, qz)
                        : launch_cout1_v2<55, 2>(d, x, w, bias, res, aux, y, (hipStream_t)stream, ch, qz);
     if (rc2 <= 0) return rc2;          // launched (0) or failed (<0); 1 = tile does not fit LDS -> v1 below

@@ -18,7 +18,7 @@ def pytest_configure(config):
 # per-shape kernel parity behind it (round 5: 208 of 289 tests never ran).
 _FILE_ORDER = ["test_kernels_gpu", "test_block_split_gpu", "test_reference_exec_gpu", "test_fullsize_gpu", "test_configs_gpu",
                "test_surface_gpu", "test_engine_gpu"]
-_LATE_WORDS = ("data_parallel", "bench", "cli", "subprocess", "torchrun", "main_py", "dp_")
+_LATE_WORDS = ("data_parallel", "two_processes", "bench", "cli", "subprocess", "torchrun", "main_py", "dp_")
 
 
 def _order_key(item):

@@ -20,7 +20,7 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 SOLO = os.environ.get("NSC_STRESS_SOLO", "") == "1"     # no communicator at all: the plain single-GPU step (run two such processes
                                                        # side by side to see what SHARING the GPU alone does)
 comm = Comm(backend="gloo")
-B = 4
+B = int(os.environ.get("NSC_STRESS_B", "4"))
 Bl = B // comm.world
 LPC = os.environ.get("NSC_DEBUG_LPC", "1") == "1"
 ps = make_store(2, [[2], [2]], [32, 32], lpc=LPC)
@@ -58,11 +58,33 @@ def restore():
     eng.reset_adam()
 
 
+WATCH = ("scope_1.code", "scope_2.code", "scope_1.dec", "scope_2.dec", "dsum1", "ddec0", "scope_1.b4.out", "scope_1.h0")
+                                                       # buffers kept elementwise: the usual first-to-differ ones and their producers' inputs
+
+
 def snapshot():
     torch.cuda.synchronize()
     g = eng.grads.detach().cpu().numpy().copy()
     sums = {k: float(v.double().sum().item()) for k, v in eng._bufs.items() if v.dtype == torch.float32}
+    sums["__watch__"] = {k: eng._bufs[k].detach().cpu().numpy().copy() for k in WATCH if k in eng._bufs}
     return g, sums
+
+
+def describe(name, a, b):
+    """Where and how two copies of a [B, C, T] buffer differ: per (frame, channel) rows, runs along time."""
+    d = np.abs(a - b)
+    nz = np.argwhere(d > 0)
+    if nz.size == 0:
+        return f"{name}: identical"
+    rows = {}
+    for f, c, t in nz:
+        rows.setdefault((int(f), int(c)), []).append(int(t))
+    parts = []
+    for (f, c), ts in list(rows.items())[:6]:
+        ts = sorted(ts)
+        lst = f" steps {ts} signed diffs {[float(f'{v:.2e}') for v in (a - b)[f, c, ts]]}" if len(ts) <= 32 else ""
+        parts.append(f"frame {f} ch {c}: {len(ts)} steps in [{ts[0]}, {ts[-1]}], max |diff| {d[f, c, ts].max():.3e} of |value| <= {np.abs(b[f, c, ts]).max():.3e}{lst}")
+    return f"{name}: {len(nz)} elements in {len(rows)} (frame, channel) rows; " + " | ".join(parts)
 
 
 def name_of(i):
@@ -95,8 +117,10 @@ for tail in (True, False):
                 if bad <= 3 and comm.rank == 0:
                     i = int(d.argmax())
                     # buffers in creation order = the order of their first use in a step: the first one named is the origin
-                    diff = [(k, f"{abs(sums[k] - base[1][k]) / (abs(base[1][k]) + 1e-30):.1e}") for k in sums if k in base[1]
+                    diff = [(k, f"{abs(sums[k] - base[1][k]) / (abs(base[1][k]) + 1e-30):.1e}") for k in sums if k in base[1] and k != "__watch__"
                             and abs(sums[k] - base[1][k]) > 1e-9 * (abs(base[1][k]) + 1e-30)]
+                    for k, v in sums["__watch__"].items():
+                        print("    " + describe(k, v, base[1]["__watch__"][k]))
                     print(f"  glitch at rep {r}: rel {rel:.3e} at {name_of(i)}; {int((d > 1e-6 * np.abs(base[0]).max()).sum())} gradient "
                           f"entries off; buffers whose checksum moved, in creation order: {diff[:10]} ... {len(diff)} in all")
         if comm.rank == 0:
