@@ -1,8 +1,10 @@
-// Data-path backward of the gated block (nn_core_operator.py:82-112) on the bf16 matrix cores with SPLIT OPERANDS, as THREE launches per
-// block instead of one fused persistent kernel:
-//   bb_gemm_kernel<C, 9, 1, NC, 0>    dg = W9^T * dy, then the GLU backward in the epilogue        -> da [B,40,T] = dlin | dgate
-//   bb_gemm_kernel<40, 15, D, NC, 1>  dh = Wl^T dlin + Wr^T dgate, . lrelu'(h)                       -> dz1 [B,20,T]
-//   bb_1x1_kernel                     dx = (W1^T dz1 + dy) . act'(x)      (HBM-bound, vector ALU)     -> dx [B,C,T]
+// Data-path backward of the gated block (nn_core_operator.py:82-112) on the bf16 matrix cores with SPLIT OPERANDS, as two or three
+// launches per block instead of one fused persistent kernel:
+//   bb_gemm_kernel<50, 9, 1, 2, 2 | 0>  dg = W9^T * dy over 50 channels of dy at a time (C = 100: a partial sum, then the rest), the GLU
+//                                       backward in the last one's epilogue                           -> da [B,40,T] = dlin | dgate
+//   bb_gemm_kernel<40, 15, D, 2, 3>     dh = Wl^T dlin + Wr^T dgate, . lrelu'(h) -> dz1 [B,20,T]; then, from the dz1 tile in LDS,
+//                                       dx = (W1^T dz1 + dy) . act'(x) on the vector ALU (HBM-bound)   -> dx [B,C,T]
+//   (one input channel: EPI 1 and bb_1x1_cin1_kernel)
 // Why not fused (block.hip: gated_block_dgrad2, block_split.hip: gated_block_dgrad3): the two long contractions have 20 output rows.
 // On 16-row matrix tiles they pad to 32, the fused kernels recompute a halo of 7 * dil columns of dg per 64-step tile, and their
 // weights (the same for every tile) only fit the registers when the REDUCTION is split over the eight waves - an eight-way partial
@@ -69,9 +71,14 @@ struct BbArgs {
   const float* pin;      // nullable: a partial sum [B,20,T] added before the epilogue (the other half of the channels)
   float* out;            // da [B,40,T] | dz1 [B,20,T] | the partial sum [B,20,T]
   int B, T, src_C, c0, ntiles, tpf;
+  // EPI 3 (the k15 launch with the 1x1 gradient behind it): dx [B,C1,T] = (W1^T dz1 + dy) . act'(x)
+  const float *w1, *dy, *x;
+  float* dx;
+  int C1, in_act;
 };
 
-// EPI 0: out = (v . th | v . lin . (1 - th^2));  EPI 1: out = v . lrelu'(h);  EPI 2: out = v (a partial sum over half of the channels)
+// EPI 0: out = (v . th | v . lin . (1 - th^2));  EPI 1: out = v . lrelu'(h);  EPI 2: out = v (a partial sum over half of the channels);
+// EPI 3: EPI 1, then dx = (W1^T dz1 + dy) . act'(x) from the dz1 tile in LDS (the HBM-bound 1x1 launch of its own was 18 us per block)
 template <int CH_, int K_, int DIL_, int NC_, int EPI>
 __global__ __launch_bounds__(512) void bb_gemm_kernel(BbArgs a) {
   using G = BbGeom<CH_, K_, DIL_, NC_>;
@@ -80,7 +87,8 @@ __global__ __launch_bounds__(512) void bb_gemm_kernel(BbArgs a) {
   extern __shared__ __attribute__((aligned(16))) u16 bb_sm[];
   u16* const wts = bb_sm;                                               // [3][PLW]   the weight pieces, resident for the whole launch
   u16* const planes = bb_sm + 3 * PLW;                                  // [3][PLS]
-  float* const outp = reinterpret_cast<float*>(planes + 3 * PLS);       // [20][OP]
+  float* const outp = reinterpret_cast<float*>(planes + 3 * PLS);       // [4][20][OP]  partial-sum slots
+  float* const w1s = outp + G::NSLOT * NARROW * OP;                     // EPI 3: [C1][20] the 1x1 kernel (parameter layout)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, q = lane >> 4;
   const int T = a.T;
@@ -143,6 +151,8 @@ __global__ __launch_bounds__(512) void bb_gemm_kernel(BbArgs a) {
   // flight at once - a load/store loop was eight serial round trips, 9 us per launch) and zeros in the planes (their pad channels
   // [CH, CP) are read against zero weights and never written by the staging) ----
   if ((int)blockIdx.x < a.ntiles) load_tile(blockIdx.x);
+  if (EPI == 3)
+    for (int e = tid; e < a.C1 * NARROW / 4; e += 512) reinterpret_cast<f32x4*>(w1s)[e] = reinterpret_cast<const f32x4*>(a.w1)[e];
   {
     constexpr int NW16 = 3 * PLW / 8, NWI = (NW16 + 511) / 512;
     uint4 wv[NWI];
@@ -168,7 +178,7 @@ __global__ __launch_bounds__(512) void bb_gemm_kernel(BbArgs a) {
       const int id = tid + 512 * it, c = id / (TS / 4), tg = id - c * (TS / 4), t = t0 + 4 * tg;
       const bool ok = c < NARROW && t < T;
       const long off = ((long)b * NARROW + (ok ? c : 0)) * T + (ok ? t : 0);
-      if (EPI != 2) ev0[it] = *reinterpret_cast<const f32x4*>(a.e0 + off);
+      if (EPI != 2) ev0[it] = *reinterpret_cast<const f32x4*>(a.e0 + off);       // (EPI 1 | 3: h)
       if (EPI == 0) ev1[it] = *reinterpret_cast<const f32x4*>(a.e1 + off);
       if (EPI == 0 && a.pin) pv[it] = *reinterpret_cast<const f32x4*>(a.pin + off);
     }
@@ -288,8 +298,53 @@ __global__ __launch_bounds__(512) void bb_gemm_kernel(BbArgs a) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) dz[i] = v[i] * (ev0[it][i] > 0.f ? 1.f : NSC_LRELU_ALPHA);
           *reinterpret_cast<f32x4*>(a.out + ((long)b * NARROW + c) * T + t) = dz;
+          if (EPI == 3) *reinterpret_cast<f32x4*>(outp + c * OP + 4 * tg) = dz;   // slot 0 becomes the dz1 tile (this thread's own entry)
+        }
+      } else if (EPI == 3 && c < NARROW) {
+        *reinterpret_cast<f32x4*>(outp + c * OP + 4 * tg) = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    if (EPI == 3) {
+      // ---- dx = (W1^T dz1 + dy) . act'(x): thread = (4 consecutive steps, every 16th channel); dz1 of its steps in registers ----
+      __syncthreads();
+      constexpr int NTG = TS / 4;                              // 32 groups of 4 steps
+      const int tg = tid % NTG, cl0 = tid / NTG;               // 16 channel lanes
+      const int t = t0 + 4 * tg;
+      const bool ok = t < T;
+      f32x4 dz[NARROW];
+#pragma unroll
+      for (int o = 0; o < NARROW; ++o) dz[o] = *reinterpret_cast<const f32x4*>(outp + o * OP + 4 * tg);
+      constexpr int CL = 512 / NTG;                            // 16
+      for (int cb = cl0; cb < a.C1; cb += 4 * CL) {            // four channels' loads in flight
+        f32x4 yv[4], xv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int c = cb + u * CL;
+          const long off = ((long)b * a.C1 + (c < a.C1 ? c : cl0)) * T + (ok ? t : 0);
+          yv[u] = *reinterpret_cast<const f32x4*>(a.dy + off);
+          xv[u] = a.in_act == NSC_ACT_LRELU ? *reinterpret_cast<const f32x4*>(a.x + off) : (f32x4){1.f, 1.f, 1.f, 1.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int c = cb + u * CL;
+          if (c < a.C1) {
+            const f32x4* w4 = reinterpret_cast<const f32x4*>(w1s + c * NARROW);
+            f32x4 acc = yv[u];
+#pragma unroll
+            for (int o4 = 0; o4 < NARROW / 4; ++o4) {
+              const f32x4 wv = w4[o4];
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = fmaf(wv[j], dz[4 * o4 + j][i], acc[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] *= xv[u][i] > 0.f ? 1.f : NSC_LRELU_ALPHA;
+            if (ok) *reinterpret_cast<f32x4*>(a.dx + ((long)b * a.C1 + c) * T + t) = acc;
+          }
         }
       }
+      __syncthreads();                                         // slot 0 is rewritten by the next tile's combine
     }
     NSC_STAMP(5);
     // (no barrier here: the next tile's staging writes the planes - last read before the combine barriers - and the slots are
@@ -298,57 +353,11 @@ __global__ __launch_bounds__(512) void bb_gemm_kernel(BbArgs a) {
   }
 }
 
-// ---- dx = (W1^T dz1 + dy) . act'(x): a workgroup = 256 steps x a chunk of channels; a lane holds dz1[0..19][its 4 steps] ----
 struct Bb1Args {
   const float *dz1, *w1, *dy, *x;
   float* dx;
   int B, C, T, in_act, tpf, chunk;
 };
-__global__ __launch_bounds__(256) void bb_1x1_kernel(Bb1Args a) {
-  __shared__ f32x4 dzs[NARROW][64];
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.x / a.tpf, t0 = (blockIdx.x - b * a.tpf) * 256;
-  const int T = a.T;
-#pragma unroll
-  for (int it = 0; it < 5; ++it) {
-    const int id = tid + 256 * it, o = id >> 6, l = id & 63, t = t0 + 4 * l;
-    dzs[o][l] = t < T ? *reinterpret_cast<const f32x4*>(a.dz1 + ((long)b * NARROW + o) * T + t) : (f32x4){0.f, 0.f, 0.f, 0.f};
-  }
-  __syncthreads();
-  f32x4 dz[NARROW];
-#pragma unroll
-  for (int o = 0; o < NARROW; ++o) dz[o] = dzs[o][lane];
-  const int t = t0 + 4 * lane;
-  const bool ok = t < T;
-  const int c0 = blockIdx.y * a.chunk, c1 = min(a.C, c0 + a.chunk);
-  for (int cb = c0 + wave; cb < c1; cb += 16) {
-    f32x4 yv[4], xv[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {                                        // four channels' loads in flight
-      const int c = cb + 4 * u;
-      const long off = ((long)b * a.C + (c < c1 ? c : c0)) * T + (ok ? t : 0);
-      yv[u] = *reinterpret_cast<const f32x4*>(a.dy + off);
-      xv[u] = a.in_act == NSC_ACT_LRELU ? *reinterpret_cast<const f32x4*>(a.x + off) : (f32x4){1.f, 1.f, 1.f, 1.f};
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int c = cb + 4 * u;
-      if (c < c1) {
-        const float* w = a.w1 + (long)c * NARROW;                         // wave-uniform: scalar loads
-        f32x4 acc = yv[u];
-#pragma unroll
-        for (int o = 0; o < NARROW; ++o) {
-          const float wv = w[o];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) acc[i] = fmaf(wv, dz[o][i], acc[i]);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] *= xv[u][i] > 0.f ? 1.f : NSC_LRELU_ALPHA;
-        if (ok) *reinterpret_cast<f32x4*>(a.dx + ((long)b * a.C + c) * T + t) = acc;
-      }
-    }
-  }
-}
 // one input channel (the first block of a decoder stage: x [B,1,T] is broadcast into the residual add): dx[b,0,t] = w1 . dz1 + sum_c dy
 __global__ __launch_bounds__(256) void bb_1x1_cin1_kernel(Bb1Args a) {
   __shared__ f32x4 part[4][64];
@@ -393,13 +402,14 @@ template <int CH_, int K_, int DIL_, int NC_, int EPI>
 int bb_launch(BbArgs a, hipStream_t st) {
   if (a.src_C == 0) a.src_C = CH_;
   using G = BbGeom<CH_, K_, DIL_, NC_>;
-  static_assert(G::smem <= 160 * 1024, "LDS of the polyphase data-gradient GEMM");
+  constexpr size_t smem_k = G::smem + (EPI == 3 ? 100 * NARROW * 4 : 0);       // (+ the 1x1 kernel of up to 100 channels)
+  static_assert(smem_k <= 160 * 1024, "LDS of the polyphase data-gradient GEMM");
   auto kern = bb_gemm_kernel<CH_, K_, DIL_, NC_, EPI>;
-  const hipError_t e = NSC_SMEM_ATTR(kern, (int)G::smem);
+  const hipError_t e = NSC_SMEM_ATTR(kern, (int)smem_k);
   NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "bb_gemm: smem attr: %s", hipGetErrorString(e));
   a.tpf = nsc_cdiv(a.T, G::TS);
   a.ntiles = a.B * a.tpf;
-  hipLaunchKernelGGL(kern, dim3(std::min(a.ntiles, bb_cu_count())), dim3(512), G::smem, st, a);
+  hipLaunchKernelGGL(kern, dim3(std::min(a.ntiles, bb_cu_count())), dim3(512), smem_k, st, a);
   NSC_CHECK_LAUNCH("bb_gemm");
   return NSC_OK;
 }
@@ -476,14 +486,15 @@ extern "C" int nsc_gated_block_dgrad_simg2(const void* img, const float* w1, con
   }
   if (rc != NSC_OK || !dz1 || only_k9) return rc;          // (profiling: the first launch(es) alone)
   BbArgs a15{da, im + 2 * (C / 50) * bb_w9_words(), h, nullptr, nullptr, dz1, B, T, 2 * NARROW, 0, 0, 0};
+  if (dx && Cin == C) {
+    // the 1x1 gradient + residual ride in the k15 launch (EPI 3)
+    a15.w1 = w1; a15.dy = dy; a15.x = x; a15.dx = dx; a15.C1 = C; a15.in_act = in_act;
+    return dil == 1 ? bb_launch<2 * NARROW, K15, 1, 2, 3>(a15, st) : bb_launch<2 * NARROW, K15, 2, 2, 3>(a15, st);
+  }
   rc = dil == 1 ? bb_launch<2 * NARROW, K15, 1, 2, 1>(a15, st) : bb_launch<2 * NARROW, K15, 2, 2, 1>(a15, st);
   if (rc != NSC_OK || !dx) return rc;
   Bb1Args a1{dz1, w1, dy, x, dx, B, C, T, in_act, nsc_cdiv(T, 256), (C + 1) / 2};
-  if (Cin == 1) {
-    hipLaunchKernelGGL(bb_1x1_cin1_kernel, dim3(B * a1.tpf), dim3(256), 0, st, a1);
-  } else {
-    hipLaunchKernelGGL(bb_1x1_kernel, dim3(B * a1.tpf, 2), dim3(256), 0, st, a1);
-  }
+  hipLaunchKernelGGL(bb_1x1_cin1_kernel, dim3(B * a1.tpf), dim3(256), 0, st, a1);
   NSC_CHECK_LAUNCH("bb_1x1");
   return NSC_OK;
 }

@@ -1,3 +1,4 @@
 #!/bin/bash
-# soak: the subprocess / two-rank / two-process tests five times over
-for i in 1 2 3 4 5; do timeout 1200 python -m pytest tests/test_engine_gpu.py tests/test_surface_gpu.py -m gpu -q -x -k "two_ranks or two_processes or cli_two" 2>&1 | tail -1; done
+mkdir -p gpurun_out/r06w
+timeout 900 python -m pytest tests/test_block_split_gpu.py -q -x -k "three_launch" 2>&1 | tail -4
+timeout 600 python tools/dgrad3l_time.py > gpurun_out/r06w/dgrad3l_time.txt 2>&1; grep -v amdgpu.ids gpurun_out/r06w/dgrad3l_time.txt
