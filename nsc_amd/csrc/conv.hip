@@ -29,7 +29,7 @@ void nsc_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* nsc_last_error(void) { return g_err; }
-extern "C" int nsc_version(void) { return 100; }
+extern "C" int nsc_version(void) { return 106; }   // 100 + the round of the last ABI change (6: + nsc_gated_block_dgrad_simg2, nsc_step_begin_chunks, - nsc_gated_block_dgrad_simg; gather index bits 26..29 reserved for word modes since 105)
 
 // ------------------------------------------------------------------------------------------------
 // forward
