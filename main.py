@@ -3,7 +3,7 @@
 
 Dropped: the three blocking input() calls at exit (main.py:49-51).  Added (all optional, defaults reproduce the
 reference's edit-the-source globals): --lpc_domain (constants.is_pure_time_domain=False), --data_root,
---max_batches_per_epoch, --out_root, --model_id, --seed, --local_entropy.  Multi-GPU: launch with torch.distributed.run; frames are
+--max_batches_per_epoch, --out_root, --model_id, --seed, --local_entropy, --tf_checkpoint.  Multi-GPU: launch with torch.distributed.run; frames are
 sharded over ranks and gradients all-reduced (sum) over RCCL.
 """
 import argparse
@@ -47,6 +47,8 @@ def build_parser():
     parser.add_argument('--seed', type=int, default=20200504, help='weights, and the per-epoch row order (identical on every rank)')
     parser.add_argument('--local_entropy', type=int, default=0,
                         help='data parallel: 1 = entropy term from each rank\'s own batch histogram (no histogram all-reduce)')
+    parser.add_argument('--tf_checkpoint', type=int, default=0,
+                        help='1: ALSO write every checkpoint in TensorFlow\'s V2 format (<name>.ckpt.index + .data-00000-of-00001), readable by the reference\'s Saver')
     parser.add_argument('--dump_rows', type=int, default=0, help='debug: write the training rows each rank fed to <out_root>/rows_rank<r>.npy')
     return parser
 

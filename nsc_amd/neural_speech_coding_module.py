@@ -178,6 +178,7 @@ class neuralSpeechCodingModule(object):
         self._out_root = getattr(arg, "out_root", ".") or "."
         self._seed = int(getattr(arg, "seed", 20200504) or 20200504)
         self._local_entropy = bool(getattr(arg, "local_entropy", 0))   # skip the histogram all-reduce
+        self._tf_checkpoint = bool(getattr(arg, "tf_checkpoint", 0))   # also write TF V2-format checkpoints (nsc_amd/tf_checkpoint.py)
         self._dump_rows = bool(getattr(arg, "dump_rows", 0))
         self._rows_seen = []
         self._comm = getattr(arg, "comm", None)
@@ -423,12 +424,24 @@ class neuralSpeechCodingModule(object):
         return os.path.join(self._out_root, "check", "model_bnn_ac_" + self._rand_model_id + '_' + save_id + ".ckpt.npz")
 
     def save(self, eng, save_id):
-        np.savez(self.ckpt_path(save_id), **{k.replace("/", "|"): v for k, v in eng.named().items()})
+        named = eng.named()
+        np.savez(self.ckpt_path(save_id), **{k.replace("/", "|"): v for k, v in named.items()})
+        if getattr(self, "_tf_checkpoint", False):
+            # what saver.save(sess, './check/model_bnn_ac_<id>_<save_id>.ckpt') leaves (nsc_module:548): same prefix, TF variable names
+            from .tf_checkpoint import write_checkpoint
+            write_checkpoint(self.ckpt_path(save_id)[:-len(".npz")], named)
         print('Model saved!')
 
     def restore(self, eng, save_id, scopes=None):
-        with np.load(self.ckpt_path(save_id)) as z:
-            named = {k.replace("|", "/"): z[k] for k in z.files}
+        path = self.ckpt_path(save_id)
+        if not os.path.exists(path) and os.path.exists(path[:-len(".npz")] + ".index"):
+            # a checkpoint written by the reference's tf.compat.v1.train.Saver (V2 format): same variable names (optimizer slots and
+            # counters, if any, are not parameters of the engine and are ignored by load_named)
+            from .tf_checkpoint import read_checkpoint
+            named = read_checkpoint(path[:-len(".npz")])
+        else:
+            with np.load(path) as z:
+                named = {k.replace("|", "/"): z[k] for k in z.files}
         if scopes is not None:
             named = {k: v for k, v in named.items() if any(k.startswith(s + "/") for s in scopes)}
         eng.load_named(named)

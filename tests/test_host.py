@@ -474,3 +474,119 @@ def test_three_launch_dgrad_image_is_the_weight_pieces_in_kernel_layout(C_):
     want = np.concatenate([w[2], w[4]], axis=2)                                      # [tap][ci][lin 0..19 | gate 20..39]
     assert np.max(np.abs(body.astype(np.float64).sum(0) - want)) <= 2.0 ** -23 * np.max(np.abs(want))
 
+
+
+# ---- TF V2 tensor-bundle checkpoints (nsc_amd/tf_checkpoint.py): what the reference's Saver reads and writes (cmrl.py:64-72, nsc_module:548)
+def test_crc32c_known_answers_and_mask():
+    from nsc_amd.tf_checkpoint import crc32c, mask_crc, unmask_crc
+    # RFC 3720 B.4 test vectors (the ones leveldb's crc32c_test holds too)
+    assert crc32c(b"123456789") == 0xe3069283
+    assert crc32c(bytes(32)) == 0x8a9136aa
+    assert crc32c(b"\xff" * 32) == 0x62a8ab43
+    assert crc32c(bytes(range(32))) == 0x46dd794e
+    assert crc32c(bytes(range(31, -1, -1))) == 0x113fdb5c
+    assert crc32c(b"hello world") == crc32c(b"world", crc32c(b"hello "))       # extendable
+    for v in (0, 1, 0xe3069283, 0xffffffff):
+        assert unmask_crc(mask_crc(v)) == v and mask_crc(v) != v
+
+
+def test_tf_checkpoint_round_trip_names_shapes_dtypes(tmp_path):
+    from nsc_amd.tf_checkpoint import write_checkpoint, read_checkpoint, read_index
+    from tests._util import make_store
+    named = dict(make_store(2, [[2], [2]], [32, 32], lpc=True).params)
+    named["global_step"] = np.array(12345, np.int64)
+    named["flags/on"] = np.array([True, False, True])
+    named["half"] = np.arange(6, dtype=np.float64).reshape(2, 3)
+    prefix = str(tmp_path / "model_bnn_ac_x_.ckpt")
+    write_checkpoint(prefix, named)
+    assert os.path.exists(prefix + ".index") and os.path.exists(prefix + ".data-00000-of-00001")
+    back = read_checkpoint(prefix)
+    assert set(back) == set(named)
+    for k, v in named.items():
+        v = np.asarray(v)
+        assert back[k].shape == v.shape and back[k].dtype == v.dtype, k
+        np.testing.assert_array_equal(back[k], v)
+    # a subset by name; the index alone lists every tensor, sorted (SSTable order), with offsets that tile the data shard
+    sub = read_checkpoint(prefix, names=["scope_1/alpha", "global_step"])
+    assert set(sub) == {"scope_1/alpha", "global_step"}
+    from nsc_amd.tf_checkpoint import _parse_entry
+    table = read_index(prefix + ".index")
+    keys = list(table)
+    assert keys == sorted(keys) and keys[0] == b"" and table[b""][:2] == b"\x08\x01"     # BundleHeaderProto.num_shards = 1
+    end = 0
+    for e in sorted((_parse_entry(v) for k, v in table.items() if k), key=lambda e: e["offset"]):
+        assert e["offset"] == end and e["shard_id"] == 0
+        end += e["size"]
+    assert end == os.path.getsize(prefix + ".data-00000-of-00001")
+    raw = open(prefix + ".index", "rb").read()
+    import struct
+    assert struct.unpack("<Q", raw[-8:])[0] == 0xdb4775248b80fb57                        # table/format.cc kTableMagicNumber
+
+
+def test_tf_checkpoint_many_blocks_and_prefix_compression(tmp_path):
+    from nsc_amd.tf_checkpoint import write_index, read_index
+    # 400 keys with long shared prefixes in 256-byte blocks: many data blocks, a multi-entry index block, restarts every 16 keys
+    items = {f"scope_{i % 3 + 1}/conv1d_{i}/kernel".encode(): bytes([i % 251]) * (i % 7 + 1) for i in range(400)}
+    path = str(tmp_path / "t.index")
+    write_index(path, items, block_bytes=256)
+    got = read_index(path)
+    assert got == items and list(got) == sorted(items)
+    raw = open(path, "rb").read()
+    payload = sum(len(k) + len(v) for k, v in items.items())
+    assert len(raw) < payload + 400 * 3                               # shared prefixes were elided (3 varints per entry + blocks' trailers otherwise)
+    # the same table assembled by hand, one entry per block with NO prefix sharing, reads the same: the reader does not lean on the writer's choices
+    from nsc_amd.tf_checkpoint import _emit_block, _block, TABLE_MAGIC
+    import struct
+    hand = str(tmp_path / "h.index")
+    with open(hand, "wb") as f:
+        index = [(k, _emit_block(f, _block([(k, items[k])]))) for k in sorted(items)[:40]]
+        meta = _emit_block(f, _block([]))
+        idx = _emit_block(f, _block(index, restart_interval=1))
+        f.write((meta + idx).ljust(40, b"\x00") + struct.pack("<Q", TABLE_MAGIC))
+    assert read_index(hand) == {k: items[k] for k in sorted(items)[:40]}
+
+
+def test_tf_checkpoint_rejects_corruption(tmp_path):
+    from nsc_amd.tf_checkpoint import write_checkpoint, read_checkpoint
+    prefix = str(tmp_path / "c.ckpt")
+    write_checkpoint(prefix, {"a/kernel": np.arange(12, dtype=np.float32).reshape(3, 4), "a/bias": np.ones(4, np.float32)})
+    data = prefix + ".data-00000-of-00001"
+    raw = bytearray(open(data, "rb").read())
+    raw[5] ^= 0x40
+    open(data, "wb").write(bytes(raw))
+    with pytest.raises(ValueError, match="checksum"):
+        read_checkpoint(prefix)
+    write_checkpoint(prefix, {"a/kernel": np.zeros((3, 4), np.float32)})
+    idx = bytearray(open(prefix + ".index", "rb").read())
+    idx[3] ^= 0x01                                                   # inside the first data block
+    open(prefix + ".index", "wb").write(bytes(idx))
+    with pytest.raises(ValueError):
+        read_checkpoint(prefix)
+    open(prefix + ".index", "wb").write(b"not a table")
+    with pytest.raises(ValueError):
+        read_checkpoint(prefix)
+
+
+def test_trainer_restores_from_a_tf_format_checkpoint(tmp_path):
+    """restore() falls back to <prefix>.index when the .npz is absent - the path a user arriving with the reference's checkpoints
+    takes (cmrl.py:67 saver.restore(sess, './check/model_bnn_ac_<id>_.ckpt'))."""
+    from nsc_amd.tf_checkpoint import write_checkpoint
+    from nsc_amd.neural_speech_coding_module import neuralSpeechCodingModule as NeuralSpeechCoding
+    from tests._util import make_store
+    named = dict(make_store(2, [[2], [2]], [32, 32], lpc=False).params)
+    m = NeuralSpeechCoding.__new__(NeuralSpeechCoding)
+    m._out_root, m._rand_model_id = str(tmp_path), "77"
+    os.makedirs(tmp_path / "check")
+    write_checkpoint(m.ckpt_path("")[:-len(".npz")], named)
+
+    class Eng:
+        def load_named(self, named):
+            self.got = named
+    e = Eng()
+    m.restore(e, "", scopes=["scope_1"])                             # cmrl.py:332-347: a follower stage restores the earlier scopes only
+    want = {k for k in named if k.startswith("scope_1/")}
+    assert set(e.got) == want and 0 < len(want) < len(named)
+    for k in want:
+        np.testing.assert_array_equal(e.got[k], np.asarray(named[k]))
+    m.restore(e, "")
+    assert set(e.got) == set(named)
