@@ -381,6 +381,12 @@ int nsc_recon_loss(const float* decoded, const float* target, int B, float ct, f
 int nsc_recon_loss_banded(const float* decoded, const float* target, int B, float ct, float cf,
                           const float* gt, const float* gf, const float* mel, const float* melT, const int* ranges,
                           float* time_out, float* freq_out, float* grad, void* stream);
+/* Backward of the pair (mse_loss, mfcc_loss) from the forward launch's leftovers (op surface): gfreq [B,512] = the `grad` of an
+ * nsc_recon_loss call with ct = 0, cf = 1 (d mfcc_loss[b] / d decoded[b,:]), time [B] its time_out;
+ * grad[b,:] = gf[b] gfreq[b,:] + gt[b] (decoded - target)[b,:] / (512 time[b]); gt / gf nullable (that loss is unused).
+ * Replaces the second traversal tf.gradients makes of loss_terms_and_measures.py:77-79, 151-175. */
+int nsc_recon_loss_combine(const float* decoded, const float* target, const float* time, const float* gt, const float* gf,
+                           const float* gfreq, int B, float* grad, void* stream);
 /* bare rFFT-512 magnitude (tf_stft): re/im/mag [B,257] (any nullable). */
 int nsc_rfft512(const float* sig, int B, float* re, float* im, float* mag, void* stream);
 
@@ -414,6 +420,9 @@ int nsc_lpc_residual(const float* x, const float* poly, float* res, int B, int o
 int nsc_lpc_synthesis(const float* poly, const float* res, float* out, int B, int order, void* stream);
 /* p[0..n) = 0 on the stream (a memset node under hipGraph capture). */
 int nsc_zero(float* p, long n, void* stream);
+/* *id = identity of the hipGraph capture `stream` is recording into, 0 when it is not capturing (host bookkeeping of the op surface:
+ * buffers prepared outside a capture must be prepared again inside it; no counterpart in the reference - TF1 sessions have no capture). */
+int nsc_stream_capture_id(void* stream, unsigned long long* id);
 
 /* ---- framing (utilities.py:7-39): frames[i,:] = utt[480 i : 480 i + 512] * window; overlap-add back ---- */
 int nsc_frame_utterance(const float* utt, long n, const float* window /*nullable [512]*/, float* frames, int nframes, void* stream);

@@ -77,6 +77,7 @@ PROTOTYPES = {
     "nsc_quantize_bwd": [_P, _P, _P, _F, _I, _I, _I, _I, _P, _P, _F, _P, _F, _I, _P, _P, _P, _P],
     "nsc_recon_loss": [_P, _P, _I, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P],
     "nsc_recon_loss_banded": [_P, _P, _I, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "nsc_recon_loss_combine": [_P, _P, _P, _P, _P, _P, _I, _P, _P],
     "nsc_rfft512": [_P, _I, _P, _P, _P, _P],
     "nsc_adam_tf1_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _P, _P],
     "nsc_increment": [_P, _P],
@@ -91,6 +92,7 @@ PROTOTYPES = {
     "nsc_lpc_residual": [_P, _P, _P, _I, _I, _P],
     "nsc_lpc_synthesis": [_P, _P, _P, _I, _I, _P],
     "nsc_zero": [_P, _L, _P],
+    "nsc_stream_capture_id": [_P, _P],
 }
 class BlockWgradJob(C.Structure):
     """include/nsc_hip.h: struct nsc_block_wgrad_job"""

@@ -172,6 +172,29 @@ extern "C" int nsc_recon_loss_banded(const float* decoded, const float* target, 
   return NSC_OK;
 }
 
+// Backward of (mse_loss, mfcc_loss) from what the FORWARD launch left behind (op surface, nsc_amd/ops.py: ReconLossFn): the forward
+// runs nsc_recon_loss once with ct = 0, cf = 1 and keeps gfreq = d mfcc_loss[b] / d decoded[b,:] and time[b]; when the upstream
+// gradients gt[b], gf[b] arrive, dL/d decoded = gf[b] gfreq + gt[b] (decoded - target) / (512 time[b]) is elementwise - instead of a
+// second pass through both FFTs and the mel banks (25 us at B = 128; tf.gradients does re-traverse: loss_terms_and_measures.py:151-175).
+__global__ void recon_combine_kernel(const float* __restrict__ decoded, const float* __restrict__ target,
+                                     const float* __restrict__ time, const float* __restrict__ gt, const float* __restrict__ gf,
+                                     const float* __restrict__ gfreq, float* __restrict__ grad, long n) {
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    const long b = e >> 9;
+    const float tscale = gt ? gt[b] / (NFFT * time[b]) : 0.f;
+    grad[e] = (gf ? gf[b] * gfreq[e] : 0.f) + tscale * (decoded[e] - target[e]);
+  }
+}
+extern "C" int nsc_recon_loss_combine(const float* decoded, const float* target, const float* time, const float* gt, const float* gf,
+                                      const float* gfreq, int B, float* grad, void* stream) {
+  NSC_REQUIRE(decoded && target && time && gfreq && grad && B > 0, NSC_ERR_BAD_ARG, "nsc_recon_loss_combine: bad args");
+  const long n = (long)B * NFFT;
+  hipLaunchKernelGGL(recon_combine_kernel, dim3(std::min<long>(2048, nsc_cdiv(n, 256))), dim3(256), 0, (hipStream_t)stream, decoded,
+                     target, time, gt, gf, gfreq, grad, n);
+  NSC_CHECK_LAUNCH("recon_loss_combine");
+  return NSC_OK;
+}
+
 // bare rFFT-512 (tf_stft): re/im [B,257], mag = sqrt(re^2 + im^2 + 1e-7)
 __global__ __launch_bounds__(256) void rfft512_kernel(const float* __restrict__ sig, float* __restrict__ re,
                                                       float* __restrict__ im, float* __restrict__ mag) {

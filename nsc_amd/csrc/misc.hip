@@ -582,14 +582,55 @@ __device__ __forceinline__ float gather_word(const float* __restrict__ src, int 
   nsc_split2(src[base], src[base + stride], pk);
   return __builtin_bit_cast(float, plane == 0 ? pk[0] : (plane == 1 ? pk[1] : pk[2]));
 }
-__global__ void gather_kernel(const float* __restrict__ src, const int* __restrict__ idx, float* __restrict__ dst,
-                              long n) {
-  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x)
-    dst[e] = gather_word(src, idx[e]);
+// words [first, first + words) of dst, words <= 1024, by one workgroup of 256 threads: four words per thread with every level of the
+// dependent chain (index -> one or two source words -> store) issued for all four at once - a plain one-word-per-thread loop is
+// serial chains of three memory round trips each, and the gather is latency, not bandwidth (round 6: nsc_step_begin_chunks; the
+// op surface's per-block image gathers ran 16.7 us for 0.1 M words in the plain form)
+__device__ __forceinline__ void gather_chunk(const float* __restrict__ src, const int* __restrict__ idx, float* __restrict__ dst,
+                                             long first, int words) {
+  int ix[4];
+  float a[4], b[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e = threadIdx.x + 256 * j;
+    ix[j] = e < words ? idx[first + e] : -1;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = ix[j], m = i < 0 ? 0 : (i >> 26), base = i < 0 ? 0 : (i & 0x3ffffff);
+    const int sel = m > 0 ? (m - 1) % 5 : 4;
+    const int stride = m == 0 ? 0 : (sel == 0 ? 20 : (sel == 1 ? 25 : (sel == 2 ? 50 : (sel == 3 ? 100 : 1))));
+    a[j] = src[base];
+    b[j] = src[base + stride];
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e = threadIdx.x + 256 * j, i = ix[j];
+    if (e < words) {
+      float v = 0.f;
+      if (i >= 0) {
+        const int m = i >> 26;
+        if (m == 0) {
+          v = a[j];
+        } else {
+          unsigned pk[3];
+          nsc_split2(a[j], b[j], pk);
+          const int plane = (m - 1) / 5;
+          v = __builtin_bit_cast(float, plane == 0 ? pk[0] : (plane == 1 ? pk[1] : pk[2]));
+        }
+      }
+      dst[first + e] = v;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ src, const int* __restrict__ idx,
+                                                     float* __restrict__ dst, long n) {
+  for (long first = blockIdx.x * 1024L; first < n; first += gridDim.x * 1024L)
+    gather_chunk(src, idx, dst, first, (int)(n - first < 1024 ? n - first : 1024));
 }
 extern "C" int nsc_gather(const float* src, const int* idx, float* dst, long n, void* stream) {
   NSC_REQUIRE(src && idx && dst && n > 0, NSC_ERR_BAD_ARG, "nsc_gather: bad args");
-  hipLaunchKernelGGL(gather_kernel, dim3(std::min<long>(2048, nsc_cdiv(n, 256))), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(gather_kernel, dim3(std::min<long>(8192, nsc_cdiv(n, 1024))), dim3(256), 0, (hipStream_t)stream,
                      src, idx, dst, n);
   NSC_CHECK_LAUNCH("gather");
   return NSC_OK;
@@ -649,42 +690,7 @@ __global__ void step_begin_chunks_kernel(const float* __restrict__ src, const in
                                          int* __restrict__ counter) {
   if ((int)blockIdx.x < nchunks) {
     const int2 c = chunks[blockIdx.x];
-    // four words per thread with every level of the dependent chain (index -> one or two source words -> store) issued for all four
-    // at once: the plain loop was four serial chains of three memory round trips each (the gather is latency, not bandwidth)
-    int ix[4];
-    float a[4], b[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int e = threadIdx.x + 256 * j;
-      ix[j] = e < c.y ? idx[c.x + e] : -1;
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int i = ix[j], m = i < 0 ? 0 : (i >> 26), base = i < 0 ? 0 : (i & 0x3ffffff);
-      const int sel = m > 0 ? (m - 1) % 5 : 4;
-      const int stride = m == 0 ? 0 : (sel == 0 ? 20 : (sel == 1 ? 25 : (sel == 2 ? 50 : (sel == 3 ? 100 : 1))));
-      a[j] = src[base];
-      b[j] = src[base + stride];
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int e = threadIdx.x + 256 * j, i = ix[j];
-      if (e < c.y) {
-        float v = 0.f;
-        if (i >= 0) {
-          const int m = i >> 26;
-          if (m == 0) {
-            v = a[j];
-          } else {
-            unsigned pk[3];
-            nsc_split2(a[j], b[j], pk);
-            const int plane = (m - 1) / 5;
-            v = __builtin_bit_cast(float, plane == 0 ? pk[0] : (plane == 1 ? pk[1] : pk[2]));
-          }
-        }
-        dst[c.x + e] = v;
-      }
-    }
+    gather_chunk(src, idx, dst, c.x, c.y);
     if (counter && blockIdx.x == 0 && threadIdx.x == 0) counter[0] += 1;
   } else {
     const int zb = gridDim.x - nchunks;
@@ -766,15 +772,31 @@ extern "C" int nsc_act_bwd(const float* dy, const float* y, float* dx, long n, i
 __global__ __launch_bounds__(256) void p_stats_kernel(const float* __restrict__ p, int L, int nb, float* __restrict__ quan,
                                                       float* __restrict__ hist) {
   __shared__ float red[4];
+  __shared__ float hs[256];
   const long b = blockIdx.x;
   const float* pb = p + b * (long)L * nb;
-  float s = 0.f;
-  for (int e = threadIdx.x; e < L * nb; e += 256) s += sqrtf(pb[e] + 1e-20f);
+  // 256 % nb == 0 (the shipped 32 / 64 bins): a thread meets the SAME bin k = tid % nb in every round of the loop, so the histogram
+  // rides the one pass over p (it used to be a second pass of nb threads x L serial loads: 22 of the launch's 35 us at B = 128)
+  const bool one_pass = hist && (256 % nb) == 0;
+  float s = 0.f, hk = 0.f;
+#pragma unroll 8
+  for (int e = threadIdx.x; e < L * nb; e += 256) {
+    const float v = pb[e];
+    s += sqrtf(v + 1e-20f);
+    hk += v;
+  }
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  hs[threadIdx.x] = hk;
   __syncthreads();
   if (threadIdx.x == 0 && quan) quan[b] = (red[0] + red[1] + red[2] + red[3]) / (float)L;
-  if (hist) {
+  if (one_pass) {
+    if ((int)threadIdx.x < nb) {
+      float h = 0.f;
+      for (int j = threadIdx.x; j < 256; j += nb) h += hs[j];
+      atomicAdd(hist + threadIdx.x, h);
+    }
+  } else if (hist) {
     for (int k = threadIdx.x; k < nb; k += 256) {
       float h = 0.f;
       for (int l = 0; l < L; ++l) h += pb[(long)l * nb + k];
@@ -835,5 +857,18 @@ extern "C" int nsc_zero(float* p, long n, void* stream) {
   NSC_REQUIRE(p && n > 0, NSC_ERR_BAD_ARG, "nsc_zero: bad args");
   hipError_t e = hipMemsetAsync(p, 0, (size_t)n * sizeof(float), (hipStream_t)stream);
   NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "nsc_zero: %s", hipGetErrorString(e));
+  return NSC_OK;
+}
+
+// Identity of the hipGraph capture the stream is in (0: not capturing).  A host that hands out pre-zeroed or pre-built device
+// buffers (nsc_amd/ops.py: the op surface's zero pool) must not reuse, inside a capture, what was prepared outside it or in an
+// earlier capture: the preparing launch would be missing from the graph being recorded.
+extern "C" int nsc_stream_capture_id(void* stream, unsigned long long* id) {
+  NSC_REQUIRE(id, NSC_ERR_BAD_ARG, "nsc_stream_capture_id: bad args");
+  hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+  unsigned long long cid = 0;
+  hipError_t e = hipStreamGetCaptureInfo((hipStream_t)stream, &status, &cid);
+  NSC_REQUIRE(e == hipSuccess, NSC_ERR_LAUNCH, "nsc_stream_capture_id: %s", hipGetErrorString(e));
+  *id = status == hipStreamCaptureStatusActive ? (cid ? cid : ~0ull) : 0ull;
   return NSC_OK;
 }

@@ -319,10 +319,9 @@ class neuralSpeechCodingModule(object):
     # ------------------------------------------------------------------ op-surface graph builders
     # (these run on the autograd op surface; the trainers below use the explicit engine for speed)
     def _down_sampling_mod(self, the_input, the_stride=2):
-        """nsc_module:152-156."""
-        out = nn.conv1d(the_input, self._bottleneck_kernel_and_dilation[2], filter_size=9, padding='SAME', dilation_rate=1,
-                        strides=the_stride, activation=None)
-        return nn.activation_func(out)
+        """nsc_module:152-156 (conv1d(activation=None) then activation_func there: the leaky-relu rides the conv's epilogue here)."""
+        return nn.conv1d(the_input, self._bottleneck_kernel_and_dilation[2], filter_size=9, padding='SAME', dilation_rate=1,
+                         strides=the_stride, activation='lrelu')
 
     def _up_sampling_mod_helper(self, the_input, the_stride=2):
         """nsc_module:158-167 (sub-pixel shuffle)."""
@@ -333,8 +332,8 @@ class neuralSpeechCodingModule(object):
     def _up_sampling_mod(self, the_input, the_stride=2):
         """nsc_module:169-181 (resnet_type 'gln' -> separable conv)."""
         out = nn.conv1d_depth(the_input, int(the_input.shape[-1]), filter_size=9, padding='SAME', dilation_rate=1, strides=1,
-                              activation=None)
-        return self._up_sampling_mod_helper(nn.activation_func(out), the_stride=the_stride)
+                              activation='lrelu')       # (activation_func(conv(...)) there: fused into the pointwise conv's epilogue)
+        return self._up_sampling_mod_helper(out, the_stride=the_stride)
 
     def _stack_bottleneck_blocks(self, compressed_bit, strides=1, is_post_up_samling=True, the_share=False, is_enc=True):
         """nsc_module:183-217."""
@@ -353,8 +352,7 @@ class neuralSpeechCodingModule(object):
 
     def _the_encoder_in_each_module(self, the_input, the_stride, the_share):
         """nsc_module:219-237."""
-        c = nn.change_channel(the_input, the_channel=self._bottleneck_kernel_and_dilation[2], kernel_size=55, activation=None)
-        c = nn.activation_func(c)
+        c = nn.change_channel(the_input, the_channel=self._bottleneck_kernel_and_dilation[2], kernel_size=55, activation='lrelu')
         for i in the_stride:
             c = self._stack_bottleneck_blocks(c, is_post_up_samling=False, the_share=the_share)
             c = self._down_sampling_mod(c, the_stride=i)
