@@ -278,6 +278,9 @@ def _defer(kind, group, job, keep, flat_g, params, sizes):
     task = torch._C._current_graph_task_id()
     st = _PENDING.get(task)
     if st is None:
+        if len(_PENDING) > 4:                     # passes that raised before their callback ran: their queues (and the tensors they hold) go
+            for old in list(_PENDING)[:-4]:
+                _PENDING.pop(old, None)
         st = _PENDING[task] = {}
         torch.autograd.Variable._execution_engine.queue_callback(lambda: _flush_wgrads(task))
     offs = np.concatenate([[0], np.cumsum(sizes)]) if sizes else []

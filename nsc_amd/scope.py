@@ -10,7 +10,8 @@ Memory: CUDA variables are carved out of one flat ARENA per store (16-byte align
 tensor on the arena's storage (its own version counter, no view bookkeeping).  Nothing at the surface depends on it - a variable
 is an ordinary ``torch.nn.Parameter`` - but the eight tensors of a gated block then lie within one nsc_gather index range, which
 is what lets ops.BlockFn build the block's kernel-ready images with one launch (the engine keeps its parameters flat for the same
-reason: engine.py, ``wt_idx``).
+reason: engine.py, ``wt_idx``).  (A variable's STORAGE is therefore the whole arena: serialise ``v.detach().clone()`` or a numpy copy,
+as the trainers do, not the parameter object itself.)
 """
 from __future__ import annotations
 
