@@ -166,7 +166,8 @@ def op_surface_leg(B, x_np, dev, steps=20, warmup=3):
                         else "eager (torch autograd tape)"),
                 ms_per_step_eager=round(1e3 * t_surface_eager, 3),
                 ms_per_step_graph=(round(1e3 * t_surface_graph, 3) if t_surface_graph is not None else None),
-                work="forward + loss + backward of one codec through nn_core_operator / loss_terms_and_measures (no optimizer)",
+                work="forward + loss + backward of one codec through nn_core_operator / loss_terms_and_measures (no optimizer); round 6: the "
+                     "blocks' forward on split operands, one image gather per pass, batched weight gradients at the end of the autograd pass (nsc_amd/ops.py)",
                 engine_config2_frames_per_s=round(B / t_eng, 1), engine_config2_ms_per_step=round(1e3 * t_eng, 3),
                 engine_config2_launch="hipGraph" if t_graph is not None else "eager",
                 engine_config2_eager_ms_per_step=round(1e3 * t_eager, 3),
@@ -731,7 +732,12 @@ def main():
 
     surface = None
     if comm.rank == 0 and comm.world == 1 and not args.no_op_surface and not args.no_infer:
-        surface = op_surface_leg(B, x_np, dev)
+        try:
+            surface = op_surface_leg(B, x_np, dev)
+        except Exception as e:                               # a side leg never takes the headline line down with it
+            print(f"[bench] op_surface leg failed ({type(e).__name__}: {e})", file=sys.stderr)
+            surface = dict(error=f"{type(e).__name__}: {e}")
+            torch.cuda.synchronize()
 
     cpu = None
     if comm.rank == 0 and comm.world == 1 and not args.no_cpu_baseline:
