@@ -508,12 +508,14 @@ def test_image_set_follows_the_parameters_between_passes_and_inside_a_captured_g
         set_store(None)
 
 
-def test_fused_block_on_plain_tensors_outside_any_store():
+@pytest.mark.parametrize("T", [128, 126])
+def test_fused_block_on_plain_tensors_outside_any_store(T):
     """ops.BlockFn on eight ordinary tensors (no VariableStore): the image pair comes from one gather over wherever they lie, or the
-    pointer entry points take over - same values as the store route."""
+    pointer entry points take over - same values as the store route.  T = 126: no split-operand forward (T % 4 != 0), the exact
+    kernels serve the block on both routes."""
     from nsc_amd import nn_core_operator as nn, ops
     from nsc_amd.scope import VariableStore, set_store, variable_scope
-    x_np = np.random.default_rng(8).standard_normal((2, 128, 100)).astype(np.float32)
+    x_np = np.random.default_rng(8).standard_normal((2, T, 100)).astype(np.float32)
     st = VariableStore(device="cuda", seed=4)
     set_store(st)
     try:
