@@ -5,9 +5,15 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 ks = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0][:70]) for r in rows)
 adam = [i for i, k in enumerate(ks) if 'adam' in k[2]]
 spans = [(ks[adam[i]][1] - ks[adam[i - 1]][1]) / 1e3 for i in range(1, len(adam))]
-med = sorted(spans)[len(spans) // 2]
-idx = [i for i, s_ in enumerate(spans) if abs(s_ - med) < 0.02 * med]
-i = idx[len(idx) // 2] + 1
+# the replayed steps: the most common dispatch count among the adam-to-adam intervals without bench.py's bracket-calibration kernels
+from collections import Counter
+plain = [i for i in range(1, len(adam)) if not any('spin' in k[2] for k in ks[adam[i - 1] + 1:adam[i] + 1])]
+count = Counter(adam[i] - adam[i - 1] for i in plain).most_common(1)[0][0]
+plain = [i for i in plain if adam[i] - adam[i - 1] == count]
+med = sorted(spans[i - 1] for i in plain)[len(plain) // 2]
+idx = [i for i in plain if abs(spans[i - 1] - med) < 0.02 * med]
+i = idx[len(idx) // 2]
+print(f"{len(plain)} intervals of {count} dispatches without calibration kernels; median span {med:.1f} us")
 lo, hi = adam[i - 1] + 1, adam[i] + 1
 t0, prev_end = ks[lo][0], ks[adam[i - 1]][1]
 tot = gaps = 0.0
