@@ -331,9 +331,8 @@ class neuralSpeechCodingModule(object):
 
     def _up_sampling_mod(self, the_input, the_stride=2):
         """nsc_module:169-181 (resnet_type 'gln' -> separable conv)."""
-        out = nn.conv1d_depth(the_input, int(the_input.shape[-1]), filter_size=9, padding='SAME', dilation_rate=1, strides=1,
-                              activation='lrelu')       # (activation_func(conv(...)) there: fused into the pointwise conv's epilogue)
-        return self._up_sampling_mod_helper(out, the_stride=the_stride)
+        # (conv1d_depth(activation=None) -> activation_func -> _up_sampling_mod_helper there: one call, one fused kernel per direction)
+        return nn.conv1d_depth_shuffle(the_input, int(the_input.shape[-1]), filter_size=9, activation='lrelu', stride=the_stride)
 
     def _stack_bottleneck_blocks(self, compressed_bit, strides=1, is_post_up_samling=True, the_share=False, is_enc=True):
         """nsc_module:183-217."""
@@ -343,11 +342,10 @@ class neuralSpeechCodingModule(object):
             wide_layer = bkd[2]
         else:
             wide_layer = int(compressed_bit.shape[-1] / strides) if is_post_up_samling else int(compressed_bit.shape[-1])
-        for i in range(len(bkd) - 4):
-            flag = i == (len(bkd) - 5)
-            compressed_bit = nn.gated_bottleneck(compressed_bit, non_dilated_neck_kernel_size=bkd[1],
-                                                 dilated_neck_kernel_size=bkd[0], wide_layer=wide_layer, narrow_layer=bkd[3],
-                                                 dilation_rate=bkd[i + 4], is_last_flat=flag, the_share=the_share)
+        # (the reference's loop over bkd[4:], one gated_bottleneck per dilation rate, the last one flat: one call here)
+        compressed_bit = nn.gated_bottleneck_stack(compressed_bit, wide_layer=wide_layer, narrow_layer=bkd[3],
+                                                   non_dilated_neck_kernel_size=bkd[1], dilation_rates=bkd[4:], is_last_flat=True,
+                                                   the_share=the_share)
         return compressed_bit
 
     def _the_encoder_in_each_module(self, the_input, the_stride, the_share):

@@ -56,6 +56,22 @@ def conv1d_depth(inputs, num_filters, filter_size, padding='SAME', dilation_rate
     return ops.Conv1dFn.apply(dw, wp, b, 1, 1, _act_name(activation))
 
 
+def conv1d_depth_shuffle(inputs, num_filters, filter_size, activation=tanh, stride=2):
+    """conv1d_depth(...) followed by the sub-pixel shuffle of neural_speech_coding_module.py:158-167 - the body of the reference's
+    _up_sampling_mod (:169-181) - creating conv1d_depth's variables.  The shipped shape (C -> C in {100, 50}, 9 taps, stride 2) is ONE
+    autograd node on the engine's fused up-sampling kernels (ops.UpsampleFn); anything else: the two calls."""
+    c = int(inputs.shape[-1])
+    if FUSED_BLOCKS and stride == 2 and filter_size == 9 and num_filters == c and c in (100, 50):
+        st = current_store()
+        name = st.uniq("separable_conv1d")
+        wd = st.get(name + "/depthwise_kernel", (filter_size, c, 1), st.glorot(filter_size * c, filter_size))
+        wp = st.get(name + "/pointwise_kernel", (1, c, num_filters), st.glorot(c, num_filters))
+        b = st.get(name + "/bias", (num_filters,), lambda s: torch.zeros(s).numpy())
+        return ops.UpsampleFn.apply(inputs, wd, wp, b, _act_name(activation))
+    assert stride == 2
+    return ops.ShuffleFn.apply(conv1d_depth(inputs, num_filters, filter_size, activation=activation))
+
+
 def activation_func(_x):
     """nn_core_operator.py:24-31: tf.nn.leaky_relu (alpha 0.2); the PReLU / ELU / ReLU variants are commented out there."""
     return ops.ActFn.apply(_x, "lrelu")
@@ -97,11 +113,8 @@ def gated_bottleneck(the_input, wide_layer=30, narrow_layer=10, non_dilated_neck
     fusable = (FUSED_BLOCKS and narrow_layer == 20 and non_dilated_neck_kernel_size == 9 and int(dilation_rate) in (1, 2) and
                ((cin == wide_layer and 1 < wide_layer <= 112) or (cin == 1 and wide_layer in (100, 50, 25))))
     if fusable:
-        w1, b1 = _conv1d_variables(cin, narrow_layer, 1)
-        wl, bl = _conv1d_variables(narrow_layer, narrow_layer, 15)
-        wr, br = _conv1d_variables(narrow_layer, narrow_layer, 15)
-        w9, b9 = _conv1d_variables(narrow_layer, wide_layer, non_dilated_neck_kernel_size)
-        return ops.BlockFn.apply(the_input, w1, b1, wl, bl, wr, br, w9, b9, int(dilation_rate), bool(is_last_flat))
+        return ops.BlockFn.apply(the_input, *_block_variables(cin, wide_layer, narrow_layer, non_dilated_neck_kernel_size),
+                                 int(dilation_rate), bool(is_last_flat))
     c2 = conv1d(the_input, narrow_layer, filter_size=1, padding='SAME', dilation_rate=1, activation=None)
     c2 = activation_func(c2)
     left = conv1d(c2, narrow_layer, filter_size=15, padding='SAME', dilation_rate=dilation_rate, activation=None)
@@ -110,6 +123,37 @@ def gated_bottleneck(the_input, wide_layer=30, narrow_layer=10, non_dilated_neck
     c2 = conv1d(c3, wide_layer, filter_size=non_dilated_neck_kernel_size, padding='SAME', dilation_rate=1, activation=None)
     y = ops.AddFn.apply(c2, the_input)
     return y if is_last_flat else activation_func(y)
+
+
+def _block_variables(cin, wide_layer, narrow_layer, k9):
+    w1, b1 = _conv1d_variables(cin, narrow_layer, 1)
+    wl, bl = _conv1d_variables(narrow_layer, narrow_layer, 15)
+    wr, br = _conv1d_variables(narrow_layer, narrow_layer, 15)
+    w9, b9 = _conv1d_variables(narrow_layer, wide_layer, k9)
+    return w1, b1, wl, bl, wr, br, w9, b9
+
+
+def gated_bottleneck_stack(the_input, wide_layer, narrow_layer, non_dilated_neck_kernel_size, dilation_rates, is_last_flat=True,
+                           the_share=False):
+    """len(dilation_rates) gated_bottleneck calls in a row - what the reference's _stack_bottleneck_blocks loop builds
+    (neural_speech_coding_module.py:209-216: every block but the last with its leaky-relu, the last one `is_last_flat`) - creating the
+    same variables in the same order.  With the shipped shapes the whole stack is ONE autograd node (ops.BlockStackFn: the leaky-relu
+    between two blocks is differentiated in the next block's data-gradient kernel); otherwise the calls are made one by one."""
+    cin = int(the_input.shape[-1])
+    dils = [int(d) for d in dilation_rates]
+    fusable = (FUSED_BLOCKS and len(dils) >= 2 and narrow_layer == 20 and non_dilated_neck_kernel_size == 9 and all(d in (1, 2) for d in dils)
+               and wide_layer in (100, 50, 25) and cin in (wide_layer, 1))
+    if not fusable:
+        c = the_input
+        for i, d in enumerate(dils):
+            c = gated_bottleneck(c, wide_layer=wide_layer, narrow_layer=narrow_layer, non_dilated_neck_kernel_size=non_dilated_neck_kernel_size,
+                                 dilated_neck_kernel_size=15, dilation_rate=d, is_last_flat=(is_last_flat if i == len(dils) - 1 else False),
+                                 the_share=the_share)
+        return c
+    params = []
+    for i in range(len(dils)):
+        params += _block_variables(cin if i == 0 else wide_layer, wide_layer, narrow_layer, non_dilated_neck_kernel_size)
+    return ops.BlockStackFn.apply(the_input, *params, tuple(dils), bool(is_last_flat))
 
 
 def gated_bottleneck_decoder(the_input, wide_layer=30, narrow_layer=10, non_dilated_neck_kernel_size=9,

@@ -535,6 +535,56 @@ class ShuffleFn(torch.autograd.Function):
         return to_btc(dx)
 
 
+class UpsampleFn(torch.autograd.Function):
+    """_up_sampling_mod (neural_speech_coding_module.py:168-181: SeparableConv1D(C, 9) -> leaky-relu -> sub-pixel shuffle) as ONE
+    autograd node on the engine's fused kernels: nsc_upsample_fwd (depthwise -> pointwise -> activation -> shuffle in one launch) and
+    nsc_upsample_bwd (un-shuffle -> pointwise^T -> depthwise^T); the pointwise kernel's gradient joins the deferred conv batch.
+    C in {100, 50}, 9 taps, stride 2 (nn_core_operator.conv1d_depth_shuffle decides)."""
+
+    @staticmethod
+    def forward(ctx, x, wd, wp, b, act):
+        lib = _lib_()
+        params = (wd, wp, b)
+        xb = to_bct(_req(x, "inputs"))
+        wd, wp, b = _req(wd).contiguous(), _req(wp).contiguous(), _req(b).contiguous()
+        B, C_, T = xb.shape
+        dwo = torch.empty_like(xb)
+        y = torch.empty((B, C_ // 2, 2 * T), dtype=torch.float32, device=xb.device)
+        check(lib.nsc_upsample_fwd(xb.data_ptr(), wd.data_ptr(), wp.data_ptr(), b.data_ptr(), dwo.data_ptr(), y.data_ptr(), B, C_, T, 9,
+                                   ACT[act], _st()), "upsample_fwd")
+        ctx.save_for_backward(xb, dwo, y, wd, wp)
+        ctx.act, ctx.params = act, params
+        return to_btc(y)
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib_()
+        xb, dwo, y, wd, wp = ctx.saved_tensors
+        B, C_, T = xb.shape
+        dev = xb.device
+        dz = to_bct(_req(dy, "grad"))
+        if ACT[ctx.act]:
+            dz = _act_bwd(lib, dz, y, ctx.act)
+        dzp, ddw, dx = (torch.empty_like(xb) for _ in range(3))
+        check(lib.nsc_upsample_bwd(dz.data_ptr(), wd.data_ptr(), wp.data_ptr(), dzp.data_ptr(), ddw.data_ptr(), dx.data_ptr(), B, C_, T, 9,
+                                   _st()), "upsample_bwd")
+        # the depthwise taps' gradient at once (its own small kernel); the pointwise kernel's with the deferred conv batch
+        dwd = _zeros(wd.numel(), dev).view(ctx.params[0].shape)
+        check(lib.nsc_depthwise_bwd(xb.data_ptr(), wd.data_ptr(), ddw.data_ptr(), None, dwd.data_ptr(), B, C_, T, 9, _st()), "depthwise wgrad")
+        sizes = [wp.numel(), C_]
+        flat_g = _zeros(sum(sizes), dev)
+        dwp, db = (gr.view(t.shape) for gr, t in zip(flat_g.split(sizes), ctx.params[1:]))
+        d = _desc(B, C_, C_, T, T, 1, 1, 1, 0)
+        if _deferrable(ctx.params[1:]):
+            _defer("conv", (dev,), _lib.ConvWgradJob(d, dwo.data_ptr(), dzp.data_ptr(), dwp.data_ptr(), db.data_ptr(), 0), (dwo, dzp), flat_g,
+                   ctx.params[1:], sizes)
+        else:
+            ws = _workspace(int(lib.nsc_conv1d_wgrad_workspace(C.byref(d))), dev)
+            check(lib.nsc_conv1d_wgrad_ws(C.byref(d), dwo.data_ptr(), dzp.data_ptr(), dwp.data_ptr(), db.data_ptr(), 0, ws.data_ptr(),
+                                          ws.numel(), _st()), "wgrad")
+        return to_btc(dx), dwd, dwp, db, None
+
+
 def _block_image_meta(lib, C_, Cin, dil):
     """(words of the forward part incl. padding, forward kind 'split' | 'exact', words of the data-gradient part) of a gated block's
     image pair, or None when the shape has no image kernels."""
@@ -602,6 +652,82 @@ def _block_images(lib, ws, C_, Cin, dil):
     return img, meta[0], meta[1]
 
 
+def _block_forward(lib, xb, ws, dil, flat):
+    """One gated block forward on [B,Cin,T] memory: (out, h, lin, th, g, data-gradient image | None)."""
+    B, Cin, T = xb.shape
+    C_ = ws[6].shape[2]
+    out = torch.empty((B, C_, T), dtype=torch.float32, device=xb.device)
+    h, lin, th, g = torch.empty((4, B, 20, T), dtype=torch.float32, device=xb.device).unbind(0)
+    sv = [t.data_ptr() for t in (h, lin, th, g)]
+    imgs = _block_images(lib, ws, C_, Cin, dil) if (C_ in (100, 50, 25) and Cin in (C_, 1)) else None
+    if imgs is not None and imgs[2] == "split" and T % 4 == 0 and xb.data_ptr() % 16 == 0:
+        check(lib.nsc_gated_block_fwd_simg(imgs[0].data_ptr(), xb.data_ptr(), out.data_ptr(), *sv, B, C_, Cin, T, dil, int(flat), _st()),
+              "gated_block_fwd_simg")
+    elif imgs is not None and imgs[2] == "exact":
+        check(lib.nsc_gated_block_fwd_img(imgs[0].data_ptr(), xb.data_ptr(), out.data_ptr(), *sv, B, C_, Cin, T, dil, int(flat), _st()),
+              "gated_block_fwd_img")
+    else:
+        fn = lib.nsc_gated_block_fwd_cin1 if Cin == 1 else lib.nsc_gated_block_fwd
+        check(fn(xb.data_ptr(), *[t.data_ptr() for t in ws], out.data_ptr(), *sv, B, C_, T, 20, 9, dil, int(flat), _st()), "gated_block_fwd")
+    # (the image's second part, as a view: it keeps the image alive until the backward has run)
+    return out, h, lin, th, g, (None if imgs is None else imgs[0][imgs[1]:])
+
+
+def _block_backward(lib, xb, h, lin, th, g, ws, img_bwd, dz, dil, in_act, params):
+    """One gated block backward from dz = dL/d(pre-activation of its output): (dx [B,Cin,T], the eight parameter gradients).  in_act:
+    the activation that PRODUCED the block's input (its derivative is applied to dx in the kernel's epilogue: dx is then dL/d of that
+    pre-activation - how a chain of blocks skips the activation-backward launches); parameter gradients deferred to the end of the pass
+    where possible (see DEFER_WGRAD)."""
+    w1, b1, wl, bl, wr, br, w9, b9 = ws
+    B, Cin, T = xb.shape
+    C_ = w9.shape[2]
+    dev = xb.device
+    n1, n15, n9 = Cin * 20, 15 * 20 * 20, 9 * 20 * C_
+    dx = torch.empty((B, Cin, T), dtype=torch.float32, device=dev)
+    da = torch.empty((B, 40, T), dtype=torch.float32, device=dev)
+    dz1 = torch.empty((B, 20, T), dtype=torch.float32, device=dev)
+    if img_bwd is not None:
+        check(lib.nsc_gated_block_dgrad_img(img_bwd.data_ptr(), None if Cin == 1 else xb.data_ptr(), h.data_ptr(), lin.data_ptr(),
+                                            th.data_ptr(), dz.data_ptr(), dx.data_ptr(), da.data_ptr(), da.data_ptr() + 4 * 20 * T,
+                                            dz1.data_ptr(), B, C_, Cin, T, dil, ACT[in_act], 40, _st()), "gated_block_dgrad_img")
+    else:
+        # flipped / transposed kernels of the four convs (what tf.gradients' conv backprop reads): one launch, one buffer
+        wt = torch.empty(n1 + 2 * n15 + n9, dtype=torch.float32, device=dev)
+        check(lib.nsc_gated_block_flip_weights(w1.data_ptr(), wl.data_ptr(), wr.data_ptr(), w9.data_ptr(), wt.data_ptr(), C_, Cin, 20,
+                                               9, _st()), "flip")
+        p0 = wt.data_ptr()
+        wts = [p0, p0 + 4 * n1, p0 + 4 * (n1 + n15), p0 + 4 * (n1 + 2 * n15)]
+        if Cin == 1:
+            assert ACT[in_act] == 0
+            check(lib.nsc_gated_block_dgrad_cin1(h.data_ptr(), lin.data_ptr(), th.data_ptr(), dz.data_ptr(), *wts,
+                                                 dx.data_ptr(), da.data_ptr(), da.data_ptr() + 4 * 20 * T, dz1.data_ptr(), B, C_, T, 20,
+                                                 9, dil, 40, _st()), "gated_block_dgrad_cin1")
+        else:
+            check(lib.nsc_gated_block_dgrad(xb.data_ptr(), h.data_ptr(), lin.data_ptr(), th.data_ptr(), dz.data_ptr(),
+                                            *wts, dx.data_ptr(), da.data_ptr(), dz1.data_ptr(), B, C_, T, 20, 9,
+                                            dil, ACT[in_act], _st()), "gated_block_dgrad")
+    # parameter gradients: the batched launch (it serves both block forms); the eight gradients are one contiguous range in
+    # creation order (a slice of the zero pool: the kernels accumulate), handed back as views of it
+    sizes = [Cin * 20, 20, n15, 20, n15, 20, n9, C_]
+    flat_g = _zeros(sum(sizes), dev)
+    job = _lib.BlockWgradJob(xb.data_ptr(), h.data_ptr(), g.data_ptr(), dz.data_ptr(), da.data_ptr(), dz1.data_ptr(),
+                             flat_g.data_ptr(), C_, T, dil, Cin)
+    grads = [gr.view(t.shape) for gr, t in zip(flat_g.split(sizes), ws)]
+    if _deferrable(params):
+        _defer("block", (dev, B), job, (xb, h, g, dz, da, dz1), flat_g, params, sizes)
+    else:
+        ws_ = _workspace(int(lib.nsc_gated_block_wgrad_batch_workspace(112)), dev)
+        fn = lib.nsc_gated_block_wgrad_batch_split if SPLIT_ARITH else lib.nsc_gated_block_wgrad_batch
+        check(fn((_lib.BlockWgradJob * 1)(job), 1, B, 20, 9, ws_.data_ptr(), ws_.numel(), _st()), "gated_block_wgrad_batch")
+    return dx, grads
+
+
+def _act_bwd(lib, dz, out, act):
+    dz2 = torch.empty_like(dz)
+    check(lib.nsc_act_bwd(dz.data_ptr(), out.data_ptr(), dz2.data_ptr(), dz.numel(), ACT[act], _st()), "act_bwd")
+    return dz2
+
+
 class BlockFn(torch.autograd.Function):
     """gated_bottleneck (nn_core_operator.py:82-112) as ONE function call, like the reference's: the fused persistent kernels of the
     engine instead of four convs + multiply + add + activations - forward on the block's kernel-ready image (bf16 matrix cores on
@@ -616,78 +742,68 @@ class BlockFn(torch.autograd.Function):
         lib = _lib_()
         xb = to_bct(_req(x, "the_input"))
         ws = [_req(t).contiguous() for t in (w1, b1, wl, bl, wr, br, w9, b9)]
-        B, Cin, T = xb.shape
-        C_ = ws[6].shape[2]
-        out = torch.empty((B, C_, T), dtype=torch.float32, device=x.device)
-        h, lin, th, g = torch.empty((4, B, 20, T), dtype=torch.float32, device=x.device).unbind(0)
-        sv = [t.data_ptr() for t in (h, lin, th, g)]
-        imgs = _block_images(lib, ws, C_, Cin, int(dil)) if (C_ in (100, 50, 25) and Cin in (C_, 1)) else None
-        if imgs is not None and imgs[2] == "split" and T % 4 == 0 and xb.data_ptr() % 16 == 0:
-            check(lib.nsc_gated_block_fwd_simg(imgs[0].data_ptr(), xb.data_ptr(), out.data_ptr(), *sv, B, C_, Cin, T, int(dil),
-                                               int(bool(flat)), _st()), "gated_block_fwd_simg")
-        elif imgs is not None and imgs[2] == "exact":
-            check(lib.nsc_gated_block_fwd_img(imgs[0].data_ptr(), xb.data_ptr(), out.data_ptr(), *sv, B, C_, Cin, T, int(dil),
-                                              int(bool(flat)), _st()), "gated_block_fwd_img")
-        else:
-            fn = lib.nsc_gated_block_fwd_cin1 if Cin == 1 else lib.nsc_gated_block_fwd
-            check(fn(xb.data_ptr(), *[t.data_ptr() for t in ws], out.data_ptr(), *sv, B, C_, T, 20, 9, int(dil), int(bool(flat)), _st()),
-                  "gated_block_fwd")
+        out, h, lin, th, g, img_bwd = _block_forward(lib, xb, ws, int(dil), bool(flat))
         ctx.save_for_backward(xb, h, lin, th, g, out, *ws)
         ctx.cfg = (int(dil), bool(flat))
-        ctx.img_bwd = None if imgs is None else imgs[0][imgs[1]:]       # (a view: keeps the image alive until the backward has run)
+        ctx.img_bwd = img_bwd
         ctx.params = (w1, b1, wl, bl, wr, br, w9, b9)
         return to_btc(out)
 
     @staticmethod
     def backward(ctx, dy):
         lib = _lib_()
-        xb, h, lin, th, g, out, w1, b1, wl, bl, wr, br, w9, b9 = ctx.saved_tensors
+        xb, h, lin, th, g, out, *ws = ctx.saved_tensors
         dil, flat = ctx.cfg
-        B, Cin, T = xb.shape
-        C_ = w9.shape[2]
-        dev = xb.device
         dz = to_bct(_req(dy, "grad"))
         if not flat:                                   # through the block's output leaky-relu
-            dz2 = torch.empty_like(dz)
-            check(lib.nsc_act_bwd(dz.data_ptr(), out.data_ptr(), dz2.data_ptr(), dz.numel(), ACT["lrelu"], _st()), "act_bwd")
-            dz = dz2
-        n1, n15, n9 = Cin * 20, 15 * 20 * 20, 9 * 20 * C_
-        dx = torch.empty((B, Cin, T), dtype=torch.float32, device=dev)
-        da = torch.empty((B, 40, T), dtype=torch.float32, device=dev)
-        dz1 = torch.empty((B, 20, T), dtype=torch.float32, device=dev)
-        if ctx.img_bwd is not None:
-            check(lib.nsc_gated_block_dgrad_img(ctx.img_bwd.data_ptr(), None if Cin == 1 else xb.data_ptr(), h.data_ptr(), lin.data_ptr(),
-                                                th.data_ptr(), dz.data_ptr(), dx.data_ptr(), da.data_ptr(), da.data_ptr() + 4 * 20 * T,
-                                                dz1.data_ptr(), B, C_, Cin, T, dil, ACT[None], 40, _st()), "gated_block_dgrad_img")
-        else:
-            # flipped / transposed kernels of the four convs (what tf.gradients' conv backprop reads): one launch, one buffer
-            wt = torch.empty(n1 + 2 * n15 + n9, dtype=torch.float32, device=dev)
-            check(lib.nsc_gated_block_flip_weights(w1.data_ptr(), wl.data_ptr(), wr.data_ptr(), w9.data_ptr(), wt.data_ptr(), C_, Cin, 20,
-                                                   9, _st()), "flip")
-            p0 = wt.data_ptr()
-            wts = [p0, p0 + 4 * n1, p0 + 4 * (n1 + n15), p0 + 4 * (n1 + 2 * n15)]
-            if Cin == 1:
-                check(lib.nsc_gated_block_dgrad_cin1(h.data_ptr(), lin.data_ptr(), th.data_ptr(), dz.data_ptr(), *wts,
-                                                     dx.data_ptr(), da.data_ptr(), da.data_ptr() + 4 * 20 * T, dz1.data_ptr(), B, C_, T, 20,
-                                                     9, dil, 40, _st()), "gated_block_dgrad_cin1")
-            else:
-                check(lib.nsc_gated_block_dgrad(xb.data_ptr(), h.data_ptr(), lin.data_ptr(), th.data_ptr(), dz.data_ptr(),
-                                                *wts, dx.data_ptr(), da.data_ptr(), dz1.data_ptr(), B, C_, T, 20, 9,
-                                                dil, ACT[None], _st()), "gated_block_dgrad")
-        # parameter gradients: the batched launch (it serves both block forms); the eight gradients are one contiguous range in
-        # creation order (a slice of the zero pool: the kernels accumulate), handed back as views of it
-        sizes = [Cin * 20, 20, n15, 20, n15, 20, n9, C_]
-        flat_g = _zeros(sum(sizes), dev)
-        job = _lib.BlockWgradJob(xb.data_ptr(), h.data_ptr(), g.data_ptr(), dz.data_ptr(), da.data_ptr(), dz1.data_ptr(),
-                                 flat_g.data_ptr(), C_, T, dil, Cin)
-        grads = [gr.view(t.shape) for gr, t in zip(flat_g.split(sizes), (w1, b1, wl, bl, wr, br, w9, b9))]
-        if _deferrable(ctx.params):
-            _defer("block", (dev, B), job, (xb, h, g, dz, da, dz1), flat_g, ctx.params, sizes)
-        else:
-            ws_ = _workspace(int(lib.nsc_gated_block_wgrad_batch_workspace(112)), dev)
-            fn = lib.nsc_gated_block_wgrad_batch_split if SPLIT_ARITH else lib.nsc_gated_block_wgrad_batch
-            check(fn((_lib.BlockWgradJob * 1)(job), 1, B, 20, 9, ws_.data_ptr(), ws_.numel(), _st()), "gated_block_wgrad_batch")
+            dz = _act_bwd(lib, dz, out, "lrelu")
+        dx, grads = _block_backward(lib, xb, h, lin, th, g, ws, ctx.img_bwd, dz, dil, None, ctx.params)
         return (to_btc(dx), *grads, None, None)
+
+
+class BlockStackFn(torch.autograd.Function):
+    """_stack_bottleneck_blocks (neural_speech_coding_module.py:183-217: n gated blocks in a row, leaky-relu between them, the last one
+    flat or not) as ONE autograd node: the same launches as n BlockFn calls, except that the backward of block i + 1 applies the
+    derivative of the leaky-relu between the blocks in its own epilogue (the kernels' in_act: what the engine's chain does) - n - 1
+    activation-backward launches and 2 (n - 1) autograd nodes less.  Arguments: x, the 8 n parameters in creation order, the n dilation
+    rates, is_last_flat."""
+
+    @staticmethod
+    def forward(ctx, x, *args):
+        lib = _lib_()
+        dils, flat_last = tuple(int(d) for d in args[-2]), bool(args[-1])
+        params = args[:-2]
+        n = len(dils)
+        assert len(params) == 8 * n
+        cur = to_bct(_req(x, "the_input"))
+        saved, imgs = [cur], []
+        for i in range(n):
+            ws = [_req(t).contiguous() for t in params[8 * i:8 * i + 8]]
+            out, h, lin, th, g, img_bwd = _block_forward(lib, cur, ws, dils[i], flat_last if i == n - 1 else False)
+            saved += [h, lin, th, g, out, *ws]
+            imgs.append(img_bwd)
+            cur = out
+        ctx.save_for_backward(*saved)
+        ctx.cfg, ctx.imgs, ctx.params = (dils, flat_last), imgs, params
+        return to_btc(cur)
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib_()
+        dils, flat_last = ctx.cfg
+        n = len(dils)
+        sv = ctx.saved_tensors
+        blk = [sv[1 + 13 * i:1 + 13 * (i + 1)] for i in range(n)]          # h, lin, th, g, out, 8 parameters
+        dz = to_bct(_req(dy, "grad"))
+        if not flat_last:
+            dz = _act_bwd(lib, dz, blk[n - 1][4], "lrelu")
+        grads = [None] * n
+        for i in reversed(range(n)):
+            h, lin, th, g, _, *ws = blk[i]
+            xin = sv[0] if i == 0 else blk[i - 1][4]                        # the block's input: x, or the previous block's output
+            dz, grads[i] = _block_backward(lib, xin, h, lin, th, g, ws, ctx.imgs[i], dz, dils[i], "lrelu" if i > 0 else None,
+                                           ctx.params[8 * i:8 * i + 8])
+        return (to_btc(dz), *[t for gs in grads for t in gs], None, None)
 
 
 class QuantizeFn(torch.autograd.Function):

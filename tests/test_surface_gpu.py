@@ -561,3 +561,67 @@ def test_two_losses_of_one_tensor_share_a_node_and_separate_backwards_still_work
     pp = p.detach().cpu().double().requires_grad_(True)
     (OT.quan_loss(pp).sum() + 3.0 * OT.entropy_coding_loss(pp)).backward()
     assert relerr(p.grad.cpu().numpy(), pp.grad.numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("C_,cin,flat", [(100, 100, True), (50, 50, False), (100, 1, True)])
+def test_block_stack_equals_the_blocks_one_by_one(C_, cin, flat):
+    """nn.gated_bottleneck_stack (one autograd node, the leaky-relu between the blocks differentiated inside the next block's
+    data-gradient kernel) against the same blocks as separate gated_bottleneck calls: same variables, values and gradients."""
+    from nsc_amd import nn_core_operator as nn
+    from nsc_amd.scope import VariableStore, set_store, variable_scope
+    x_np = np.random.default_rng(12).standard_normal((2, 192, cin)).astype(np.float32)
+    w_np = np.random.default_rng(13).standard_normal((2, 192, C_)).astype(np.float32)
+    res = {}
+    for stacked in (True, False):
+        st = VariableStore(device="cuda", seed=6)
+        set_store(st)
+        try:
+            x = dev(x_np).requires_grad_(True)
+            with variable_scope("s"):
+                if stacked:
+                    y = nn.gated_bottleneck_stack(x, C_, 20, 9, [1, 2, 1], is_last_flat=flat)
+                else:
+                    y = nn.gated_bottleneck(x, C_, 20, 9, 9, 1, False)
+                    y = nn.gated_bottleneck(y, C_, 20, 9, 9, 2, False)
+                    y = nn.gated_bottleneck(y, C_, 20, 9, 9, 1, flat)
+            (y * dev(w_np)).sum().backward()
+            res[stacked] = (list(st.vars), y.detach().cpu().numpy(), x.grad.cpu().numpy(), _grads(st))
+        finally:
+            set_store(None)
+    (na, ya, dxa, ga), (nb, yb, dxb, gb) = res[True], res[False]
+    assert na == nb and len(na) == 24
+    assert np.array_equal(ya, yb)
+    assert relerr(dxa, dxb) < 1e-6
+    assert _max_rel(ga, gb) < 1e-5, _max_rel(ga, gb)
+
+
+@pytest.mark.parametrize("C_", [100, 50])
+def test_fused_up_sampling_equals_the_three_ops(C_):
+    """nn.conv1d_depth_shuffle (ops.UpsampleFn: nsc_upsample_fwd / _bwd) against conv1d_depth -> shuffle composed op by op: same
+    variables, values and gradients (neural_speech_coding_module.py:158-181)."""
+    from nsc_amd import nn_core_operator as nn, ops
+    from nsc_amd.scope import VariableStore, set_store, variable_scope
+    x_np = np.random.default_rng(21).standard_normal((3, 128, C_)).astype(np.float32)
+    w_np = np.random.default_rng(22).standard_normal((3, 256, C_ // 2)).astype(np.float32)
+    res = {}
+    for fused in (True, False):
+        st = VariableStore(device="cuda", seed=9)
+        set_store(st)
+        try:
+            x = dev(x_np).requires_grad_(True)
+            with variable_scope("s"):
+                if fused:
+                    y = nn.conv1d_depth_shuffle(x, C_, 9, activation='lrelu', stride=2)
+                else:
+                    y = ops.ShuffleFn.apply(nn.activation_func(nn.conv1d_depth(x, C_, 9, activation=None)))
+            with torch.no_grad():
+                st.vars["s/separable_conv1d/bias"].add_(0.01)            # (zero-initialised: give the bias path something to do)
+            assert y.shape == (3, 256, C_ // 2)
+            (y * dev(w_np)).sum().backward()
+            res[fused] = (list(st.vars), y.detach().cpu().numpy(), x.grad.cpu().numpy(), _grads(st))
+        finally:
+            set_store(None)
+    (na, ya, dxa, ga), (nb, yb, dxb, gb) = res[True], res[False]
+    assert na == nb == ["s/separable_conv1d/depthwise_kernel", "s/separable_conv1d/pointwise_kernel", "s/separable_conv1d/bias"]
+    assert relerr(ya, yb) < 1e-6 and relerr(dxa, dxb) < 1e-5
+    assert _max_rel(ga, gb) < 2e-5, _max_rel(ga, gb)
