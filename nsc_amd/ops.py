@@ -167,16 +167,23 @@ class _ImageSet:
         self.idx_all, self.n_all, self.total_all = None, 0, 0
         self.token, self.buf = None, None
 
-    def get(self, key, make_index):
+    @staticmethod
+    def _versions(refs):
+        return tuple(-1 if t is None else t._version for t in (r() for r in refs))
+
+    def get(self, key, make_index, tensors):
+        import weakref
         lib, dev, base = _lib_(), self.arena.device, self.arena.data_ptr()
         it = self.items.get(key)
         if it is None:
             idx = np.ascontiguousarray(make_index(), np.int32)
-            it = self.items[key] = (self.total, idx.size, torch.from_numpy(idx).to(dev))
+            it = self.items[key] = [self.total, idx.size, torch.from_numpy(idx).to(dev), [weakref.ref(t) for t in tensors], None]
             self.parts.append(idx)
             self.total += (idx.size + 3) // 4 * 4
         token = (self.store().pass_id, _capture_id())
-        if token != self.token:                      # first request of a pass
+        # a new pass - or parameters of THIS item changed in place since the gather that served it (an optimizer step between two uses
+        # without store.begin_pass(): every in-place update moves the tensor's version counter; assignments through .data do not)
+        if token != self.token or (it[4] is not None and it[4] != self._versions(it[3])):
             if self.n_all != len(self.items) and not token[1]:
                 flat = np.full(self.total, -1, np.int32)
                 o = 0
@@ -188,8 +195,10 @@ class _ImageSet:
             if self.idx_all is not None:
                 self.buf = torch.empty(self.total_all, dtype=torch.float32, device=dev)
                 check(lib.nsc_gather(base, self.idx_all.data_ptr(), self.buf.data_ptr(), self.total_all, _st()), "gather (image set)")
+            for other in self.items.values():
+                other[4] = self._versions(other[3]) if (self.buf is not None and other[0] + other[1] <= self.buf.numel()) else None
             self.token = token
-        start, n, dev_idx = it
+        start, n, dev_idx, refs, _ = it
         if self.buf is not None and start + n <= self.buf.numel():
             return self.buf[start:start + n]
         img = torch.empty(n, dtype=torch.float32, device=dev)
@@ -221,7 +230,7 @@ def _flipped_kernel(lib, w):
     found = _image_set([w])
     if found is not None:
         iset, (off,) = found
-        return iset.get(("flip", K, Cin, Cout, off), lambda: _flip_index(K, Cin, Cout, off))
+        return iset.get(("flip", K, Cin, Cout, off), lambda: _flip_index(K, Cin, Cout, off), [w])
     wt = torch.empty((K, Cout, Cin), dtype=torch.float32, device=w.device)
     check(lib.nsc_weight_flip_transpose(w.data_ptr(), wt.data_ptr(), K, Cin, Cout, _st()), "flip")
     return wt
@@ -244,7 +253,7 @@ def _split_conv_image(lib, which, d, w):
     found = _image_set([w])
     if found is not None:
         iset, (off,) = found
-        return iset.get(("conv", which, tuple(w.shape), off), lambda: index(off))
+        return iset.get(("conv", which, tuple(w.shape), off), lambda: index(off), [w])
     key = ("cs_idx", which, str(w.device), tuple(w.shape))
     if key not in _CACHE:
         _CACHE[key] = torch.from_numpy(index(0)).to(w.device)
@@ -636,7 +645,7 @@ def _block_images(lib, ws, C_, Cin, dil):
     if found is not None:
         iset, offs = found
         if max(offs) < (1 << 25):
-            return iset.get(("blk", C_, Cin, dil, offs), lambda: _block_image_index(lib, C_, Cin, dil, offs)), meta[0], meta[1]
+            return iset.get(("blk", C_, Cin, dil, offs), lambda: _block_image_index(lib, C_, Cin, dil, offs), ws), meta[0], meta[1]
     ptrs = [t.data_ptr() for t in ws]
     base = min(ptrs)
     offs = tuple((q - base) // 4 for q in ptrs)

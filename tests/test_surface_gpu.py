@@ -625,3 +625,31 @@ def test_fused_up_sampling_equals_the_three_ops(C_):
     assert na == nb == ["s/separable_conv1d/depthwise_kernel", "s/separable_conv1d/pointwise_kernel", "s/separable_conv1d/bias"]
     assert relerr(ya, yb) < 1e-6 and relerr(dxa, dxb) < 1e-5
     assert _max_rel(ga, gb) < 2e-5, _max_rel(ga, gb)
+
+
+def test_in_place_parameter_updates_are_seen_without_a_new_pass():
+    """Store variables handed to ops.BlockFn directly, twice, with an optimizer-style in-place update in between and NO begin_pass():
+    the image set notices the version counters of the block's tensors and gathers again."""
+    from nsc_amd import nn_core_operator as nn, ops
+    from nsc_amd.scope import VariableStore, set_store, variable_scope
+    x = dev(np.random.default_rng(31).standard_normal((2, 128, 100)).astype(np.float32))
+    st = VariableStore(device="cuda", seed=14)
+    set_store(st)
+    try:
+        with variable_scope("s"):
+            nn.gated_bottleneck(x, 100, 20, 9, 9, 1, True)               # creates the eight variables (and registers the image pair)
+        vs = list(st.vars.values())
+        st.begin_pass()
+        y0 = ops.BlockFn.apply(x, *vs, 1, True).detach().clone()         # pass 2: served from the consolidated buffer
+        y0b = ops.BlockFn.apply(x, *vs, 1, True).detach().clone()
+        assert torch.equal(y0, y0b)
+        with torch.no_grad():
+            for v in vs:
+                v.mul_(1.5)                                              # what an optimizer step does: in place, version bump
+        y1 = ops.BlockFn.apply(x, *vs, 1, True).detach().clone()         # same pass id
+        ref = ops.BlockFn.apply(x, *[v.detach().clone() for v in vs], 1, True).detach()   # plain tensors: gathered per call
+        torch.cuda.synchronize()
+        assert relerr(y1.cpu().numpy(), ref.cpu().numpy()) < 1e-6
+        assert relerr(y1.cpu().numpy(), y0.cpu().numpy()) > 1e-2
+    finally:
+        set_store(None)
