@@ -155,7 +155,7 @@ class _ImageSet:
     """Everything the kernels DERIVE from the parameters of one scope.VariableStore arena - kernel-ready images of the gated blocks
     (forward + data gradient), of the stride-2 convs, flipped / transposed kernels of the other convs - rebuilt by ONE nsc_gather
     launch per pass, the engine's arrangement (engine.py: wt_idx / nsc_step_begin; a gather launch is latency: 16 us for the 0.1 M
-    words of one block and 16 us for all of them).  An item is registered the first time an op asks for it (that request, and any
+    words of one block, 25 us for the 1.2 M words of a whole codec).  An item is registered the first time an op asks for it (that request, and any
     other before the next pass, is served by a gather of its own); from the next store.begin_pass() on, the first request of a pass
     gathers the whole set into a fresh buffer and every request is a slice of it.  A graph capture counts as a pass of its own
     (nsc_stream_capture_id), so a captured step always contains its gather."""

@@ -315,6 +315,18 @@ def test_cli_two_ranks_shard_the_data_file_and_match_one_process(tmp_path):
     j3 = _cli(tmp_path, tmp_path / "loc", 2, 2, tmp_path / "frames.npy", extra=("--local_entropy", "1"))
     c = np.array(num(j3))
     assert c.shape == a.shape and np.all(np.isfinite(c[~np.isnan(a)]))
+    # --tf_checkpoint: every checkpoint also in TensorFlow's V2 format under the reference's prefix, same variables, same values
+    (tmp_path / "tf").mkdir()
+    _cli(tmp_path, tmp_path / "tf", 4, 1, tmp_path / "frames.npy", extra=("--tf_checkpoint", "1"))
+    from nsc_amd.tf_checkpoint import read_checkpoint
+    idx = glob.glob(os.path.join(str(tmp_path / "tf"), "check", "model_bnn_ac_7654321_*.ckpt.index"))
+    assert idx, os.listdir(tmp_path / "tf" / "check")
+    for f in idx:
+        named = read_checkpoint(f[:-len(".index")])
+        with np.load(f[:-len(".index")] + ".npz") as z:
+            assert set(named) == {k.replace("|", "/") for k in z.files} and len(named) >= 70
+            for k in z.files:
+                assert np.array_equal(named[k.replace("|", "/")], z[k]), k
 
 
 @pytest.mark.parametrize("key,strides", [("s2", [2]), ("s22", [2, 2])])
