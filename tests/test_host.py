@@ -590,3 +590,51 @@ def test_trainer_restores_from_a_tf_format_checkpoint(tmp_path):
         np.testing.assert_array_equal(e.got[k], np.asarray(named[k]))
     m.restore(e, "")
     assert set(e.got) == set(named)
+
+
+# ---- op surface host logic (nsc_amd/ops.py): the index maps of the per-store image set, on CPU ----
+def test_flip_index_is_the_flipped_transposed_kernel():
+    from nsc_amd.ops import _flip_index
+    for K, Cin, Cout in ((9, 20, 100), (15, 20, 20), (1, 100, 20), (55, 1, 100)):
+        w = np.arange(K * Cin * Cout, dtype=np.int64).reshape(K, Cin, Cout) + 1000
+        wt = w[::-1].transpose(0, 2, 1)                                   # wt[k', o, i] = w[K - 1 - k', i, o]
+        assert np.array_equal(_flip_index(K, Cin, Cout, 1000), wt.reshape(-1))
+
+
+@pytest.mark.parametrize("C_,Cin,dil", [(100, 100, 1), (50, 50, 2), (100, 1, 1)])
+def test_block_image_pair_index_composes_the_flip_with_the_data_gradient_image(C_, Cin, dil):
+    """ops._block_image_index: [forward image | data-gradient image] of a gated block straight from its eight parameters.  The second
+    part must equal the library's own data-gradient image index applied to the FLIPPED kernels (what the engine gathers in two
+    steps); the first part the library's forward (split) image index; both from the same offsets."""
+    import ctypes as C
+    from nsc_amd import _lib, ops
+    lib = _lib.load()
+    sizes = [Cin * 20, 20, 6000, 20, 6000, 20, 9 * 20 * C_, C_]
+    offs = tuple(int(v) for v in (np.concatenate([[0], np.cumsum([s_ + 4 for s_ in sizes])[:-1]]) + 64))    # (gaps: any placement works)
+    meta = ops._block_image_meta(lib, C_, Cin, dil)
+    assert meta is not None
+    nf, kind, nb = meta
+    idx = ops._block_image_index(lib, C_, Cin, dil, offs)
+    assert idx.shape == (nf + nb,) and idx.dtype == np.int32 and nf % 4 == 0
+    # forward part == the library's index for the same offsets
+    n = int(lib.nsc_gated_block_simage_words(0, C_, Cin, dil)) if kind == "split" else int(lib.nsc_gated_block_image_floats(0, C_, Cin, dil))
+    ref = np.empty(n, np.int32)
+    fn = lib.nsc_gated_block_simage_index if kind == "split" else lib.nsc_gated_block_image_index
+    assert fn(0, C_, Cin, dil, (C.c_long * 8)(*offs), ref.ctypes.data_as(C.c_void_p)) == 0
+    assert np.array_equal(idx[:n], ref) and np.all(idx[n:nf] == -1)
+    # data-gradient part: gather it from a parameter buffer == the library's image of the flipped kernels
+    rng = np.random.default_rng(0)
+    buf = rng.standard_normal(offs[-1] + sizes[-1] + 8).astype(np.float32)
+    w1 = buf[offs[0]:offs[0] + sizes[0]].reshape(1, Cin, 20)
+    wl = buf[offs[2]:offs[2] + sizes[2]].reshape(15, 20, 20)
+    wr = buf[offs[4]:offs[4] + sizes[4]].reshape(15, 20, 20)
+    w9 = buf[offs[6]:offs[6] + sizes[6]].reshape(9, 20, C_)
+    flipped = np.concatenate([w[::-1].transpose(0, 2, 1).reshape(-1) for w in (w1, wl, wr, w9)])
+    n1, n15 = Cin * 20, 6000
+    bw = np.empty(nb, np.int32)
+    assert lib.nsc_gated_block_image_index(1, C_, Cin, dil, (C.c_long * 4)(0, n1, n1 + n15, n1 + 2 * n15), bw.ctypes.data_as(C.c_void_p)) == 0
+    want = np.where(bw >= 0, flipped[np.maximum(bw, 0)], 0.0)
+    got_i = idx[nf:]
+    assert np.all(got_i < (1 << 26))                                      # (plain words: no split modes in the exact image)
+    got = np.where(got_i >= 0, buf[np.maximum(got_i, 0)], 0.0)
+    assert np.array_equal(got, want)
