@@ -682,7 +682,7 @@ def _block_forward(lib, xb, ws, dil, flat):
     return out, h, lin, th, g, (None if imgs is None else imgs[0][imgs[1]:])
 
 
-def _block_backward(lib, xb, h, lin, th, g, ws, img_bwd, dz, dil, in_act, params):
+def _block_backward(lib, xb, h, lin, th, g, ws, img_bwd, dz, dil, in_act, params, need_w=True):
     """One gated block backward from dz = dL/d(pre-activation of its output): (dx [B,Cin,T], the eight parameter gradients).  in_act:
     the activation that PRODUCED the block's input (its derivative is applied to dx in the kernel's epilogue: dx is then dL/d of that
     pre-activation - how a chain of blocks skips the activation-backward launches); parameter gradients deferred to the end of the pass
@@ -715,6 +715,8 @@ def _block_backward(lib, xb, h, lin, th, g, ws, img_bwd, dz, dil, in_act, params
             check(lib.nsc_gated_block_dgrad(xb.data_ptr(), h.data_ptr(), lin.data_ptr(), th.data_ptr(), dz.data_ptr(),
                                             *wts, dx.data_ptr(), da.data_ptr(), dz1.data_ptr(), B, C_, T, 20, 9,
                                             dil, ACT[in_act], _st()), "gated_block_dgrad")
+    if not need_w:                                     # a frozen block (an earlier codec in a follower phase): data path only
+        return dx, [None] * 8
     # parameter gradients: the batched launch (it serves both block forms); the eight gradients are one contiguous range in
     # creation order (a slice of the zero pool: the kernels accumulate), handed back as views of it
     sizes = [Cin * 20, 20, n15, 20, n15, 20, n9, C_]
@@ -766,7 +768,7 @@ class BlockFn(torch.autograd.Function):
         dz = to_bct(_req(dy, "grad"))
         if not flat:                                   # through the block's output leaky-relu
             dz = _act_bwd(lib, dz, out, "lrelu")
-        dx, grads = _block_backward(lib, xb, h, lin, th, g, ws, ctx.img_bwd, dz, dil, None, ctx.params)
+        dx, grads = _block_backward(lib, xb, h, lin, th, g, ws, ctx.img_bwd, dz, dil, None, ctx.params, any(ctx.needs_input_grad[1:9]))
         return (to_btc(dx), *grads, None, None)
 
 
@@ -811,7 +813,7 @@ class BlockStackFn(torch.autograd.Function):
             h, lin, th, g, _, *ws = blk[i]
             xin = sv[0] if i == 0 else blk[i - 1][4]                        # the block's input: x, or the previous block's output
             dz, grads[i] = _block_backward(lib, xin, h, lin, th, g, ws, ctx.imgs[i], dz, dils[i], "lrelu" if i > 0 else None,
-                                           ctx.params[8 * i:8 * i + 8])
+                                           ctx.params[8 * i:8 * i + 8], any(ctx.needs_input_grad[1 + 8 * i:9 + 8 * i]))
         return (to_btc(dz), *[t for gs in grads for t in gs], None, None)
 
 

@@ -665,3 +665,34 @@ def test_in_place_parameter_updates_are_seen_without_a_new_pass():
         assert relerr(y1.cpu().numpy(), y0.cpu().numpy()) > 1e-2
     finally:
         set_store(None)
+
+
+def test_frozen_blocks_skip_their_weight_gradients_and_pass_the_data_gradient():
+    """A stack whose variables do not require gradients (an earlier codec in a follower phase, cmrl.py:106-113): no weight-gradient job is
+    queued for it, dx is what the trainable stack gives."""
+    from nsc_amd import nn_core_operator as nn, ops
+    from nsc_amd.scope import VariableStore, set_store, variable_scope
+    x_np = np.random.default_rng(41).standard_normal((2, 128, 100)).astype(np.float32)
+    res = {}
+    for frozen in (False, True):
+        st = VariableStore(device="cuda", seed=17)
+        set_store(st)
+        try:
+            x = dev(x_np).requires_grad_(True)
+            with variable_scope("s"):
+                y = nn.gated_bottleneck_stack(x, 100, 20, 9, [1, 2], is_last_flat=True)
+            if frozen:
+                for v in st.vars.values():
+                    v.requires_grad_(False)
+                st.begin_pass()
+                with variable_scope("s"):
+                    y = nn.gated_bottleneck_stack(x, 100, 20, 9, [1, 2], is_last_flat=True)
+            n0 = len(ops._PENDING)
+            (y * y).sum().backward()
+            torch.cuda.synchronize()
+            assert len(ops._PENDING) == n0
+            res[frozen] = x.grad.cpu().numpy()
+            assert all((v.grad is None) == frozen for v in st.vars.values())
+        finally:
+            set_store(None)
+    assert relerr(res[True], res[False]) < 1e-6
