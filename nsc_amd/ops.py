@@ -368,36 +368,39 @@ class Conv1dFn(torch.autograd.Function):
             dz2 = torch.empty_like(dz)
             check(lib.nsc_act_bwd(dz.data_ptr(), y.data_ptr(), dz2.data_ptr(), dz.numel(), ACT[act], _st()), "act_bwd")
             dz = dz2
-        dwb = _zeros(w.numel() + Cout, w.device)                                        # dw | db
-        dw, db = dwb[:w.numel()].view(w.shape), dwb[w.numel():]
-        # partial sums of the (b,t) splits go to private slabs + one reduce launch (nsc_conv1d_wgrad_ws) instead of same-address atomics
+        need_w = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]        # (a frozen conv: the data path only)
+        dw = db = None
         dfw = _desc(B, Cin, Cout, T, Tout, K, dil, stride, padL)
         split = (stride == 2 and SPLIT_ARITH and int(lib.nsc_conv1d_simage_words(0, C.byref(dfw))) > 0 and
                  (xb.data_ptr() | dz.data_ptr() | w.data_ptr()) % 16 == 0)
-        if split:
-            ws = _workspace(int(lib.nsc_conv1d_wgrad_split_workspace()), w.device)
-            job = _lib.ConvWgradJob(dfw, xb.data_ptr(), dz.data_ptr(), dw.data_ptr(), db.data_ptr(), 0)
-            check(lib.nsc_conv1d_wgrad_split((_lib.ConvWgradJob * 1)(job), 1, ws.data_ptr(), ws.numel(), _st()), "wgrad (split)")
-        elif Cout == 1:      # roles swapped: "input" = dz, "gradient" = x, flipped taps; the bias gradient is the plain sum of dz
-            d = _desc(B, 1, Cin, Tout, T, K, dil, 1, (K - 1) * dil - padL)
-            if _deferrable(ctx.params):
-                _defer("conv", (w.device,), _lib.ConvWgradJob(d, dz.data_ptr(), xb.data_ptr(), dw.data_ptr(), None, 1), (xb, dz), dwb,
-                       ctx.params, [w.numel(), Cout])
-                _defer("sum", (w.device,), _lib.SumJob(dz.data_ptr(), db.data_ptr(), dz.numel()), (dz, dwb), dwb, (), [])
+        if need_w:
+            dwb = _zeros(w.numel() + Cout, w.device)                                        # dw | db
+            dw, db = dwb[:w.numel()].view(w.shape), dwb[w.numel():]
+            # partial sums of the (b,t) splits go to private slabs + one reduce launch (nsc_conv1d_wgrad_ws) instead of same-address atomics
+            if split:
+                ws = _workspace(int(lib.nsc_conv1d_wgrad_split_workspace()), w.device)
+                job = _lib.ConvWgradJob(dfw, xb.data_ptr(), dz.data_ptr(), dw.data_ptr(), db.data_ptr(), 0)
+                check(lib.nsc_conv1d_wgrad_split((_lib.ConvWgradJob * 1)(job), 1, ws.data_ptr(), ws.numel(), _st()), "wgrad (split)")
+            elif Cout == 1:      # roles swapped: "input" = dz, "gradient" = x, flipped taps; the bias gradient is the plain sum of dz
+                d = _desc(B, 1, Cin, Tout, T, K, dil, 1, (K - 1) * dil - padL)
+                if _deferrable(ctx.params):
+                    _defer("conv", (w.device,), _lib.ConvWgradJob(d, dz.data_ptr(), xb.data_ptr(), dw.data_ptr(), None, 1), (xb, dz), dwb,
+                           ctx.params, [w.numel(), Cout])
+                    _defer("sum", (w.device,), _lib.SumJob(dz.data_ptr(), db.data_ptr(), dz.numel()), (dz, dwb), dwb, (), [])
+                else:
+                    ws = _workspace(int(lib.nsc_conv1d_wgrad_workspace(C.byref(d))), w.device)
+                    check(lib.nsc_conv1d_wgrad_ws(C.byref(d), dz.data_ptr(), xb.data_ptr(), dw.data_ptr(), None, 1, ws.data_ptr(), ws.numel(),
+                                                  _st()), "wgrad")
+                    check(lib.nsc_sum_all(dz.data_ptr(), db.data_ptr(), dz.numel(), _st()), "bias grad")
             else:
-                ws = _workspace(int(lib.nsc_conv1d_wgrad_workspace(C.byref(d))), w.device)
-                check(lib.nsc_conv1d_wgrad_ws(C.byref(d), dz.data_ptr(), xb.data_ptr(), dw.data_ptr(), None, 1, ws.data_ptr(), ws.numel(),
-                                              _st()), "wgrad")
-                check(lib.nsc_sum_all(dz.data_ptr(), db.data_ptr(), dz.numel(), _st()), "bias grad")
-        else:
-            d = _desc(B, Cin, Cout, T, Tout, K, dil, stride, padL)
-            if _deferrable(ctx.params):
-                _defer("conv", (w.device,), _lib.ConvWgradJob(d, xb.data_ptr(), dz.data_ptr(), dw.data_ptr(), db.data_ptr(), 0), (xb, dz),
-                       dwb, ctx.params, [w.numel(), Cout])
-            else:
-                ws = _workspace(int(lib.nsc_conv1d_wgrad_workspace(C.byref(d))), w.device)
-                check(lib.nsc_conv1d_wgrad_ws(C.byref(d), xb.data_ptr(), dz.data_ptr(), dw.data_ptr(), db.data_ptr(), 0, ws.data_ptr(),
-                                              ws.numel(), _st()), "wgrad")
+                d = _desc(B, Cin, Cout, T, Tout, K, dil, stride, padL)
+                if _deferrable(ctx.params):
+                    _defer("conv", (w.device,), _lib.ConvWgradJob(d, xb.data_ptr(), dz.data_ptr(), dw.data_ptr(), db.data_ptr(), 0), (xb, dz),
+                           dwb, ctx.params, [w.numel(), Cout])
+                else:
+                    ws = _workspace(int(lib.nsc_conv1d_wgrad_workspace(C.byref(d))), w.device)
+                    check(lib.nsc_conv1d_wgrad_ws(C.byref(d), xb.data_ptr(), dz.data_ptr(), dw.data_ptr(), db.data_ptr(), 0, ws.data_ptr(),
+                                                  ws.numel(), _st()), "wgrad")
         dx = None
         img = _split_conv_image(lib, 1, dfw, w) if (split and ctx.needs_input_grad[0]) else None
         if img is not None:

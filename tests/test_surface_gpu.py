@@ -668,8 +668,8 @@ def test_in_place_parameter_updates_are_seen_without_a_new_pass():
 
 
 def test_frozen_blocks_skip_their_weight_gradients_and_pass_the_data_gradient():
-    """A stack whose variables do not require gradients (an earlier codec in a follower phase, cmrl.py:106-113): no weight-gradient job is
-    queued for it, dx is what the trainable stack gives."""
+    """Convs and a stack whose variables do not require gradients (an earlier codec in a follower phase, cmrl.py:106-113): no
+    weight-gradient job is queued for them, dx is what the trainable graph gives."""
     from nsc_amd import nn_core_operator as nn, ops
     from nsc_amd.scope import VariableStore, set_store, variable_scope
     x_np = np.random.default_rng(41).standard_normal((2, 128, 100)).astype(np.float32)
@@ -679,14 +679,18 @@ def test_frozen_blocks_skip_their_weight_gradients_and_pass_the_data_gradient():
         set_store(st)
         try:
             x = dev(x_np).requires_grad_(True)
-            with variable_scope("s"):
-                y = nn.gated_bottleneck_stack(x, 100, 20, 9, [1, 2], is_last_flat=True)
+
+            def graph():
+                with variable_scope("s"):
+                    c = nn.conv1d(x, 100, 9, strides=2, activation='lrelu')          # (the split-operand stride-2 conv)
+                    c = nn.conv1d(c, 100, 3, activation=None)                        # (a generic conv)
+                    return nn.gated_bottleneck_stack(c, 100, 20, 9, [1, 2], is_last_flat=True)
+            y = graph()
             if frozen:
                 for v in st.vars.values():
                     v.requires_grad_(False)
                 st.begin_pass()
-                with variable_scope("s"):
-                    y = nn.gated_bottleneck_stack(x, 100, 20, 9, [1, 2], is_last_flat=True)
+                y = graph()
             n0 = len(ops._PENDING)
             (y * y).sum().backward()
             torch.cuda.synchronize()
