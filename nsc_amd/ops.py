@@ -648,14 +648,14 @@ def _block_images(lib, ws, C_, Cin, dil):
     if found is not None:
         iset, offs = found
         if max(offs) < (1 << 25):
-            return iset.get(("blk", C_, Cin, dil, offs), lambda: _block_image_index(lib, C_, Cin, dil, offs), ws), meta[0], meta[1]
+            return iset.get(("blk", meta[1], C_, Cin, dil, offs), lambda: _block_image_index(lib, C_, Cin, dil, offs), ws), meta[0], meta[1]
     ptrs = [t.data_ptr() for t in ws]
     base = min(ptrs)
     offs = tuple((q - base) // 4 for q in ptrs)
     if any((q - base) % 4 for q in ptrs) or max(offs) >= (1 << 25):
         return None
     dev = ws[0].device
-    key = ("blk_idx", str(dev), C_, Cin, dil, offs)
+    key = ("blk_idx", meta[1], str(dev), C_, Cin, dil, offs)
     if key not in _CACHE:
         _CACHE[key] = torch.from_numpy(_block_image_index(lib, C_, Cin, dil, offs)).to(dev)
     idx = _CACHE[key]

@@ -700,3 +700,36 @@ def test_frozen_blocks_skip_their_weight_gradients_and_pass_the_data_gradient():
         finally:
             set_store(None)
     assert relerr(res[True], res[False]) < 1e-6
+
+
+def test_surface_blocks_on_the_exact_instruction_agree_with_the_split_operands(monkeypatch):
+    """NSC_BLOCK_ARITH=exact (ops.SPLIT_ARITH False): the surface's blocks and stride-2 conv on the fp32 matrix instruction - the same
+    values and gradients as the default split-operand kernels to fp32-class error, in the same store (the image set keeps both kinds)."""
+    from nsc_amd import nn_core_operator as nn, ops
+    from nsc_amd.scope import VariableStore, set_store, variable_scope
+    x_np = np.random.default_rng(51).standard_normal((2, 256, 100)).astype(np.float32)
+    w_np = np.random.default_rng(52).standard_normal((2, 128, 100)).astype(np.float32)
+    st = VariableStore(device="cuda", seed=23)
+    set_store(st)
+    try:
+        res = {}
+        for split in (True, False, True):
+            monkeypatch.setattr(ops, "SPLIT_ARITH", split)
+            st.begin_pass()
+            for v in st.vars.values():
+                v.grad = None
+            x = dev(x_np).requires_grad_(True)
+            with variable_scope("s"):
+                c = nn.conv1d(x, 100, 9, strides=2, activation='lrelu')
+                y = nn.gated_bottleneck_stack(c, 100, 20, 9, [1, 2], is_last_flat=False)
+            (y * dev(w_np)).sum().backward()
+            cur = (y.detach().cpu().numpy(), x.grad.cpu().numpy(), _grads(st))
+            if split in res:                                             # the second split pass: the first one's results again
+                assert np.array_equal(cur[0], res[True][0])
+            res[split] = cur
+        ys, dxs, gs = res[True]
+        ye, dxe, ge = res[False]
+        assert 0 < relerr(ys, ye) < 2e-5 and relerr(dxs, dxe) < 5e-5      # (different arithmetic, fp32-class agreement)
+        assert _max_rel(gs, ge) < 1e-4, _max_rel(gs, ge)
+    finally:
+        set_store(None)
