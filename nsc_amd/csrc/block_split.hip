@@ -378,10 +378,13 @@ __device__ __forceinline__ void gated_block_fwd3_body(const BlockArgs& a, int nt
         };
         fetch_b(0, 0);
         fetch_a(0, 0);
+        if (NSC_EXP & 8192) { fetch_b(1, 1); fetch_a(1, 1); }
 #pragma unroll
         for (int u = 0; u < 2 * SPL_KS2; ++u) {
+          if (!(NSC_EXP & 8192)) {      // (timing experiment 8192: no operand fetches after the first - WRONG RESULTS)
           if (u + 1 < 2 * SPL_KS2) fetch_a(u + 1, (u + 1) & 1);
           if ((u & 1) && (u >> 1) + 1 < SPL_KS2) fetch_b((u >> 1) + 1, ((u >> 1) + 1) & 1);
+          }
           __builtin_amdgcn_sched_barrier(0);
           acc[u & 1] = mfma_split6(aa[u & 1], bb[(u >> 1) & 1], acc[u & 1]);
           __builtin_amdgcn_sched_barrier(0);
@@ -410,9 +413,10 @@ __device__ __forceinline__ void gated_block_fwd3_body(const BlockArgs& a, int nt
             }
           };
           fetch(0, 0);
+          if (NSC_EXP & 8192) fetch(1, 1);
 #pragma unroll
           for (int u = 0; u < 2 * SPL_KS2; ++u) {
-            if (u + 1 < 2 * SPL_KS2) fetch(u + 1, (u + 1) & 1);
+            if (!(NSC_EXP & 8192) && u + 1 < 2 * SPL_KS2) fetch(u + 1, (u + 1) & 1);
               __builtin_amdgcn_sched_barrier(0);
             acc[u & 1] = mfma_split6(aa[u & 1], bb[u & 1], acc[u & 1]);
             __builtin_amdgcn_sched_barrier(0);
@@ -426,15 +430,17 @@ __device__ __forceinline__ void gated_block_fwd3_body(const BlockArgs& a, int nt
             }
           };
           fetch(0, 0);
+          if (NSC_EXP & 8192) fetch(1, 1);
 #pragma unroll
           for (int s_ = 0; s_ < SPL_KS2; ++s_) {
-            if (s_ + 1 < SPL_KS2) fetch(s_ + 1, (s_ + 1) & 1);
+            if (!(NSC_EXP & 8192) && s_ + 1 < SPL_KS2) fetch(s_ + 1, (s_ + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
             acc[0] = mfma_split6(aa[s_ & 1], bb[s_ & 1], acc[0]);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
       }
+      NSC_STAMP(44);
       // epilogue: the lane holds (lin c0, lin c0+1, tanh-pre c0, tanh-pre c0+1) of one step
       const int s_lo = fresh ? 4 : 8, s_hi = next_steady ? WGW : 4 + TT;   // columns kept for the backward pass (see save_lg in block.hip)
 #pragma unroll
@@ -523,7 +529,9 @@ __device__ __forceinline__ void gated_block_fwd3_body(const BlockArgs& a, int nt
       // Every vector-memory operation this wave has issued so far has completed - the next x tile's DMA (which the compiler does not
       // see) among them: the loop-end barrier then means "the x tile is in LDS".  Everything outstanding here is old (the DMA and the
       // residual went out before ~150 MFMAs), the output stores below are not waited for.
+      NSC_STAMP(45);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      NSC_STAMP(46);
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         const int tt = (ct0 + c) * 16 + 4 * kqp;

@@ -41,3 +41,7 @@ for (B, C_, T, dil, save) in [(128, 100, 512, 1, 1), (128, 100, 512, 2, 1), (128
         print(f"{'split' if split else 'exact'} B={B} C={C_} T={T} dil={dil} save={save}: kernel {v[11]-v[0]} cycles, last tile {v[10]-v[2]}   (wave 0 | wave 4)")
         for i in range(1, 12):
             print(f"  {names[i]:>14}: +{v[i]-v[i-1]:6d} | +{w4[i]-w4[i-1]:6d}")
+        if split:
+            a, b = list(buf)[:64], list(buf)[64:128]
+            print(f"  inside ph2: MFMA loop +{a[44]-a[38]} | +{b[44]-b[38]}, epilogue +{a[39]-a[44]} | +{b[39]-b[44]};  inside ph3: MFMA loop "
+                  f"+{a[45]-a[40]} | +{b[45]-b[40]}, vmcnt wait +{a[46]-a[45]} | +{b[46]-b[45]}, epilogue +{a[41]-a[46]} | +{b[41]-b[46]}")
