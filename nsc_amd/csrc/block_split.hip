@@ -173,8 +173,7 @@ __device__ __forceinline__ void gated_block_fwd3_body(const BlockArgs& a, int nt
   const rsrc4_t sxd = {(int)(unsigned)xaddr, (int)((unsigned)(xaddr >> 32) & 0xFFFFu), (int)(unsigned)((long)a.B * Cin * T * 4), 0x00020000};
   const __amdgpu_buffer_rsrc_t sx =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (unsigned)((long)a.B * Cin * T * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t sout =
-      __builtin_amdgcn_make_buffer_rsrc(a.out, 0, FIRST ? (unsigned)((long)a.B * a.C * T * 4) : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t sout = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (unsigned)((long)a.B * a.C * T * 4), 0x00020000);
   const unsigned lds_x = (unsigned)(unsigned long long)(nsc_lds_cu16)reinterpret_cast<const u16*>(sm);
   auto dma_x = [&](int tile) {
     const int tl = __builtin_amdgcn_readfirstlane(tile < ntiles ? tile : 0);
@@ -483,14 +482,10 @@ __device__ __forceinline__ void gated_block_fwd3_body(const BlockArgs& a, int nt
     int lane3 = lane;
     asm volatile("" : "+v"(lane3));
     const int l15p = lane3 & 15, kqp = lane3 >> 4;
-    auto out_store4 = [&](const f32x4& v, int b_, int o, int t) {
-      float* gptr = a.out + ((long)b_ * C + o) * T + t;
-      if constexpr (FIRST) {
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, v), sout, ((b_ * C + o) * T + t) * 4, 0, NSC_AUX_COHERENT);   // (pairs: T % 4 == 0)
-      } else {
-        *reinterpret_cast<f32x4*>(gptr) = v;                             // (T % 4 == 0 and a 16-byte aligned tensor: checked by the launcher)
-      }
-    };
+    // (round 6: the epilogue's addresses are 32-bit buffer offsets built ONCE per tile - the lane's row, the tile's scalar part - plus
+    // constants; it used to form a 64-bit address per store: two quarter-rate multiplies and a 64-bit mad each.  The activation is
+    // max(u, slope u), slope = 1 for a flat block: two instructions instead of a compare and two selects.)
+    const float slope3 = a.flat ? 1.f : NSC_LRELU_ALPHA;
     auto dense3 = [&](auto nc_c, int ct0) {
       constexpr int NC = decltype(nc_c)::value;
       f32x4 acc[NC];
@@ -498,11 +493,13 @@ __device__ __forceinline__ void gated_block_fwd3_body(const BlockArgs& a, int nt
       for (int c = 0; c < NC; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
       // the residual x[o][t .. t + 3] from memory (the LDS tile already belongs to the next step): requested before the MFMA loop
       const int o = rt3 * 16 + l15p;
+      const int tt0 = ct0 * 16 + 4 * kqp;                                  // first step of this lane's group in column tile ct0
+      const int xrow = ((b * Cin + (NK1 == 1 ? 0 : o)) * T + t0 + tt0) * 4;   // Cin = 1: broadcast residual
+      const int orow = ((b * C + o) * T + t0 + tt0) * 4;
       f32x4 xr4[NC];
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
-        const int t = t0 + (ct0 + c) * 16 + 4 * kqp;
-        const int vo = (o < C && t < T) ? ((b * Cin + (NK1 == 1 ? 0 : o)) * T + t) * 4 : 0x7ffffff0;       // Cin = 1: broadcast residual
+        const int vo = (o < C && t0 + tt0 + 16 * c < T) ? xrow + 64 * c : 0x7ffffff0;
         xr4[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(sx, vo, 0, PAIRED ? NSC_AUX_COHERENT : 0));
       }
       // (software-pipelined by hand like phase 2: step i = (k-step i / NC, column tile i % NC); opaque bases per plane and pair of
@@ -534,17 +531,14 @@ __device__ __forceinline__ void gated_block_fwd3_body(const BlockArgs& a, int nt
       NSC_STAMP(46);
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
-        const int tt = (ct0 + c) * 16 + 4 * kqp;
-        const int t = t0 + tt;
-        if (o < C && t < T) {
+        if (o < C && t0 + tt0 + 16 * c < T) {                              // (T % 4 == 0: a lane's four steps are in or out together)
           f32x4 v;
 #pragma unroll
           for (int reg = 0; reg < 4; ++reg) {
-            float u_ = acc[c][reg] + b9l + xr4[c][reg];
-            if (!a.flat) u_ = u_ > 0.f ? u_ : NSC_LRELU_ALPHA * u_;
-            v[reg] = u_;
+            const float u_ = acc[c][reg] + b9l + xr4[c][reg];
+            v[reg] = fmaxf(u_, slope3 * u_);
           }
-          out_store4(v, b, o, t);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, v), sout, orow + 64 * c, 0, FIRST ? NSC_AUX_COHERENT : 0);
         }
       }
     };
