@@ -126,15 +126,9 @@ def op_surface_leg(B, x_np, dev, steps=20, warmup=3):
         # place by the replay) - what a user of the op surface does when the host is the bottleneck, and what the engine's figure uses
         t_surface_graph = None
         try:
-            s_ = torch.cuda.Stream()
-            s_.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s_):
-                surface_step()
-            torch.cuda.current_stream().wait_stream(s_)
-            gs = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gs, stream=s_):
-                surface_step()
-            t_surface_graph = timed(gs.replay, steps)
+            from nsc_amd.graph import capture_step
+            gs = capture_step(surface_step, warmup=1)
+            t_surface_graph = timed(gs, steps)
         except Exception as e:
             print(f"[bench] op_surface: graph capture of the surface step failed ({type(e).__name__}: {e}); eager figure stands", file=sys.stderr)
             torch.cuda.synchronize()

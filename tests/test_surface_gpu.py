@@ -733,3 +733,37 @@ def test_surface_blocks_on_the_exact_instruction_agree_with_the_split_operands(m
         assert _max_rel(gs, ge) < 1e-4, _max_rel(gs, ge)
     finally:
         set_store(None)
+
+
+def test_captured_surface_step_trains_like_the_eager_one():
+    """nsc_amd.graph.capture_step: three SGD steps (in-place parameter updates between replays, new frames copied into the static input)
+    through the replayed graph end where three eager steps end."""
+    from nsc_amd.graph import capture_step
+    from nsc_amd.scope import VariableStore, set_store
+    B = 4
+    frames = [dev(synth_frames(B + 8)[k:k + B]) for k in (0, 4, 8)]
+    res = {}
+    for mode in ("eager", "graph"):
+        st = VariableStore(device="cuda", seed=33)
+        set_store(st)
+        try:
+            m = _module()
+            xd = frames[0].clone()
+            tgt = torch.empty((B, 512), device="cuda")
+
+            def step():
+                tgt.copy_(xd[:, :, 0])
+                _surface_step(st, m, xd, tgt, B)
+            step()                                                       # creates the variables
+            run = capture_step(step) if mode == "graph" else step
+            for f in frames:
+                xd.copy_(f)
+                run()
+                with torch.no_grad():
+                    for v in st.vars.values():
+                        v.add_(v.grad, alpha=-1e-3)
+            torch.cuda.synchronize()
+            res[mode] = {k: v.detach().cpu().numpy().copy() for k, v in st.vars.items()}
+        finally:
+            set_store(None)
+    assert _max_rel(res["eager"], res["graph"]) < 1e-5, _max_rel(res["eager"], res["graph"])
